@@ -1,0 +1,158 @@
+/*
+ * mispec.h -- C ABI of libmispec.so, the MI355X (gfx950) spectrogram hot path.
+ *
+ * The reference (KinWaiCheuk/nnAudio, pure Python) has no FFI layer: its operator
+ * boundary is the set of ATen calls inside the feature modules' forward():
+ *
+ *   F.conv1d(x, wsin/wcos, stride=hop) + pad + |.|/stack/atan2
+ *                       Installation/nnAudio/features/stft.py:278-316
+ *   F.conv1d(x, cqt_kernels_real/imag, stride=hop) + sqrt(lenghts) scaling
+ *                       Installation/nnAudio/features/cqt.py:740-780
+ *   pad + 2x conv1d per octave (get_cqt_complex)
+ *                       Installation/nnAudio/utils.py:498-521
+ *   F.conv1d(x, lowpass, stride=n, padding=127) (downsampling_by_n)
+ *                       Installation/nnAudio/utils.py:73-124
+ *   spec ** power ; torch.matmul(mel_basis | gammatone_basis, spec)
+ *                       Installation/nnAudio/features/mel.py:184-189,
+ *                       Installation/nnAudio/features/gammatone.py:184-189
+ *
+ * Each entry point below replaces one of those call groups.  Conventions:
+ *   - every pointer is a DEVICE pointer to fp32 (or int32 where stated), owned by the
+ *     caller; the library never allocates, frees or synchronises;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*) of the CURRENT device;
+ *     the functions are re-entrant and thread-safe (one host thread per GPU is the
+ *     reference's nn.DataParallel calling pattern, tests/test_stft.py:134-139);
+ *   - return value 0 = enqueued; negative = MISPEC_E_*; mispec_last_error() returns a
+ *     thread-local message for the last failure on the calling thread.
+ */
+#ifndef MISPEC_H
+#define MISPEC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MISPEC_ABI_VERSION 1
+
+enum {
+  MISPEC_OK = 0,
+  MISPEC_E_INVALID = -1,     /* bad argument (null pointer, non-positive size, ...)   */
+  MISPEC_E_UNSUPPORTED = -2, /* well-formed but outside what the kernels implement    */
+  MISPEC_E_HIP = -3          /* a HIP runtime call failed (launch, attribute, ...)    */
+};
+
+/* how samples outside [0, n_samples) are produced while framing (never materialised) */
+enum {
+  MISPEC_PAD_NONE = 0,   /* center=False: every frame lies inside the signal            */
+  MISPEC_PAD_ZERO = 1,   /* nn.ConstantPad1d(pad, 0)                                    */
+  MISPEC_PAD_REFLECT = 2 /* nn.ReflectionPad1d(pad): mirror without repeating the edge  */
+};
+
+/* pointwise epilogue applied to (re, im) = (sum x*basis_re, im_sign * sum x*basis_im),
+ * both first multiplied by row_scale[bin] when given */
+enum {
+  MISPEC_EPI_COMPLEX = 0,      /* out[..., 0:2] = (re, im)          stft.py:308-311, cqt.py:774-775 */
+  MISPEC_EPI_MAGNITUDE = 1,    /* sqrt(re^2 + im^2 + eps)            stft.py:299-306, cqt.py:766-772 */
+  MISPEC_EPI_POWER = 2,        /* sqrt(re^2 + im^2 + eps) ** power   mel.py:186 (fused pow)          */
+  MISPEC_EPI_PHASE_ATAN2 = 3,  /* atan2(im + 0.0, re)                stft.py:313-316                 */
+  MISPEC_EPI_PHASE_COSSIN = 4, /* (cos a, sin a), a = atan2(im, re)  cqt.py:777-780                  */
+  MISPEC_EPI_REAL = 5          /* basis_im == NULL: out = scaled sum (real contraction)              */
+};
+
+/* tile shapes of the MFMA kernel (rows x frames per workgroup); 0 lets the library pick */
+enum {
+  MISPEC_TILE_AUTO = 0,
+  MISPEC_TILE_128x128 = 1,
+  MISPEC_TILE_32x256 = 2,
+  MISPEC_TILE_64x256 = 3,
+  MISPEC_TILE_128x128_TALL = 4, /* one wave column: every wave owns all 4 row tiles */
+  MISPEC_TILE_192x128 = 5,
+  MISPEC_TILE_256x128 = 6
+};
+
+/*
+ * Framed contraction ("strided conv1d as a GEMM whose B operand is never materialised"):
+ *
+ *   acc_re[c,f,t] = sum_{n<kernel} X(c, t*hop - pad + n) * basis_re[f, n]
+ *   acc_im[c,f,t] = sum_{n<kernel} X(c, t*hop - pad + n) * basis_im[f, n]
+ *
+ * X(c, p) = x[c, p] inside the signal, else per pad_mode.  Output element (c, f, t) goes to
+ *   out + c*out_clip_stride + (out_row_offset + f)*out_row_stride + t*E   (E = 2 for the
+ *   two-component epilogues, else 1), i.e. the reference's (batch, freq_bins, n_frames[, 2])
+ *   layout when out_row_stride = n_frames*E and out_clip_stride = rows_total*n_frames*E.
+ */
+typedef struct mispec_framed_gemm_args {
+  uint32_t struct_size;        /* sizeof(mispec_framed_gemm_args), for ABI evolution       */
+  int32_t tile;                /* MISPEC_TILE_*                                            */
+
+  const float *x;              /* (n_clips, n_samples), row stride x_clip_stride elements  */
+  int64_t x_clip_stride;
+  int32_t n_clips;
+  int32_t n_samples;
+
+  int32_t hop;                 /* samples between successive frames (> 0)                  */
+  int32_t pad;                 /* virtual padding on each side (0 with MISPEC_PAD_NONE)    */
+  int32_t pad_mode;            /* MISPEC_PAD_*                                             */
+  int32_t n_frames;            /* frames per clip; caller guarantees the last frame fits   */
+
+  const float *basis_re;       /* (n_bins, kernel), row stride basis_row_stride elements   */
+  const float *basis_im;       /* same shape, or NULL for a real contraction               */
+  int64_t basis_row_stride;
+  int32_t n_bins;
+  int32_t kernel;
+  const int32_t *row_support;  /* optional (n_bins, 2) [start, stop): taps outside are     */
+                               /* KNOWN to be zero in both bases and may be skipped        */
+  const float *row_scale;      /* optional (n_bins,) multiplier (sqrt(lenghts) etc.)       */
+
+  int32_t epilogue;            /* MISPEC_EPI_*                                             */
+  float im_sign;               /* -1 reproduces the reference's "-conv1d(x, imag)"         */
+  float eps;                   /* added under the square root (1e-8 when trainable)        */
+  float power;                 /* exponent for MISPEC_EPI_POWER                            */
+
+  float *out;
+  int64_t out_clip_stride;     /* elements                                                 */
+  int64_t out_row_stride;      /* elements                                                 */
+  int32_t out_row_offset;      /* first output row this call writes (octave row block)     */
+  int32_t reserved;
+} mispec_framed_gemm_args;
+
+/* Launch the MFMA framed contraction.  Replaces stft.py:278-316, cqt.py:740-780,
+ * utils.py:498-521 (one call per octave).                                             */
+int mispec_framed_gemm_f32(const mispec_framed_gemm_args *args, void *stream);
+
+/* Same contract, one thread per output element, no MFMA, no LDS: a slow device-side
+ * cross-check used only by the test-suite to separate indexing bugs from MFMA bugs.   */
+int mispec_framed_gemm_f32_ref(const mispec_framed_gemm_args *args, void *stream);
+
+/*
+ * Filterbank reduction  out[c, m, t] = sum_{f<n_freq} fb[m, f] * spec[c, f, t]
+ * (torch.matmul(mel_basis, spec), mel.py:188 / gammatone.py:188).  spec is the
+ * (n_clips, n_freq, n_frames) tensor produced with MISPEC_EPI_POWER; out is
+ * (n_clips, n_filters, n_frames); both contiguous.
+ */
+int mispec_filterbank_f32(const float *fb, int32_t n_filters, int32_t n_freq,
+                          const float *spec, int32_t n_clips, int32_t n_frames,
+                          float *out, void *stream);
+
+/*
+ * Strided FIR decimation  y[c, i] = sum_{n<n_taps} taps[n] * x[c, i*stride + n - pad]
+ * with zeros outside the signal (F.conv1d(x, taps, stride, padding=pad),
+ * utils.py:98-99 where pad = (n_taps-1)//2).  n_out = (n_samples + 2*pad - n_taps)/stride + 1.
+ */
+int mispec_fir_decimate_f32(const float *x, int64_t x_clip_stride, int32_t n_clips,
+                            int32_t n_samples, const float *taps, int32_t n_taps,
+                            int32_t stride, int32_t pad, float *y, int64_t y_clip_stride,
+                            int32_t n_out, void *stream);
+
+/* ABI version of the loaded library (== MISPEC_ABI_VERSION it was built with). */
+int mispec_version(void);
+
+/* Message describing the last non-zero return on this thread ("" if none). */
+const char *mispec_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MISPEC_H */

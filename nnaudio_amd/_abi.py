@@ -1,0 +1,114 @@
+"""ctypes binding of ``libmispec.so`` (C ABI declared in ``include/mispec.h``).
+
+There is deliberately no fallback: if the shared library is missing or does not export
+the expected symbols, importing the compute path raises.  The library is built in-tree
+by ``__graft_entry__.build()`` / ``python -m nnaudio_amd.build``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmispec.so")
+
+ABI_VERSION = 1
+
+# enums (mirror include/mispec.h)
+PAD_NONE, PAD_ZERO, PAD_REFLECT = 0, 1, 2
+EPI_COMPLEX, EPI_MAGNITUDE, EPI_POWER, EPI_PHASE_ATAN2, EPI_PHASE_COSSIN, EPI_REAL = range(6)
+TILE_AUTO, TILE_128x128, TILE_32x256, TILE_64x256, TILE_128x128_TALL, TILE_192x128, TILE_256x128 = range(7)
+
+EXPORTS = (
+    "mispec_version",
+    "mispec_last_error",
+    "mispec_framed_gemm_f32",
+    "mispec_framed_gemm_f32_ref",
+    "mispec_filterbank_f32",
+    "mispec_fir_decimate_f32",
+)
+
+
+class FramedGemmArgs(ctypes.Structure):
+    """struct mispec_framed_gemm_args"""
+
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32),
+        ("tile", ctypes.c_int32),
+        ("x", ctypes.c_void_p),
+        ("x_clip_stride", ctypes.c_int64),
+        ("n_clips", ctypes.c_int32),
+        ("n_samples", ctypes.c_int32),
+        ("hop", ctypes.c_int32),
+        ("pad", ctypes.c_int32),
+        ("pad_mode", ctypes.c_int32),
+        ("n_frames", ctypes.c_int32),
+        ("basis_re", ctypes.c_void_p),
+        ("basis_im", ctypes.c_void_p),
+        ("basis_row_stride", ctypes.c_int64),
+        ("n_bins", ctypes.c_int32),
+        ("kernel", ctypes.c_int32),
+        ("row_support", ctypes.c_void_p),
+        ("row_scale", ctypes.c_void_p),
+        ("epilogue", ctypes.c_int32),
+        ("im_sign", ctypes.c_float),
+        ("eps", ctypes.c_float),
+        ("power", ctypes.c_float),
+        ("out", ctypes.c_void_p),
+        ("out_clip_stride", ctypes.c_int64),
+        ("out_row_stride", ctypes.c_int64),
+        ("out_row_offset", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+
+class MispecError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle; raise if the extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MispecError(
+            "libmispec.so not found at %s -- build it with `python -m nnaudio_amd.build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise MispecError("libmispec.so does not export %s" % name)
+    lib.mispec_version.restype = ctypes.c_int
+    lib.mispec_version.argtypes = []
+    lib.mispec_last_error.restype = ctypes.c_char_p
+    lib.mispec_last_error.argtypes = []
+    for fn in (lib.mispec_framed_gemm_f32, lib.mispec_framed_gemm_f32_ref):
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.POINTER(FramedGemmArgs), ctypes.c_void_p]
+    lib.mispec_filterbank_f32.restype = ctypes.c_int
+    lib.mispec_filterbank_f32.argtypes = [
+        ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+        ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+    ]
+    lib.mispec_fir_decimate_f32.restype = ctypes.c_int
+    lib.mispec_fir_decimate_f32.argtypes = [
+        ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+        ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64,
+        ctypes.c_int32, ctypes.c_void_p,
+    ]
+    v = lib.mispec_version()
+    if v != ABI_VERSION:
+        raise MispecError("libmispec ABI version %d, expected %d" % (v, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().mispec_last_error()
+        raise MispecError(
+            "libmispec call failed (%d): %s" % (rc, msg.decode() if msg else "")
+        )

@@ -1,0 +1,219 @@
+"""Host-side dispatch from torch CUDA tensors into the C ABI of ``libmispec.so``.
+
+torch is plumbing here (device memory from the caching allocator, the caller's current
+stream and device); every FLOP of the hot path is issued by the HIP kernels.  There is
+no CPU / eager fallback: CPU tensors raise, a missing extension raises.
+"""
+import ctypes
+
+import torch
+
+from . import _abi
+from ._abi import (  # noqa: F401  (re-exported for the feature modules)
+    EPI_COMPLEX, EPI_MAGNITUDE, EPI_PHASE_ATAN2, EPI_PHASE_COSSIN, EPI_POWER, EPI_REAL,
+    PAD_NONE, PAD_REFLECT, PAD_ZERO, TILE_AUTO,
+)
+from .basis import decimated_length
+
+_PAD_MODES = {"constant": PAD_ZERO, "reflect": PAD_REFLECT, None: PAD_NONE}
+
+
+def _require_device(*tensors):
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "nnaudio_amd computes on the GPU only (libmispec HIP kernels); got a %s tensor. "
+                "Move the module and its input with .to('cuda') -- there is no CPU fallback."
+                % t.device
+            )
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(
+                "Expected all tensors to be on the same device, but found at least two devices, "
+                "%s and %s!" % (dev, t.device)
+            )
+    return dev
+
+
+def _f32(t, what):
+    if t.dtype != torch.float32:
+        raise RuntimeError(
+            "%s must be float32 (the reference's conv1d weights are float32), got %s"
+            % (what, t.dtype)
+        )
+    return t
+
+
+def _rows(t, what):
+    """(F,1,K) / (F,K) -> 2-D view with unit inner stride."""
+    t = _f32(t, what)
+    if t.dim() == 3:
+        t = t.reshape(t.shape[0], t.shape[-1])
+    if t.dim() != 2:
+        raise RuntimeError("%s must be (bins, 1, kernel) or (bins, kernel)" % what)
+    if t.stride(1) != 1:
+        t = t.contiguous()
+    return t
+
+
+def _signal(x):
+    """(B,1,L) / (B,L) -> 2-D float32 view with unit inner stride."""
+    x = _f32(x, "input")
+    if x.dim() == 3:
+        if x.shape[1] != 1:
+            raise RuntimeError(
+                "Given groups=1, expected input to have 1 channel, got %d" % x.shape[1]
+            )
+        x = x[:, 0, :]
+    if x.dim() != 2:
+        raise RuntimeError("signal must be (batch, length)")
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    return x
+
+
+def n_frames(length, kernel, hop, pad):
+    span = length + 2 * pad - kernel
+    if span < 0:
+        raise RuntimeError(
+            "Calculated padded input size per channel: (%d). Kernel size: (%d). "
+            "Kernel size can't be greater than actual input size" % (length + 2 * pad, kernel)
+        )
+    if hop <= 0:
+        raise RuntimeError("non-positive stride is not supported")
+    return span // hop + 1
+
+
+def framed_gemm(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign=-1.0,
+                eps=0.0, power=2.0, row_scale=None, row_support=None, out=None,
+                out_rows_total=None, out_row_offset=0, tile=TILE_AUTO, reference_kernel=False):
+    """``out[b, row_offset + f, t(, 0:2)]`` <- epilogue(sum_n x_pad[b, t*hop + n] * basis[f, n]).
+
+    ``pad_mode`` is one of ``PAD_*``; ``out`` may be a pre-allocated (B, rows_total, T[, 2])
+    tensor (octave assembly / all-gather slices write in place)."""
+    dev = _require_device(x, basis_re, basis_im, row_scale, row_support, out)
+    x = _signal(x)
+    wr = _rows(basis_re, "basis_re")
+    wi = _rows(basis_im, "basis_im") if basis_im is not None else None
+    if wi is not None and (wi.shape != wr.shape or wi.stride(0) != wr.stride(0)):
+        raise RuntimeError("real / imaginary bases must have identical shape and layout")
+    B, L = x.shape
+    F, K = wr.shape
+    if pad_mode == PAD_REFLECT and pad >= L:
+        raise RuntimeError(
+            "Argument #4: Padding size should be less than the corresponding input dimension, "
+            "but got: padding (%d, %d) at dimension 2 of input %s" % (pad, pad, [B, 1, L])
+        )
+    T = n_frames(L, K, hop, pad)
+    two = epilogue in (EPI_COMPLEX, EPI_PHASE_COSSIN)
+    rows_total = F if out_rows_total is None else out_rows_total
+    if out is None:
+        shape = (B, rows_total, T, 2) if two else (B, rows_total, T)
+        out = torch.empty(shape, dtype=torch.float32, device=dev)
+    else:
+        want = (B, rows_total, T, 2) if two else (B, rows_total, T)
+        if tuple(out.shape) != want or not out.is_contiguous() or out.dtype != torch.float32:
+            raise RuntimeError("out must be a contiguous float32 tensor of shape %s" % (want,))
+    if out_row_offset < 0 or out_row_offset + F > rows_total:
+        raise RuntimeError("row block [%d, %d) outside the output's %d rows"
+                           % (out_row_offset, out_row_offset + F, rows_total))
+    if row_scale is not None:
+        row_scale = _f32(row_scale, "row_scale").contiguous()
+        if row_scale.numel() != F:
+            raise RuntimeError("row_scale must have one entry per basis row")
+    if row_support is not None:
+        if row_support.dtype != torch.int32 or tuple(row_support.shape) != (F, 2):
+            raise RuntimeError("row_support must be int32 (n_bins, 2)")
+        row_support = row_support.contiguous()
+
+    E = 2 if two else 1
+    a = _abi.FramedGemmArgs()
+    a.struct_size = ctypes.sizeof(_abi.FramedGemmArgs)
+    a.tile = int(tile)
+    a.x = x.data_ptr()
+    a.x_clip_stride = x.stride(0)
+    a.n_clips, a.n_samples = B, L
+    a.hop, a.pad, a.pad_mode, a.n_frames = int(hop), int(pad), int(pad_mode), T
+    a.basis_re = wr.data_ptr()
+    a.basis_im = wi.data_ptr() if wi is not None else None
+    a.basis_row_stride = wr.stride(0)
+    a.n_bins, a.kernel = F, K
+    a.row_support = row_support.data_ptr() if row_support is not None else None
+    a.row_scale = row_scale.data_ptr() if row_scale is not None else None
+    a.epilogue = int(epilogue)
+    a.im_sign, a.eps, a.power = float(im_sign), float(eps), float(power)
+    a.out = out.data_ptr()
+    a.out_clip_stride = rows_total * T * E
+    a.out_row_stride = T * E
+    a.out_row_offset = int(out_row_offset)
+    lib = _abi.load()
+    fn = lib.mispec_framed_gemm_f32_ref if reference_kernel else lib.mispec_framed_gemm_f32
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _abi.check(fn(ctypes.byref(a), ctypes.c_void_p(stream)))
+    return out
+
+
+def filterbank(fb, spec):
+    """(M, F) x (B, F, T) -> (B, M, T)   [torch.matmul(mel_basis, spec), mel.py:188]."""
+    dev = _require_device(fb, spec)
+    fb = _f32(fb, "filterbank").contiguous()
+    spec = _f32(spec, "spectrogram").contiguous()
+    if fb.dim() != 2 or spec.dim() != 3 or fb.shape[1] != spec.shape[1]:
+        raise RuntimeError(
+            "mat1 and mat2 shapes cannot be multiplied (%s and %s)"
+            % (tuple(fb.shape), tuple(spec.shape))
+        )
+    B, F, T = spec.shape
+    M = fb.shape[0]
+    out = torch.empty((B, M, T), dtype=torch.float32, device=dev)
+    lib = _abi.load()
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _abi.check(lib.mispec_filterbank_f32(
+            fb.data_ptr(), M, F, spec.data_ptr(), B, T, out.data_ptr(), ctypes.c_void_p(stream)))
+    return out
+
+
+def fir_decimate(x, taps, stride):
+    """conv1d(x, taps, stride=stride, padding=(len-1)//2)  [utils.py:73-124] -> (B, n_out)."""
+    dev = _require_device(x, taps)
+    x = _signal(x)
+    taps = _f32(taps, "filter").reshape(-1).contiguous()
+    B, L = x.shape
+    nt = taps.numel()
+    pad = (nt - 1) // 2
+    n_out = decimated_length(L, nt, int(stride))
+    if n_out <= 0:
+        raise RuntimeError(
+            "Calculated padded input size per channel: (%d). Kernel size: (%d). "
+            "Kernel size can't be greater than actual input size" % (L + 2 * pad, nt)
+        )
+    y = torch.empty((B, n_out), dtype=torch.float32, device=dev)
+    lib = _abi.load()
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _abi.check(lib.mispec_fir_decimate_f32(
+            x.data_ptr(), x.stride(0), B, L, taps.data_ptr(), nt, int(stride), pad,
+            y.data_ptr(), y.stride(0), n_out, ctypes.c_void_p(stream)))
+    return y
+
+
+def pad_mode_id(name):
+    return _PAD_MODES[name]
+
+
+def grad_guard(module, x):
+    """The HIP path is forward-only this round: refuse to silently drop a graph."""
+    if torch.is_grad_enabled() and (
+        x.requires_grad or any(p.requires_grad for p in module.parameters())
+    ):
+        raise NotImplementedError(
+            "%s: backward through the HIP kernels is not implemented yet (trainable bases / "
+            "requires_grad inputs). Call under torch.no_grad() for inference."
+            % type(module).__name__
+        )

@@ -1,0 +1,155 @@
+"""STFT front-end module (drop-in for ``nnAudio.features.STFT``,
+reference: Installation/nnAudio/features/stft.py:68-361).
+
+Construction builds the windowed Fourier bases on the host (``basis.fourier_basis``) and
+registers them under the reference's buffer names; ``forward`` is a single launch of the
+MFMA framed contraction with the Magnitude / Complex / Phase epilogue fused.
+"""
+from time import time
+
+import torch
+import torch.nn as nn
+
+from .. import engine
+from ..basis import fourier_basis
+from ..utils import broadcast_dim
+
+
+class STFT(nn.Module):
+    """Short-time Fourier transform of ``(len,)``, ``(batch, len)`` or ``(batch, 1, len)``
+    float32 waveforms.
+
+    Same constructor arguments, defaults, attributes (``stride``, ``n_fft``, ``pad_amount``,
+    ``bins2freq``, ``bin_list`` ...) and ``state_dict`` keys (``wsin``, ``wcos``,
+    ``window_mask``, optionally ``kernel_sin_inv`` / ``kernel_cos_inv``) as the reference.
+    Output: ``(batch, freq_bins, frames)`` for Magnitude / Phase (radians),
+    ``(batch, freq_bins, frames, 2)`` for Complex."""
+
+    def __init__(
+        self,
+        n_fft=2048,
+        win_length=None,
+        freq_bins=None,
+        hop_length=None,
+        window="hann",
+        freq_scale="no",
+        center=True,
+        pad_mode="reflect",
+        iSTFT=False,
+        fmin=50,
+        fmax=6000,
+        sr=22050,
+        trainable=False,
+        output_format="Complex",
+        verbose=True,
+    ):
+        super().__init__()
+        if win_length is None:
+            win_length = n_fft
+        if hop_length is None:
+            hop_length = int(win_length // 4)
+
+        self.output_format = output_format
+        self.trainable = trainable
+        self.stride = hop_length
+        self.center = center
+        self.pad_mode = pad_mode
+        self.n_fft = n_fft
+        self.freq_bins = freq_bins
+        self.pad_amount = self.n_fft // 2
+        self.window = window
+        self.win_length = win_length
+        self.iSTFT = iSTFT
+        start = time()
+
+        ksin, kcos, self.bins2freq, self.bin_list, win = fourier_basis(
+            n_fft,
+            win_length=win_length,
+            freq_bins=freq_bins,
+            window=window,
+            freq_scale=freq_scale,
+            fmin=fmin,
+            fmax=fmax,
+            sr=sr,
+            verbose=verbose,
+        )
+        ksin = torch.from_numpy(ksin)
+        kcos = torch.from_numpy(kcos)
+
+        if iSTFT:
+            # full-spectrum inverse bases, only kept for state_dict compatibility this round
+            self.register_buffer(
+                "kernel_sin_inv", torch.cat((ksin, -ksin[1:-1].flip(0)), 0).unsqueeze(-1)
+            )
+            self.register_buffer(
+                "kernel_cos_inv", torch.cat((kcos, kcos[1:-1].flip(0)), 0).unsqueeze(-1)
+            )
+
+        # the window is folded into the basis in float32 (stft.py:230-232)
+        win = torch.from_numpy(win)
+        wsin = ksin * win
+        wcos = kcos * win
+        if trainable:
+            self.register_parameter("wsin", nn.Parameter(wsin, requires_grad=True))
+            self.register_parameter("wcos", nn.Parameter(wcos, requires_grad=True))
+        else:
+            self.register_buffer("wsin", wsin)
+            self.register_buffer("wcos", wcos)
+        self.register_buffer("window_mask", win.unsqueeze(0).unsqueeze(-1))
+
+        if verbose:
+            print("STFT kernels created, time used = {:.4f} seconds".format(time() - start))
+
+    # ------------------------------------------------------------------ #
+    def _framing(self, num_samples):
+        """(pad, PAD_* id) for this module, with the reference's error behaviour."""
+        if not self.center:
+            return 0, engine.PAD_NONE
+        if self.pad_mode == "constant":
+            return self.pad_amount, engine.PAD_ZERO
+        if self.pad_mode == "reflect":
+            if num_samples < self.pad_amount:
+                raise AssertionError(
+                    "Signal length shorter than reflect padding length (n_fft // 2)."
+                )
+            return self.pad_amount, engine.PAD_REFLECT
+        # the reference leaves `padding` unbound for any other mode (stft.py:279-289)
+        raise UnboundLocalError("local variable 'padding' referenced before assignment")
+
+    def _spectrum(self, x, epilogue, power=2.0):
+        pad, mode = self._framing(x.shape[-1])
+        wsin, wcos = self.wsin, self.wcos
+        if self.freq_bins is not None:
+            wsin, wcos = wsin[: self.freq_bins], wcos[: self.freq_bins]
+        return engine.framed_gemm(
+            x, wcos, wsin, hop=self.stride, pad=pad, pad_mode=mode, epilogue=epilogue,
+            im_sign=-1.0, eps=1e-8 if self.trainable else 0.0, power=power,
+        )
+
+    def forward(self, x, output_format=None):
+        """Waveform batch -> spectrogram; ``output_format`` overrides the constructor's."""
+        output_format = output_format or self.output_format
+        self.num_samples = x.shape[-1]
+        x = broadcast_dim(x)
+        engine.grad_guard(self, x)
+        if output_format == "Magnitude":
+            return self._spectrum(x, engine.EPI_MAGNITUDE)
+        if output_format == "Complex":
+            return self._spectrum(x, engine.EPI_COMPLEX)
+        if output_format == "Phase":
+            return self._spectrum(x, engine.EPI_PHASE_ATAN2)
+        return None  # the reference falls through its if/elif chain (stft.py:299-316)
+
+    def inverse(self, X, onesided=True, length=None, refresh_win=True):
+        if not (hasattr(self, "kernel_sin_inv") and hasattr(self, "kernel_cos_inv")):
+            raise NameError(
+                "Please activate the iSTFT module by setting `iSTFT=True` if you want to use `inverse`"
+            )
+        raise NotImplementedError(
+            "inverse STFT is outside this build's hot path (SURVEY.md 8f, rank 2)"
+        )
+
+    def extra_repr(self) -> str:
+        return "n_fft={}, Fourier Kernel size={}, iSTFT={}, trainable={}".format(
+            self.n_fft, (*self.wsin.shape,), self.iSTFT, self.trainable
+        )

@@ -1,0 +1,288 @@
+"""CPU oracle for the spectrogram hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A plain numpy restatement of what the reference (KinWaiCheuk/nnAudio v0.3.3,
+``/root/reference/Installation/nnAudio``) computes in ``forward`` for
+STFT / MelSpectrogram / Gammatonegram / CQT1992v2 / CQT2010v2 / VQT, written as
+"pad -> frame -> contract with the basis -> pointwise epilogue" on explicit arrays.
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module; the shipped package (``nnaudio_amd``) never does.
+
+Parity status: PINNED.  ``tests/test_oracle_golden.py`` checks every function here
+against (a) the reference's own asserted ground-truth arrays
+(``tests/ground-truths/*-cqt-{1992,2010}-{mag,complex,phase}*.npy``, the ten files its
+``tests/test_cqt.py:94-262`` asserts, copied to ``tests/golden/ref_ground_truths``) and
+(b) outputs of the reference itself run in the authoring container on seeded inputs
+(``tests/golden/fwd_*.npz``, produced by ``oracle/gen_golden.py``).
+
+All functions take the *constant operands* (bases, taps, lengths) as arguments, so the
+oracle is independent of how the product builds them; accumulation is float64 unless
+``acc=np.float32`` is requested (the cpu_baseline leg times the float32/BLAS form).
+
+Each function cites the reference lines it follows.
+"""
+import warnings
+
+import numpy as np
+
+
+# --------------------------------------------------------------------------- #
+# input plumbing
+# --------------------------------------------------------------------------- #
+def broadcast_dim(x):
+    """(L,) / (B,L) / (B,1,L) -> (B,L)  [utils.py:206-222; the singleton channel the
+    reference keeps for conv1d is dropped here]."""
+    x = np.asarray(x)
+    if x.ndim == 1:
+        return x[None, :]
+    if x.ndim == 2:
+        return x
+    if x.ndim == 3:
+        if x.shape[1] != 1:
+            raise ValueError("expected a single channel")
+        return x[:, 0, :]
+    raise ValueError("Only support input with shape = (batch, len) or shape = (len)")
+
+
+def pad_signal(x, pad, mode):
+    """Zero ('constant') or mirror-without-edge-repeat ('reflect') padding of the last
+    axis [nn.ConstantPad1d / nn.ReflectionPad1d as used at stft.py:278-289,
+    cqt.py:740-746, 1065-1068, vqt.py:175-179]."""
+    if pad == 0:
+        return x
+    if mode == "constant":
+        return np.pad(x, ((0, 0), (pad, pad)), mode="constant")
+    if mode == "reflect":
+        if pad >= x.shape[-1]:
+            raise RuntimeError(
+                "Padding size should be less than the corresponding input dimension"
+            )
+        return np.pad(x, ((0, 0), (pad, pad)), mode="reflect")
+    raise ValueError("unknown pad mode %r" % (mode,))
+
+
+def frames(xp, K, hop):
+    """(B, Lp) -> strided view (B, T, K), frame t = xp[:, t*hop : t*hop+K]."""
+    B, Lp = xp.shape
+    if Lp < K:
+        raise RuntimeError("Kernel size can't be greater than actual input size")
+    T = (Lp - K) // hop + 1
+    s0, s1 = xp.strides
+    return np.lib.stride_tricks.as_strided(
+        xp, shape=(B, T, K), strides=(s0, s1 * hop, s1), writeable=False
+    )
+
+
+def correlate_strided(xp, basis, hop, acc=np.float64):
+    """out[b,f,t] = sum_n xp[b, t*hop+n] * basis[f,n]   (= F.conv1d(x, basis, stride=hop),
+    stft.py:290-293, cqt.py:749-750, utils.py:518-519).  Returns ``acc`` dtype."""
+    fr = frames(np.ascontiguousarray(xp, dtype=acc), basis.shape[-1], hop)
+    w = np.asarray(basis, dtype=acc)
+    B, T, K = fr.shape
+    out = np.empty((B, w.shape[0], T), dtype=acc)
+    # chunk frames so the materialised (T,K) block stays small
+    step = max(1, (1 << 24) // max(K, 1))
+    for b in range(B):
+        for t0 in range(0, T, step):
+            blk = np.ascontiguousarray(fr[b, t0 : t0 + step])  # (t, K)
+            out[b, :, t0 : t0 + step] = w @ blk.T
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# STFT family
+# --------------------------------------------------------------------------- #
+def stft(x, wsin, wcos, hop, center=True, pad_mode="reflect", output_format="Complex",
+         trainable=False, acc=np.float64):
+    """STFT.forward [stft.py:256-316].  ``wsin``/``wcos`` are the *windowed* bases
+    (F,1,K) or (F,K).  Returns float32."""
+    x = broadcast_dim(x)
+    wsin = np.asarray(wsin).reshape(wsin.shape[0], -1)
+    wcos = np.asarray(wcos).reshape(wcos.shape[0], -1)
+    K = wsin.shape[-1]
+    pad = K // 2
+    if center:
+        if pad_mode == "constant":
+            xp = pad_signal(x, pad, "constant")
+        elif pad_mode == "reflect":
+            if x.shape[-1] < pad:
+                raise AssertionError(
+                    "Signal length shorter than reflect padding length (n_fft // 2)."
+                )
+            xp = pad_signal(x, pad, "reflect")
+        else:
+            raise UnboundLocalError("padding")
+    else:
+        xp = x
+    im = correlate_strided(xp, wsin, hop, acc)
+    re = correlate_strided(xp, wcos, hop, acc)
+    if output_format == "Magnitude":
+        p = re * re + im * im
+        if trainable:
+            p = p + 1e-8
+        return np.sqrt(p).astype(np.float32)
+    if output_format == "Complex":
+        return np.stack((re, -im), -1).astype(np.float32)
+    if output_format == "Phase":
+        return np.arctan2(-im + 0.0, re).astype(np.float32)
+    raise ValueError(output_format)
+
+
+def filterbank_spectrogram(x, wsin, wcos, hop, fb, power=2.0, center=True,
+                           pad_mode="reflect", trainable_stft=False, acc=np.float64):
+    """MelSpectrogram.forward / Gammatonegram.forward [mel.py:171-189,
+    gammatone.py:171-189]: matmul(fb, STFT_magnitude ** power)."""
+    x = broadcast_dim(x)
+    wsin = np.asarray(wsin).reshape(wsin.shape[0], -1)
+    wcos = np.asarray(wcos).reshape(wcos.shape[0], -1)
+    K = wsin.shape[-1]
+    pad = K // 2
+    if center:
+        if pad_mode == "reflect" and x.shape[-1] < pad:
+            raise AssertionError(
+                "Signal length shorter than reflect padding length (n_fft // 2)."
+            )
+        xp = pad_signal(x, pad, pad_mode)
+    else:
+        xp = x
+    im = correlate_strided(xp, wsin, hop, acc)
+    re = correlate_strided(xp, wcos, hop, acc)
+    p = re * re + im * im
+    if trainable_stft:
+        p = p + 1e-8
+    spec = np.sqrt(p) ** power
+    return np.matmul(np.asarray(fb, dtype=acc), spec).astype(np.float32)
+
+
+# --------------------------------------------------------------------------- #
+# CQT family
+# --------------------------------------------------------------------------- #
+def _normalisation_rows(lengths, normalization_type, extra=1.0):
+    lengths = np.asarray(lengths, dtype=np.float32)
+    if normalization_type == "librosa":
+        return np.sqrt(lengths).astype(np.float64) * extra
+    if normalization_type == "convolutional":
+        return np.full(lengths.shape, extra, dtype=np.float64)
+    if normalization_type == "wrap":
+        return np.full(lengths.shape, 2.0 * extra, dtype=np.float64)
+    raise ValueError(
+        "The normalization_type %r is not part of our current options."
+        % normalization_type
+    )
+
+
+def _cqt_epilogue(re, im, output_format, trainable):
+    if output_format == "Magnitude":
+        p = re * re + im * im
+        if trainable:
+            p = p + 1e-8
+        return np.sqrt(p).astype(np.float32)
+    if output_format == "Complex":
+        return np.stack((re, im), -1).astype(np.float32)
+    if output_format == "Phase":
+        ang = np.arctan2(im, re)
+        return np.stack((np.cos(ang), np.sin(ang)), -1).astype(np.float32)
+    raise ValueError(output_format)
+
+
+def cqt1992v2(x, kern_real, kern_imag, lengths, hop, center=True, pad_mode="reflect",
+              output_format="Magnitude", normalization_type="librosa", trainable=False,
+              acc=np.float64):
+    """CQT1992v2.forward [cqt.py:712-780]."""
+    x = broadcast_dim(x)
+    kr = np.asarray(kern_real).reshape(kern_real.shape[0], -1)
+    ki = np.asarray(kern_imag).reshape(kern_imag.shape[0], -1)
+    K = kr.shape[-1]
+    if center:
+        if pad_mode not in ("constant", "reflect"):
+            raise UnboundLocalError("padding")
+        xp = pad_signal(x, K // 2, pad_mode)
+    else:
+        xp = x
+    re = correlate_strided(xp, kr, hop, acc)
+    im = -correlate_strided(xp, ki, hop, acc)
+    scale = _normalisation_rows(lengths, normalization_type)[None, :, None]
+    re = re * scale
+    im = im * scale
+    return _cqt_epilogue(re, im, output_format, trainable)
+
+
+def fir_decimate(x, taps, stride):
+    """conv1d(x, taps, stride=stride, padding=(len(taps)-1)//2) [utils.py:73-124]."""
+    x = broadcast_dim(x).astype(np.float64)
+    taps = np.asarray(taps, dtype=np.float64).reshape(-1)
+    pad = (taps.shape[0] - 1) // 2
+    xp = np.pad(x, ((0, 0), (pad, pad)))
+    return correlate_strided(xp, taps[None, :], stride)[:, 0, :].astype(np.float32)
+
+
+def cqt_octave(x, kr, ki, hop, pad_mode, acc=np.float64):
+    """get_cqt_complex [utils.py:498-521]: pad by K//2 (mirror; zero-pad with a warning
+    when mirroring is impossible), then (re, im) = (x*kr, -(x*ki)) at stride hop."""
+    K = kr.shape[-1]
+    try:
+        xp = pad_signal(x, K // 2, pad_mode)
+    except RuntimeError:
+        warnings.warn(
+            "padding with reflection mode might not be the best choice, try using constant padding",
+            UserWarning,
+        )
+        xp = pad_signal(x, K // 2, "constant")
+    return correlate_strided(xp, kr, hop, acc), -correlate_strided(xp, ki, hop, acc)
+
+
+def cqt2010v2(x, kern_real, kern_imag, lengths, hop, n_bins, n_octaves, lowpass,
+              early_taps=None, downsample_factor=1, pad_mode="reflect",
+              output_format="Magnitude", normalization_type="librosa", trainable=False,
+              acc=np.float64):
+    """CQT2010v2.forward [cqt.py:1070-1139].  ``hop`` is the module's *post early
+    down-sampling* hop (``self.hop_length`` after ``__init__``); one top-octave kernel bank
+    is re-used for every octave, the signal is halved between octaves."""
+    x = broadcast_dim(x).astype(np.float32)
+    kr = np.asarray(kern_real).reshape(kern_real.shape[0], -1)
+    ki = np.asarray(kern_imag).reshape(kern_imag.shape[0], -1)
+    if early_taps is not None:
+        x = fir_decimate(x, early_taps, int(downsample_factor))
+    banks = [(kr, ki)] * n_octaves
+    return _octave_recursion(x, banks, lengths, hop, n_bins, lowpass, downsample_factor,
+                             pad_mode, output_format, normalization_type, trainable, acc)
+
+
+def vqt(x, banks, lengths, hop, n_bins, lowpass, early_taps=None, downsample_factor=1,
+        pad_mode="reflect", output_format="Magnitude", normalization_type="librosa",
+        trainable=False, acc=np.float64):
+    """VQT.forward [vqt.py:143-215]; ``banks[i] = (real_i, imag_i)`` is octave i's own
+    kernel bank (i = 0 is the top octave)."""
+    x = broadcast_dim(x).astype(np.float32)
+    if early_taps is not None:
+        x = fir_decimate(x, early_taps, int(downsample_factor))
+    banks = [
+        (np.asarray(r).reshape(r.shape[0], -1), np.asarray(i).reshape(i.shape[0], -1))
+        for r, i in banks
+    ]
+    return _octave_recursion(x, banks, lengths, hop, n_bins, lowpass, downsample_factor,
+                             pad_mode, output_format, normalization_type, trainable, acc)
+
+
+def _octave_recursion(x, banks, lengths, hop, n_bins, lowpass, downsample_factor,
+                      pad_mode, output_format, normalization_type, trainable, acc):
+    xd = x
+    blocks_re, blocks_im = [], []
+    for i, (kr, ki) in enumerate(banks):
+        if i > 0:
+            hop = hop // 2
+            xd = fir_decimate(xd, lowpass, 2)
+        re, im = cqt_octave(xd, kr, ki, hop, pad_mode, acc)
+        blocks_re.insert(0, re)
+        blocks_im.insert(0, im)
+    T = {b.shape[-1] for b in blocks_re}
+    if len(T) != 1:
+        raise RuntimeError(
+            "Sizes of tensors must match except in dimension 1 (octave frame counts %s)"
+            % sorted(T)
+        )
+    re = np.concatenate(blocks_re, 1)[:, -n_bins:]
+    im = np.concatenate(blocks_im, 1)[:, -n_bins:]
+    scale = _normalisation_rows(lengths, normalization_type, float(downsample_factor))
+    re = re * scale[None, :, None]
+    im = im * scale[None, :, None]
+    return _cqt_epilogue(re, im, output_format, trainable)

@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""Benchmark of the spectrogram hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one forward of the hot path over one batch of synthetic waveforms already
+resident in HBM.  Workload at every N (weak scaling, per-GPU work fixed) is BASELINE.json's
+configs[1]: STFT n_fft=2048 hop=512 hann, batch 64 x 10 s @ 44.1 kHz, Magnitude output.
+The batch shards across ranks as independent clips (nnaudio_amd.dist); computing needs no
+collective, so the timed region has none; the RCCL all-gather that reassembles the output
+tensor is timed separately and reported on stderr / in "extra" (never in `value`).
+
+Rank 0 prints ONE JSON line: metric = spectrogram frames/s (whole job), plus
+  "roofline":     the framed-GEMM kernel against the fp32 MFMA peak (157.3 TFLOP/s) --
+                  algorithmic flops per launch / average launch duration (HIP events on the
+                  launch stream) -- and its HBM-roofline fraction on algorithmic bytes;
+  "cpu_baseline": the numpy port of the reference algorithm (oracle/, float32 BLAS) timed on
+                  this host on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA = 157.3e12  # FLOP/s, MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
+PEAK_HBM = 8.0e12         # B/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def workload(name, device):
+    """-> (module, make_input(seed), meta) ; meta: algorithmic flops / bytes per launch."""
+    from nnaudio_amd import features
+
+    if name == "stft":
+        B, L, K, hop = 64, 441000, 2048, 512
+        F, T = K // 2 + 1, L // hop + 1
+        m = features.STFT(n_fft=K, hop_length=hop, window="hann", output_format="Magnitude",
+                          verbose=False).to(device)
+        flops = 2.0 * (2 * F) * K * B * T
+        byts = 4.0 * (B * L + B * F * T + 2 * F * K)
+        tag = "STFT n_fft=2048 hop=512 hann, B=64 x 10 s @ 44.1 kHz, Magnitude (configs[1])"
+    elif name == "mel":
+        B, L, K, hop, M = 256, 110250, 1024, 512, 128
+        F, T = K // 2 + 1, L // hop + 1
+        m = features.MelSpectrogram(sr=22050, n_fft=K, n_mels=M, hop_length=hop,
+                                    verbose=False).to(device)
+        flops = 2.0 * (2 * F) * K * B * T + 2.0 * M * F * B * T
+        byts = 4.0 * (B * L + B * M * T + 2 * F * K + M * F)
+        tag = "MelSpectrogram n_fft=1024 hop=512 n_mels=128, B=256 x 5 s @ 22.05 kHz (configs[2])"
+    elif name == "cqt":
+        B, L, hop = 64, 441000, 512
+        m = features.CQT1992v2(sr=44100, hop_length=hop, fmin=32.70, n_bins=84, bins_per_octave=12,
+                               verbose=False).to(device)
+        T = L // hop + 1
+        useful = float(m.lenghts.sum().item())
+        flops = 2.0 * 2 * useful * B * T  # support-aware ("useful") flops
+        byts = 4.0 * (B * L + B * 84 * T + 2 * useful)
+        tag = "CQT1992v2 84 bins / 12 bpo hop=512, B=64 x 10 s @ 44.1 kHz, Magnitude"
+    elif name == "cqt2010":
+        B, L, hop = 64, 1323000, 512
+        m = features.CQT2010v2(sr=44100, hop_length=hop, n_bins=96, verbose=False).to(device)
+        T = L // hop + 1
+        nt = 256 * 2 * 12 * 8 * B * T * 2.0
+        dec = sum(2.0 * 256 * B * (L // (2 ** o)) for o in range(1, 8))
+        flops = nt + dec
+        byts = 4.0 * (B * L + B * 96 * T)
+        tag = "CQT2010v2 96 bins hop=512, B=64 x 30 s @ 44.1 kHz (one rank's shard of configs[4])"
+    else:
+        raise SystemExit("unknown workload %r" % name)
+
+    def make_input(seed):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        return torch.randn(B, L, generator=g, dtype=torch.float32).to(device)
+
+    return m, make_input, dict(B=B, L=L, T=T, frames=B * T, flops=flops, bytes=byts, tag=tag)
+
+
+def timed_steps(module, x, steps, warmup, sync):
+    """W untimed steps, then exactly K timed steps bracketed by sync() on both sides.
+    Returns (wall seconds, device seconds from events on the launch stream)."""
+    with torch.no_grad():
+        for _ in range(warmup):
+            y = module(x)
+        sync()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(steps):
+            y = module(x)
+        e1.record()
+        sync()
+        t1 = time.perf_counter()
+    del y
+    return t1 - t0, e0.elapsed_time(e1) * 1e-3
+
+
+def cpu_baseline(budget_s=15.0):
+    """The oracle (numpy restatement of the reference's conv1d STFT, float32 BLAS) on a
+    bounded sample of the configs[1] workload: n clips of 10 s; frames/s."""
+    from nnaudio_amd import features
+    from oracle import spectral_oracle as O
+
+    m = features.STFT(n_fft=2048, hop_length=512, window="hann", output_format="Magnitude",
+                      verbose=False)
+    wsin, wcos = m.wsin.numpy(), m.wcos.numpy()
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((1, 441000)).astype(np.float32)
+    t0 = time.perf_counter()
+    O.stft(x, wsin, wcos, 512, output_format="Magnitude", acc=np.float32)
+    one = time.perf_counter() - t0
+    n = int(max(1, min(64, budget_s / max(one, 1e-3))))
+    x = rng.standard_normal((n, 441000)).astype(np.float32)
+    t0 = time.perf_counter()
+    O.stft(x, wsin, wcos, 512, output_format="Magnitude", acc=np.float32)
+    dt = time.perf_counter() - t0
+    try:
+        from threadpoolctl import threadpool_info
+
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count()])
+    except Exception:
+        cores = os.cpu_count()
+    return dict(value=n * 862 / dt, unit="frames/s", cores=int(cores), kind="port",
+                sample="%d of 64 clips (10 s @ 44.1 kHz) of configs[1], numpy float32 BLAS port "
+                       "of the reference conv1d STFT (oracle/spectral_oracle.py), %.1f s" % (n, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="stft", choices=["stft", "mel", "cqt", "cqt2010"])
+    ap.add_argument("--extras", type=int, default=1, help="also time CQT84 / Mel / gather (untimed region)")
+    ap.add_argument("--cpu-baseline", type=int, default=1)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    module, make_input, meta = workload(args.workload, device)
+    x = make_input(rank)
+    wall, dev_s = timed_steps(module, x, args.steps, args.warmup, sync)
+    t = torch.tensor([wall, dev_s], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall, dev_s = float(t[0]), float(t[1])
+
+    frames_total = meta["frames"] * world * args.steps
+    kern_s = dev_s / args.steps
+    achieved = meta["flops"] / kern_s
+    out = {
+        "metric": "spectrogram frames/sec",
+        "value": frames_total / wall,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": wall / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": meta["tag"], "global_batch": meta["B"] * world,
+                   "clip_samples": meta["L"], "frames_per_clip": meta["T"],
+                   "parallelism": "batch-sharded x%d, no data-path collective" % world},
+        "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_F32_MFMA / 1e12,
+                     "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA, "traffic": None,
+                     "kernel": "framed_gemm_kernel<2,2,2,2,framed> (v_mfma_f32_32x32x2_f32)",
+                     "kernel_ms": kern_s * 1e3, "algorithmic_flops_per_launch": meta["flops"],
+                     "algorithmic_bytes_per_launch": meta["bytes"],
+                     "hbm_frac_on_algorithmic_bytes": meta["bytes"] / kern_s / PEAK_HBM},
+    }
+    traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(traffic_file) and args.workload == "stft":
+        try:
+            out["roofline"]["traffic"] = json.load(open(traffic_file))["stft_cfg2_bytes_per_launch"]
+        except Exception:
+            pass
+
+    extra = {}
+    if args.extras:
+        del x
+        torch.cuda.empty_cache()
+        for name in ("cqt", "mel"):
+            if name == args.workload:
+                continue
+            try:
+                m2, mk2, me2 = workload(name, device)
+                x2 = mk2(100 + rank)
+                w2, d2 = timed_steps(m2, x2, max(3, args.steps // 4), 2, sync)
+                n2 = max(3, args.steps // 4)
+                tt = torch.tensor([w2, d2], dtype=torch.float64, device=device)
+                if world > 1:
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                w2, d2 = float(tt[0]), float(tt[1])
+                extra[name] = {"workload": me2["tag"], "frames_per_s": me2["frames"] * world * n2 / w2,
+                               "ms_per_step": w2 / n2 * 1e3,
+                               "mfma_frac": me2["flops"] / (d2 / n2) / PEAK_F32_MFMA,
+                               "hbm_frac_on_algorithmic_bytes": me2["bytes"] / (d2 / n2) / PEAK_HBM}
+                del m2, x2
+                torch.cuda.empty_cache()
+            except Exception as e:  # extras must never take the primary number down
+                extra[name] = {"error": repr(e)}
+        out["extra"] = extra
+
+    if rank == 0 and world == 1 and args.cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline()
+        except Exception as e:
+            out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(),
+                                   "kind": "port", "sample": "failed: %r" % (e,)}
+    elif rank == 0:
+        out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": None, "kind": "port",
+                               "sample": "measured at N=1 only"}
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+    # output reassembly over xGMI (RCCL all-gather), outside the reported value
+    if world > 1 and args.extras:
+        try:
+            from nnaudio_amd import dist as D
+
+            x = make_input(rank)
+            with torch.no_grad():
+                y = module(x)
+                for _ in range(2):
+                    D.gather_batch(y, meta["B"] * world)
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    full = D.gather_batch(y, meta["B"] * world)
+                sync()
+                dt = (time.perf_counter() - t0) / 5
+            if rank == 0:
+                log("all-gather of the %s output: %.3f ms per step (%.1f MB per rank)"
+                    % (tuple(full.shape), dt * 1e3, y.numel() * 4 / 1e6))
+        except Exception as e:
+            log("gather timing failed: %r" % (e,))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

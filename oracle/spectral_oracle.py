@@ -286,3 +286,32 @@ def _octave_recursion(x, banks, lengths, hop, n_bins, lowpass, downsample_factor
     re = re * scale[None, :, None]
     im = im * scale[None, :, None]
     return _cqt_epilogue(re, im, output_format, trainable)
+
+
+# --------------------------------------------------------------------------- #
+# sampled evaluation for full-size checks (cheap: only the requested frames)
+# --------------------------------------------------------------------------- #
+def gather_frames(x, clips, frames_idx, K, hop, pad, mode):
+    """float64 (n, K) matrix of the frames (clip, t) of the virtually padded signal."""
+    x = broadcast_dim(x)
+    L = x.shape[-1]
+    n = np.arange(K)[None, :]
+    p = np.asarray(frames_idx)[:, None] * hop - pad + n
+    if mode == "reflect":
+        p = np.where(p < 0, -p, p)
+        p = np.where(p >= L, 2 * (L - 1) - p, p)
+        ok = np.ones_like(p, dtype=bool)
+    else:
+        ok = (p >= 0) & (p < L)
+        p = np.clip(p, 0, L - 1)
+    v = x[np.asarray(clips)[:, None], p].astype(np.float64)
+    return np.where(ok, v, 0.0)
+
+
+def sampled_complex(x, basis_re, basis_im, clips, frames_idx, hop, pad, mode):
+    """(re, im) float64 arrays (n, F) for the sampled frames: re = fr @ basis_re.T,
+    im = -(fr @ basis_im.T) (the sign convention of stft.py:308-311 / cqt.py:749-750)."""
+    wr = np.asarray(basis_re, dtype=np.float64).reshape(basis_re.shape[0], -1)
+    wi = np.asarray(basis_im, dtype=np.float64).reshape(basis_im.shape[0], -1)
+    fr = gather_frames(x, clips, frames_idx, wr.shape[1], hop, pad, mode)
+    return fr @ wr.T, -(fr @ wi.T)

@@ -1,0 +1,101 @@
+"""The C-ABI shared library loads and exports every symbol include/mispec.h declares;
+host-side guards fail loudly (no GPU needed: no compute call is made here)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "mispec.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mispec_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from nnaudio_amd import _abi, build
+
+    build.build(verbose=False)
+    lib = ctypes.CDLL(_abi.LIB_PATH)
+    names = _declared_functions()
+    assert set(names) == set(_abi.EXPORTS)
+    for n in names:
+        assert hasattr(lib, n), n
+    assert _abi.load().mispec_version() == _abi.ABI_VERSION
+    assert _abi.load().mispec_last_error() == b""
+
+
+def test_args_struct_layout_matches_header(tmp_path):
+    """sizeof / offsetof as the C compiler sees include/mispec.h == the ctypes mirror."""
+    import shutil
+    import subprocess
+
+    from nnaudio_amd import _abi
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no C compiler")
+    fields = [f[0] for f in _abi.FramedGemmArgs._fields_]
+    prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "mispec.h"', 'int main(void){',
+            'printf("%zu\\n", sizeof(mispec_framed_gemm_args));']
+    for f in fields:
+        prog.append('printf("%%zu\\n", offsetof(mispec_framed_gemm_args, %s));' % f)
+    prog.append("return 0;}")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(prog))
+    exe = tmp_path / "layout"
+    subprocess.check_call([gcc, "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    vals = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert vals[0] == ctypes.sizeof(_abi.FramedGemmArgs)
+    for f, off in zip(fields, vals[1:]):
+        assert getattr(_abi.FramedGemmArgs, f).offset == off, f
+
+
+def test_invalid_arguments_are_rejected_without_a_gpu():
+    from nnaudio_amd import _abi
+
+    lib = _abi.load()
+    assert lib.mispec_framed_gemm_f32(None, None) == -1
+    assert b"NULL" in lib.mispec_last_error()
+    a = _abi.FramedGemmArgs()
+    a.struct_size = 4
+    assert lib.mispec_framed_gemm_f32(ctypes.byref(a), None) == -1
+    assert b"struct_size" in lib.mispec_last_error()
+    assert lib.mispec_fir_decimate_f32(None, 0, 1, 1, None, 1, 1, 0, None, 0, 1, None) == -1
+    assert lib.mispec_filterbank_f32(None, 1, 1, None, 1, 1, None, None) == -1
+
+
+def test_cpu_tensors_fail_loudly():
+    from nnaudio_amd import features
+
+    m = features.STFT(n_fft=64, hop_length=16, verbose=False)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        m(torch.zeros(1, 256))
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 1, 1, 256))
+    with pytest.raises(AssertionError):
+        m(torch.zeros(1, 16))
+
+
+def test_trainable_needs_no_grad():
+    from nnaudio_amd import features
+
+    m = features.STFT(n_fft=64, hop_length=16, trainable=True, verbose=False)
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1, 256))
+
+
+def test_legacy_import_shim_warns():
+    import importlib
+    import warnings
+
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        mod = importlib.import_module("nnaudio_amd.Spectrogram")
+        importlib.reload(mod)
+    assert any("deprecated" in str(i.message) for i in w)
+    assert hasattr(mod, "STFT") and hasattr(mod, "CQT2010v2") and hasattr(mod, "VQT")

@@ -1,0 +1,408 @@
+"""Parity of the HIP path (through the C ABI) with the reference / the pinned oracle.
+Everything here needs the MI355X: run with ``pytest -m gpu``.
+
+Tolerance (north_star "within 1e-4 rel fp32"): max|y-ref| <= 1e-4*max|ref| and
+allclose(rtol=1e-4, atol=1e-4*max|ref|); phase compared where the bin carries energy."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+from scipy.signal import chirp
+
+from tests import _golden
+from tests._golden import (assert_parity, assert_phase_parity, build_module, check_ground_truth,
+                           is_phase, oracle_forward)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU; torch.cuda.is_available() is False")
+    from nnaudio_amd import _abi
+
+    _abi.load()  # fail loudly if the extension is not built
+
+
+def run(mod, x, **fwd):
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        y = mod(torch.as_tensor(x).to(DEV), **fwd)
+    torch.cuda.synchronize()
+    return y.cpu().numpy()
+
+
+# ---------------------------------------------------------------------------------------
+# every manifest case: HIP vs the reference's own output AND vs the oracle
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", _golden.case_names(forward_only=True))
+def test_case_matches_reference_and_oracle(golden, name):
+    case = golden.cases[name]
+    x = golden.inputs[case["input"]]
+    ref = golden.forward[name]
+    mod = build_module(case, DEV)
+    y = run(mod, x, **case["fwd"])
+    assert y.dtype == np.float32 and list(y.shape) == case["out_shape"]
+    orc = oracle_forward(build_module(case), case, x)
+    if is_phase(case):
+        mcase = dict(case, ctor=dict(case["ctor"], output_format="Magnitude"), fwd={})
+        mag = oracle_forward(build_module(mcase), mcase, x)
+        assert_phase_parity(y, ref, mag, what=name + " vs reference")
+        assert_phase_parity(y, orc, mag, what=name + " vs oracle")
+    else:
+        assert_parity(y, ref, rel=1e-4, what=name + " vs reference")
+        assert_parity(y, orc, rel=1e-4, what=name + " vs oracle")
+
+
+# ---------------------------------------------------------------------------------------
+# the reference's own ground-truth arrays (its tests/test_cqt.py:94-262)
+# ---------------------------------------------------------------------------------------
+def _chirp(method):
+    s = np.linspace(0, 1, 44100)
+    return chirp(s, 55, 1, 22050, method=method).astype(np.float32)[None, :]
+
+
+GT_CASES = [
+    (sweep, method, cls, tagc, fmt, tag)
+    for sweep, method in (("log", "logarithmic"), ("linear", "linear"))
+    for cls, tagc in (("CQT1992v2", "1992"), ("CQT2010v2", "2010"))
+    for fmt, tag in (("Magnitude", "mag"), ("Complex", "complex"), ("Phase", "phase"))
+    if not (tagc == "2010" and fmt == "Phase")
+]
+
+
+@pytest.mark.parametrize("sweep,method,cls,tagc,fmt,tag", GT_CASES)
+def test_reference_ground_truths(golden, sweep, method, cls, tagc, fmt, tag):
+    case = dict(cls=cls, ctor=dict(sr=44100, fmin=55, n_bins=207, bins_per_octave=24,
+                                   output_format=fmt), fwd={})
+    y = run(build_module(case, DEV), _chirp(method))
+    gt = golden.ground_truth("%s-sweep-cqt-%s-%s-ground-truth.npy" % (sweep, tagc, tag))
+    gtc = golden.ground_truth("%s-sweep-cqt-%s-complex-ground-truth.npy" % (sweep, tagc))
+    check_ground_truth(y, gt, fmt, 1e-5 if tagc == "1992" else 1e-2, gtc,
+                       what="%s %s %s" % (sweep, cls, fmt))
+
+
+def test_vqt_gamma0_is_bit_identical_to_cqt2010v2(golden):
+    """reference tests/test_vqt.py:30-41 asserts exact equality."""
+    from nnaudio_amd import features
+
+    x = golden.inputs["x_1s22k"]
+    a = run(features.CQT2010v2(sr=22050, verbose=False).to(DEV), x)
+    b = run(features.VQT(sr=22050, gamma=0, verbose=False).to(DEV), x)
+    assert (a == b).all()
+
+
+# ---------------------------------------------------------------------------------------
+# kernel-level: MFMA kernel vs the one-thread-per-output device kernel vs numpy, over every
+# tile shape, epilogue, padding mode and ragged size
+# ---------------------------------------------------------------------------------------
+def _np_framed(x, wr, wi, hop, pad, mode, scale=None):
+    from oracle import spectral_oracle as O
+
+    xp = O.pad_signal(x, pad, {1: "constant", 2: "reflect"}[mode]) if mode else x
+    re = O.correlate_strided(xp, wr, hop)
+    im = -O.correlate_strided(xp, wi, hop) if wi is not None else None
+    if scale is not None:
+        re = re * scale[None, :, None]
+        if im is not None:
+            im = im * scale[None, :, None]
+    return re, im
+
+
+SHAPES = [
+    # B, L, F, K, hop, pad, mode
+    (3, 1000, 5, 64, 16, 32, 2),
+    (2, 777, 16, 96, 17, 48, 1),
+    (1, 4096, 70, 200, 50, 0, 0),
+    (5, 300, 33, 130, 7, 65, 2),
+    (2, 2500, 129, 256, 64, 128, 2),
+    (1, 9000, 1, 33, 1, 16, 1),
+]
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_mfma_kernel_all_tiles(tile, shape):
+    from nnaudio_amd import engine
+
+    B, L, F, K, hop, pad, mode = shape
+    rng = np.random.default_rng(B * 1000 + F)
+    x = rng.standard_normal((B, L)).astype(np.float32)
+    wr = rng.standard_normal((F, K)).astype(np.float32)
+    wi = rng.standard_normal((F, K)).astype(np.float32)
+    sc = rng.uniform(0.5, 2.0, F).astype(np.float32)
+    xd, wrd, wid, scd = (torch.as_tensor(a).to(DEV) for a in (x, wr, wi, sc))
+    kw = dict(hop=hop, pad=pad, pad_mode=mode, epilogue=engine.EPI_COMPLEX, row_scale=scd)
+    y = engine.framed_gemm(xd, wrd, wid, tile=tile, **kw).cpu().numpy()
+    yr = engine.framed_gemm(xd, wrd, wid, reference_kernel=True, **kw).cpu().numpy()
+    re, im = _np_framed(x, wr, wi, hop, pad, mode, sc.astype(np.float64))
+    want = np.stack((re, im), -1)
+    assert_parity(yr, want, rel=2e-5, what="device reference kernel")
+    assert_parity(y, want, rel=2e-5, what="mfma tile %d" % tile)
+    # fp32 fma chains in different association: tiny
+    assert np.abs(y - yr).max() <= 2e-5 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("epi", ["magnitude", "magnitude_eps", "power2", "power1", "power3.5",
+                                 "phase", "cossin", "real"])
+def test_epilogues(epi):
+    from nnaudio_amd import engine
+
+    rng = np.random.default_rng(7)
+    B, L, F, K, hop, pad = 2, 3000, 40, 128, 32, 64
+    x = rng.standard_normal((B, L)).astype(np.float32)
+    wr = rng.standard_normal((F, K)).astype(np.float32)
+    wi = rng.standard_normal((F, K)).astype(np.float32)
+    xd, wrd, wid = (torch.as_tensor(a).to(DEV) for a in (x, wr, wi))
+    re, im = _np_framed(x, wr, wi, hop, pad, 2)
+    mag = np.sqrt(re * re + im * im)
+    kw = dict(hop=hop, pad=pad, pad_mode=2)
+    if epi == "magnitude":
+        y = engine.framed_gemm(xd, wrd, wid, epilogue=engine.EPI_MAGNITUDE, **kw)
+        assert_parity(y.cpu().numpy(), mag, what=epi)
+    elif epi == "magnitude_eps":
+        y = engine.framed_gemm(xd, wrd, wid, epilogue=engine.EPI_MAGNITUDE, eps=1e-8, **kw)
+        assert_parity(y.cpu().numpy(), np.sqrt(mag ** 2 + 1e-8), what=epi)
+    elif epi.startswith("power"):
+        p = float(epi[5:])
+        y = engine.framed_gemm(xd, wrd, wid, epilogue=engine.EPI_POWER, power=p, **kw)
+        assert_parity(y.cpu().numpy(), mag ** p, what=epi)
+    elif epi == "phase":
+        y = engine.framed_gemm(xd, wrd, wid, epilogue=engine.EPI_PHASE_ATAN2, **kw)
+        assert_phase_parity(y.cpu().numpy(), np.arctan2(im, re), mag, what=epi, tol=1e-4)
+    elif epi == "cossin":
+        y = engine.framed_gemm(xd, wrd, wid, epilogue=engine.EPI_PHASE_COSSIN, **kw)
+        a = np.arctan2(im, re)
+        assert_phase_parity(y.cpu().numpy(), np.stack((np.cos(a), np.sin(a)), -1), mag, what=epi,
+                            tol=1e-4)
+    else:
+        y = engine.framed_gemm(xd, wrd, None, epilogue=engine.EPI_REAL, im_sign=1.0, **kw)
+        assert_parity(y.cpu().numpy(), re, what=epi)
+
+
+def test_phase_zero_input_matches_reference_convention():
+    """atan2(-0 + 0.0, 0) = 0 and (cos, sin)(atan2(0, 0)) = (1, 0), as torch computes."""
+    from nnaudio_amd import features
+
+    x = torch.zeros(1, 2048, device=DEV)
+    y = run(features.STFT(n_fft=256, hop_length=64, output_format="Phase", verbose=False).to(DEV), x)
+    assert (y == 0).all()
+    y = run(features.CQT1992v2(fmin=440, n_bins=12, output_format="Phase", verbose=False).to(DEV), x)
+    assert (y[..., 0] == 1).all() and (y[..., 1] == 0).all()
+
+
+def test_row_support_skipping_and_row_offset():
+    from nnaudio_amd import engine
+
+    rng = np.random.default_rng(11)
+    B, L, F, K, hop = 2, 6000, 50, 1024, 64
+    x = rng.standard_normal((B, L)).astype(np.float32)
+    wr = np.zeros((F, K), np.float32)
+    wi = np.zeros((F, K), np.float32)
+    sup = np.zeros((F, 2), np.int32)
+    for f in range(F):
+        ln = max(3, int(900 / (1 + f)))
+        s = (K - ln) // 2
+        wr[f, s:s + ln] = rng.standard_normal(ln)
+        wi[f, s:s + ln] = rng.standard_normal(ln)
+        sup[f] = (s, s + ln)
+    xd, wrd, wid, supd = (torch.as_tensor(a).to(DEV) for a in (x, wr, wi, sup))
+    re, im = _np_framed(x, wr, wi, hop, K // 2, 2)
+    want = np.sqrt(re * re + im * im)
+    T = want.shape[-1]
+    for tile in (0, 1, 4, 5, 6):
+        out = torch.full((B, F + 7, T), -1.0, device=DEV)
+        engine.framed_gemm(xd, wrd, wid, hop=hop, pad=K // 2, pad_mode=2,
+                           epilogue=engine.EPI_MAGNITUDE, row_support=supd, out=out,
+                           out_rows_total=F + 7, out_row_offset=3, tile=tile)
+        o = out.cpu().numpy()
+        assert (o[:, :3] == -1).all() and (o[:, F + 3:] == -1).all()
+        assert_parity(o[:, 3:F + 3], want, what="support tile %d" % tile)
+
+
+@pytest.mark.parametrize("L,stride", [(1000, 2), (1001, 2), (4097, 2), (300, 2), (5000, 4), (20000, 8),
+                                       (255, 2)])
+def test_fir_decimate(L, stride):
+    from nnaudio_amd import engine
+    from nnaudio_amd.basis import lowpass_taps
+    from oracle import spectral_oracle as O
+
+    rng = np.random.default_rng(L)
+    x = rng.standard_normal((3, L)).astype(np.float32)
+    taps = lowpass_taps(1.0 / stride, 256, 0.03)
+    y = engine.fir_decimate(torch.as_tensor(x).to(DEV), torch.as_tensor(taps).to(DEV), stride)
+    want = O.fir_decimate(x, taps, stride)
+    assert_parity(y.cpu().numpy(), want, rel=2e-5, what="fir L=%d s=%d" % (L, stride))
+
+
+@pytest.mark.parametrize("M,F,T,B", [(128, 513, 216, 3), (40, 257, 33, 2), (64, 1025, 100, 1),
+                                     (7, 30, 5, 4), (229, 1025, 77, 2)])
+def test_filterbank(M, F, T, B):
+    from nnaudio_amd import engine
+
+    rng = np.random.default_rng(M)
+    fb = rng.uniform(0, 1, (M, F)).astype(np.float32)
+    sp = rng.uniform(0, 4, (B, F, T)).astype(np.float32)
+    y = engine.filterbank(torch.as_tensor(fb).to(DEV), torch.as_tensor(sp).to(DEV))
+    want = np.matmul(fb.astype(np.float64), sp.astype(np.float64))
+    assert_parity(y.cpu().numpy(), want, rel=2e-5, what="filterbank")
+
+
+# ---------------------------------------------------------------------------------------
+# plumbing: input layouts, streams, errors
+# ---------------------------------------------------------------------------------------
+def test_input_layouts_and_streams(golden):
+    from nnaudio_amd import features
+
+    m = features.STFT(n_fft=512, hop_length=128, output_format="Magnitude", verbose=False).to(DEV)
+    x = torch.as_tensor(golden.inputs["x_short"]).to(DEV)
+    base = m(x)
+    assert torch.equal(m(x[:, None, :]), base)
+    assert torch.equal(m(x[1]), base[1:2])
+    wide = torch.zeros(3, 8000, device=DEV)
+    wide[:, ::2] = x
+    assert torch.equal(m(wide[:, ::2]), base)  # non-unit inner stride
+    padded = torch.zeros(3, 5000, device=DEV)
+    padded[:, :4000] = x
+    assert torch.equal(m(padded[:, :4000]), base)  # batch stride != length
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        y = m(x)
+    s.synchronize()
+    assert torch.equal(y, base)
+    assert m.num_samples == 4000
+
+
+def test_error_behaviour_on_device():
+    from nnaudio_amd import features
+
+    m = features.STFT(n_fft=512, hop_length=128, verbose=False).to(DEV)
+    with pytest.raises(AssertionError):
+        m(torch.zeros(1, 100, device=DEV))
+    with pytest.raises(RuntimeError):  # reflect needs pad < L (nn.ReflectionPad1d)
+        m(torch.zeros(1, 256, device=DEV))
+    with pytest.raises(RuntimeError):  # kernel longer than the signal without centring
+        features.STFT(n_fft=512, hop_length=128, center=False, verbose=False).to(DEV)(
+            torch.zeros(1, 300, device=DEV))
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 4000, device=DEV, dtype=torch.float64))
+    c = features.CQT1992v2(fmin=220, n_bins=24, verbose=False).to(DEV)
+    with pytest.raises(ValueError):
+        c(torch.zeros(1, 22050, device=DEV), normalization_type="nope")
+    with pytest.raises(RuntimeError):  # octave frame counts diverge (torch.cat fails upstream)
+        features.CQT2010v2(hop_length=100, earlydownsample=False, verbose=False).to(DEV)(
+            torch.zeros(1, 22050, device=DEV))
+    assert m(torch.zeros(1, 4000, device=DEV), output_format="nonsense") is None
+
+
+def test_reflect_fallback_warns_like_reference():
+    """utils.py:505-517: when mirroring is impossible an octave is zero-padded with a warning."""
+    from nnaudio_amd import features
+
+    m = features.CQT2010v2(sr=22050, fmin=55, n_bins=72, verbose=False).to(DEV)
+    x = torch.randn(1, 3000, device=DEV)
+    with pytest.warns(UserWarning):
+        y = m(x)
+    assert torch.isfinite(y).all()
+
+
+# ---------------------------------------------------------------------------------------
+# BASELINE.json full-size configurations: sampled exact check + size-independent properties
+# ---------------------------------------------------------------------------------------
+def _sample_cols(rng, B, T, n):
+    return rng.integers(0, B, n), rng.integers(0, T, n)
+
+
+def test_cfg2_stft_full_size_sampled_and_linear():
+    from nnaudio_amd import features
+    from oracle import spectral_oracle as O
+
+    B, L = 64, 441000
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn(B, L, generator=g)
+    m = features.STFT(n_fft=2048, hop_length=512, window="hann", output_format="Complex",
+                      verbose=False).to(DEV)
+    xd = x.to(DEV)
+    y = m(xd)
+    assert tuple(y.shape) == (64, 1025, 862, 2)
+    rng = np.random.default_rng(0)
+    cb, ct = _sample_cols(rng, B, 862, 96)
+    ct[:8] = [0, 1, 2, 3, 858, 859, 860, 861]  # frames that touch the reflected edges
+    re, im = O.sampled_complex(x.numpy(), m.wcos.cpu().numpy(), m.wsin.cpu().numpy(), cb, ct,
+                               512, 1024, "reflect")
+    got = y[torch.as_tensor(cb), :, torch.as_tensor(ct)].cpu().numpy()  # (n, F, 2)
+    peak = max(np.abs(re).max(), np.abs(im).max())
+    assert np.abs(got[..., 0] - re).max() <= 1e-4 * peak
+    assert np.abs(got[..., 1] - im).max() <= 1e-4 * peak
+    # magnitude path agrees with |complex|
+    mag = m(xd, output_format="Magnitude")
+    assert torch.allclose(mag, torch.sqrt(y[..., 0] ** 2 + y[..., 1] ** 2), rtol=1e-5, atol=1e-4)
+    # linearity in the waveform
+    x2 = torch.randn(B, L, generator=g).to(DEV)
+    lhs = m(0.5 * xd - 2.0 * x2)
+    rhs = 0.5 * y - 2.0 * m(x2)
+    assert (lhs - rhs).abs().max().item() <= 1e-4 * rhs.abs().max().item()
+
+
+def test_cfg3_mel_full_size_sampled():
+    from nnaudio_amd import features
+    from oracle import spectral_oracle as O
+
+    B, L = 256, 110250
+    x = torch.randn(B, L, generator=torch.Generator().manual_seed(1))
+    m = features.MelSpectrogram(sr=22050, n_fft=1024, n_mels=128, verbose=False).to(DEV)
+    y = m(x.to(DEV))
+    assert tuple(y.shape) == (256, 128, 216)
+    rng = np.random.default_rng(1)
+    cb, ct = _sample_cols(rng, B, 216, 64)
+    ct[:4] = [0, 1, 214, 215]
+    re, im = O.sampled_complex(x.numpy(), m.stft.wcos.cpu().numpy(), m.stft.wsin.cpu().numpy(),
+                               cb, ct, 512, 512, "reflect")
+    want = (re * re + im * im) @ m.mel_basis.cpu().numpy().astype(np.float64).T  # (n, M)
+    got = y[torch.as_tensor(cb), :, torch.as_tensor(ct)].cpu().numpy()
+    assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
+
+
+def test_cfg4_cqt1992v2_full_size_sampled():
+    from nnaudio_amd import features
+    from oracle import spectral_oracle as O
+
+    B, L = 16, 441000  # one rank's shard of cfg4 (128 clips over 8 GPUs)
+    x = torch.randn(B, L, generator=torch.Generator().manual_seed(2))
+    m = features.CQT1992v2(sr=44100, hop_length=512, fmin=32.70, n_bins=84, bins_per_octave=12,
+                           output_format="Complex", verbose=False).to(DEV)
+    y = m(x.to(DEV))
+    assert tuple(y.shape) == (16, 84, 862, 2)
+    rng = np.random.default_rng(2)
+    cb, ct = _sample_cols(rng, B, 862, 24)
+    ct[:6] = [0, 1, 30, 840, 860, 861]
+    re, im = O.sampled_complex(x.numpy(), m.cqt_kernels_real.cpu().numpy(),
+                               m.cqt_kernels_imag.cpu().numpy(), cb, ct, 512, 16384, "reflect")
+    s = np.sqrt(m.lenghts.cpu().numpy().astype(np.float64))[None, :]
+    got = y[torch.as_tensor(cb), :, torch.as_tensor(ct)].cpu().numpy()
+    peak = max(np.abs(re * s).max(), np.abs(im * s).max())
+    assert np.abs(got[..., 0] - re * s).max() <= 1e-4 * peak
+    assert np.abs(got[..., 1] - im * s).max() <= 1e-4 * peak
+
+
+def test_cfg5_cqt2010v2_vqt_full_length():
+    """30 s clips (one small shard of cfg5): VQT(gamma=0) == CQT2010v2 bit-exactly, the octave
+    recursion is linear, and a short prefix agrees with the oracle away from the right edge."""
+    from nnaudio_amd import features
+
+    B, L = 4, 1323000
+    x = torch.randn(B, L, generator=torch.Generator().manual_seed(3)).to(DEV)
+    c = features.CQT2010v2(sr=44100, hop_length=512, n_bins=96, output_format="Complex",
+                           verbose=False).to(DEV)
+    v = features.VQT(sr=44100, hop_length=512, n_bins=96, gamma=0, output_format="Complex",
+                     verbose=False).to(DEV)
+    yc, yv = c(x), v(x)
+    assert tuple(yc.shape) == (4, 96, 2584, 2)
+    assert torch.equal(yc, yv)
+    x2 = torch.randn(B, L, generator=torch.Generator().manual_seed(4)).to(DEV)
+    lhs = c(x - 3.0 * x2)
+    rhs = yc - 3.0 * c(x2)
+    assert (lhs - rhs).abs().max().item() <= 1e-4 * rhs.abs().max().item()

@@ -69,7 +69,10 @@ enum {
   MISPEC_TILE_64x256 = 3,
   MISPEC_TILE_128x128_TALL = 4, /* one wave column: every wave owns all 4 row tiles */
   MISPEC_TILE_192x128 = 5,
-  MISPEC_TILE_256x128 = 6
+  MISPEC_TILE_256x128 = 6,
+  MISPEC_TILE_256x128_SQ = 7, /* 2x2 waves, 128x64 per wave: one wave per SIMD           */
+  MISPEC_TILE_128x256_SQ = 8, /* 2x2 waves, 64x128 per wave                              */
+  MISPEC_TILE_256x256 = 9     /* 2x2 waves, 128x128 per wave (256 accumulator registers)  */
 };
 
 /*

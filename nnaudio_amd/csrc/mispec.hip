@@ -137,47 +137,41 @@ __device__ __forceinline__ int epilogue_width(int epi) {
   return (epi == MISPEC_EPI_COMPLEX || epi == MISPEC_EPI_PHASE_COSSIN) ? 2 : 1;
 }
 
-// A[row, k] for the two A modes (row is a global row index; bounds already checked for k < K)
-__device__ __forceinline__ float fetch_a(const KParams &p, int row, int k) {
-  if (p.amode == AMODE_TOEPLITZ) {
-    int tap = k - p.toep_stride * row;
-    float v = 0.f;
-    if (tap >= 0 && tap < p.n_taps && row < p.n_bins) v = p.a_re[tap];
-    return v;
-  }
-  const bool cplx = p.a_im != nullptr;
-  const int bin = cplx ? (row >> 1) : row;
-  const float *src = (cplx && (row & 1)) ? p.a_im : p.a_re;
-  float v = 0.f;
-  if (bin < p.n_bins) v = src[(long long)bin * p.a_row_stride + k];
-  return v;
-}
+// 4 consecutive floats with only element alignment guaranteed (hop / pad / clip length are
+// arbitrary); the hardware handles dword-aligned 16-byte global loads.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
 // ---------------------------------------------------------------------------------
 // MFMA kernel.  Workgroup = WM x WN waves; each wave owns MR x NR tiles of 32x32.
 //   BM = WM*MR*32 basis rows,  BN = WN*NR*32 frames per workgroup.
+// Loader geometry (256 threads): thread (r32 = tid>>3, c4 = tid&7) moves the 4 consecutive
+// K elements 4*c4.. of row r32 of each 32-row "pass"; a pass of the A tile is one 32-row
+// MFMA tile, a pass of the B tile is 32 consecutive frames.
 // ---------------------------------------------------------------------------------
-template <int WM, int WN, int MR, int NR, int BMODE>
+template <int WM, int WN, int MR, int NR, int BMODE, int AMODE, bool MASKED>
 __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams p) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * MR * 32;
   constexpr int BN = WN * NR * 32;
   constexpr int MT = WM * MR;
-  constexpr int RPP = NT / 32;  // tile rows covered by one loader pass
+  constexpr int RPP = NT / 8;  // tile rows covered by one loader pass (4 floats per thread)
+  static_assert(RPP == 32, "loader geometry assumes 256 threads");
   constexpr int APASS = BM / RPP;
+  constexpr int BPASS = BN / RPP;  // framed mode
   constexpr int A_STAGE = BM * LDT;
   constexpr int B_STAGE = (BMODE == BMODE_FRAMED) ? BN * LDT : KC * BN;
-  constexpr int BPASS = (BMODE == BMODE_FRAMED) ? (BN / RPP) : (KC * BN / NT);
-  static_assert(32 % RPP == 0, "loader pass must not straddle a 32-row tile");
-  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile / loader mismatch");
-  static_assert(BMODE == BMODE_FRAMED || (NT % BN == 0 || BN % NT == 0), "planar loader shape");
+  constexpr int PPASS = KC * BN / NT;  // planar mode: scalar elements per thread
+  static_assert(BMODE == BMODE_FRAMED || NT % BN == 0 || BN % NT == 0, "planar loader shape");
+  constexpr int STORE_MODE = (AMODE == AMODE_TOEPLITZ) ? STORE_ROWS_INNER : STORE_FRAMES_INNER;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float *sA = reinterpret_cast<float *>(smem_raw);
   float *sB = sA + 2 * A_STAGE;
   long long *sColBase = reinterpret_cast<long long *>(sB + 2 * B_STAGE);
-  int *sColPos = reinterpret_cast<int *>(sColBase + BN);
-  int *sTileLo = sColPos + BN;
+  long long *sPassBase = sColBase + BN;  // [BPASS] clip offset of a single-clip pass, else -1
+  int *sColPos = reinterpret_cast<int *>(sPassBase + 8);
+  int *sPassPos = sColPos + BN;          // [BPASS] signal position of the pass's first frame
+  int *sTileLo = sPassPos + 8;
   int *sTileHi = sTileLo + MT;
 
   const int tid = threadIdx.x;
@@ -187,6 +181,8 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
   const int wn = wave % WN;
   const int li = lane & 31;
   const int lh = lane >> 5;
+  const int r32 = tid >> 3;  // loader row inside a pass
+  const int c4 = tid & 7;    // loader K offset / 4
 
   // ---- XCD-aware tile order: workgroup b runs on XCD b % 8; give every XCD a contiguous
   // range of tiles with the frame-tile index fastest, so the basis rows an XCD streams
@@ -204,10 +200,10 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
   const int m0 = tile_m * BM;
   const long long n0 = (long long)tile_n * BN;
 
-  const bool cplx = p.a_im != nullptr;
+  const bool cplx = (AMODE == AMODE_ROWS) && p.a_im != nullptr;
   const int rpb = cplx ? 2 : 1;
 
-  // ---- per-column (frame) tables and per-row-tile K ranges
+  // ---- per-column (frame) tables, per-pass fast-path descriptors, per-row-tile K ranges
   for (int j = tid; j < BN; j += NT) {
     const long long col = n0 + j;
     long long base = -1;
@@ -225,10 +221,24 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
     sColBase[j] = base;
     sColPos[j] = pos;
   }
+  if (BMODE == BMODE_FRAMED && tid < BPASS) {
+    const long long c0 = n0 + tid * 32, c1 = c0 + 31;
+    long long base = -1;
+    int pos = 0;
+    if (c1 < p.n_cols) {
+      const int ca = (int)(c0 / p.n_frames), cb = (int)(c1 / p.n_frames);
+      if (ca == cb) {
+        base = (long long)ca * p.x_clip_stride;
+        pos = (int)(c0 - (long long)ca * p.n_frames) * p.hop - p.pad;
+      }
+    }
+    sPassBase[tid] = base;
+    sPassPos[tid] = pos;
+  }
   if (tid < MT) {
     const int row_lo = m0 + tid * 32;
     int lo = 0, hi = 0;
-    if (p.amode == AMODE_TOEPLITZ) {
+    if (AMODE == AMODE_TOEPLITZ) {
       if (row_lo < p.n_bins) hi = p.K;
     } else {
       const int bin_lo = row_lo / rpb;
@@ -258,61 +268,163 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
   }
   __syncthreads();
 
+  // row-tile K ranges -> scalar registers (read once; the per-stage masks are SALU work)
+  int tlo[MT], thi[MT];
   int kb = p.K, ke = 0;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const int lo = sTileLo[i], hi = sTileHi[i];
-    if (hi > lo) {
-      kb = lo < kb ? lo : kb;
-      ke = hi > ke ? hi : ke;
+    tlo[i] = __builtin_amdgcn_readfirstlane(sTileLo[i]);
+    thi[i] = __builtin_amdgcn_readfirstlane(sTileHi[i]);
+    if (thi[i] > tlo[i]) {
+      kb = tlo[i] < kb ? tlo[i] : kb;
+      ke = thi[i] > ke ? thi[i] : ke;
     }
   }
-  kb = __builtin_amdgcn_readfirstlane(kb) & ~(KC - 1);
-  ke = __builtin_amdgcn_readfirstlane(ke);
+  kb = kb & ~(KC - 1);
   const int nchunks = ke > kb ? (ke - kb + KC - 1) / KC : 0;
 
   // which of the workgroup's row tiles intersect K stage [kc, kc+KC)
   auto stage_mask = [&](int kc) -> unsigned {
+    if (!MASKED) return (1u << MT) - 1u;
     unsigned m = 0;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int lo = sTileLo[i], hi = sTileHi[i];
-      if (hi > kc && lo < kc + KC) m |= 1u << i;
-    }
-    return (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+    for (int i = 0; i < MT; ++i)
+      if (thi[i] > kc && tlo[i] < kc + KC) m |= 1u << i;
+    return m;
   };
 
-  float ra[APASS];
-  float rb[BPASS];
-
-  const int lr0 = tid >> 5;  // loader row within a pass
-  const int lc = tid & 31;   // loader k offset
-
-  auto load_stage = [&](int kc, unsigned amask) {
-    const int k = kc + lc;
-    const bool kin = k < p.K;
+  // ---- per-thread source pointers (one per pass), computed once
+  const float *aptr[APASS];
+  if (AMODE == AMODE_ROWS) {
 #pragma unroll
     for (int ps = 0; ps < APASS; ++ps) {
-      const int row = ps * RPP + lr0;
-      float v = 0.f;
-      if ((amask >> ((ps * RPP) >> 5)) & 1u) {
-        if (kin) v = fetch_a(p, m0 + row, k);
+      const int row = m0 + ps * 32 + r32;
+      int bin = cplx ? (row >> 1) : row;
+      bin = bin < p.n_bins ? bin : p.n_bins - 1;  // rows past the end feed unused accumulators
+      const float *src = (cplx && (row & 1)) ? p.a_im : p.a_re;
+      aptr[ps] = src + (long long)bin * p.a_row_stride + 4 * c4;
+    }
+  }
+  const float *bptr[BPASS];
+  int pass_ok[BPASS];   // wave-uniform: the pass's 32 frames lie in one clip
+  int pass_pos[BPASS];  // wave-uniform: signal position of the pass's first frame
+  if (BMODE == BMODE_FRAMED) {
+#pragma unroll
+    for (int ps = 0; ps < BPASS; ++ps) {
+      const long long pb = sPassBase[ps];
+      const int pp = sPassPos[ps];
+      pass_ok[ps] = __builtin_amdgcn_readfirstlane(pb >= 0 ? 1 : 0);
+      pass_pos[ps] = __builtin_amdgcn_readfirstlane(pp);
+      bptr[ps] = p.x + (pb < 0 ? 0 : pb) + pp + (long long)r32 * p.hop + 4 * c4;
+    }
+  }
+
+  // K stages [plain_lo, plain_hi] (multiples of KC) can be loaded with unpredicated 16-byte
+  // loads for every pass of both tiles: all frames of every pass in one clip, inside the signal
+  int plain_lo = 0x7fffffff, plain_hi = -1;
+  if (AMODE == AMODE_ROWS && BMODE == BMODE_FRAMED) {
+    long long lo = 0, hi = (long long)p.K - KC;
+    bool ok = true;
+#pragma unroll
+    for (int ps = 0; ps < BPASS; ++ps) {
+      ok = ok && pass_ok[ps];
+      const long long a = -(long long)pass_pos[ps];
+      const long long b = (long long)p.n_samples - KC - pass_pos[ps] - 31LL * p.hop;
+      lo = a > lo ? a : lo;
+      hi = b < hi ? b : hi;
+    }
+    if (ok && hi >= lo) {
+      plain_lo = (int)lo;
+      plain_hi = (int)hi;
+    }
+  }
+
+  f32x4v ra[APASS];
+  f32x4v rb[(BMODE == BMODE_FRAMED) ? BPASS : 1];
+  float rp[(BMODE == BMODE_PLANAR) ? PPASS : 1];
+
+  auto stage_is_plain = [&](int kc, unsigned amask) -> bool {
+    bool ok = kc >= plain_lo && kc <= plain_hi;
+    if (MASKED) ok = ok && (amask == ((1u << MT) - 1u));
+    return ok;
+  };
+
+  auto load_stage = [&](int kc, unsigned amask) {
+    if (stage_is_plain(kc, amask)) {
+#pragma unroll
+      for (int ps = 0; ps < APASS; ++ps)
+        ra[ps] = *reinterpret_cast<const f32x4u *>(aptr[ps] + kc);
+#pragma unroll
+      for (int ps = 0; ps < BPASS; ++ps)
+        rb[ps] = *reinterpret_cast<const f32x4u *>(bptr[ps] + kc);
+      return;
+    }
+    const int k = kc + 4 * c4;
+    const bool full_k = (kc + KC) <= p.K;  // uniform
+    // ---------------- A tile
+#pragma unroll
+    for (int ps = 0; ps < APASS; ++ps) {
+      f32x4v v = {0.f, 0.f, 0.f, 0.f};
+      if ((amask >> ps) & 1u) {
+        if (AMODE == AMODE_ROWS) {
+          if (full_k) {
+            v = *reinterpret_cast<const f32x4u *>(aptr[ps] + kc);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const bool ok = (k + e) < p.K;
+              const float t = (aptr[ps] - 4 * c4)[ok ? k + e : 0];  // clamp into the row
+              v[e] = ok ? t : 0.f;
+            }
+          }
+        } else {
+          const int row = m0 + ps * 32 + r32;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int tap = k + e - p.toep_stride * row;
+            const bool ok = tap >= 0 && tap < p.n_taps && row < p.n_bins && (k + e) < p.K;
+            const float t = p.a_re[ok ? tap : 0];
+            v[e] = ok ? t : 0.f;
+          }
+        }
       }
       ra[ps] = v;
     }
+    // ---------------- B tile
     if (BMODE == BMODE_FRAMED) {
 #pragma unroll
       for (int ps = 0; ps < BPASS; ++ps) {
-        const int j = ps * RPP + lr0;
-        const long long base = sColBase[j];
-        const int pos = sColPos[j];
-        rb[ps] = fetch_sample(p.x, base, pos + k, p.n_samples, p.pad_mode, kin && base >= 0);
+        // per-pass fast path: the pass's 32 frames lie in one clip and this K stage of all of
+        // them is inside the signal -> one unpredicated 16-byte load
+        const int pf = pass_pos[ps];
+        const bool fast = pass_ok[ps] && full_k && (pf + kc >= 0) &&
+                          ((long long)pf + 31LL * p.hop + kc + KC <= (long long)p.n_samples);
+        if (fast) {
+          rb[ps] = *reinterpret_cast<const f32x4u *>(bptr[ps] + kc);
+        } else {
+          const int j = ps * 32 + r32;
+          const long long base = sColBase[j];
+          const int pos = sColPos[j];
+          f32x4v v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            int pp = pos + k + e;
+            if (p.pad_mode == MISPEC_PAD_REFLECT) {
+              pp = pp < 0 ? -pp : pp;
+              pp = pp >= p.n_samples ? 2 * p.n_samples - 2 - pp : pp;
+            }
+            const bool ok = base >= 0 && (k + e) < p.K && pp >= 0 && pp < p.n_samples;
+            const float t = p.x[ok ? base + pp : 0];
+            v[e] = ok ? t : 0.f;
+          }
+          rb[ps] = v;
+        }
       }
     } else {
       constexpr int KPP = (NT >= BN) ? NT / BN : 1;  // k rows per pass
       constexpr int JPP = (NT >= BN) ? 1 : BN / NT;  // column groups per k row
 #pragma unroll
-      for (int ps = 0; ps < BPASS; ++ps) {
+      for (int ps = 0; ps < PPASS; ++ps) {
         int kl, j;
         if (NT >= BN) {
           kl = ps * KPP + tid / BN;
@@ -323,9 +435,9 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
         }
         const int kk = kc + kl;
         const long long base = sColBase[j];
-        float v = 0.f;
-        if (base >= 0 && kk < p.K) v = p.x[base + (long long)kk * p.x_k_stride];
-        rb[ps] = v;
+        const bool ok = base >= 0 && kk < p.K;
+        const float t = p.x[ok ? base + (long long)kk * p.x_k_stride : 0];
+        rp[ps] = ok ? t : 0.f;
       }
     }
   };
@@ -334,15 +446,17 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
     float *a = sA + buf * A_STAGE;
     float *b = sB + buf * B_STAGE;
 #pragma unroll
-    for (int ps = 0; ps < APASS; ++ps) a[(ps * RPP + lr0) * LDT + lc] = ra[ps];
+    for (int ps = 0; ps < APASS; ++ps)
+      *reinterpret_cast<f32x4v *>(a + (ps * 32 + r32) * LDT + 4 * c4) = ra[ps];
     if (BMODE == BMODE_FRAMED) {
 #pragma unroll
-      for (int ps = 0; ps < BPASS; ++ps) b[(ps * RPP + lr0) * LDT + lc] = rb[ps];
+      for (int ps = 0; ps < BPASS; ++ps)
+        *reinterpret_cast<f32x4v *>(b + (ps * 32 + r32) * LDT + 4 * c4) = rb[ps];
     } else {
       constexpr int KPP = (NT >= BN) ? NT / BN : 1;
       constexpr int JPP = (NT >= BN) ? 1 : BN / NT;
 #pragma unroll
-      for (int ps = 0; ps < BPASS; ++ps) {
+      for (int ps = 0; ps < PPASS; ++ps) {
         int kl, j;
         if (NT >= BN) {
           kl = ps * KPP + tid / BN;
@@ -351,7 +465,7 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
           kl = ps / JPP;
           j = (ps % JPP) * NT + tid;
         }
-        b[kl * BN + j] = rb[ps];
+        b[kl * BN + j] = rp[ps];
       }
     }
   };
@@ -386,34 +500,37 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
         b_base = sB + buf * B_STAGE + ((wn * NR) * 32 + li) * LDT + 4 * lh;
       else
         b_base = sB + buf * B_STAGE + (4 * lh) * BN + (wn * NR) * 32 + li;
-      const unsigned wmask = (mask_cur >> (wm * MR));
+      const unsigned wmask = MASKED ? (mask_cur >> (wm * MR)) : ~0u;
 
+      // fragments of K group q (8 K elements): lane (li, lh) holds k = 8q + 4lh + s for MFMA s
+      f32x4v av[2][MR], bv[2][NR];
+      auto load_frags = [&](int q, int slot) {
 #pragma unroll
-      for (int q = 0; q < KC / 8; ++q) {
-        f32x4v av[MR], bv[NR];
-#pragma unroll
-        for (int m = 0; m < MR; ++m) {
-          if ((wmask >> m) & 1u)
-            av[m] = *reinterpret_cast<const f32x4v *>(a_base + m * 32 * LDT + 8 * q);
-        }
+        for (int m = 0; m < MR; ++m)
+          av[slot][m] = *reinterpret_cast<const f32x4v *>(a_base + m * 32 * LDT + 8 * q);
 #pragma unroll
         for (int n = 0; n < NR; ++n) {
           if (BMODE == BMODE_FRAMED) {
-            bv[n] = *reinterpret_cast<const f32x4v *>(b_base + n * 32 * LDT + 8 * q);
+            bv[slot][n] = *reinterpret_cast<const f32x4v *>(b_base + n * 32 * LDT + 8 * q);
           } else {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) bv[n][s] = b_base[(8 * q + s) * BN + n * 32];
+            for (int s = 0; s < 4; ++s) bv[slot][n][s] = b_base[(8 * q + s) * BN + n * 32];
           }
         }
+      };
+      load_frags(0, 0);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+      for (int q = 0; q < KC / 8; ++q) {
+        if (q + 1 < KC / 8) load_frags(q + 1, (q + 1) & 1);  // prefetch under this group's MFMAs
 #pragma unroll
-          for (int m = 0; m < MR; ++m) {
-            if ((wmask >> m) & 1u) {
+        for (int m = 0; m < MR; ++m) {
+          if (!MASKED || ((wmask >> m) & 1u)) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
 #pragma unroll
               for (int n = 0; n < NR; ++n)
-                acc[m][n] =
-                    __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][s], bv[n][s], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q & 1][m][s], bv[q & 1][n][s],
+                                                                 acc[m][n], 0, 0, 0);
             }
           }
         }
@@ -451,7 +568,7 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
     const int tm = ti / NR, tn = ti - tm * NR;
     const int row_base = m0 + (wm * MR + tm) * 32;           // first basis row of this tile
     const long long col_base = n0 + (wn * NR + tn) * 32;     // first frame column of this tile
-    if (p.store_mode == STORE_ROWS_INNER) {
+    if (STORE_MODE == STORE_ROWS_INNER) {
       // lane = row (output sample within the 32-block), iterate over the tile's 32 frames
       const int row = row_base + li;
 #pragma unroll 1
@@ -556,7 +673,7 @@ int fail(int code, const char *fmt, const char *detail = "") {
   return code;
 }
 
-template <int WM, int WN, int MR, int NR, int BMODE>
+template <int WM, int WN, int MR, int NR, int BMODE, int AMODE = AMODE_ROWS, bool MASKED = true>
 int launch_cfg(KParams p, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * MR * 32;
@@ -564,8 +681,8 @@ int launch_cfg(KParams p, hipStream_t stream) {
   constexpr int MT = WM * MR;
   constexpr int A_STAGE = BM * LDT;
   constexpr int B_STAGE = (BMODE == BMODE_FRAMED) ? BN * LDT : KC * BN;
-  constexpr size_t smem = sizeof(float) * 2 * (A_STAGE + B_STAGE) + sizeof(long long) * BN +
-                          sizeof(int) * BN + sizeof(int) * 2 * MT;
+  constexpr size_t smem = sizeof(float) * 2 * (A_STAGE + B_STAGE) + sizeof(long long) * (BN + 8) +
+                          sizeof(int) * (BN + 8) + sizeof(int) * 2 * MT;
 
   const int rows = p.amode == AMODE_TOEPLITZ ? p.n_bins : p.n_bins * (p.a_im ? 2 : 1);
   p.n_tiles_m = (rows + BM - 1) / BM;
@@ -573,7 +690,7 @@ int launch_cfg(KParams p, hipStream_t stream) {
   if (tn * p.n_tiles_m > 0x7fffffffLL) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
   p.n_tiles_n = (int)tn;
 
-  auto kern = framed_gemm_kernel<WM, WN, MR, NR, BMODE>;
+  auto kern = framed_gemm_kernel<WM, WN, MR, NR, BMODE, AMODE, MASKED>;
   // opt in to > 64 KiB of dynamic LDS once per (kernel, device)
   static std::atomic<unsigned long long> configured{0};
   int dev = 0;
@@ -593,42 +710,75 @@ int launch_cfg(KParams p, hipStream_t stream) {
   return MISPEC_OK;
 }
 
-int launch_framed(const KParams &p, int tile, hipStream_t stream) {
-  const int rows = p.amode == AMODE_TOEPLITZ ? p.n_bins : p.n_bins * (p.a_im ? 2 : 1);
-  if (tile == MISPEC_TILE_AUTO) {
-    if (rows <= 32)
-      tile = MISPEC_TILE_32x256;
-    else if (rows <= 64)
-      tile = MISPEC_TILE_64x256;
-    else if (p.row_support) {
-      // support-aware: every wave owns all row tiles of the workgroup so skipped
-      // K stages shorten the whole workgroup instead of idling some waves
-      if (rows <= 128)
-        tile = MISPEC_TILE_128x128_TALL;
-      else if (rows <= 192)
-        tile = MISPEC_TILE_192x128;
-      else
-        tile = MISPEC_TILE_256x128;
-    } else {
-      tile = MISPEC_TILE_128x128;
-    }
-  }
+template <int WM, int WN, int MR, int NR>
+int launch_pick_mask(const KParams &p, bool masked, hipStream_t stream) {
+  if (masked) return launch_cfg<WM, WN, MR, NR, BMODE_FRAMED, AMODE_ROWS, true>(p, stream);
+  return launch_cfg<WM, WN, MR, NR, BMODE_FRAMED, AMODE_ROWS, false>(p, stream);
+}
+
+int launch_tile(const KParams &p, int tile, hipStream_t stream) {
+  // skipping row tiles per K stage only pays (and is only needed) with per-row supports
+  const bool masked = p.row_support != nullptr;
   switch (tile) {
     case MISPEC_TILE_128x128:
-      return launch_cfg<2, 2, 2, 2, BMODE_FRAMED>(p, stream);
-    case MISPEC_TILE_32x256:
-      return launch_cfg<1, 4, 1, 2, BMODE_FRAMED>(p, stream);
+      return launch_pick_mask<2, 2, 2, 2>(p, masked, stream);
+    case MISPEC_TILE_32x256:  // one row tile: the workgroup K range is the tile's range
+      return launch_cfg<1, 4, 1, 2, BMODE_FRAMED, AMODE_ROWS, false>(p, stream);
     case MISPEC_TILE_64x256:
-      return launch_cfg<1, 4, 2, 2, BMODE_FRAMED>(p, stream);
+      return launch_pick_mask<1, 4, 2, 2>(p, masked, stream);
     case MISPEC_TILE_128x128_TALL:
-      return launch_cfg<1, 4, 4, 1, BMODE_FRAMED>(p, stream);
+      return launch_pick_mask<1, 4, 4, 1>(p, masked, stream);
     case MISPEC_TILE_192x128:
-      return launch_cfg<1, 4, 6, 1, BMODE_FRAMED>(p, stream);
+      return launch_pick_mask<1, 4, 6, 1>(p, masked, stream);
     case MISPEC_TILE_256x128:
-      return launch_cfg<1, 4, 8, 1, BMODE_FRAMED>(p, stream);
+      return launch_pick_mask<1, 4, 8, 1>(p, masked, stream);
+    case MISPEC_TILE_256x128_SQ:
+      return launch_pick_mask<2, 2, 4, 2>(p, masked, stream);
+    case MISPEC_TILE_128x256_SQ:
+      return launch_pick_mask<2, 2, 2, 4>(p, masked, stream);
+    case MISPEC_TILE_256x256:
+      return launch_pick_mask<2, 2, 4, 4>(p, masked, stream);
     default:
       return fail(MISPEC_E_INVALID, "unknown tile id%s");
   }
+}
+
+int auto_tile(int rows, bool support) {
+  if (rows <= 32) return MISPEC_TILE_32x256;
+  if (rows <= 64) return MISPEC_TILE_64x256;
+  if (support) {
+    // support-aware: every wave owns all row tiles of the workgroup so skipped
+    // K stages shorten the whole workgroup instead of idling some waves
+    if (rows <= 128) return MISPEC_TILE_128x128_TALL;
+    if (rows <= 192) return MISPEC_TILE_192x128;
+    return MISPEC_TILE_256x128;
+  }
+  return MISPEC_TILE_128x128;
+}
+
+int launch_framed(const KParams &p, int tile, hipStream_t stream) {
+  const int rpb = p.a_im ? 2 : 1;
+  const int rows = p.n_bins * rpb;
+  if (tile != MISPEC_TILE_AUTO) return launch_tile(p, tile, stream);
+  if (p.row_support || rows <= 128) return launch_tile(p, auto_tile(rows, p.row_support != nullptr), stream);
+  // dense basis, many rows: full 128-row workgroups run the unmasked kernel; the leftover
+  // rows (e.g. the Nyquist bin of an n_fft/2+1 STFT) go to a second, narrow launch instead
+  // of a 17th mostly-empty row block.
+  const int bins_per_wg = 128 / rpb;
+  const int main_bins = (p.n_bins / bins_per_wg) * bins_per_wg;
+  KParams q = p;
+  q.n_bins = main_bins;
+  int rc = launch_tile(q, MISPEC_TILE_128x128, stream);
+  if (rc != MISPEC_OK) return rc;
+  const int rem = p.n_bins - main_bins;
+  if (rem == 0) return MISPEC_OK;
+  q = p;
+  q.n_bins = rem;
+  q.a_re = p.a_re + (long long)main_bins * p.a_row_stride;
+  if (p.a_im) q.a_im = p.a_im + (long long)main_bins * p.a_row_stride;
+  if (p.row_scale) q.row_scale = p.row_scale + main_bins;
+  q.out_row_offset = p.out_row_offset + main_bins;
+  return launch_tile(q, auto_tile(rem * rpb, false), stream);
 }
 
 int fill_params(const mispec_framed_gemm_args *a, KParams &p) {
@@ -743,9 +893,9 @@ int mispec_filterbank_f32(const float *fb, int32_t n_filters, int32_t n_freq, co
   p.out_row_stride = n_frames;
   p.store_mode = STORE_FRAMES_INNER;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (n_filters <= 32) return launch_cfg<1, 4, 1, 2, BMODE_PLANAR>(p, s);
-  if (n_filters <= 64) return launch_cfg<1, 4, 2, 2, BMODE_PLANAR>(p, s);
-  return launch_cfg<2, 2, 2, 2, BMODE_PLANAR>(p, s);
+  if (n_filters <= 32) return launch_cfg<1, 4, 1, 2, BMODE_PLANAR, AMODE_ROWS, false>(p, s);
+  if (n_filters <= 64) return launch_cfg<1, 4, 2, 2, BMODE_PLANAR, AMODE_ROWS, false>(p, s);
+  return launch_cfg<2, 2, 2, 2, BMODE_PLANAR, AMODE_ROWS, false>(p, s);
 }
 
 int mispec_fir_decimate_f32(const float *x, int64_t x_clip_stride, int32_t n_clips,
@@ -787,7 +937,7 @@ int mispec_fir_decimate_f32(const float *x, int64_t x_clip_stride, int32_t n_cli
   p.out_row_stride = 0;
   p.store_mode = STORE_ROWS_INNER;
   p.out_len = n_out;
-  return launch_cfg<1, 4, 1, 2, BMODE_FRAMED>(p, static_cast<hipStream_t>(stream));
+  return launch_cfg<1, 4, 1, 2, BMODE_FRAMED, AMODE_TOEPLITZ, false>(p, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

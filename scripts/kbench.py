@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks on the GPU box: per-workload, per-tile timings of the C-ABI calls
+(events on the launch stream).  Usage: python scripts/kbench.py [stft|cqt|mel|cqt2010|fir|all]"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from nnaudio_amd import engine, features  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def timeit(fn, n=10, w=3):
+    for _ in range(w):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def stft():
+    B, L = 64, 441000
+    x = torch.randn(B, L, device=DEV)
+    m = features.STFT(n_fft=2048, hop_length=512, output_format="Magnitude", verbose=False).to(DEV)
+    flops = 2.0 * 2050 * 2048 * B * 862
+    for tile in (1, 4, 7, 8, 9):
+        ms = timeit(lambda: engine.framed_gemm(x, m.wcos, m.wsin, hop=512, pad=1024, pad_mode=2,
+                                               epilogue=engine.EPI_MAGNITUDE, tile=tile))
+        print("stft cfg2 tile %d: %.3f ms  %.1f TF (%.1f%% of 157.3)" % (tile, ms, flops / ms / 1e9, flops / ms / 1e9 / 1.573))
+    for fmt in ("Complex", "Phase"):
+        ms = timeit(lambda: m(x, output_format=fmt))
+        print("stft cfg2 %s: %.3f ms" % (fmt, ms))
+
+
+def mel():
+    B, L = 256, 110250
+    x = torch.randn(B, L, device=DEV)
+    m = features.MelSpectrogram(sr=22050, n_fft=1024, n_mels=128, verbose=False).to(DEV)
+    ms = timeit(lambda: m(x))
+    print("mel cfg3 total: %.3f ms" % ms)
+    ms1 = timeit(lambda: m.stft._spectrum(x[:, None, :], engine.EPI_POWER))
+    sp = m.stft._spectrum(x[:, None, :], engine.EPI_POWER)
+    ms2 = timeit(lambda: engine.filterbank(m.mel_basis, sp))
+    print("   stft-power %.3f ms, filterbank %.3f ms" % (ms1, ms2))
+
+
+def cqt():
+    B, L = 64, 441000
+    x = torch.randn(B, L, device=DEV)
+    m = features.CQT1992v2(sr=44100, hop_length=512, n_bins=84, verbose=False).to(DEV)
+    useful = 2.0 * 2 * float(m.lenghts.sum()) * B * 862
+    dense = 2.0 * 168 * 32768 * B * 862
+    sup = m._support.get(m.cqt_kernels_real, m.cqt_kernels_imag)
+    sc = torch.sqrt(m.lenghts)
+    for tile, s in ((5, sup), (6, sup), (1, sup), (4, sup), (5, None)):
+        ms = timeit(lambda: engine.framed_gemm(x, m.cqt_kernels_real, m.cqt_kernels_imag, hop=512,
+                                               pad=16384, pad_mode=2, epilogue=engine.EPI_MAGNITUDE,
+                                               row_scale=sc, row_support=s, tile=tile), n=5, w=2)
+        print("cqt1992v2 B=64 tile %d support=%s: %.3f ms  useful %.1f TF dense-equiv %.1f TF"
+              % (tile, s is not None, ms, useful / ms / 1e9, dense / ms / 1e9))
+
+
+def cqt2010():
+    B, L = 64, 1323000
+    x = torch.randn(B, L, device=DEV)
+    for cls, kw in ((features.CQT2010v2, {}), (features.VQT, dict(gamma=0))):
+        m = cls(sr=44100, hop_length=512, n_bins=96, verbose=False, **kw).to(DEV)
+        ms = timeit(lambda: m(x), n=5, w=2)
+        print("%s cfg5 shard B=64: %.3f ms" % (cls.__name__, ms))
+    lp = m.lowpass_filter
+    xs = x
+    for o in range(3):
+        ms = timeit(lambda: engine.fir_decimate(xs, lp, 2), n=5, w=2)
+        print("   fir_decimate L=%d: %.3f ms (%.1f GB/s in+out, %.1f TF)" % (
+            xs.shape[-1], ms, (xs.numel() * 6) / ms / 1e6, 2.0 * 256 * xs.numel() / 2 / ms / 1e9))
+        xs = engine.fir_decimate(xs, lp, 2)
+    kr, ki = m.cqt_kernels_real_0, m.cqt_kernels_imag_0
+    ms = timeit(lambda: engine.framed_gemm(x, kr, ki, hop=512, pad=128, pad_mode=2,
+                                           epilogue=engine.EPI_MAGNITUDE), n=5, w=2)
+    print("   top-octave framed gemm (12 bins, K=256, hop 512): %.3f ms" % ms)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["all"]
+    torch.manual_seed(0)
+    for name, fn in (("stft", stft), ("mel", mel), ("cqt", cqt), ("cqt2010", cqt2010)):
+        if "all" in which or name in which:
+            t0 = time.time()
+            fn()
+            torch.cuda.synchronize()
+            print("  [%s done in %.1f s]" % (name, time.time() - t0), flush=True)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MISPEC_ABI_VERSION 1
+#define MISPEC_ABI_VERSION 2
 
 enum {
   MISPEC_OK = 0,
@@ -118,8 +118,20 @@ typedef struct mispec_framed_gemm_args {
   int64_t out_clip_stride;     /* elements                                                 */
   int64_t out_row_stride;      /* elements                                                 */
   int32_t out_row_offset;      /* first output row this call writes (octave row block)     */
-  int32_t reserved;
+  int32_t reserved;            /* must be 0 (benchmark ablation bits)                      */
+
+  void *workspace;             /* device scratch of >= mispec_framed_gemm_workspace_bytes() */
+  int64_t workspace_bytes;     /* bytes; may be NULL/0 when the query returns 0            */
 } mispec_framed_gemm_args;
+
+/*
+ * Scratch the framed contraction needs for this problem: the padded edge spans of every clip
+ * (the handful of frames per clip that touch the virtual padding or run past the clip end are
+ * staged there by a pre-pass so that every frame is a plain run of memory; interior frames are
+ * read straight from x).  Depends only on the sizes in `args`; 0 when every frame is interior
+ * (center=False with kernel % 32 == 0).  Negative = MISPEC_E_*.
+ */
+int64_t mispec_framed_gemm_workspace_bytes(const mispec_framed_gemm_args *args);
 
 /* Launch the MFMA framed contraction.  Replaces stft.py:278-316, cqt.py:740-780,
  * utils.py:498-521 (one call per octave).                                             */
@@ -147,7 +159,12 @@ int mispec_filterbank_f32(const float *fb, int32_t n_filters, int32_t n_freq,
 int mispec_fir_decimate_f32(const float *x, int64_t x_clip_stride, int32_t n_clips,
                             int32_t n_samples, const float *taps, int32_t n_taps,
                             int32_t stride, int32_t pad, float *y, int64_t y_clip_stride,
-                            int32_t n_out, void *stream);
+                            int32_t n_out, void *workspace, int64_t workspace_bytes,
+                            void *stream);
+
+/* Scratch bytes mispec_fir_decimate_f32 needs (zero-padded clip edges); negative = error. */
+int64_t mispec_fir_decimate_workspace_bytes(int32_t n_clips, int32_t n_samples, int32_t n_taps,
+                                            int32_t stride, int32_t pad, int32_t n_out);
 
 /* ABI version of the loaded library (== MISPEC_ABI_VERSION it was built with). */
 int mispec_version(void);

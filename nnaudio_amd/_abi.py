@@ -10,20 +10,23 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmispec.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # enums (mirror include/mispec.h)
 PAD_NONE, PAD_ZERO, PAD_REFLECT = 0, 1, 2
 EPI_COMPLEX, EPI_MAGNITUDE, EPI_POWER, EPI_PHASE_ATAN2, EPI_PHASE_COSSIN, EPI_REAL = range(6)
-TILE_AUTO, TILE_128x128, TILE_32x256, TILE_64x256, TILE_128x128_TALL, TILE_192x128, TILE_256x128 = range(7)
+(TILE_AUTO, TILE_128x128, TILE_32x256, TILE_64x256, TILE_128x128_TALL, TILE_192x128, TILE_256x128,
+ TILE_256x128_SQ, TILE_128x256_SQ, TILE_256x256) = range(10)
 
 EXPORTS = (
     "mispec_version",
     "mispec_last_error",
     "mispec_framed_gemm_f32",
     "mispec_framed_gemm_f32_ref",
+    "mispec_framed_gemm_workspace_bytes",
     "mispec_filterbank_f32",
     "mispec_fir_decimate_f32",
+    "mispec_fir_decimate_workspace_bytes",
 )
 
 
@@ -57,6 +60,8 @@ class FramedGemmArgs(ctypes.Structure):
         ("out_row_stride", ctypes.c_int64),
         ("out_row_offset", ctypes.c_int32),
         ("reserved", ctypes.c_int32),
+        ("workspace", ctypes.c_void_p),
+        ("workspace_bytes", ctypes.c_int64),
     ]
 
 
@@ -88,6 +93,10 @@ def load():
     for fn in (lib.mispec_framed_gemm_f32, lib.mispec_framed_gemm_f32_ref):
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(FramedGemmArgs), ctypes.c_void_p]
+    lib.mispec_framed_gemm_workspace_bytes.restype = ctypes.c_int64
+    lib.mispec_framed_gemm_workspace_bytes.argtypes = [ctypes.POINTER(FramedGemmArgs)]
+    lib.mispec_fir_decimate_workspace_bytes.restype = ctypes.c_int64
+    lib.mispec_fir_decimate_workspace_bytes.argtypes = [ctypes.c_int32] * 6
     lib.mispec_filterbank_f32.restype = ctypes.c_int
     lib.mispec_filterbank_f32.argtypes = [
         ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
@@ -97,7 +106,7 @@ def load():
     lib.mispec_fir_decimate_f32.argtypes = [
         ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
         ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64,
-        ctypes.c_int32, ctypes.c_void_p,
+        ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
     ]
     v = lib.mispec_version()
     if v != ABI_VERSION:

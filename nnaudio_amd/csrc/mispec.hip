@@ -8,14 +8,17 @@
 //
 //   A   = basis rows, interleaved (re, im) per frequency bin           (M = 2*n_bins rows)
 //   Bop = the frame matrix  X(clip, t*hop - pad + k)                   (N = n_clips*n_frames cols)
-//         generated on the fly from the waveform: reflect / zero padding is index
-//         arithmetic inside the loader, frames are never materialised in HBM.
+//         read straight from the waveform: frames are never materialised in HBM.  Only the
+//         few frames per clip that touch the virtual padding (reflect / zero) or run past
+//         the clip are served from a small caller-provided workspace that a pre-pass fills
+//         with the padded edge spans, so that EVERY frame is a contiguous run of memory and
+//         the K loop contains no control flow around its loads.
 //
 // The contraction runs on the matrix cores with v_mfma_f32_32x32x2_f32 (fp32 in, fp32
 // accumulate: bit-for-bit an fmaf chain, so the 1e-4 parity bar is met with ~1e-6),
-// 64-wide wavefronts, 32-deep K stages double-buffered through LDS, and the
-// magnitude / power / phase / complex epilogue applied on the accumulators in
-// registers before a (batch, bin, frame[,2]) store with frames innermost (coalesced).
+// 64-wide wavefronts, 32-deep K stages double-buffered through LDS and software-pipelined
+// two stages ahead in registers, and the magnitude / power / phase / complex epilogue applied
+// to the accumulators before a (batch, bin, frame[,2]) store with frames innermost.
 //
 // Variants of the same template:
 //   * A as a banded Toeplitz matrix of FIR taps  -> strided decimation (utils.py:73-124)
@@ -34,6 +37,9 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+// 4 consecutive floats with only element alignment guaranteed (hop / pad / clip length are
+// arbitrary); the hardware handles dword-aligned 16-byte global loads.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
 constexpr int KC = 32;   // K depth of one LDS stage
 constexpr int LDT = 36;  // LDS row stride in floats: 16-B aligned rows, conflict-free ds_read_b128
@@ -41,6 +47,7 @@ constexpr int LDT = 36;  // LDS row stride in floats: 16-B aligned rows, conflic
 enum { BMODE_FRAMED = 0, BMODE_PLANAR = 1 };
 enum { AMODE_ROWS = 0, AMODE_TOEPLITZ = 1 };
 enum { STORE_FRAMES_INNER = 0, STORE_ROWS_INNER = 1 };
+enum { EDGE_NONE = 0, EDGE_SPANS = 1, EDGE_FULL = 2 };
 
 struct KParams {
   // B operand (signal / planar tensor)
@@ -54,6 +61,13 @@ struct KParams {
   int pad_mode;
   int n_frames;
   long long n_cols;  // n_clips * n_frames
+  // padded edge spans (see EdgePlan)
+  const float *edge;
+  long long edge_clip_stride;
+  int edge_mode;
+  int n_left;   // frames t < n_left start before the signal
+  int t_r0;     // frames t >= t_r0 run past the end of the signal
+  int edge_ll;  // length of the left span (the right span starts there)
   // A operand
   const float *a_re;
   const float *a_im;
@@ -62,7 +76,6 @@ struct KParams {
   int K;
   const int *row_support;
   const float *row_scale;
-  int amode;
   int toep_stride;
   int n_taps;
   // epilogue / output
@@ -74,11 +87,66 @@ struct KParams {
   long long out_clip_stride;
   long long out_row_stride;
   int out_row_offset;
-  int store_mode;
   int out_len;
   int n_tiles_m;
   int n_tiles_n;
+  int n_group;  // frame tiles crossed with all row tiles before advancing (L2 blocking)
+  int debug;    // ablation bits (benchmarking only), see framed_gemm_kernel
 };
+
+// ---------------------------------------------------------------------------------
+// Which frames of a clip are not plain runs of the waveform, and where their padded
+// copies live.  A frame is "interior" when [pos, pos + Kr) lies inside [0, n_samples),
+// Kr = K rounded up to a whole LDS stage (so even the K tail stage reads in bounds).
+//   EDGE_SPANS: per clip [left span | right span]; left span = positions -pad .. of the
+//               first n_left frames, right span = positions of frames t_r0 .. T-1
+//   EDGE_FULL : short clips whose left and right edge frames overlap: the whole virtually
+//               padded clip (what the reference materialises for every clip)
+// ---------------------------------------------------------------------------------
+struct EdgePlan {
+  int mode;
+  int n_left;
+  int t_r0;
+  long long ll;      // floats in the left span
+  long long lr;      // floats in the right span
+  long long stride;  // floats per clip
+};
+
+inline int round_up_kc(int k) { return (k + KC - 1) / KC * KC; }
+
+EdgePlan plan_edges(int n_samples, int kernel, int hop, int pad, int n_frames) {
+  EdgePlan e{};
+  const long long kr = round_up_kc(kernel);
+  const long long T = n_frames;
+  long long n_left = pad > 0 ? ((long long)pad + hop - 1) / hop : 0;
+  if (n_left > T) n_left = T;
+  const long long lim = (long long)n_samples - kr + pad;  // pos_t + kr <= L  <=>  t*hop <= lim
+  long long t_r0 = lim >= 0 ? lim / hop + 1 : 0;
+  if (t_r0 > T) t_r0 = T;
+  if (n_left == 0 && t_r0 == T) {
+    e.mode = EDGE_NONE;
+    e.n_left = 0;
+    e.t_r0 = (int)T;
+    return e;
+  }
+  const long long full = (T - 1) * hop + kr;
+  e.mode = EDGE_SPANS;
+  e.n_left = (int)n_left;
+  e.t_r0 = (int)t_r0;
+  e.ll = n_left > 0 ? (n_left - 1) * hop + kr : 0;
+  e.lr = t_r0 < T ? (T - 1 - t_r0) * hop + kr : 0;
+  e.stride = e.ll + e.lr;
+  if (t_r0 < n_left || e.stride >= full) {
+    // overlapping edge frames, or spans larger than the padded clip itself
+    e.mode = EDGE_FULL;
+    e.n_left = (int)T;
+    e.t_r0 = (int)T;
+    e.ll = full;
+    e.lr = 0;
+    e.stride = full;
+  }
+  return e;
+}
 
 // ---------------------------------------------------------------------------------
 // sample fetch with virtual padding (reflect = nn.ReflectionPad1d: no edge repeat)
@@ -93,6 +161,33 @@ __device__ __forceinline__ float fetch_sample(const float *__restrict__ x, long 
   float v = 0.f;
   if (ok) v = x[base + pp];
   return v;
+}
+
+// Pre-pass: materialise the padded edge spans of every clip (a few frames' worth of samples).
+__global__ void __launch_bounds__(256) edge_fill_kernel(const KParams p, float *__restrict__ ws) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y;
+  if (i >= p.edge_clip_stride) return;
+  long long q;  // signal position of workspace element i
+  if (p.edge_mode == EDGE_FULL || i < p.edge_ll)
+    q = i - p.pad;
+  else
+    q = (long long)p.t_r0 * p.hop - p.pad + (i - p.edge_ll);
+  float v = 0.f;
+  // positions beyond the virtually padded signal only ever meet zero taps / unused columns
+  if (q >= -(long long)p.pad && q < (long long)p.n_samples + p.pad)
+    v = fetch_sample(p.x, (long long)c * p.x_clip_stride, (int)q, p.n_samples, p.pad_mode, true);
+  ws[(long long)c * p.edge_clip_stride + i] = v;
+}
+
+// address of sample position 0 of frame (c, t): a plain run of >= Kr floats
+__device__ __forceinline__ const float *frame_ptr(const KParams &p, int c, int t) {
+  if (p.edge_mode != EDGE_NONE) {
+    const float *e = p.edge + (long long)c * p.edge_clip_stride;
+    if (t < p.n_left) return e + (long long)t * p.hop;
+    if (t >= p.t_r0) return e + p.edge_ll + (long long)(t - p.t_r0) * p.hop;
+  }
+  return p.x + (long long)c * p.x_clip_stride + ((long long)t * p.hop - p.pad);
 }
 
 // ---------------------------------------------------------------------------------
@@ -137,16 +232,16 @@ __device__ __forceinline__ int epilogue_width(int epi) {
   return (epi == MISPEC_EPI_COMPLEX || epi == MISPEC_EPI_PHASE_COSSIN) ? 2 : 1;
 }
 
-// 4 consecutive floats with only element alignment guaranteed (hop / pad / clip length are
-// arbitrary); the hardware handles dword-aligned 16-byte global loads.
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-
 // ---------------------------------------------------------------------------------
-// MFMA kernel.  Workgroup = WM x WN waves; each wave owns MR x NR tiles of 32x32.
+// MFMA kernel.  Workgroup = WM x WN waves (256 threads); each wave owns MR x NR tiles of 32x32.
 //   BM = WM*MR*32 basis rows,  BN = WN*NR*32 frames per workgroup.
-// Loader geometry (256 threads): thread (r32 = tid>>3, c4 = tid&7) moves the 4 consecutive
-// K elements 4*c4.. of row r32 of each 32-row "pass"; a pass of the A tile is one 32-row
-// MFMA tile, a pass of the B tile is 32 consecutive frames.
+// Loader geometry: thread (r32 = tid>>3, c4 = tid&7) moves the 4 consecutive K elements
+// 4*c4.. of row r32 of each 32-row "pass"; a pass of the A tile is one 32-row MFMA tile, a
+// pass of the B tile is 32 consecutive frames.  Every thread keeps one source pointer per pass.
+//
+// debug bits (benchmark ablations; results are wrong when set): 1 no global loads in the
+// loop, 2 no LDS stores, 4 no barrier, 8 no fragment reads, 0x100 / 0x200 force the
+// frame-tile-fastest / L2-blocked tile order.
 // ---------------------------------------------------------------------------------
 template <int WM, int WN, int MR, int NR, int BMODE, int AMODE, bool MASKED>
 __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams p) {
@@ -154,24 +249,23 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
   constexpr int BM = WM * MR * 32;
   constexpr int BN = WN * NR * 32;
   constexpr int MT = WM * MR;
-  constexpr int RPP = NT / 8;  // tile rows covered by one loader pass (4 floats per thread)
-  static_assert(RPP == 32, "loader geometry assumes 256 threads");
-  constexpr int APASS = BM / RPP;
-  constexpr int BPASS = BN / RPP;  // framed mode
+  static_assert(NT == 256, "loader geometry assumes 256 threads");
+  constexpr int APASS = BM / 32;
+  constexpr int BPASS = BN / 32;  // framed mode
   constexpr int A_STAGE = BM * LDT;
   constexpr int B_STAGE = (BMODE == BMODE_FRAMED) ? BN * LDT : KC * BN;
   constexpr int PPASS = KC * BN / NT;  // planar mode: scalar elements per thread
   static_assert(BMODE == BMODE_FRAMED || NT % BN == 0 || BN % NT == 0, "planar loader shape");
   constexpr int STORE_MODE = (AMODE == AMODE_TOEPLITZ) ? STORE_ROWS_INNER : STORE_FRAMES_INNER;
+  // planar loader: which (k row, column) a thread moves in pass ps
+  constexpr int KPP = (NT >= BN) ? NT / BN : 1;
+  constexpr int JPP = (NT >= BN) ? 1 : BN / NT;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float *sA = reinterpret_cast<float *>(smem_raw);
   float *sB = sA + 2 * A_STAGE;
-  long long *sColBase = reinterpret_cast<long long *>(sB + 2 * B_STAGE);
-  long long *sPassBase = sColBase + BN;  // [BPASS] clip offset of a single-clip pass, else -1
-  int *sColPos = reinterpret_cast<int *>(sPassBase + 8);
-  int *sPassPos = sColPos + BN;          // [BPASS] signal position of the pass's first frame
-  int *sTileLo = sPassPos + 8;
+  const float **sColPtr = reinterpret_cast<const float **>(sB + 2 * B_STAGE);  // [BN]
+  int *sTileLo = reinterpret_cast<int *>(sColPtr + BN);
   int *sTileHi = sTileLo + MT;
 
   const int tid = threadIdx.x;
@@ -184,9 +278,9 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
   const int r32 = tid >> 3;  // loader row inside a pass
   const int c4 = tid & 7;    // loader K offset / 4
 
-  // ---- XCD-aware tile order: workgroup b runs on XCD b % 8; give every XCD a contiguous
-  // range of tiles with the frame-tile index fastest, so the basis rows an XCD streams
-  // stay resident in its private L2 while the waveform is streamed through.
+  // ---- XCD-aware tile order.  Workgroup b runs on XCD b % 8 (observed; only speed depends on
+  // it) and every XCD has a private 4 MiB L2.  Each XCD gets a contiguous range of a linear
+  // tile order in which `n_group` consecutive frame tiles are crossed with all row tiles.
   int tile;
   {
     const int nwg = gridDim.x;
@@ -195,45 +289,37 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
     const int xcd = b & 7, idx = b >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tile_m = tile / p.n_tiles_n;
-  const int tile_n = tile - tile_m * p.n_tiles_n;
+  int tile_m, tile_n;
+  {
+    const int G = p.n_group;
+    const int per_group = G * p.n_tiles_m;
+    const int full = (p.n_tiles_n / G) * per_group;
+    if (tile < full) {
+      const int g = tile / per_group;
+      const int rest = tile - g * per_group;
+      tile_m = rest / G;
+      tile_n = g * G + (rest - tile_m * G);
+    } else {
+      const int Gt = p.n_tiles_n % G;  // > 0 here
+      const int rest = tile - full;
+      tile_m = rest / Gt;
+      tile_n = (p.n_tiles_n / G) * G + (rest - tile_m * Gt);
+    }
+  }
   const int m0 = tile_m * BM;
   const long long n0 = (long long)tile_n * BN;
 
   const bool cplx = (AMODE == AMODE_ROWS) && p.a_im != nullptr;
   const int rpb = cplx ? 2 : 1;
 
-  // ---- per-column (frame) tables, per-pass fast-path descriptors, per-row-tile K ranges
+  // ---- per-column source pointers and per-row-tile K ranges
   for (int j = tid; j < BN; j += NT) {
-    const long long col = n0 + j;
-    long long base = -1;
-    int pos = 0;
-    if (col < p.n_cols) {
-      const int c = (int)(col / p.n_frames);
-      const int t = (int)(col - (long long)c * p.n_frames);
-      if (BMODE == BMODE_FRAMED) {
-        base = (long long)c * p.x_clip_stride;
-        pos = t * p.hop - p.pad;
-      } else {
-        base = (long long)c * p.x_clip_stride + t;
-      }
-    }
-    sColBase[j] = base;
-    sColPos[j] = pos;
-  }
-  if (BMODE == BMODE_FRAMED && tid < BPASS) {
-    const long long c0 = n0 + tid * 32, c1 = c0 + 31;
-    long long base = -1;
-    int pos = 0;
-    if (c1 < p.n_cols) {
-      const int ca = (int)(c0 / p.n_frames), cb = (int)(c1 / p.n_frames);
-      if (ca == cb) {
-        base = (long long)ca * p.x_clip_stride;
-        pos = (int)(c0 - (long long)ca * p.n_frames) * p.hop - p.pad;
-      }
-    }
-    sPassBase[tid] = base;
-    sPassPos[tid] = pos;
+    long long col = n0 + j;
+    if (col >= p.n_cols) col = 0;  // unused column: any valid frame, its results are not stored
+    const int c = (int)(col / p.n_frames);
+    const int t = (int)(col - (long long)c * p.n_frames);
+    sColPtr[j] = (BMODE == BMODE_FRAMED) ? frame_ptr(p, c, t)
+                                         : p.x + (long long)c * p.x_clip_stride + t;
   }
   if (tid < MT) {
     const int row_lo = m0 + tid * 32;
@@ -281,10 +367,14 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
     }
   }
   kb = kb & ~(KC - 1);
-  const int nchunks = ke > kb ? (ke - kb + KC - 1) / KC : 0;
+  const int nstages = ke > kb ? (ke - kb + KC - 1) / KC : 0;
+  // stages whose whole K range lies inside the basis rows can use 16-byte A loads; the one
+  // possible K-tail stage (K % 32 != 0) is peeled out of the pipelined loop
+  const bool a_tail = (AMODE == AMODE_ROWS) && nstages > 0 && (kb + nstages * KC > p.K);
+  const int nloop = a_tail ? nstages - 1 : nstages;
 
   // which of the workgroup's row tiles intersect K stage [kc, kc+KC)
-  auto stage_mask = [&](int kc) -> unsigned {
+  auto stage_mask = [&](int kc) __attribute__((always_inline)) -> unsigned {
     if (!MASKED) return (1u << MT) - 1u;
     unsigned m = 0;
 #pragma unroll
@@ -305,146 +395,72 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
       aptr[ps] = src + (long long)bin * p.a_row_stride + 4 * c4;
     }
   }
-  const float *bptr[BPASS];
-  int pass_ok[BPASS];   // wave-uniform: the pass's 32 frames lie in one clip
-  int pass_pos[BPASS];  // wave-uniform: signal position of the pass's first frame
+  const float *bptr[(BMODE == BMODE_FRAMED) ? BPASS : PPASS];
   if (BMODE == BMODE_FRAMED) {
 #pragma unroll
-    for (int ps = 0; ps < BPASS; ++ps) {
-      const long long pb = sPassBase[ps];
-      const int pp = sPassPos[ps];
-      pass_ok[ps] = __builtin_amdgcn_readfirstlane(pb >= 0 ? 1 : 0);
-      pass_pos[ps] = __builtin_amdgcn_readfirstlane(pp);
-      bptr[ps] = p.x + (pb < 0 ? 0 : pb) + pp + (long long)r32 * p.hop + 4 * c4;
-    }
-  }
-
-  // K stages [plain_lo, plain_hi] (multiples of KC) can be loaded with unpredicated 16-byte
-  // loads for every pass of both tiles: all frames of every pass in one clip, inside the signal
-  int plain_lo = 0x7fffffff, plain_hi = -1;
-  if (AMODE == AMODE_ROWS && BMODE == BMODE_FRAMED) {
-    long long lo = 0, hi = (long long)p.K - KC;
-    bool ok = true;
+    for (int ps = 0; ps < BPASS; ++ps) bptr[ps] = sColPtr[ps * 32 + r32] + 4 * c4;
+  } else {
 #pragma unroll
-    for (int ps = 0; ps < BPASS; ++ps) {
-      ok = ok && pass_ok[ps];
-      const long long a = -(long long)pass_pos[ps];
-      const long long b = (long long)p.n_samples - KC - pass_pos[ps] - 31LL * p.hop;
-      lo = a > lo ? a : lo;
-      hi = b < hi ? b : hi;
-    }
-    if (ok && hi >= lo) {
-      plain_lo = (int)lo;
-      plain_hi = (int)hi;
+    for (int ps = 0; ps < PPASS; ++ps) {
+      const int j = (NT >= BN) ? tid % BN : (ps % JPP) * NT + tid;
+      bptr[ps] = sColPtr[j];
     }
   }
 
   f32x4v ra[APASS];
   f32x4v rb[(BMODE == BMODE_FRAMED) ? BPASS : 1];
   float rp[(BMODE == BMODE_PLANAR) ? PPASS : 1];
+  unsigned toep_bits = 0;  // Toeplitz A: which of the 4*APASS loaded taps are inside the band
 
-  auto stage_is_plain = [&](int kc, unsigned amask) -> bool {
-    bool ok = kc >= plain_lo && kc <= plain_hi;
-    if (MASKED) ok = ok && (amask == ((1u << MT) - 1u));
-    return ok;
-  };
-
-  auto load_stage = [&](int kc, unsigned amask) {
-    if (stage_is_plain(kc, amask)) {
-#pragma unroll
-      for (int ps = 0; ps < APASS; ++ps)
-        ra[ps] = *reinterpret_cast<const f32x4u *>(aptr[ps] + kc);
+  // ---- stage loads: no control flow, every address is valid memory by construction
+  auto load_b = [&](int kc) __attribute__((always_inline)) {
+    if (BMODE == BMODE_FRAMED) {
 #pragma unroll
       for (int ps = 0; ps < BPASS; ++ps)
         rb[ps] = *reinterpret_cast<const f32x4u *>(bptr[ps] + kc);
-      return;
-    }
-    const int k = kc + 4 * c4;
-    const bool full_k = (kc + KC) <= p.K;  // uniform
-    // ---------------- A tile
-#pragma unroll
-    for (int ps = 0; ps < APASS; ++ps) {
-      f32x4v v = {0.f, 0.f, 0.f, 0.f};
-      if ((amask >> ps) & 1u) {
-        if (AMODE == AMODE_ROWS) {
-          if (full_k) {
-            v = *reinterpret_cast<const f32x4u *>(aptr[ps] + kc);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const bool ok = (k + e) < p.K;
-              const float t = (aptr[ps] - 4 * c4)[ok ? k + e : 0];  // clamp into the row
-              v[e] = ok ? t : 0.f;
-            }
-          }
-        } else {
-          const int row = m0 + ps * 32 + r32;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int tap = k + e - p.toep_stride * row;
-            const bool ok = tap >= 0 && tap < p.n_taps && row < p.n_bins && (k + e) < p.K;
-            const float t = p.a_re[ok ? tap : 0];
-            v[e] = ok ? t : 0.f;
-          }
-        }
-      }
-      ra[ps] = v;
-    }
-    // ---------------- B tile
-    if (BMODE == BMODE_FRAMED) {
-#pragma unroll
-      for (int ps = 0; ps < BPASS; ++ps) {
-        // per-pass fast path: the pass's 32 frames lie in one clip and this K stage of all of
-        // them is inside the signal -> one unpredicated 16-byte load
-        const int pf = pass_pos[ps];
-        const bool fast = pass_ok[ps] && full_k && (pf + kc >= 0) &&
-                          ((long long)pf + 31LL * p.hop + kc + KC <= (long long)p.n_samples);
-        if (fast) {
-          rb[ps] = *reinterpret_cast<const f32x4u *>(bptr[ps] + kc);
-        } else {
-          const int j = ps * 32 + r32;
-          const long long base = sColBase[j];
-          const int pos = sColPos[j];
-          f32x4v v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            int pp = pos + k + e;
-            if (p.pad_mode == MISPEC_PAD_REFLECT) {
-              pp = pp < 0 ? -pp : pp;
-              pp = pp >= p.n_samples ? 2 * p.n_samples - 2 - pp : pp;
-            }
-            const bool ok = base >= 0 && (k + e) < p.K && pp >= 0 && pp < p.n_samples;
-            const float t = p.x[ok ? base + pp : 0];
-            v[e] = ok ? t : 0.f;
-          }
-          rb[ps] = v;
-        }
-      }
     } else {
-      constexpr int KPP = (NT >= BN) ? NT / BN : 1;  // k rows per pass
-      constexpr int JPP = (NT >= BN) ? 1 : BN / NT;  // column groups per k row
 #pragma unroll
       for (int ps = 0; ps < PPASS; ++ps) {
-        int kl, j;
-        if (NT >= BN) {
-          kl = ps * KPP + tid / BN;
-          j = tid % BN;
-        } else {
-          kl = ps / JPP;
-          j = (ps % JPP) * NT + tid;
-        }
-        const int kk = kc + kl;
-        const long long base = sColBase[j];
-        const bool ok = base >= 0 && kk < p.K;
-        const float t = p.x[ok ? base + (long long)kk * p.x_k_stride : 0];
-        rp[ps] = ok ? t : 0.f;
+        const int kl = (NT >= BN) ? ps * KPP + tid / BN : ps / JPP;
+        int kk = kc + kl;
+        kk = kk < p.K ? kk : p.K - 1;  // K tail: any finite value, the A side is zero there
+        rp[ps] = bptr[ps][(long long)kk * p.x_k_stride];
       }
     }
   };
-
-  auto store_stage = [&](int buf) {
+  auto load_a = [&](int kc) __attribute__((always_inline)) {
+    if (AMODE == AMODE_ROWS) {
+#pragma unroll
+      for (int ps = 0; ps < APASS; ++ps)
+        ra[ps] = *reinterpret_cast<const f32x4u *>(aptr[ps] + kc);
+    } else {
+      // banded Toeplitz matrix of the FIR taps: A[row, k] = taps[k - stride*row]
+      const int k = kc + 4 * c4;
+      unsigned bits = 0;
+#pragma unroll
+      for (int ps = 0; ps < APASS; ++ps) {
+        const int row = m0 + ps * 32 + r32;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int tap = k + e - p.toep_stride * row;
+          const bool ok = tap >= 0 && tap < p.n_taps && row < p.n_bins && (k + e) < p.K;
+          ra[ps][e] = p.a_re[ok ? tap : 0];
+          bits |= (ok ? 1u : 0u) << (4 * ps + e);
+        }
+      }
+      toep_bits = bits;
+    }
+  };
+  auto store_stage = [&](int buf) __attribute__((always_inline)) {
     float *a = sA + buf * A_STAGE;
     float *b = sB + buf * B_STAGE;
+    if (AMODE == AMODE_TOEPLITZ) {
+#pragma unroll
+      for (int ps = 0; ps < APASS; ++ps)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          ra[ps][e] = ((toep_bits >> (4 * ps + e)) & 1u) ? ra[ps][e] : 0.f;
+    }
 #pragma unroll
     for (int ps = 0; ps < APASS; ++ps)
       *reinterpret_cast<f32x4v *>(a + (ps * 32 + r32) * LDT + 4 * c4) = ra[ps];
@@ -453,18 +469,10 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
       for (int ps = 0; ps < BPASS; ++ps)
         *reinterpret_cast<f32x4v *>(b + (ps * 32 + r32) * LDT + 4 * c4) = rb[ps];
     } else {
-      constexpr int KPP = (NT >= BN) ? NT / BN : 1;
-      constexpr int JPP = (NT >= BN) ? 1 : BN / NT;
 #pragma unroll
       for (int ps = 0; ps < PPASS; ++ps) {
-        int kl, j;
-        if (NT >= BN) {
-          kl = ps * KPP + tid / BN;
-          j = tid % BN;
-        } else {
-          kl = ps / JPP;
-          j = (ps % JPP) * NT + tid;
-        }
+        const int kl = (NT >= BN) ? ps * KPP + tid / BN : ps / JPP;
+        const int j = (NT >= BN) ? tid % BN : (ps % JPP) * NT + tid;
         b[kl * BN + j] = rp[ps];
       }
     }
@@ -478,68 +486,106 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
 
-  if (nchunks > 0) {
-    unsigned mask_cur = stage_mask(kb);
-    load_stage(kb, mask_cur);
-    store_stage(0);
-    __syncthreads();
-
-    for (int c = 0; c < nchunks; ++c) {
-      const int buf = c & 1;
-      const int kc_next = kb + (c + 1) * KC;
-      const bool more = (c + 1) < nchunks;
-      unsigned mask_next = 0;
-      if (more) {
-        mask_next = stage_mask(kc_next);
-        load_stage(kc_next, mask_next);  // global loads in flight under the MFMAs below
-      }
-
-      const float *a_base = sA + buf * A_STAGE + ((wm * MR) * 32 + li) * LDT + 4 * lh;
-      const float *b_base;
-      if (BMODE == BMODE_FRAMED)
-        b_base = sB + buf * B_STAGE + ((wn * NR) * 32 + li) * LDT + 4 * lh;
-      else
-        b_base = sB + buf * B_STAGE + (4 * lh) * BN + (wn * NR) * 32 + li;
-      const unsigned wmask = MASKED ? (mask_cur >> (wm * MR)) : ~0u;
-
-      // fragments of K group q (8 K elements): lane (li, lh) holds k = 8q + 4lh + s for MFMA s
-      f32x4v av[2][MR], bv[2][NR];
-      auto load_frags = [&](int q, int slot) {
+  // One K stage out of LDS buffer `buf`: 4 K groups of 8; lane (li, lh) supplies k = 8q+4lh+s to
+  // MFMA s of group q.  `mid0` / `mid1` run after groups 0 / 1 (LDS stores of the next stage and
+  // global loads of the one after), i.e. inside the MFMA stream.
+  auto mfma_stage = [&](int buf, unsigned mask, bool frags, auto &&mid0,
+                        auto &&mid1) __attribute__((always_inline)) {
+    const float *a_base = sA + buf * A_STAGE + ((wm * MR) * 32 + li) * LDT + 4 * lh;
+    const float *b_base;
+    if (BMODE == BMODE_FRAMED)
+      b_base = sB + buf * B_STAGE + ((wn * NR) * 32 + li) * LDT + 4 * lh;
+    else
+      b_base = sB + buf * B_STAGE + (4 * lh) * BN + (wn * NR) * 32 + li;
+    const unsigned wmask = MASKED ? (mask >> (wm * MR)) : ~0u;
+    f32x4v av[2][MR], bv[2][NR];
+    auto load_frags = [&](int q, int slot) __attribute__((always_inline)) {
 #pragma unroll
-        for (int m = 0; m < MR; ++m)
-          av[slot][m] = *reinterpret_cast<const f32x4v *>(a_base + m * 32 * LDT + 8 * q);
+      for (int m = 0; m < MR; ++m)
+        av[slot][m] = *reinterpret_cast<const f32x4v *>(a_base + m * 32 * LDT + 8 * q);
 #pragma unroll
-        for (int n = 0; n < NR; ++n) {
-          if (BMODE == BMODE_FRAMED) {
-            bv[slot][n] = *reinterpret_cast<const f32x4v *>(b_base + n * 32 * LDT + 8 * q);
-          } else {
+      for (int n = 0; n < NR; ++n) {
+        if (BMODE == BMODE_FRAMED) {
+          bv[slot][n] = *reinterpret_cast<const f32x4v *>(b_base + n * 32 * LDT + 8 * q);
+        } else {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) bv[slot][n][s] = b_base[(8 * q + s) * BN + n * 32];
-          }
+          for (int s = 0; s < 4; ++s) bv[slot][n][s] = b_base[(8 * q + s) * BN + n * 32];
         }
-      };
-      load_frags(0, 0);
+      }
+    };
+    if (frags) load_frags(0, 0);
 #pragma unroll
-      for (int q = 0; q < KC / 8; ++q) {
-        if (q + 1 < KC / 8) load_frags(q + 1, (q + 1) & 1);  // prefetch under this group's MFMAs
+    for (int q = 0; q < KC / 8; ++q) {
+      if (q + 1 < KC / 8 && frags) load_frags(q + 1, (q + 1) & 1);  // prefetch under the MFMAs
 #pragma unroll
-        for (int m = 0; m < MR; ++m) {
-          if (!MASKED || ((wmask >> m) & 1u)) {
+      for (int m = 0; m < MR; ++m) {
+        if (!MASKED || ((wmask >> m) & 1u)) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+          for (int s = 0; s < 4; ++s) {
 #pragma unroll
-              for (int n = 0; n < NR; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q & 1][m][s], bv[q & 1][n][s],
-                                                                 acc[m][n], 0, 0, 0);
-            }
+            for (int n = 0; n < NR; ++n)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q & 1][m][s], bv[q & 1][n][s],
+                                                               acc[m][n], 0, 0, 0);
           }
         }
       }
-
-      if (more) store_stage(buf ^ 1);
-      mask_cur = mask_next;
-      __syncthreads();
+      if (q == 0) mid0();
+      if (q == 1) mid1();
     }
+  };
+
+  // ---- software pipeline over the nloop full stages (stage c covers K [kb + c*KC, +KC)):
+  //   LDS holds stage c (being multiplied) and receives stage c+1 during the same iteration;
+  //   registers hold stage c+1 until it is written, then receive stage c+2.
+  if (nloop > 0) {
+    load_a(kb);
+    load_b(kb);
+    store_stage(0);
+    if (nloop > 1) {
+      load_a(kb + KC);
+      load_b(kb + KC);
+    }
+    __syncthreads();
+    for (int c = 0; c < nloop; ++c) {
+      const int buf = c & 1;
+      const bool has1 = (c + 1) < nloop;
+      const bool has2 = (c + 2) < nloop;
+      mfma_stage(
+          buf, stage_mask(kb + c * KC), !(p.debug & 8) || c == 0,
+          [&]() __attribute__((always_inline)) {
+            if (has1 && !(p.debug & 2)) store_stage(buf ^ 1);  // stage c+1: registers -> LDS
+          },
+          [&]() __attribute__((always_inline)) {
+            if (has2 && !(p.debug & 1)) {  // stage c+2: HBM/L2 -> registers
+              load_a(kb + (c + 2) * KC);
+              load_b(kb + (c + 2) * KC);
+            }
+          });
+      if (!(p.debug & 4)) __syncthreads();
+    }
+  }
+  // ---- peeled K-tail stage (only when K is not a multiple of 32): element-wise clamped A loads
+  if (a_tail) {
+    const int kc = kb + nloop * KC;
+    const int k = kc + 4 * c4;
+    if (AMODE == AMODE_ROWS) {
+#pragma unroll
+      for (int ps = 0; ps < APASS; ++ps) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool ok = (k + e) < p.K;
+          const float t = (aptr[ps] - 4 * c4)[ok ? k + e : 0];
+          ra[ps][e] = ok ? t : 0.f;
+        }
+      }
+    }
+    load_b(kc);  // in bounds by construction (frames are runs of >= Kr floats)
+    const int buf = nloop & 1;
+    store_stage(buf);
+    __syncthreads();
+    mfma_stage(
+        buf, stage_mask(kc), true, [&]() __attribute__((always_inline)) {},
+        [&]() __attribute__((always_inline)) {});
   }
 
   // ---- epilogue.  Accumulator element e of lane (li, lh) is D[row = (e&3) + 8*(e>>2) + 4*lh][col = li].
@@ -566,8 +612,8 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
     }
     __syncthreads();
     const int tm = ti / NR, tn = ti - tm * NR;
-    const int row_base = m0 + (wm * MR + tm) * 32;           // first basis row of this tile
-    const long long col_base = n0 + (wn * NR + tn) * 32;     // first frame column of this tile
+    const int row_base = m0 + (wm * MR + tm) * 32;        // first basis row of this tile
+    const long long col_base = n0 + (wn * NR + tn) * 32;  // first frame column of this tile
     if (STORE_MODE == STORE_ROWS_INNER) {
       // lane = row (output sample within the 32-block), iterate over the tile's 32 frames
       const int row = row_base + li;
@@ -681,14 +727,26 @@ int launch_cfg(KParams p, hipStream_t stream) {
   constexpr int MT = WM * MR;
   constexpr int A_STAGE = BM * LDT;
   constexpr int B_STAGE = (BMODE == BMODE_FRAMED) ? BN * LDT : KC * BN;
-  constexpr size_t smem = sizeof(float) * 2 * (A_STAGE + B_STAGE) + sizeof(long long) * (BN + 8) +
-                          sizeof(int) * (BN + 8) + sizeof(int) * 2 * MT;
+  constexpr size_t smem = sizeof(float) * 2 * (A_STAGE + B_STAGE) + sizeof(const float *) * BN +
+                          sizeof(int) * 2 * MT;
 
-  const int rows = p.amode == AMODE_TOEPLITZ ? p.n_bins : p.n_bins * (p.a_im ? 2 : 1);
+  const int rows = AMODE == AMODE_TOEPLITZ ? p.n_bins : p.n_bins * (p.a_im ? 2 : 1);
   p.n_tiles_m = (rows + BM - 1) / BM;
   const long long tn = (p.n_cols + BN - 1) / BN;
   if (tn * p.n_tiles_m > 0x7fffffffLL) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
   p.n_tiles_n = (int)tn;
+  {
+    // ~64 workgroups are resident per XCD (32 CUs x 2).  A group of n_group frame tiles is
+    // crossed with all row tiles before the order advances.  Measured on the STFT shape the
+    // frame-tile-fastest order (basis rows L2-resident, waveform streamed) is the faster one
+    // once there are many row tiles; the blocked order wins when there are only a few.
+    int g = p.n_tiles_m >= 8 ? (1 << 20) : (64 + p.n_tiles_m / 2) / p.n_tiles_m;
+    if (p.debug & 0x100) g = 1 << 20;
+    if (p.debug & 0x200) g = (64 + p.n_tiles_m / 2) / p.n_tiles_m;
+    if (g < 1) g = 1;
+    if (g > p.n_tiles_n) g = p.n_tiles_n;
+    p.n_group = g;
+  }
 
   auto kern = framed_gemm_kernel<WM, WN, MR, NR, BMODE, AMODE, MASKED>;
   // opt in to > 64 KiB of dynamic LDS once per (kernel, device)
@@ -746,13 +804,9 @@ int launch_tile(const KParams &p, int tile, hipStream_t stream) {
 int auto_tile(int rows, bool support) {
   if (rows <= 32) return MISPEC_TILE_32x256;
   if (rows <= 64) return MISPEC_TILE_64x256;
-  if (support) {
-    // support-aware: every wave owns all row tiles of the workgroup so skipped
-    // K stages shorten the whole workgroup instead of idling some waves
-    if (rows <= 128) return MISPEC_TILE_128x128_TALL;
-    if (rows <= 192) return MISPEC_TILE_192x128;
-    return MISPEC_TILE_256x128;
-  }
+  // support-aware: every wave owns all 4 row tiles of the workgroup, so skipped K stages
+  // shorten the whole workgroup instead of idling some of its waves
+  if (support) return MISPEC_TILE_128x128_TALL;
   return MISPEC_TILE_128x128;
 }
 
@@ -760,7 +814,8 @@ int launch_framed(const KParams &p, int tile, hipStream_t stream) {
   const int rpb = p.a_im ? 2 : 1;
   const int rows = p.n_bins * rpb;
   if (tile != MISPEC_TILE_AUTO) return launch_tile(p, tile, stream);
-  if (p.row_support || rows <= 128) return launch_tile(p, auto_tile(rows, p.row_support != nullptr), stream);
+  if (p.row_support || rows <= 128)
+    return launch_tile(p, auto_tile(rows, p.row_support != nullptr), stream);
   // dense basis, many rows: full 128-row workgroups run the unmasked kernel; the leftover
   // rows (e.g. the Nyquist bin of an n_fft/2+1 STFT) go to a second, narrow launch instead
   // of a 17th mostly-empty row block.
@@ -779,6 +834,31 @@ int launch_framed(const KParams &p, int tile, hipStream_t stream) {
   if (p.row_scale) q.row_scale = p.row_scale + main_bins;
   q.out_row_offset = p.out_row_offset + main_bins;
   return launch_tile(q, auto_tile(rem * rpb, false), stream);
+}
+
+// attach the edge workspace to p and enqueue the fill pre-pass
+int setup_edges(KParams &p, void *workspace, long long workspace_bytes, hipStream_t stream) {
+  const EdgePlan e = plan_edges(p.n_samples, p.K, p.hop, p.pad, p.n_frames);
+  p.edge_mode = e.mode;
+  p.n_left = e.n_left;
+  p.t_r0 = e.t_r0;
+  p.edge_ll = (int)e.ll;
+  p.edge_clip_stride = e.stride;
+  p.edge = nullptr;
+  if (e.mode == EDGE_NONE) return MISPEC_OK;
+  if (e.ll > 0x7fffffffLL || e.stride > 0x7fffffffLL)
+    return fail(MISPEC_E_UNSUPPORTED, "edge span overflows int32%s");
+  const long long need = e.stride * p.n_clips * (long long)sizeof(float);
+  if (!workspace || workspace_bytes < need)
+    return fail(MISPEC_E_INVALID,
+                "workspace too small: size it with the *_workspace_bytes query%s");
+  p.edge = static_cast<const float *>(workspace);
+  const unsigned gx = (unsigned)((e.stride + 255) / 256);
+  hipLaunchKernelGGL(edge_fill_kernel, dim3(gx, (unsigned)p.n_clips), dim3(256), 0, stream, p,
+                     static_cast<float *>(workspace));
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail(MISPEC_E_HIP, "edge fill launch: %s", hipGetErrorString(err));
+  return MISPEC_OK;
 }
 
 int fill_params(const mispec_framed_gemm_args *a, KParams &p) {
@@ -803,7 +883,7 @@ int fill_params(const mispec_framed_gemm_args *a, KParams &p) {
   const long long last_end = (long long)(a->n_frames - 1) * a->hop - a->pad + a->kernel;
   if (last_end > (long long)a->n_samples + a->pad)
     return fail(MISPEC_E_INVALID, "n_frames overruns the padded signal%s");
-  if ((long long)(a->n_frames - 1) * a->hop + a->kernel > 0x7fffffffLL)
+  if ((long long)(a->n_frames - 1) * a->hop + a->kernel + KC > 0x7fffffffLL)
     return fail(MISPEC_E_UNSUPPORTED, "signal position overflows int32%s");
 
   memset(&p, 0, sizeof(p));
@@ -823,7 +903,6 @@ int fill_params(const mispec_framed_gemm_args *a, KParams &p) {
   p.K = a->kernel;
   p.row_support = a->row_support;
   p.row_scale = a->row_scale;
-  p.amode = AMODE_ROWS;
   p.epilogue = a->epilogue;
   p.im_sign = a->im_sign;
   p.eps = a->eps;
@@ -832,7 +911,44 @@ int fill_params(const mispec_framed_gemm_args *a, KParams &p) {
   p.out_clip_stride = a->out_clip_stride;
   p.out_row_stride = a->out_row_stride;
   p.out_row_offset = a->out_row_offset;
-  p.store_mode = STORE_FRAMES_INNER;
+  p.debug = a->reserved;
+  return MISPEC_OK;
+}
+
+// 32 consecutive outputs form one "frame" of the Toeplitz contraction:
+//   y[32 q + r] = sum_m x[32*stride*q + m - pad] * taps[m - stride*r],  m < n_taps + 31*stride
+int fir_params(KParams &p, const float *x, int64_t x_clip_stride, int32_t n_clips,
+               int32_t n_samples, const float *taps, int32_t n_taps, int32_t stride, int32_t pad,
+               float *y, int64_t y_clip_stride, int32_t n_out) {
+  if (n_clips <= 0 || n_samples <= 0 || n_taps <= 0 || stride <= 0 || pad < 0 || n_out <= 0)
+    return fail(MISPEC_E_INVALID, "non-positive size%s");
+  const long long span = (long long)n_samples + 2LL * pad - n_taps;
+  if (span < 0 || (long long)n_out != span / stride + 1)
+    return fail(MISPEC_E_INVALID, "n_out != (n_samples + 2*pad - n_taps)/stride + 1%s");
+  if ((long long)n_out * stride + n_taps + 64LL * stride > 0x7fffffffLL)
+    return fail(MISPEC_E_UNSUPPORTED, "signal position overflows int32%s");
+  memset(&p, 0, sizeof(p));
+  p.x = x;
+  p.x_clip_stride = x_clip_stride;
+  p.n_clips = n_clips;
+  p.n_samples = n_samples;
+  p.hop = 32 * stride;
+  p.pad = pad;
+  p.pad_mode = MISPEC_PAD_ZERO;
+  p.n_frames = (n_out + 31) / 32;
+  p.n_cols = (long long)n_clips * p.n_frames;
+  p.a_re = taps;
+  p.a_im = nullptr;
+  p.n_bins = 32;
+  p.K = n_taps + 31 * stride;
+  p.toep_stride = stride;
+  p.n_taps = n_taps;
+  p.epilogue = MISPEC_EPI_REAL;
+  p.im_sign = 1.f;
+  p.out = y;
+  p.out_clip_stride = y_clip_stride;
+  p.out_row_stride = 0;
+  p.out_len = n_out;
   return MISPEC_OK;
 }
 
@@ -844,11 +960,22 @@ int mispec_version(void) { return MISPEC_ABI_VERSION; }
 
 const char *mispec_last_error(void) { return g_err; }
 
+int64_t mispec_framed_gemm_workspace_bytes(const mispec_framed_gemm_args *args) {
+  KParams p;
+  int rc = fill_params(args, p);
+  if (rc != MISPEC_OK) return rc;
+  const EdgePlan e = plan_edges(p.n_samples, p.K, p.hop, p.pad, p.n_frames);
+  return e.stride * p.n_clips * (int64_t)sizeof(float);
+}
+
 int mispec_framed_gemm_f32(const mispec_framed_gemm_args *args, void *stream) {
   KParams p;
   int rc = fill_params(args, p);
   if (rc != MISPEC_OK) return rc;
-  return launch_framed(p, args->tile, static_cast<hipStream_t>(stream));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  rc = setup_edges(p, args->workspace, args->workspace_bytes, s);
+  if (rc != MISPEC_OK) return rc;
+  return launch_framed(p, args->tile, s);
 }
 
 int mispec_framed_gemm_f32_ref(const mispec_framed_gemm_args *args, void *stream) {
@@ -885,59 +1012,40 @@ int mispec_filterbank_f32(const float *fb, int32_t n_filters, int32_t n_freq, co
   p.a_row_stride = n_freq;
   p.n_bins = n_filters;
   p.K = n_freq;
-  p.amode = AMODE_ROWS;
   p.epilogue = MISPEC_EPI_REAL;
   p.im_sign = 1.f;
   p.out = out;
   p.out_clip_stride = (long long)n_filters * n_frames;
   p.out_row_stride = n_frames;
-  p.store_mode = STORE_FRAMES_INNER;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (n_filters <= 32) return launch_cfg<1, 4, 1, 2, BMODE_PLANAR, AMODE_ROWS, false>(p, s);
   if (n_filters <= 64) return launch_cfg<1, 4, 2, 2, BMODE_PLANAR, AMODE_ROWS, false>(p, s);
   return launch_cfg<2, 2, 2, 2, BMODE_PLANAR, AMODE_ROWS, false>(p, s);
 }
 
+int64_t mispec_fir_decimate_workspace_bytes(int32_t n_clips, int32_t n_samples, int32_t n_taps,
+                                            int32_t stride, int32_t pad, int32_t n_out) {
+  KParams p;
+  int rc = fir_params(p, nullptr, 0, n_clips, n_samples, nullptr, n_taps, stride, pad, nullptr, 0,
+                      n_out);
+  if (rc != MISPEC_OK) return rc;
+  const EdgePlan e = plan_edges(p.n_samples, p.K, p.hop, p.pad, p.n_frames);
+  return e.stride * p.n_clips * (int64_t)sizeof(float);
+}
+
 int mispec_fir_decimate_f32(const float *x, int64_t x_clip_stride, int32_t n_clips,
                             int32_t n_samples, const float *taps, int32_t n_taps, int32_t stride,
                             int32_t pad, float *y, int64_t y_clip_stride, int32_t n_out,
-                            void *stream) {
+                            void *workspace, int64_t workspace_bytes, void *stream) {
   if (!x || !taps || !y) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
-  if (n_clips <= 0 || n_samples <= 0 || n_taps <= 0 || stride <= 0 || pad < 0 || n_out <= 0)
-    return fail(MISPEC_E_INVALID, "non-positive size%s");
-  const long long span = (long long)n_samples + 2LL * pad - n_taps;
-  if (span < 0 || (long long)n_out != span / stride + 1)
-    return fail(MISPEC_E_INVALID, "n_out != (n_samples + 2*pad - n_taps)/stride + 1%s");
-  if ((long long)n_out * stride + n_taps > 0x7fffffffLL)
-    return fail(MISPEC_E_UNSUPPORTED, "signal position overflows int32%s");
-  // 32 consecutive outputs form one "frame" of the Toeplitz contraction:
-  //   y[32 q + r] = sum_m x[32*stride*q + m - pad] * taps[m - stride*r],  m < n_taps + 31*stride
   KParams p;
-  memset(&p, 0, sizeof(p));
-  p.x = x;
-  p.x_clip_stride = x_clip_stride;
-  p.n_clips = n_clips;
-  p.n_samples = n_samples;
-  p.hop = 32 * stride;
-  p.pad = pad;
-  p.pad_mode = MISPEC_PAD_ZERO;
-  p.n_frames = (n_out + 31) / 32;
-  p.n_cols = (long long)n_clips * p.n_frames;
-  p.a_re = taps;
-  p.a_im = nullptr;
-  p.n_bins = 32;
-  p.K = n_taps + 31 * stride;
-  p.amode = AMODE_TOEPLITZ;
-  p.toep_stride = stride;
-  p.n_taps = n_taps;
-  p.epilogue = MISPEC_EPI_REAL;
-  p.im_sign = 1.f;
-  p.out = y;
-  p.out_clip_stride = y_clip_stride;
-  p.out_row_stride = 0;
-  p.store_mode = STORE_ROWS_INNER;
-  p.out_len = n_out;
-  return launch_cfg<1, 4, 1, 2, BMODE_FRAMED, AMODE_TOEPLITZ, false>(p, static_cast<hipStream_t>(stream));
+  int rc = fir_params(p, x, x_clip_stride, n_clips, n_samples, taps, n_taps, stride, pad, y,
+                      y_clip_stride, n_out);
+  if (rc != MISPEC_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  rc = setup_edges(p, workspace, workspace_bytes, s);
+  if (rc != MISPEC_OK) return rc;
+  return launch_cfg<1, 4, 1, 2, BMODE_FRAMED, AMODE_TOEPLITZ, false>(p, s);
 }
 
 }  // extern "C"

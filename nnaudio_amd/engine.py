@@ -90,7 +90,8 @@ def n_frames(length, kernel, hop, pad):
 
 def framed_gemm(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign=-1.0,
                 eps=0.0, power=2.0, row_scale=None, row_support=None, out=None,
-                out_rows_total=None, out_row_offset=0, tile=TILE_AUTO, reference_kernel=False):
+                out_rows_total=None, out_row_offset=0, tile=TILE_AUTO, reference_kernel=False,
+                _debug=0):
     """``out[b, row_offset + f, t(, 0:2)]`` <- epilogue(sum_n x_pad[b, t*hop + n] * basis[f, n]).
 
     ``pad_mode`` is one of ``PAD_*``; ``out`` may be a pre-allocated (B, rows_total, T[, 2])
@@ -150,7 +151,17 @@ def framed_gemm(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign=
     a.out_clip_stride = rows_total * T * E
     a.out_row_stride = T * E
     a.out_row_offset = int(out_row_offset)
+    a.reserved = int(_debug)
     lib = _abi.load()
+    ws = None
+    if not reference_kernel:
+        need = lib.mispec_framed_gemm_workspace_bytes(ctypes.byref(a))
+        if need < 0:
+            _abi.check(int(need))
+        if need > 0:
+            # padded edge spans; stream-ordered reuse through the caching allocator
+            ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
+            a.workspace, a.workspace_bytes = ws.data_ptr(), need
     fn = lib.mispec_framed_gemm_f32_ref if reference_kernel else lib.mispec_framed_gemm_f32
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
@@ -195,11 +206,16 @@ def fir_decimate(x, taps, stride):
         )
     y = torch.empty((B, n_out), dtype=torch.float32, device=dev)
     lib = _abi.load()
+    need = lib.mispec_fir_decimate_workspace_bytes(B, L, nt, int(stride), pad, n_out)
+    if need < 0:
+        _abi.check(int(need))
+    ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev) if need > 0 else None
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
         _abi.check(lib.mispec_fir_decimate_f32(
             x.data_ptr(), x.stride(0), B, L, taps.data_ptr(), nt, int(stride), pad,
-            y.data_ptr(), y.stride(0), n_out, ctypes.c_void_p(stream)))
+            y.data_ptr(), y.stride(0), n_out, ws.data_ptr() if ws is not None else None, need,
+            ctypes.c_void_p(stream)))
     return y
 
 

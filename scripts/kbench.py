@@ -36,6 +36,18 @@ def stft():
         ms = timeit(lambda: engine.framed_gemm(x, m.wcos, m.wsin, hop=512, pad=1024, pad_mode=2,
                                                epilogue=engine.EPI_MAGNITUDE, tile=tile))
         print("stft cfg2 tile %d: %.3f ms  %.1f TF (%.1f%% of 157.3)" % (tile, ms, flops / ms / 1e9, flops / ms / 1e9 / 1.573))
+    sup = torch.tensor([[0, 2048]] * 1025, dtype=torch.int32, device=DEV)
+    ms = timeit(lambda: engine.framed_gemm(x, m.wcos, m.wsin, hop=512, pad=1024, pad_mode=2,
+                                           epilogue=engine.EPI_MAGNITUDE, tile=1, row_support=sup))
+    print("stft cfg2 tile 1 MASKED single launch (17 row blocks): %.3f ms" % ms)
+    x8 = x[:, : 441000 - 512 * 6]  # 856 frames -> 54784 = 428*128 columns
+    ms = timeit(lambda: engine.framed_gemm(x, m.wcos[:1024], m.wsin[:1024], hop=512, pad=1024, pad_mode=2,
+                                           epilogue=engine.EPI_MAGNITUDE, tile=1))
+    print("stft 1024 bins only (16 full row blocks, unmasked): %.3f ms -> %.1f TF" % (ms, 2.0*2048*2048*64*862/ms/1e9))
+    for dbg, what in ((0, "auto order"), (0x100, "frame-tile-fastest order"), (0x200, "L2-blocked order"), (1, "no global loads")):
+        ms = timeit(lambda: engine.framed_gemm(x, m.wcos[:1024], m.wsin[:1024], hop=512, pad=1024, pad_mode=2,
+                                               epilogue=engine.EPI_MAGNITUDE, tile=1, _debug=dbg))
+        print("ablate[%-28s] tile 1, 1024 bins: %.3f ms -> %.1f TF (%.1f%%)" % (what, ms, 2.0*2048*2048*64*862/ms/1e9, 2.0*2048*2048*64*862/ms/1e9/1.573))
     for fmt in ("Complex", "Phase"):
         ms = timeit(lambda: m(x, output_format=fmt))
         print("stft cfg2 %s: %.3f ms" % (fmt, ms))

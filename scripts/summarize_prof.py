@@ -36,3 +36,39 @@ for f in find("*counter_collection.csv"):
         for c, v in sorted(d.items()):
             n = cnt[(k, c)]
             print("     %-34s sum=%.6g  per-dispatch=%.6g  (dispatch rows=%d)" % (c, v, v / max(n, 1), n))
+
+
+# derived: effective clock and MFMA busy fraction of the dominant kernel
+try:
+    import re
+    dur = None
+    for f in find("*kernel_stats.csv"):
+        for r in csv.DictReader(open(f)):
+            if "framed_gemm" in r.get("Name", "") and dur is None:
+                dur = float(r["AverageNs"]) * 1e-9
+    vals = {}
+    for f in find("*counter_collection.csv"):
+        agg = defaultdict(float); n = defaultdict(int)
+        for r in csv.DictReader(open(f)):
+            if "framed_gemm" in r.get("Kernel_Name", ""):
+                agg[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
+        for k in agg:
+            vals[k] = agg[k] / n[k]
+    if dur and "GRBM_GUI_ACTIVE" in vals:
+        cyc = vals["GRBM_GUI_ACTIVE"] / 8.0
+        print("\n## derived (dominant kernel, per dispatch)")
+        print("  avg duration (trace pass)        : %.3f ms" % (dur * 1e3))
+        print("  GRBM_GUI_ACTIVE/8 (cycles)        : %.4g  -> effective clock %.2f GHz (if durations match)" % (cyc, cyc / dur / 1e9))
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in vals:
+            print("  MFMA busy fraction                : %.1f %%  (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMD * cycles))" % (100 * vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc)))
+        if "SQ_WAVE_CYCLES" in vals:
+            w = vals["SQ_WAVE_CYCLES"]
+            for k in ("SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS"):
+                if k in vals:
+                    print("  %-34s: %.1f %% of wave cycles" % (k, 100 * vals[k] / w))
+        if "FETCH_SIZE" in vals:
+            print("  FETCH_SIZE (KB) per dispatch      : %.4g  (x2 on gfx950 for 16B/lane streams -> %.1f MB read)" % (vals["FETCH_SIZE"], 2 * vals["FETCH_SIZE"] * 1024 / 1e6))
+        if "WRITE_SIZE" in vals:
+            print("  WRITE_SIZE (KB) per dispatch      : %.4g  (%.1f MB written)" % (vals["WRITE_SIZE"], vals["WRITE_SIZE"] * 1024 / 1e6))
+except Exception as e:
+    print("derived metrics failed:", e)

@@ -65,7 +65,7 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     a.struct_size = 4
     assert lib.mispec_framed_gemm_f32(ctypes.byref(a), None) == -1
     assert b"struct_size" in lib.mispec_last_error()
-    assert lib.mispec_fir_decimate_f32(None, 0, 1, 1, None, 1, 1, 0, None, 0, 1, None) == -1
+    assert lib.mispec_fir_decimate_f32(None, 0, 1, 1, None, 1, 1, 0, None, 0, 1, None, 0, None) == -1
     assert lib.mispec_filterbank_f32(None, 1, 1, None, 1, 1, None, None) == -1
 
 

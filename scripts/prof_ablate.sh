@@ -1,14 +1,12 @@
 #!/bin/bash
+# FETCH/WRITE traffic of the dominant STFT kernel under the two tile orders
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/ablate
 mkdir -p $OUT
-P1="SQ_INST_CYCLES_VMEM_RD SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES"
-P2="SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_ACTIVE_INST_MISC GRBM_GUI_ACTIVE"
-for dbg in 256 257 259; do
-  i=1
-  for P in "$P1" "$P2"; do
-    rocprofv3 --pmc $P --output-format csv -d $OUT/d${dbg}_p$i -o pmc -- python scripts/prof_ablate.py $dbg > $OUT/d${dbg}_p$i.log 2>&1
-    i=$((i+1))
+for dbg in 256 512; do
+  for P in FETCH_SIZE WRITE_SIZE "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES"; do
+    tag=$(echo $P | tr ' ' '_')
+    rocprofv3 --pmc $P --output-format csv -d $OUT/d${dbg}_$tag -o pmc -- python scripts/prof_ablate.py $dbg > $OUT/d${dbg}_$tag.log 2>&1
+    echo "=== debug=$dbg $P"; python scripts/summarize_prof.py $OUT/d${dbg}_$tag | grep -A6 "2, 2, 2, 2" | grep per-dispatch
   done
-  echo "=== debug=$dbg"; python scripts/summarize_prof.py $OUT/d${dbg}_p1 | grep -A12 "2, 2, 2, 2" | grep -v "^##"; python scripts/summarize_prof.py $OUT/d${dbg}_p2 | grep -A12 "2, 2, 2, 2" | grep -v "^##"
 done

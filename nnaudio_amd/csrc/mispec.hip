@@ -28,7 +28,9 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cstdint>
 #include <cstdio>
+#include <type_traits>
 #include <cstring>
 
 #include "mispec.h"
@@ -240,10 +242,10 @@ __device__ __forceinline__ int epilogue_width(int epi) {
 // pass of the B tile is 32 consecutive frames.  Every thread keeps one source pointer per pass.
 //
 // debug bits (benchmark ablations; results are wrong when set): 1 no global loads in the
-// loop, 2 no LDS stores, 4 no barrier, 8 no fragment reads, 0x100 / 0x200 force the
+// loop, 2 no LDS stores, 4 no barrier, 8 no fragment reads, 16 no MFMAs, 0x100 / 0x200 force the
 // frame-tile-fastest / L2-blocked tile order.
 // ---------------------------------------------------------------------------------
-template <int WM, int WN, int MR, int NR, int BMODE, int AMODE, bool MASKED>
+template <int WM, int WN, int MR, int NR, int BMODE, int AMODE, bool MASKED, bool GLDS>
 __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams p) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * MR * 32;
@@ -252,8 +254,14 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
   static_assert(NT == 256, "loader geometry assumes 256 threads");
   constexpr int APASS = BM / 32;
   constexpr int BPASS = BN / 32;  // framed mode
-  constexpr int A_STAGE = BM * LDT;
-  constexpr int B_STAGE = (BMODE == BMODE_FRAMED) ? BN * LDT : KC * BN;
+  static_assert(!GLDS || (BMODE == BMODE_FRAMED && AMODE == AMODE_ROWS), "LDS-direct loads: framed rows only");
+  // LDS row stride in floats.  Register-staged path: 36 (padding keeps ds_read_b128 conflict
+  // free).  LDS-direct path: the DMA writes lane-linear 16-byte pieces, so rows are the bare
+  // 32 floats and the 16-byte chunks of a row are XOR-swizzled by (row >> 1) & 7 instead
+  // (applied to the per-lane SOURCE address and again on the fragment reads).
+  constexpr int LROW = GLDS ? KC : LDT;
+  constexpr int A_STAGE = BM * LROW;
+  constexpr int B_STAGE = (BMODE == BMODE_FRAMED) ? BN * LROW : KC * BN;
   constexpr int PPASS = KC * BN / NT;  // planar mode: scalar elements per thread
   static_assert(BMODE == BMODE_FRAMED || NT % BN == 0 || BN % NT == 0, "planar loader shape");
   constexpr int STORE_MODE = (AMODE == AMODE_TOEPLITZ) ? STORE_ROWS_INNER : STORE_FRAMES_INNER;
@@ -276,7 +284,9 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
   const int li = lane & 31;
   const int lh = lane >> 5;
   const int r32 = tid >> 3;  // loader row inside a pass
-  const int c4 = tid & 7;    // loader K offset / 4
+  const int c4 = tid & 7;    // LDS 16-byte chunk this thread fills in its row
+  // ... which holds this chunk of the row's K stage (identity unless swizzled)
+  const int cg = GLDS ? (c4 ^ ((r32 >> 1) & 7)) : c4;
 
   // ---- XCD-aware tile order.  Workgroup b runs on XCD b % 8 (observed; only speed depends on
   // it) and every XCD has a private 4 MiB L2.  Each XCD gets a contiguous range of a linear
@@ -392,13 +402,13 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
       int bin = cplx ? (row >> 1) : row;
       bin = bin < p.n_bins ? bin : p.n_bins - 1;  // rows past the end feed unused accumulators
       const float *src = (cplx && (row & 1)) ? p.a_im : p.a_re;
-      aptr[ps] = src + (long long)bin * p.a_row_stride + 4 * c4;
+      aptr[ps] = src + (long long)bin * p.a_row_stride + 4 * cg;
     }
   }
   const float *bptr[(BMODE == BMODE_FRAMED) ? BPASS : PPASS];
   if (BMODE == BMODE_FRAMED) {
 #pragma unroll
-    for (int ps = 0; ps < BPASS; ++ps) bptr[ps] = sColPtr[ps * 32 + r32] + 4 * c4;
+    for (int ps = 0; ps < BPASS; ++ps) bptr[ps] = sColPtr[ps * 32 + r32] + 4 * cg;
   } else {
 #pragma unroll
     for (int ps = 0; ps < PPASS; ++ps) {
@@ -412,7 +422,8 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
   float rp[(BMODE == BMODE_PLANAR) ? PPASS : 1];
   unsigned toep_bits = 0;  // Toeplitz A: which of the 4*APASS loaded taps are inside the band
 
-  // ---- stage loads: no control flow, every address is valid memory by construction
+  // ---- stage loads: no control flow, every address is valid memory by construction.
+  // NA = number of leading A passes (row tiles) a loop instance moves and multiplies.
   auto load_b = [&](int kc) __attribute__((always_inline)) {
     if (BMODE == BMODE_FRAMED) {
 #pragma unroll
@@ -428,17 +439,18 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
       }
     }
   };
-  auto load_a = [&](int kc) __attribute__((always_inline)) {
+  auto load_a = [&](int kc, auto na_tag) __attribute__((always_inline)) {
+    constexpr int NA = decltype(na_tag)::value;
     if (AMODE == AMODE_ROWS) {
 #pragma unroll
-      for (int ps = 0; ps < APASS; ++ps)
+      for (int ps = 0; ps < NA; ++ps)
         ra[ps] = *reinterpret_cast<const f32x4u *>(aptr[ps] + kc);
     } else {
       // banded Toeplitz matrix of the FIR taps: A[row, k] = taps[k - stride*row]
       const int k = kc + 4 * c4;
       unsigned bits = 0;
 #pragma unroll
-      for (int ps = 0; ps < APASS; ++ps) {
+      for (int ps = 0; ps < NA; ++ps) {
         const int row = m0 + ps * 32 + r32;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -451,23 +463,24 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
       toep_bits = bits;
     }
   };
-  auto store_stage = [&](int buf) __attribute__((always_inline)) {
+  auto store_stage = [&](int buf, auto na_tag) __attribute__((always_inline)) {
+    constexpr int NA = decltype(na_tag)::value;
     float *a = sA + buf * A_STAGE;
     float *b = sB + buf * B_STAGE;
     if (AMODE == AMODE_TOEPLITZ) {
 #pragma unroll
-      for (int ps = 0; ps < APASS; ++ps)
+      for (int ps = 0; ps < NA; ++ps)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           ra[ps][e] = ((toep_bits >> (4 * ps + e)) & 1u) ? ra[ps][e] : 0.f;
     }
 #pragma unroll
-    for (int ps = 0; ps < APASS; ++ps)
-      *reinterpret_cast<f32x4v *>(a + (ps * 32 + r32) * LDT + 4 * c4) = ra[ps];
+    for (int ps = 0; ps < NA; ++ps)
+      *reinterpret_cast<f32x4v *>(a + (ps * 32 + r32) * LROW + 4 * c4) = ra[ps];
     if (BMODE == BMODE_FRAMED) {
 #pragma unroll
       for (int ps = 0; ps < BPASS; ++ps)
-        *reinterpret_cast<f32x4v *>(b + (ps * 32 + r32) * LDT + 4 * c4) = rb[ps];
+        *reinterpret_cast<f32x4v *>(b + (ps * 32 + r32) * LROW + 4 * c4) = rb[ps];
     } else {
 #pragma unroll
       for (int ps = 0; ps < PPASS; ++ps) {
@@ -488,25 +501,31 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
 
   // One K stage out of LDS buffer `buf`: 4 K groups of 8; lane (li, lh) supplies k = 8q+4lh+s to
   // MFMA s of group q.  `mid0` / `mid1` run after groups 0 / 1 (LDS stores of the next stage and
-  // global loads of the one after), i.e. inside the MFMA stream.
-  auto mfma_stage = [&](int buf, unsigned mask, bool frags, auto &&mid0,
-                        auto &&mid1) __attribute__((always_inline)) {
-    const float *a_base = sA + buf * A_STAGE + ((wm * MR) * 32 + li) * LDT + 4 * lh;
+  // global loads of the one after), i.e. inside the MFMA stream.  MRA = number of this wave's
+  // leading row tiles that are multiplied (compile time); `mask` skips tiles at run time in the
+  // generic instance.
+  auto mfma_stage = [&](int buf, unsigned mask, bool frags, auto mra_tag, auto use_mask_tag,
+                        auto &&mid0, auto &&mid1) __attribute__((always_inline)) {
+    constexpr int MRA = decltype(mra_tag)::value;
+    constexpr bool USE_MASK = decltype(use_mask_tag)::value;
+    const float *a_base = sA + buf * A_STAGE + ((wm * MR) * 32 + li) * LROW + (GLDS ? 0 : 4 * lh);
     const float *b_base;
     if (BMODE == BMODE_FRAMED)
-      b_base = sB + buf * B_STAGE + ((wn * NR) * 32 + li) * LDT + 4 * lh;
+      b_base = sB + buf * B_STAGE + ((wn * NR) * 32 + li) * LROW + (GLDS ? 0 : 4 * lh);
     else
       b_base = sB + buf * B_STAGE + (4 * lh) * BN + (wn * NR) * 32 + li;
-    const unsigned wmask = MASKED ? (mask >> (wm * MR)) : ~0u;
+    const unsigned wmask = USE_MASK ? (mask >> (wm * MR)) : ~0u;
+    const int fsw = (li >> 1) & 7;  // GLDS: chunk swizzle of this lane's rows (tile rows = li + 32k)
     f32x4v av[2][MR], bv[2][NR];
     auto load_frags = [&](int q, int slot) __attribute__((always_inline)) {
+      const int off = GLDS ? 4 * ((2 * q + lh) ^ fsw) : 8 * q;
 #pragma unroll
-      for (int m = 0; m < MR; ++m)
-        av[slot][m] = *reinterpret_cast<const f32x4v *>(a_base + m * 32 * LDT + 8 * q);
+      for (int m = 0; m < MRA; ++m)
+        av[slot][m] = *reinterpret_cast<const f32x4v *>(a_base + m * 32 * LROW + off);
 #pragma unroll
       for (int n = 0; n < NR; ++n) {
         if (BMODE == BMODE_FRAMED) {
-          bv[slot][n] = *reinterpret_cast<const f32x4v *>(b_base + n * 32 * LDT + 8 * q);
+          bv[slot][n] = *reinterpret_cast<const f32x4v *>(b_base + n * 32 * LROW + off);
         } else {
 #pragma unroll
           for (int s = 0; s < 4; ++s) bv[slot][n][s] = b_base[(8 * q + s) * BN + n * 32];
@@ -518,8 +537,8 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
     for (int q = 0; q < KC / 8; ++q) {
       if (q + 1 < KC / 8 && frags) load_frags(q + 1, (q + 1) & 1);  // prefetch under the MFMAs
 #pragma unroll
-      for (int m = 0; m < MR; ++m) {
-        if (!MASKED || ((wmask >> m) & 1u)) {
+      for (int m = 0; m < MRA; ++m) {
+        if ((!USE_MASK || ((wmask >> m) & 1u)) && !(p.debug & 16)) {
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -534,57 +553,133 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
     }
   };
 
-  // ---- software pipeline over the nloop full stages (stage c covers K [kb + c*KC, +KC)):
+  // ---- software pipeline over full stages [c0, c1) (stage c covers K [kb + c*KC, +KC)):
   //   LDS holds stage c (being multiplied) and receives stage c+1 during the same iteration;
   //   registers hold stage c+1 until it is written, then receive stage c+2.
-  if (nloop > 0) {
-    load_a(kb);
-    load_b(kb);
-    store_stage(0);
-    if (nloop > 1) {
-      load_a(kb + KC);
-      load_b(kb + KC);
+  // NA: leading row tiles of the workgroup this instance moves through LDS; MRA: leading row
+  // tiles of each wave it multiplies; USE_MASK: consult the per-stage mask at run time.
+  auto run_stages = [&](int c0, int c1, auto na_tag, auto mra_tag,
+                        auto use_mask_tag) __attribute__((always_inline)) {
+    if (c1 <= c0) return;
+    if (GLDS) {
+      // LDS-direct: stage c+1 is DMA'd into the other buffer while stage c is multiplied; the
+      // barrier at the end of the iteration (which carries the vmcnt(0)) publishes it.
+      constexpr int NA = decltype(na_tag)::value;
+      auto dma_stage = [&](int c, int buf) __attribute__((always_inline)) {
+        const int kc = kb + c * KC;
+        typedef __attribute__((address_space(1))) const void *gptr_t;
+        typedef __attribute__((address_space(3))) void *lptr_t;
+#pragma unroll
+        for (int ps = 0; ps < NA; ++ps)
+          __builtin_amdgcn_global_load_lds((gptr_t)(aptr[ps] + kc),
+                                           (lptr_t)(sA + buf * A_STAGE + (ps * 32 + wave * 8) * LROW),
+                                           16, 0, 0);
+#pragma unroll
+        for (int ps = 0; ps < BPASS; ++ps)
+          __builtin_amdgcn_global_load_lds((gptr_t)(bptr[ps] + kc),
+                                           (lptr_t)(sB + buf * B_STAGE + (ps * 32 + wave * 8) * LROW),
+                                           16, 0, 0);
+      };
+      dma_stage(c0, 0);
+      __syncthreads();
+      for (int c = c0; c < c1; ++c) {
+        const int buf = (c - c0) & 1;
+        if ((c + 1) < c1 && !(p.debug & 1)) dma_stage(c + 1, buf ^ 1);
+        mfma_stage(
+            buf, stage_mask(kb + c * KC), !(p.debug & 8) || c == c0, mra_tag, use_mask_tag,
+            [&]() __attribute__((always_inline)) {}, [&]() __attribute__((always_inline)) {});
+        if (!(p.debug & 4)) __syncthreads();
+      }
+      return;
+    }
+    load_a(kb + c0 * KC, na_tag);
+    load_b(kb + c0 * KC);
+    store_stage(0, na_tag);
+    if (c1 - c0 > 1) {
+      load_a(kb + (c0 + 1) * KC, na_tag);
+      load_b(kb + (c0 + 1) * KC);
     }
     __syncthreads();
-    for (int c = 0; c < nloop; ++c) {
-      const int buf = c & 1;
-      const bool has1 = (c + 1) < nloop;
-      const bool has2 = (c + 2) < nloop;
+    for (int c = c0; c < c1; ++c) {
+      const int buf = (c - c0) & 1;
+      const bool has1 = (c + 1) < c1;
+      const bool has2 = (c + 2) < c1;
       mfma_stage(
-          buf, stage_mask(kb + c * KC), !(p.debug & 8) || c == 0,
+          buf, stage_mask(kb + c * KC), !(p.debug & 8) || c == c0, mra_tag, use_mask_tag,
           [&]() __attribute__((always_inline)) {
-            if (has1 && !(p.debug & 2)) store_stage(buf ^ 1);  // stage c+1: registers -> LDS
+            if (has1 && !(p.debug & 2)) store_stage(buf ^ 1, na_tag);  // stage c+1: regs -> LDS
           },
           [&]() __attribute__((always_inline)) {
             if (has2 && !(p.debug & 1)) {  // stage c+2: HBM/L2 -> registers
-              load_a(kb + (c + 2) * KC);
+              load_a(kb + (c + 2) * KC, na_tag);
               load_b(kb + (c + 2) * KC);
             }
           });
       if (!(p.debug & 4)) __syncthreads();
     }
+  };
+  using std::integral_constant;
+  constexpr bool PHASED = MASKED && (WM == 1) && (AMODE == AMODE_ROWS);
+  if (!PHASED) {
+    run_stages(0, nloop, integral_constant<int, APASS>{}, integral_constant<int, MR>{},
+               integral_constant<bool, MASKED>{});
+  } else {
+    // Support-aware contraction, every wave owns all MR row tiles (WM == 1).  Runs of stages in
+    // which exactly the first n row tiles are active (CQT banks: supports are centred and
+    // shrink with the bin index, so the active set is a prefix that grows then shrinks) use a
+    // loop compiled for n tiles; anything else falls back to the masked instance.
+    int c = 0;
+    while (c < nloop) {
+      const unsigned m = stage_mask(kb + c * KC);
+      int c1 = c + 1;
+      while (c1 < nloop && stage_mask(kb + c1 * KC) == m) ++c1;
+      bool done = false;
+      if (c1 - c >= 4) {  // short runs are not worth a pipeline restart
+#pragma unroll
+        for (int n = 1; n < MR; ++n) {
+          if (!done && m == ((1u << n) - 1u)) {
+            // n is a compile-time constant after unrolling
+            switch (n) {
+              case 1: run_stages(c, c1, integral_constant<int, 1>{}, integral_constant<int, 1>{}, integral_constant<bool, false>{}); break;
+              case 2: if (MR > 2) run_stages(c, c1, integral_constant<int, (MR > 2 ? 2 : 1)>{}, integral_constant<int, (MR > 2 ? 2 : 1)>{}, integral_constant<bool, false>{}); break;
+              case 3: if (MR > 3) run_stages(c, c1, integral_constant<int, (MR > 3 ? 3 : 1)>{}, integral_constant<int, (MR > 3 ? 3 : 1)>{}, integral_constant<bool, false>{}); break;
+              case 4: if (MR > 4) run_stages(c, c1, integral_constant<int, (MR > 4 ? 4 : 1)>{}, integral_constant<int, (MR > 4 ? 4 : 1)>{}, integral_constant<bool, false>{}); break;
+              case 5: if (MR > 5) run_stages(c, c1, integral_constant<int, (MR > 5 ? 5 : 1)>{}, integral_constant<int, (MR > 5 ? 5 : 1)>{}, integral_constant<bool, false>{}); break;
+              case 6: if (MR > 6) run_stages(c, c1, integral_constant<int, (MR > 6 ? 6 : 1)>{}, integral_constant<int, (MR > 6 ? 6 : 1)>{}, integral_constant<bool, false>{}); break;
+              case 7: if (MR > 7) run_stages(c, c1, integral_constant<int, (MR > 7 ? 7 : 1)>{}, integral_constant<int, (MR > 7 ? 7 : 1)>{}, integral_constant<bool, false>{}); break;
+              default: break;
+            }
+            done = true;
+          }
+        }
+      }
+      if (!done)
+        run_stages(c, c1, integral_constant<int, APASS>{}, integral_constant<int, MR>{},
+                   integral_constant<bool, true>{});
+      c = c1;
+    }
   }
   // ---- peeled K-tail stage (only when K is not a multiple of 32): element-wise clamped A loads
   if (a_tail) {
     const int kc = kb + nloop * KC;
-    const int k = kc + 4 * c4;
+    const int k = kc + 4 * cg;
     if (AMODE == AMODE_ROWS) {
 #pragma unroll
       for (int ps = 0; ps < APASS; ++ps) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const bool ok = (k + e) < p.K;
-          const float t = (aptr[ps] - 4 * c4)[ok ? k + e : 0];
+          const float t = (aptr[ps] - 4 * cg)[ok ? k + e : 0];
           ra[ps][e] = ok ? t : 0.f;
         }
       }
     }
     load_b(kc);  // in bounds by construction (frames are runs of >= Kr floats)
-    const int buf = nloop & 1;
-    store_stage(buf);
+    store_stage(0, std::integral_constant<int, APASS>{});
     __syncthreads();
     mfma_stage(
-        buf, stage_mask(kc), true, [&]() __attribute__((always_inline)) {},
+        0, stage_mask(kc), true, std::integral_constant<int, MR>{},
+        std::integral_constant<bool, MASKED>{}, [&]() __attribute__((always_inline)) {},
         [&]() __attribute__((always_inline)) {});
   }
 
@@ -719,14 +814,16 @@ int fail(int code, const char *fmt, const char *detail = "") {
   return code;
 }
 
-template <int WM, int WN, int MR, int NR, int BMODE, int AMODE = AMODE_ROWS, bool MASKED = true>
+template <int WM, int WN, int MR, int NR, int BMODE, int AMODE = AMODE_ROWS, bool MASKED = true,
+          bool GLDS = false>
 int launch_cfg(KParams p, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * MR * 32;
   constexpr int BN = WN * NR * 32;
   constexpr int MT = WM * MR;
-  constexpr int A_STAGE = BM * LDT;
-  constexpr int B_STAGE = (BMODE == BMODE_FRAMED) ? BN * LDT : KC * BN;
+  constexpr int LROW = GLDS ? KC : LDT;
+  constexpr int A_STAGE = BM * LROW;
+  constexpr int B_STAGE = (BMODE == BMODE_FRAMED) ? BN * LROW : KC * BN;
   constexpr size_t smem = sizeof(float) * 2 * (A_STAGE + B_STAGE) + sizeof(const float *) * BN +
                           sizeof(int) * 2 * MT;
 
@@ -748,7 +845,7 @@ int launch_cfg(KParams p, hipStream_t stream) {
     p.n_group = g;
   }
 
-  auto kern = framed_gemm_kernel<WM, WN, MR, NR, BMODE, AMODE, MASKED>;
+  auto kern = framed_gemm_kernel<WM, WN, MR, NR, BMODE, AMODE, MASKED, GLDS>;
   // opt in to > 64 KiB of dynamic LDS once per (kernel, device)
   static std::atomic<unsigned long long> configured{0};
   int dev = 0;
@@ -768,10 +865,27 @@ int launch_cfg(KParams p, hipStream_t stream) {
   return MISPEC_OK;
 }
 
+// LDS-direct loads move 16-byte pieces: every source address must be 16-byte aligned
+bool glds_ok(const KParams &p) {
+  if (p.debug & 0x800) return false;
+  if (p.debug & 0x400) return true;  // benchmarking / alignment experiments
+  auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+  bool ok = al16(p.x) && al16(p.a_re) && (!p.a_im || al16(p.a_im)) && (p.x_clip_stride % 4 == 0) &&
+            (p.a_row_stride % 4 == 0) && (p.hop % 4 == 0) && (p.pad % 4 == 0);
+  if (p.edge_mode != EDGE_NONE)
+    ok = ok && al16(p.edge) && (p.edge_clip_stride % 4 == 0) && (p.edge_ll % 4 == 0);
+  return ok;
+}
+
 template <int WM, int WN, int MR, int NR>
 int launch_pick_mask(const KParams &p, bool masked, hipStream_t stream) {
-  if (masked) return launch_cfg<WM, WN, MR, NR, BMODE_FRAMED, AMODE_ROWS, true>(p, stream);
-  return launch_cfg<WM, WN, MR, NR, BMODE_FRAMED, AMODE_ROWS, false>(p, stream);
+  const bool g = glds_ok(p);
+  if (masked) {
+    if (g) return launch_cfg<WM, WN, MR, NR, BMODE_FRAMED, AMODE_ROWS, true, true>(p, stream);
+    return launch_cfg<WM, WN, MR, NR, BMODE_FRAMED, AMODE_ROWS, true, false>(p, stream);
+  }
+  if (g) return launch_cfg<WM, WN, MR, NR, BMODE_FRAMED, AMODE_ROWS, false, true>(p, stream);
+  return launch_cfg<WM, WN, MR, NR, BMODE_FRAMED, AMODE_ROWS, false, false>(p, stream);
 }
 
 int launch_tile(const KParams &p, int tile, hipStream_t stream) {
@@ -781,7 +895,7 @@ int launch_tile(const KParams &p, int tile, hipStream_t stream) {
     case MISPEC_TILE_128x128:
       return launch_pick_mask<2, 2, 2, 2>(p, masked, stream);
     case MISPEC_TILE_32x256:  // one row tile: the workgroup K range is the tile's range
-      return launch_cfg<1, 4, 1, 2, BMODE_FRAMED, AMODE_ROWS, false>(p, stream);
+      return launch_pick_mask<1, 4, 1, 2>(p, false, stream);
     case MISPEC_TILE_64x256:
       return launch_pick_mask<1, 4, 2, 2>(p, masked, stream);
     case MISPEC_TILE_128x128_TALL:

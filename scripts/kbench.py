@@ -44,7 +44,7 @@ def stft():
     ms = timeit(lambda: engine.framed_gemm(x, m.wcos[:1024], m.wsin[:1024], hop=512, pad=1024, pad_mode=2,
                                            epilogue=engine.EPI_MAGNITUDE, tile=1))
     print("stft 1024 bins only (16 full row blocks, unmasked): %.3f ms -> %.1f TF" % (ms, 2.0*2048*2048*64*862/ms/1e9))
-    for dbg, what in ((0, "auto order"), (0x100, "frame-tile-fastest order"), (0x200, "L2-blocked order"), (1, "no global loads")):
+    for dbg, what in ((0, "auto (LDS-direct)"), (0x800, "register-staged"), (0x100, "frame-tile-fastest order"), (0x200, "L2-blocked order"), (1, "no global loads"), (16, "no MFMA (load path only)"), (16 + 8, "no MFMA, no frag reads")):
         ms = timeit(lambda: engine.framed_gemm(x, m.wcos[:1024], m.wsin[:1024], hop=512, pad=1024, pad_mode=2,
                                                epilogue=engine.EPI_MAGNITUDE, tile=1, _debug=dbg))
         print("ablate[%-28s] tile 1, 1024 bins: %.3f ms -> %.1f TF (%.1f%%)" % (what, ms, 2.0*2048*2048*64*862/ms/1e9, 2.0*2048*2048*64*862/ms/1e9/1.573))
@@ -73,7 +73,12 @@ def cqt():
     dense = 2.0 * 168 * 32768 * B * 862
     sup = m._support.get(m.cqt_kernels_real, m.cqt_kernels_imag)
     sc = torch.sqrt(m.lenghts)
-    for tile, s in ((5, sup), (6, sup), (1, sup), (4, sup), (5, None)):
+    for dbg in (16, 16 + 8):
+        ms = timeit(lambda: engine.framed_gemm(x, m.cqt_kernels_real, m.cqt_kernels_imag, hop=512,
+                                               pad=16384, pad_mode=2, epilogue=engine.EPI_MAGNITUDE,
+                                               row_scale=sc, row_support=sup, tile=4, _debug=dbg), n=5, w=2)
+        print("cqt1992v2 tile 4 ablation dbg=%d: %.3f ms" % (dbg, ms))
+    for tile, s in ((1, sup), (4, sup)):
         ms = timeit(lambda: engine.framed_gemm(x, m.cqt_kernels_real, m.cqt_kernels_imag, hop=512,
                                                pad=16384, pad_mode=2, epilogue=engine.EPI_MAGNITUDE,
                                                row_scale=sc, row_support=s, tile=tile), n=5, w=2)

@@ -15,6 +15,9 @@ from ._abi import (  # noqa: F401  (re-exported for the feature modules)
 )
 from .basis import decimated_length
 
+# benchmarking / bring-up only: OR-ed into the ablation bits of every framed_gemm call
+_ENV_DEBUG = int(__import__("os").environ.get("MISPEC_DEBUG", "0"), 0)
+
 _PAD_MODES = {"constant": PAD_ZERO, "reflect": PAD_REFLECT, None: PAD_NONE}
 
 
@@ -151,7 +154,7 @@ def framed_gemm(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign=
     a.out_clip_stride = rows_total * T * E
     a.out_row_stride = T * E
     a.out_row_offset = int(out_row_offset)
-    a.reserved = int(_debug)
+    a.reserved = int(_debug) | _ENV_DEBUG
     lib = _abi.load()
     ws = None
     if not reference_kernel:

@@ -40,25 +40,25 @@ for f in find("*counter_collection.csv"):
 
 # derived: effective clock and MFMA busy fraction of the dominant kernel
 try:
-    import re
-    dur = None
+    dom, dur, best = None, None, -1.0
     for f in find("*kernel_stats.csv"):
         for r in csv.DictReader(open(f)):
-            if "framed_gemm" in r.get("Name", "") and dur is None:
-                dur = float(r["AverageNs"]) * 1e-9
+            if "framed_gemm" in r.get("Name", "") and float(r["TotalDurationNs"]) > best:
+                best = float(r["TotalDurationNs"])
+                dom, dur = r["Name"], float(r["AverageNs"]) * 1e-9
     vals = {}
     for f in find("*counter_collection.csv"):
         agg = defaultdict(float); n = defaultdict(int)
         for r in csv.DictReader(open(f)):
-            if "framed_gemm" in r.get("Kernel_Name", ""):
+            if dom and r.get("Kernel_Name", "") == dom:
                 agg[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
         for k in agg:
             vals[k] = agg[k] / n[k]
     if dur and "GRBM_GUI_ACTIVE" in vals:
         cyc = vals["GRBM_GUI_ACTIVE"] / 8.0
-        print("\n## derived (dominant kernel, per dispatch)")
-        print("  avg duration (trace pass)        : %.3f ms" % (dur * 1e3))
-        print("  GRBM_GUI_ACTIVE/8 (cycles)        : %.4g  -> effective clock %.2f GHz (if durations match)" % (cyc, cyc / dur / 1e9))
+        print("\n## derived (dominant kernel, per dispatch): %s" % dom[:100])
+        print("  avg duration (kernel-trace pass)  : %.3f ms" % (dur * 1e3))
+        print("  GRBM_GUI_ACTIVE/8 (cycles)        : %.4g  -> effective clock %.2f GHz" % (cyc, cyc / dur / 1e9))
         if "SQ_VALU_MFMA_BUSY_CYCLES" in vals:
             print("  MFMA busy fraction                : %.1f %%  (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMD * cycles))" % (100 * vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc)))
         if "SQ_WAVE_CYCLES" in vals:

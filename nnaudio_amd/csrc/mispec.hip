@@ -768,6 +768,144 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
 }
 
 // ---------------------------------------------------------------------------------
+// Dedicated stride-2 FIR decimator (the octave recursion of CQT2010v2 / VQT spends most of its
+// time here).  Same Toeplitz contraction as the generic kernel,
+//     y[32 q + r] = sum_m T[r, m] * x[64 q + m - pad],   T[r, m] = taps[m - 2 r],  m < n_taps + 62,
+// but organised around what is constant and what is reused:
+//   * the whole 32 x 320 Toeplitz matrix lives in registers as MFMA A-fragments (40 K groups x
+//     4 floats per lane), built once per workgroup from a zero-guarded copy of the taps in LDS;
+//   * the input span of the workgroup's outputs (2 * n_out_wg + 320 samples) is loaded into LDS
+//     ONCE, so every input sample is read from HBM/L2 once instead of K'/hop' = 5 times;
+//     rows of 64 samples are padded to 68 floats so the hop-64 fragment reads (ds_read_b128) are
+//     bank-conflict free;
+//   * the K loop is 40 groups x (NRW ds_read_b128 + 4 NRW MFMA) with no barrier and no global
+//     traffic; two workgroups per CU overlap one's span load with the other's MFMAs.
+// Each wave owns NRW 32x32 tiles = 1024 NRW consecutive outputs; a workgroup 4096 NRW outputs
+// of one clip.
+// ---------------------------------------------------------------------------------
+#ifndef FIR_NRW
+#define FIR_NRW 1
+#endif
+#ifndef FIR_AREG
+#define FIR_AREG false
+#endif
+constexpr int FIR_KG = 40;                   // K groups of 8: n_taps + 62 <= 320
+constexpr int FIR_ROW = 68;                  // LDS row: 64 samples + 4 pad
+template <int NRW, bool AREG>
+__global__ void __launch_bounds__(256) fir_decimate2_kernel(const KParams p) {
+  constexpr int OUT_WG = 4096 * NRW;                 // outputs per workgroup
+  constexpr int SPAN = 2 * OUT_WG + 64 * 5;          // input samples staged (incl. K' = 320 halo)
+  constexpr int ROWS = SPAN / 64;                    // 64-sample rows
+  constexpr int TAPZ = 62 + 320 + 2;                 // zero-guarded taps: index i + 62, i in [-62, 320)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float *sX = reinterpret_cast<float *>(smem_raw);   // [ROWS][FIR_ROW]
+  float *sT = sX + ROWS * FIR_ROW;                   // [TAPZ]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int c = blockIdx.y;
+  const long long o0 = (long long)blockIdx.x * OUT_WG;        // first output of this workgroup
+  const long long p0 = 2 * o0 - p.pad;                        // signal position of span element 0
+  const float *xc = p.x + (long long)c * p.x_clip_stride;
+
+  // ---- stage the span (zero outside the clip) and the zero-guarded taps.  All loads are issued
+  // before the first LDS store (no control flow between them); the few 16-byte pieces that
+  // straddle a clip edge are patched element-wise afterwards.
+  constexpr int NLD = (SPAN / 4 + 255) / 256;
+  f32x4v stage[NLD];
+#pragma unroll
+  for (int it = 0; it < NLD; ++it) {
+    const int i = tid + 256 * it;
+    const long long q = p0 + 4LL * i;
+    const bool inside = (i < SPAN / 4) && q >= 0 && q + 3 < p.n_samples;
+    stage[it] = *reinterpret_cast<const f32x4u *>(xc + (inside ? q : 0));
+  }
+#pragma unroll
+  for (int it = 0; it < NLD; ++it) {
+    const int i = tid + 256 * it;
+    const long long q = p0 + 4LL * i;
+    if (i < SPAN / 4) {
+      f32x4v v = stage[it];
+      if (!(q >= 0 && q + 3 < p.n_samples)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (q + e >= 0 && q + e < p.n_samples) ? xc[q + e] : 0.f;
+      }
+      const int pp = 4 * i;
+      *reinterpret_cast<f32x4v *>(sX + (pp >> 6) * FIR_ROW + (pp & 63)) = v;
+    }
+  }
+  for (int i = tid; i < TAPZ; i += 256) {
+    const int t = i - 62;
+    sT[i] = (t >= 0 && t < p.n_taps) ? p.a_re[t] : 0.f;
+  }
+  __syncthreads();
+
+  // ---- Toeplitz A-fragments: lane (r = li, lh), group g, element e <-> T[r, 8g + 4lh + e]
+  f32x4v afr[FIR_KG];
+#pragma unroll
+  for (int g = 0; g < FIR_KG; ++g) {
+    const int idx = 8 * g + 4 * lh - 2 * li + 62;  // even: 8-byte aligned pairs
+    const float2 lo = *reinterpret_cast<const float2 *>(sT + idx);
+    const float2 hi = *reinterpret_cast<const float2 *>(sT + idx + 2);
+    afr[g] = f32x4v{lo.x, lo.y, hi.x, hi.y};
+    // AREG: keep the fragment resident (otherwise the compiler re-reads it from LDS in the K
+    // loop, trading 160 VGPRs for two ds_read_b64 per group and twice the occupancy)
+    if (AREG) asm volatile("" : "+v"(afr[g]));
+  }
+
+  f32x16 acc[NRW];
+#pragma unroll
+  for (int n = 0; n < NRW; ++n)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+
+  // B fragment of tile n: frame q = 32 (wave NRW + n) + li starts at span row q; element
+  // m = 8g + 4lh + e of it sits at row q + m/64, column m%64
+  const float *bbase = sX + (32 * (wave * NRW) + li) * FIR_ROW + 4 * lh;
+  f32x4v bv[2][NRW];
+  auto load_b = [&](int g, int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int n = 0; n < NRW; ++n)
+      bv[slot][n] =
+          *reinterpret_cast<const f32x4v *>(bbase + (32 * n + (g >> 3)) * FIR_ROW + 8 * (g & 7));
+  };
+  load_b(0, 0);
+#pragma unroll
+  for (int g = 0; g < FIR_KG; ++g) {
+    if (g + 1 < FIR_KG) load_b(g + 1, (g + 1) & 1);  // prefetch under this group's MFMAs
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int n = 0; n < NRW; ++n)
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[g][e], bv[g & 1][n][e], acc[n], 0, 0, 0);
+  }
+
+  // ---- epilogue: D[r][q] -> y[o0 + 32 (32 (wave NRW + n) + q) + r], transposed through LDS so
+  // that a lane stores consecutive outputs
+  __syncthreads();  // every wave is done reading the span
+  constexpr int LDC = 33;
+  float *sC = reinterpret_cast<float *>(smem_raw) + wave * (32 * LDC);
+  float *yc = p.out + (long long)c * p.out_clip_stride;
+#pragma unroll
+  for (int n = 0; n < NRW; ++n) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      sC[li * LDC + (e & 3) + 8 * (e >> 2) + 4 * lh] = acc[n][e];  // [q][r]
+    __syncthreads();
+    const long long ob = o0 + 1024LL * (wave * NRW + n);
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int q = 2 * it + lh;
+      const long long o = ob + 32 * q + li;
+      if (o < p.out_len) yc[o] = sC[q * LDC + li];
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // Reference kernel: one thread per output element, straight loop (test cross-check only)
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) framed_gemm_ref_kernel(const KParams p) {
@@ -1149,6 +1287,29 @@ int mispec_fir_decimate_f32(const float *x, int64_t x_clip_stride, int32_t n_cli
                       y_clip_stride, n_out);
   if (rc != MISPEC_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (stride == 2 && n_taps + 62 <= 8 * FIR_KG && !(p.debug & 0x1000)) {
+    // dedicated kernel: span staged once in LDS, Toeplitz taps re-read from a tiny LDS table
+    constexpr int NRW = FIR_NRW;
+    constexpr int OUT_WG = 4096 * NRW;
+    constexpr size_t smem = sizeof(float) * ((2 * OUT_WG + 320) / 64 * FIR_ROW + 62 + 320 + 2);
+    auto kern = fir_decimate2_kernel<NRW, FIR_AREG>;
+    static std::atomic<unsigned long long> configured{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(MISPEC_E_HIP, "hipGetDevice failed%s");
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(configured.load(std::memory_order_acquire) & bit)) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess)
+        return fail(MISPEC_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+      configured.fetch_or(bit, std::memory_order_release);
+    }
+    const unsigned gx = (unsigned)((n_out + OUT_WG - 1) / OUT_WG);
+    hipLaunchKernelGGL(kern, dim3(gx, (unsigned)n_clips), dim3(256), smem, s, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return MISPEC_OK;
+  }
   rc = setup_edges(p, workspace, workspace_bytes, s);
   if (rc != MISPEC_OK) return rc;
   return launch_cfg<1, 4, 1, 2, BMODE_FRAMED, AMODE_TOEPLITZ, false>(p, s);

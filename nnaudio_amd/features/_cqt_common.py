@@ -39,26 +39,30 @@ def normalisation_scale(lenghts, normalization_type, extra=1.0):
 
 class SupportCache:
     """[start, stop) of the non-zero taps of every kernel row, recomputed whenever the
-    kernel tensors are replaced or modified in place (``load_state_dict``, ``.to``)."""
+    kernel tensors are replaced or modified in place (``load_state_dict``, ``.to``).
+
+    One entry per device: ``nn.DataParallel`` replicas share this object and call from one
+    host thread per GPU, so entries are only ever replaced whole (no torn key/value pair)."""
 
     def __init__(self):
-        self._key = None
-        self._val = None
+        self._entries = {}
 
     def get(self, real, imag):
-        key = (real.data_ptr(), real._version, imag.data_ptr(), imag._version, real.device)
-        if key != self._key:
-            nz = (real.reshape(real.shape[0], -1) != 0) | (imag.reshape(imag.shape[0], -1) != 0)
-            K = nz.shape[1]
-            idx = torch.arange(K, device=nz.device)
-            big = torch.where(nz, idx, torch.full_like(idx, K))
-            small = torch.where(nz, idx + 1, torch.zeros_like(idx))
-            start = big.min(dim=1).values
-            stop = small.max(dim=1).values
-            start = torch.minimum(start, stop)
-            self._val = torch.stack((start, stop), 1).to(torch.int32).contiguous()
-            self._key = key
-        return self._val
+        key = (real.data_ptr(), real._version, imag.data_ptr(), imag._version)
+        hit = self._entries.get(real.device)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        nz = (real.reshape(real.shape[0], -1) != 0) | (imag.reshape(imag.shape[0], -1) != 0)
+        K = nz.shape[1]
+        idx = torch.arange(K, device=nz.device)
+        big = torch.where(nz, idx, torch.full_like(idx, K))
+        small = torch.where(nz, idx + 1, torch.zeros_like(idx))
+        start = big.min(dim=1).values
+        stop = small.max(dim=1).values
+        start = torch.minimum(start, stop)
+        val = torch.stack((start, stop), 1).to(torch.int32).contiguous()
+        self._entries[real.device] = (key, val)
+        return val
 
 
 def octave_recursion(x, banks, lenghts, hop, n_bins, lowpass, downsample_factor, pad_mode,

@@ -137,6 +137,12 @@ int64_t mispec_framed_gemm_workspace_bytes(const mispec_framed_gemm_args *args);
  * utils.py:498-521 (one call per octave).                                             */
 int mispec_framed_gemm_f32(const mispec_framed_gemm_args *args, void *stream);
 
+/* `n` (<= 8) independent contractions in ONE launch: the octaves of CQT2010v2 / VQT
+ * (cqt.py:1091-1105, vqt.py:167-188) are each too small to fill the chip.  Every problem must
+ * use the same narrow tile shape (<= 64 basis rows, no per-stage row masking); otherwise
+ * MISPEC_E_UNSUPPORTED is returned and the caller launches them one by one.                */
+int mispec_framed_gemm_group_f32(const mispec_framed_gemm_args *args, int32_t n, void *stream);
+
 /* Same contract, one thread per output element, no MFMA, no LDS: a slow device-side
  * cross-check used only by the test-suite to separate indexing bugs from MFMA bugs.   */
 int mispec_framed_gemm_f32_ref(const mispec_framed_gemm_args *args, void *stream);

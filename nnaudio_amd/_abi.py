@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmispec.so")
 
 ABI_VERSION = 2
+E_INVALID, E_UNSUPPORTED, E_HIP = -1, -2, -3
 
 # enums (mirror include/mispec.h)
 PAD_NONE, PAD_ZERO, PAD_REFLECT = 0, 1, 2
@@ -23,6 +24,7 @@ EXPORTS = (
     "mispec_last_error",
     "mispec_framed_gemm_f32",
     "mispec_framed_gemm_f32_ref",
+    "mispec_framed_gemm_group_f32",
     "mispec_framed_gemm_workspace_bytes",
     "mispec_filterbank_f32",
     "mispec_fir_decimate_f32",
@@ -93,6 +95,9 @@ def load():
     for fn in (lib.mispec_framed_gemm_f32, lib.mispec_framed_gemm_f32_ref):
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(FramedGemmArgs), ctypes.c_void_p]
+    lib.mispec_framed_gemm_group_f32.restype = ctypes.c_int
+    lib.mispec_framed_gemm_group_f32.argtypes = [ctypes.POINTER(FramedGemmArgs), ctypes.c_int32,
+                                                 ctypes.c_void_p]
     lib.mispec_framed_gemm_workspace_bytes.restype = ctypes.c_int64
     lib.mispec_framed_gemm_workspace_bytes.argtypes = [ctypes.POINTER(FramedGemmArgs)]
     lib.mispec_fir_decimate_workspace_bytes.restype = ctypes.c_int64

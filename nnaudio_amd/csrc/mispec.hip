@@ -246,7 +246,8 @@ __device__ __forceinline__ int epilogue_width(int epi) {
 // frame-tile-fastest / L2-blocked tile order.
 // ---------------------------------------------------------------------------------
 template <int WM, int WN, int MR, int NR, int BMODE, int AMODE, bool MASKED, bool GLDS>
-__global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams p) {
+__device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_index,
+                                                 const int wg_count) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * MR * 32;
   constexpr int BN = WN * NR * 32;
@@ -293,8 +294,8 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
   // tile order in which `n_group` consecutive frame tiles are crossed with all row tiles.
   int tile;
   {
-    const int nwg = gridDim.x;
-    const int b = blockIdx.x;
+    const int nwg = wg_count;
+    const int b = wg_index;
     const int q = nwg >> 3, r = nwg & 7;
     const int xcd = b & 7, idx = b >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -767,6 +768,32 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
   }
 }
 
+template <int WM, int WN, int MR, int NR, int BMODE, int AMODE, bool MASKED, bool GLDS>
+__global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams p) {
+  framed_gemm_body<WM, WN, MR, NR, BMODE, AMODE, MASKED, GLDS>(p, blockIdx.x, gridDim.x);
+}
+
+// Several independent contractions of the same tile shape in one launch (the octaves of
+// CQT2010v2 / VQT: each is a short-K, few-hundred-workgroup problem that cannot fill the chip on
+// its own).  Workgroups [first[i], first[i+1]) belong to problem i.
+constexpr int GROUP_MAX = 8;
+struct KGroup {
+  int n;
+  int first[GROUP_MAX + 1];
+  KParams p[GROUP_MAX];
+};
+
+template <int WM, int WN, int MR, int NR, int BMODE, int AMODE, bool MASKED, bool GLDS>
+__global__ void __launch_bounds__(WM *WN * 64) framed_gemm_group_kernel(const KGroup g) {
+  int pid = 0;
+#pragma unroll
+  for (int i = 1; i < GROUP_MAX; ++i)
+    if (i < g.n && (int)blockIdx.x >= g.first[i]) pid = i;
+  pid = __builtin_amdgcn_readfirstlane(pid);
+  framed_gemm_body<WM, WN, MR, NR, BMODE, AMODE, MASKED, GLDS>(
+      g.p[pid], blockIdx.x - g.first[pid], g.first[pid + 1] - g.first[pid]);
+}
+
 // ---------------------------------------------------------------------------------
 // Dedicated stride-2 FIR decimator (the octave recursion of CQT2010v2 / VQT spends most of its
 // time here).  Same Toeplitz contraction as the generic kernel,
@@ -950,40 +977,43 @@ int fail(int code, const char *fmt, const char *detail = "") {
   return code;
 }
 
-template <int WM, int WN, int MR, int NR, int BMODE, int AMODE = AMODE_ROWS, bool MASKED = true,
-          bool GLDS = false>
-int launch_cfg(KParams p, hipStream_t stream) {
-  constexpr int NT = WM * WN * 64;
+template <int WM, int WN, int MR, int NR, int BMODE, bool GLDS>
+constexpr size_t cfg_smem() {
   constexpr int BM = WM * MR * 32;
   constexpr int BN = WN * NR * 32;
-  constexpr int MT = WM * MR;
   constexpr int LROW = GLDS ? KC : LDT;
   constexpr int A_STAGE = BM * LROW;
   constexpr int B_STAGE = (BMODE == BMODE_FRAMED) ? BN * LROW : KC * BN;
-  constexpr size_t smem = sizeof(float) * 2 * (A_STAGE + B_STAGE) + sizeof(const float *) * BN +
-                          sizeof(int) * 2 * MT;
+  return sizeof(float) * 2 * (A_STAGE + B_STAGE) + sizeof(const float *) * BN +
+         sizeof(int) * 2 * (WM * MR);
+}
 
+// fill the tiling fields of p for a tile shape; returns the number of workgroups (or < 0)
+template <int WM, int WN, int MR, int NR, int AMODE>
+long long prepare_tiling(KParams &p) {
+  constexpr int BM = WM * MR * 32;
+  constexpr int BN = WN * NR * 32;
   const int rows = AMODE == AMODE_TOEPLITZ ? p.n_bins : p.n_bins * (p.a_im ? 2 : 1);
   p.n_tiles_m = (rows + BM - 1) / BM;
   const long long tn = (p.n_cols + BN - 1) / BN;
-  if (tn * p.n_tiles_m > 0x7fffffffLL) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
+  if (tn * p.n_tiles_m > 0x7fffffffLL) return -1;
   p.n_tiles_n = (int)tn;
-  {
-    // ~64 workgroups are resident per XCD (32 CUs x 2): cross all row tiles with about
-    // 64 / n_tiles_m frame tiles before advancing.  On the STFT cfg2 shape this order runs at
-    // the same speed as the frame-tile-fastest one but moves 2.8x less data across the fabric
-    // (rocprofv3 FETCH_SIZE 1.28e6 KB vs 3.64e6 KB per launch): the K/hop-fold re-reads of the
-    // waveform hit L2 instead of the Infinity Cache.
-    int g = (64 + p.n_tiles_m / 2) / p.n_tiles_m;
-    if (p.debug & 0x100) g = 1 << 20;  // benchmarking: frame-tile-fastest order
-    if (g < 1) g = 1;
-    if (g > p.n_tiles_n) g = p.n_tiles_n;
-    p.n_group = g;
-  }
+  // ~64 workgroups are resident per XCD (32 CUs x 2): cross all row tiles with about
+  // 64 / n_tiles_m frame tiles before advancing.  On the STFT cfg2 shape this order runs at
+  // the same speed as the frame-tile-fastest one but moves 2.8x less data across the fabric
+  // (rocprofv3 FETCH_SIZE 1.28e6 KB vs 3.64e6 KB per launch): the K/hop-fold re-reads of the
+  // waveform hit L2 instead of the Infinity Cache.
+  int g = (64 + p.n_tiles_m / 2) / p.n_tiles_m;
+  if (p.debug & 0x100) g = 1 << 20;  // benchmarking: frame-tile-fastest order
+  if (g < 1) g = 1;
+  if (g > p.n_tiles_n) g = p.n_tiles_n;
+  p.n_group = g;
+  return tn * p.n_tiles_m;
+}
 
-  auto kern = framed_gemm_kernel<WM, WN, MR, NR, BMODE, AMODE, MASKED, GLDS>;
-  // opt in to > 64 KiB of dynamic LDS once per (kernel, device)
-  static std::atomic<unsigned long long> configured{0};
+// opt in to > 64 KiB of dynamic LDS once per (kernel, device)
+template <typename K>
+int configure_lds(K kern, size_t smem, std::atomic<unsigned long long> &configured) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return fail(MISPEC_E_HIP, "hipGetDevice failed%s");
   const unsigned long long bit = 1ull << (dev & 63);
@@ -993,9 +1023,49 @@ int launch_cfg(KParams p, hipStream_t stream) {
     if (e != hipSuccess) return fail(MISPEC_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     configured.fetch_or(bit, std::memory_order_release);
   }
-  const unsigned grid = (unsigned)(p.n_tiles_m * p.n_tiles_n);
+  return MISPEC_OK;
+}
+
+template <int WM, int WN, int MR, int NR, int BMODE, int AMODE = AMODE_ROWS, bool MASKED = true,
+          bool GLDS = false>
+int launch_cfg(KParams p, hipStream_t stream) {
+  constexpr size_t smem = cfg_smem<WM, WN, MR, NR, BMODE, GLDS>();
+  const long long grid = prepare_tiling<WM, WN, MR, NR, AMODE>(p);
+  if (grid < 0) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
   if (grid == 0) return MISPEC_OK;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), smem, stream, p);
+  auto kern = framed_gemm_kernel<WM, WN, MR, NR, BMODE, AMODE, MASKED, GLDS>;
+  static std::atomic<unsigned long long> configured{0};
+  int rc = configure_lds(kern, smem, configured);
+  if (rc != MISPEC_OK) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WM * WN * 64), smem, stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+
+// grouped launch of up to GROUP_MAX problems with one tile shape
+template <int WM, int WN, int MR, int NR, bool MASKED, bool GLDS>
+int launch_group_cfg(KParams *ps, int n, hipStream_t stream) {
+  constexpr size_t smem = cfg_smem<WM, WN, MR, NR, BMODE_FRAMED, GLDS>();
+  KGroup g;
+  memset(&g, 0, sizeof(g));
+  g.n = n;
+  long long total = 0;
+  for (int i = 0; i < n; ++i) {
+    const long long grid = prepare_tiling<WM, WN, MR, NR, AMODE_ROWS>(ps[i]);
+    if (grid < 0 || total + grid > 0x7fffffffLL)
+      return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
+    g.first[i] = (int)total;
+    total += grid;
+    g.p[i] = ps[i];
+  }
+  for (int i = n; i <= GROUP_MAX; ++i) g.first[i] = (int)total;
+  if (total == 0) return MISPEC_OK;
+  auto kern = framed_gemm_group_kernel<WM, WN, MR, NR, BMODE_FRAMED, AMODE_ROWS, MASKED, GLDS>;
+  static std::atomic<unsigned long long> configured{0};
+  int rc = configure_lds(kern, smem, configured);
+  if (rc != MISPEC_OK) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(WM * WN * 64), smem, stream, g);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
   return MISPEC_OK;
@@ -1220,6 +1290,31 @@ int mispec_framed_gemm_f32(const mispec_framed_gemm_args *args, void *stream) {
   rc = setup_edges(p, args->workspace, args->workspace_bytes, s);
   if (rc != MISPEC_OK) return rc;
   return launch_framed(p, args->tile, s);
+}
+
+int mispec_framed_gemm_group_f32(const mispec_framed_gemm_args *args, int32_t n, void *stream) {
+  if (!args || n <= 0) return fail(MISPEC_E_INVALID, "empty group%s");
+  if (n > GROUP_MAX) return fail(MISPEC_E_UNSUPPORTED, "more than 8 problems in a group%s");
+  KParams ps[GROUP_MAX];
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int tile = -1;
+  for (int i = 0; i < n; ++i) {
+    int rc = fill_params(&args[i], ps[i]);
+    if (rc != MISPEC_OK) return rc;
+    const int rows = ps[i].n_bins * (ps[i].a_im ? 2 : 1);
+    const int t = args[i].tile != MISPEC_TILE_AUTO ? args[i].tile
+                                                    : auto_tile(rows, ps[i].row_support != nullptr);
+    if (i == 0) tile = t;
+    if (t != tile || (t != MISPEC_TILE_32x256 && t != MISPEC_TILE_64x256))
+      return fail(MISPEC_E_UNSUPPORTED,
+                  "grouped launch needs one narrow tile shape (<= 64 basis rows) for every problem%s");
+  }
+  for (int i = 0; i < n; ++i) {
+    int rc = setup_edges(ps[i], args[i].workspace, args[i].workspace_bytes, s);
+    if (rc != MISPEC_OK) return rc;
+  }
+  if (tile == MISPEC_TILE_32x256) return launch_group_cfg<1, 4, 1, 2, false, true>(ps, n, s);
+  return launch_group_cfg<1, 4, 2, 2, false, true>(ps, n, s);
 }
 
 int mispec_framed_gemm_f32_ref(const mispec_framed_gemm_args *args, void *stream) {

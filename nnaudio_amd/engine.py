@@ -91,14 +91,12 @@ def n_frames(length, kernel, hop, pad):
     return span // hop + 1
 
 
-def framed_gemm(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign=-1.0,
-                eps=0.0, power=2.0, row_scale=None, row_support=None, out=None,
-                out_rows_total=None, out_row_offset=0, tile=TILE_AUTO, reference_kernel=False,
-                _debug=0):
-    """``out[b, row_offset + f, t(, 0:2)]`` <- epilogue(sum_n x_pad[b, t*hop + n] * basis[f, n]).
-
-    ``pad_mode`` is one of ``PAD_*``; ``out`` may be a pre-allocated (B, rows_total, T[, 2])
-    tensor (octave assembly / all-gather slices write in place)."""
+def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign=-1.0,
+                 eps=0.0, power=2.0, row_scale=None, row_support=None, out=None,
+                 out_rows_total=None, out_row_offset=0, tile=TILE_AUTO, _debug=0,
+                 need_workspace=True):
+    """Validate one framed-contraction problem and fill its C argument block.
+    Returns (args, out, device, keepalive tensors)."""
     dev = _require_device(x, basis_re, basis_im, row_scale, row_support, out)
     x = _signal(x)
     wr = _rows(basis_re, "basis_re")
@@ -155,21 +153,58 @@ def framed_gemm(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign=
     a.out_row_stride = T * E
     a.out_row_offset = int(out_row_offset)
     a.reserved = int(_debug) | _ENV_DEBUG
-    lib = _abi.load()
-    ws = None
-    if not reference_kernel:
-        need = lib.mispec_framed_gemm_workspace_bytes(ctypes.byref(a))
+    keep = [x, wr, wi, row_scale, row_support]
+    if need_workspace:
+        need = _abi.load().mispec_framed_gemm_workspace_bytes(ctypes.byref(a))
         if need < 0:
             _abi.check(int(need))
         if need > 0:
             # padded edge spans; stream-ordered reuse through the caching allocator
             ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
             a.workspace, a.workspace_bytes = ws.data_ptr(), need
+            keep.append(ws)
+    return a, out, dev, keep
+
+
+def framed_gemm(x, basis_re, basis_im, *, reference_kernel=False, **kw):
+    """``out[b, row_offset + f, t(, 0:2)]`` <- epilogue(sum_n x_pad[b, t*hop + n] * basis[f, n]).
+
+    Keyword arguments: hop, pad, pad_mode (``PAD_*``), epilogue (``EPI_*``), im_sign, eps, power,
+    row_scale, row_support, out (pre-allocated (B, rows_total, T[, 2]) tensor: octave assembly /
+    all-gather slices write in place), out_rows_total, out_row_offset, tile."""
+    a, out, dev, _keep = _framed_args(x, basis_re, basis_im, need_workspace=not reference_kernel,
+                                      **kw)
+    lib = _abi.load()
     fn = lib.mispec_framed_gemm_f32_ref if reference_kernel else lib.mispec_framed_gemm_f32
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
         _abi.check(fn(ctypes.byref(a), ctypes.c_void_p(stream)))
     return out
+
+
+def framed_gemm_group(problems):
+    """Launch several independent framed contractions (the octaves of CQT2010v2 / VQT) as one
+    grouped kernel launch; ``problems`` is a list of ``(x, basis_re, basis_im, kwargs)``.
+    Falls back to one launch per problem when the library reports the group as unsupported
+    (different tile shapes, more than 8 problems)."""
+    if not problems:
+        return
+    lib = _abi.load()
+    built = [_framed_args(x, wr, wi, **kw) for (x, wr, wi, kw) in problems]
+    dev = built[0][2]
+    if any(b[2] != dev for b in built):
+        raise RuntimeError("grouped problems must live on one device")
+    with torch.cuda.device(dev):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        for i in range(0, len(built), 8):
+            chunk = built[i:i + 8]
+            arr = (_abi.FramedGemmArgs * len(chunk))(*[b[0] for b in chunk])
+            rc = lib.mispec_framed_gemm_group_f32(arr, len(chunk), stream)
+            if rc == _abi.E_UNSUPPORTED:
+                for b in chunk:
+                    _abi.check(lib.mispec_framed_gemm_f32(ctypes.byref(b[0]), stream))
+            else:
+                _abi.check(rc)
 
 
 def filterbank(fb, spec):

@@ -82,6 +82,7 @@ def octave_recursion(x, banks, lenghts, hop, n_bins, lowpass, downsample_factor,
     out = None
     xd = x
     T_ref = None
+    launches = []  # the per-octave contractions are independent: one grouped launch at the end
     for i, (kr, ki) in enumerate(banks):
         if i > 0:
             hop = hop // 2
@@ -123,11 +124,11 @@ def octave_recursion(x, banks, lenghts, hop, n_bins, lowpass, downsample_factor,
         sup = None
         if supports is not None and not trainable:
             sup = supports[i].get(kr, ki)[first:].contiguous()
-        engine.framed_gemm(
-            xd, kr_i, ki_i, hop=hop, pad=pad, pad_mode=mode, epilogue=epi, im_sign=-1.0,
+        launches.append((xd, kr_i, ki_i, dict(
+            hop=hop, pad=pad, pad_mode=mode, epilogue=epi, im_sign=-1.0,
             eps=1e-8 if trainable else 0.0, row_scale=scale[row0:row0 + rows].contiguous(),
-            row_support=sup, out=out, out_rows_total=n_bins, out_row_offset=row0,
-        )
+            row_support=sup, out=out, out_rows_total=n_bins, out_row_offset=row0)))
+    engine.framed_gemm_group(launches)
     return out
 
 

@@ -794,6 +794,20 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_group_kernel(const KG
       g.p[pid], blockIdx.x - g.first[pid], g.first[pid + 1] - g.first[pid]);
 }
 
+// Two tile shapes in one launch: workgroups [0, n_main) run the dense 128x128 contraction over
+// the rows that fill whole 128-row blocks, the rest run a narrow tile over the leftover rows
+// (the Nyquist bin of an n_fft/2+1 STFT).  Appended at the end of the grid, the narrow
+// workgroups fill the tail of the main grid instead of paying for a launch of their own.
+template <int RMR>
+__global__ void __launch_bounds__(256) framed_gemm_pair_kernel(const KParams pm, const KParams pr,
+                                                               const int n_main) {
+  if ((int)blockIdx.x < n_main)
+    framed_gemm_body<2, 2, 2, 2, BMODE_FRAMED, AMODE_ROWS, false, true>(pm, blockIdx.x, n_main);
+  else
+    framed_gemm_body<1, 4, RMR, 2, BMODE_FRAMED, AMODE_ROWS, false, true>(
+        pr, blockIdx.x - n_main, gridDim.x - n_main);
+}
+
 // ---------------------------------------------------------------------------------
 // Dedicated stride-2 FIR decimator (the octave recursion of CQT2010v2 / VQT spends most of its
 // time here).  Same Toeplitz contraction as the generic kernel,
@@ -1137,17 +1151,48 @@ int launch_framed(const KParams &p, int tile, hipStream_t stream) {
   const int main_bins = (p.n_bins / bins_per_wg) * bins_per_wg;
   KParams q = p;
   q.n_bins = main_bins;
+  const int rem = p.n_bins - main_bins;
+  if (rem == 0) return launch_tile(q, MISPEC_TILE_128x128, stream);
+  KParams r = p;
+  r.n_bins = rem;
+  r.a_re = p.a_re + (long long)main_bins * p.a_row_stride;
+  if (p.a_im) r.a_im = p.a_im + (long long)main_bins * p.a_row_stride;
+  if (p.row_scale) r.row_scale = p.row_scale + main_bins;
+  r.out_row_offset = p.out_row_offset + main_bins;
+  const int rem_rows = rem * rpb;
+  if (rem_rows <= 64 && glds_ok(p) && !(p.debug & 0x2000)) {
+    // one launch: main grid + narrow workgroups for the leftover rows in its tail
+    const long long gm = prepare_tiling<2, 2, 2, 2, AMODE_ROWS>(q);
+    const long long gr = rem_rows <= 32 ? prepare_tiling<1, 4, 1, 2, AMODE_ROWS>(r)
+                                        : prepare_tiling<1, 4, 2, 2, AMODE_ROWS>(r);
+    if (gm < 0 || gr < 0 || gm + gr > 0x7fffffffLL)
+      return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
+    constexpr size_t sm_main = cfg_smem<2, 2, 2, 2, BMODE_FRAMED, true>();
+    constexpr size_t sm_r1 = cfg_smem<1, 4, 1, 2, BMODE_FRAMED, true>();
+    constexpr size_t sm_r2 = cfg_smem<1, 4, 2, 2, BMODE_FRAMED, true>();
+    hipError_t e;
+    if (rem_rows <= 32) {
+      constexpr size_t smem = sm_main > sm_r1 ? sm_main : sm_r1;
+      auto kern = framed_gemm_pair_kernel<1>;
+      static std::atomic<unsigned long long> configured{0};
+      int rc = configure_lds(kern, smem, configured);
+      if (rc != MISPEC_OK) return rc;
+      hipLaunchKernelGGL(kern, dim3((unsigned)(gm + gr)), dim3(256), smem, stream, q, r, (int)gm);
+    } else {
+      constexpr size_t smem = sm_main > sm_r2 ? sm_main : sm_r2;
+      auto kern = framed_gemm_pair_kernel<2>;
+      static std::atomic<unsigned long long> configured{0};
+      int rc = configure_lds(kern, smem, configured);
+      if (rc != MISPEC_OK) return rc;
+      hipLaunchKernelGGL(kern, dim3((unsigned)(gm + gr)), dim3(256), smem, stream, q, r, (int)gm);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return MISPEC_OK;
+  }
   int rc = launch_tile(q, MISPEC_TILE_128x128, stream);
   if (rc != MISPEC_OK) return rc;
-  const int rem = p.n_bins - main_bins;
-  if (rem == 0) return MISPEC_OK;
-  q = p;
-  q.n_bins = rem;
-  q.a_re = p.a_re + (long long)main_bins * p.a_row_stride;
-  if (p.a_im) q.a_im = p.a_im + (long long)main_bins * p.a_row_stride;
-  if (p.row_scale) q.row_scale = p.row_scale + main_bins;
-  q.out_row_offset = p.out_row_offset + main_bins;
-  return launch_tile(q, auto_tile(rem * rpb, false), stream);
+  return launch_tile(r, auto_tile(rem_rows, false), stream);
 }
 
 // attach the edge workspace to p and enqueue the fill pre-pass

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MISPEC_ABI_VERSION 2
+#define MISPEC_ABI_VERSION 3
 
 enum {
   MISPEC_OK = 0,
@@ -73,6 +73,15 @@ enum {
   MISPEC_TILE_256x128_SQ = 7, /* 2x2 waves, 128x64 per wave: one wave per SIMD           */
   MISPEC_TILE_128x256_SQ = 8, /* 2x2 waves, 64x128 per wave                              */
   MISPEC_TILE_256x256 = 9     /* 2x2 waves, 128x128 per wave (256 accumulator registers)  */
+};
+
+/* arithmetic of the framed contraction (the north star allows "MFMA bf16/fp32" at 1e-4 rel) */
+enum {
+  MISPEC_PREC_F32 = 0,   /* v_mfma_f32_32x32x2_f32: fp32 operands, fp32 accumulate (an fmaf chain) */
+  MISPEC_PREC_BF16X3 = 1 /* fp32 operands split into bf16 (hi, lo) pairs; every product is          */
+                         /* a_hi*x_hi + a_hi*x_lo + a_lo*x_hi on v_mfma_f32_32x32x16_bf16 with fp32   */
+                         /* accumulate: ~16 operand mantissa bits, error ~5e-6 of the spectrum peak. */
+                         /* Needs basis_split; shapes it does not cover run in MISPEC_PREC_F32.      */
 };
 
 /*
@@ -122,6 +131,11 @@ typedef struct mispec_framed_gemm_args {
 
   void *workspace;             /* device scratch of >= mispec_framed_gemm_workspace_bytes() */
   int64_t workspace_bytes;     /* bytes; may be NULL/0 when the query returns 0            */
+
+  int32_t precision;           /* MISPEC_PREC_*: the LOWEST precision the caller accepts   */
+  int32_t reserved2;           /* must be 0                                                */
+  const void *basis_split;     /* MISPEC_PREC_BF16X3: output of mispec_split_basis_bf16()  */
+  int64_t basis_split_bytes;   /* for this (basis_re, basis_im, n_bins, kernel); else NULL */
 } mispec_framed_gemm_args;
 
 /*
@@ -129,9 +143,22 @@ typedef struct mispec_framed_gemm_args {
  * (the handful of frames per clip that touch the virtual padding or run past the clip end are
  * staged there by a pre-pass so that every frame is a plain run of memory; interior frames are
  * read straight from x).  Depends only on the sizes in `args`; 0 when every frame is interior
- * (center=False with kernel % 32 == 0).  Negative = MISPEC_E_*.
+ * (center=False with kernel % 32 == 0).  With MISPEC_PREC_BF16X3 it also holds the (hi, lo)
+ * bf16 planes of the waveform and of the edge spans (4 more bytes per sample).
+ * Negative = MISPEC_E_*.
  */
 int64_t mispec_framed_gemm_workspace_bytes(const mispec_framed_gemm_args *args);
+
+/*
+ * MISPEC_PREC_BF16X3 operand preparation for a basis: (hi, lo) bf16 planes of basis_re (and
+ * basis_im), rows zero-padded to a multiple of 32 taps.  Done once per basis (the bases are the
+ * modules' precomputed buffers, stft.py:230-245 / cqt.py:682-702) and again only when the basis
+ * changes.  `dst` is caller-owned device memory of mispec_basis_split_bytes() bytes.
+ */
+int64_t mispec_basis_split_bytes(int32_t n_bins, int32_t kernel, int32_t has_im);
+int mispec_split_basis_bf16(const float *basis_re, const float *basis_im,
+                            int64_t basis_row_stride, int32_t n_bins, int32_t kernel,
+                            void *dst, int64_t dst_bytes, void *stream);
 
 /* Launch the MFMA framed contraction.  Replaces stft.py:278-316, cqt.py:740-780,
  * utils.py:498-521 (one call per octave).                                             */

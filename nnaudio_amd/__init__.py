@@ -4,3 +4,18 @@
 ``forward`` routes through the C ABI of ``csrc/libmispec.so`` (hand-written HIP for gfx950).
 """
 __version__ = "0.1.0"
+
+
+def set_precision(name):
+    """Process-wide arithmetic of the framed contraction: "fp32" (default; fp32 MFMA) or
+    "bf16x3" (split-bf16 operands on the bf16 MFMA, fp32 accumulate).  A module's own
+    ``precision`` attribute, when not None, takes precedence."""
+    from . import engine
+
+    engine.set_precision(name)
+
+
+def get_precision():
+    from . import engine
+
+    return engine.get_precision()

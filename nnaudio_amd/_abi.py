@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmispec.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 E_INVALID, E_UNSUPPORTED, E_HIP = -1, -2, -3
 
 # enums (mirror include/mispec.h)
@@ -18,6 +18,7 @@ PAD_NONE, PAD_ZERO, PAD_REFLECT = 0, 1, 2
 EPI_COMPLEX, EPI_MAGNITUDE, EPI_POWER, EPI_PHASE_ATAN2, EPI_PHASE_COSSIN, EPI_REAL = range(6)
 (TILE_AUTO, TILE_128x128, TILE_32x256, TILE_64x256, TILE_128x128_TALL, TILE_192x128, TILE_256x128,
  TILE_256x128_SQ, TILE_128x256_SQ, TILE_256x256) = range(10)
+PREC_F32, PREC_BF16X3 = 0, 1
 
 EXPORTS = (
     "mispec_version",
@@ -26,6 +27,8 @@ EXPORTS = (
     "mispec_framed_gemm_f32_ref",
     "mispec_framed_gemm_group_f32",
     "mispec_framed_gemm_workspace_bytes",
+    "mispec_basis_split_bytes",
+    "mispec_split_basis_bf16",
     "mispec_filterbank_f32",
     "mispec_fir_decimate_f32",
     "mispec_fir_decimate_workspace_bytes",
@@ -64,6 +67,10 @@ class FramedGemmArgs(ctypes.Structure):
         ("reserved", ctypes.c_int32),
         ("workspace", ctypes.c_void_p),
         ("workspace_bytes", ctypes.c_int64),
+        ("precision", ctypes.c_int32),
+        ("reserved2", ctypes.c_int32),
+        ("basis_split", ctypes.c_void_p),
+        ("basis_split_bytes", ctypes.c_int64),
     ]
 
 
@@ -100,6 +107,13 @@ def load():
                                                  ctypes.c_void_p]
     lib.mispec_framed_gemm_workspace_bytes.restype = ctypes.c_int64
     lib.mispec_framed_gemm_workspace_bytes.argtypes = [ctypes.POINTER(FramedGemmArgs)]
+    lib.mispec_basis_split_bytes.restype = ctypes.c_int64
+    lib.mispec_basis_split_bytes.argtypes = [ctypes.c_int32] * 3
+    lib.mispec_split_basis_bf16.restype = ctypes.c_int
+    lib.mispec_split_basis_bf16.argtypes = [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+        ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+    ]
     lib.mispec_fir_decimate_workspace_bytes.restype = ctypes.c_int64
     lib.mispec_fir_decimate_workspace_bytes.argtypes = [ctypes.c_int32] * 6
     lib.mispec_filterbank_f32.restype = ctypes.c_int

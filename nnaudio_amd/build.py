@@ -19,7 +19,10 @@ def hipcc():
 
 
 def build(force=False, verbose=True):
-    deps = [SRC, os.path.join(INC, "mispec.h")]
+    csrc = os.path.dirname(SRC)
+    deps = [os.path.join(INC, "mispec.h")] + [
+        os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".inl", ".h"))
+    ]
     if (not force and os.path.exists(OUT)
             and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps)):
         return OUT

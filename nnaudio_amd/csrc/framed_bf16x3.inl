@@ -1,0 +1,405 @@
+// framed_bf16x3.inl -- MISPEC_PREC_BF16X3: the framed contraction on the bf16 matrix pipe.
+// Included by mispec.hip inside its anonymous namespace (shares KParams, the edge plan, the
+// XCD-aware tile order and the pointwise epilogue with the fp32 kernel).
+//
+// gfx950 has no fast fp32 MFMA (v_mfma_f32_32x32x2_f32: 157 TFLOP/s) but a 16x faster bf16 one
+// (v_mfma_f32_32x32x16_bf16: 2.5 PFLOP/s).  Every fp32 operand v is split once into two bf16
+// numbers  v ~= hi + lo  (hi = rne(v), lo = rne(v - hi): 16 significant bits, full fp32 exponent
+// range) and every product is taken as
+//        a*x ~= a_lo*x_hi + a_hi*x_lo + a_hi*x_hi          (fp32 accumulate on the MFMA)
+// i.e. three bf16 MFMAs per fp32 MFMA-equivalent, a 16/3 = 5.3x higher matrix-pipe ceiling.
+// The dropped a_lo*x_lo term and the split error are ~2^-17 per product; measured error is
+// ~5e-6 of the spectrum peak against 6e-7 for the fp32 path (tests/test_gpu_parity.py), inside
+// the 1e-4 bar of the north star.
+//
+// Operands (all bf16, prepared by the two pre-pass kernels below):
+//   basis : planes [re_hi | re_lo | im_hi | im_lo], each (n_bins, Ks), Ks = K rounded up to 32
+//           with zero taps -> no K-tail handling; split once per basis (cached by the caller)
+//   signal: planes [hi | lo], each (n_clips, S): a clip slot = [waveform, Ls | padded edge
+//           spans]: every frame is a plain run of >= Ks elements at an EVEN element offset
+//           (hop and pad even), so 16-byte LDS-direct pieces start 4-byte aligned.
+//
+// Workgroup = WM x WN waves, wave tile MR x NR MFMA tiles of 32x32, K stage = 32 taps.
+// LDS stage = [A_hi | A_lo | X_hi | X_lo], rows of 64 B (32 bf16), double buffered, filled by
+// global_load_lds_dwordx4 (one instruction = 16 rows x 64 B).  The four 16-byte chunks of a row
+// are XOR-swizzled by (row >> 2) & 3 -- applied to the per-lane SOURCE address of the DMA and
+// again on the fragment reads -- which makes every ds_read_b128 lane group conflict free
+// (rows r, r+4, r+8, r+12 share banks; MI355X_MICROARCH.md, LDS table).
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned bf16_rne_bits(float v) {
+  const unsigned u = __float_as_uint(v);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;  // NaN stays NaN
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+// v ~= hi + lo, both bf16 (returned as bit patterns)
+__device__ __forceinline__ void bf16_split(float v, unsigned &hi, unsigned &lo) {
+  hi = bf16_rne_bits(v);
+  const float hf = __uint_as_float(hi << 16);
+  const float r = v - hf;
+  // |v| beyond the bf16 range rounds hi to inf: keep lo finite (inf - inf would be NaN)
+  lo = ((hi & 0x7f80u) == 0x7f80u) ? 0u : bf16_rne_bits(r);
+}
+
+// basis rows -> (hi, lo) planes, zero-padded to Ks taps.  grid (ceil(Ks/256), n_bins, 1 or 2)
+__global__ void __launch_bounds__(256) split_basis_kernel(const float *__restrict__ re,
+                                                          const float *__restrict__ im,
+                                                          long long row_stride, int n_bins, int K,
+                                                          int Ks, unsigned short *__restrict__ dst) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= Ks) return;
+  const int bin = blockIdx.y;
+  const int z = blockIdx.z;
+  const float *src = z ? im : re;
+  const float v = k < K ? src[(long long)bin * row_stride + k] : 0.f;
+  unsigned hi, lo;
+  bf16_split(v, hi, lo);
+  const long long plane = (long long)n_bins * Ks;
+  const long long o = (long long)bin * Ks + k;
+  dst[(2 * z) * plane + o] = (unsigned short)hi;
+  dst[(2 * z + 1) * plane + o] = (unsigned short)lo;
+}
+
+// waveform + padded edge spans of every clip -> (hi, lo) planes.  One thread = 4 consecutive
+// elements of a clip slot (S % 8 == 0).  grid (ceil(S/1024), n_clips)
+__global__ void __launch_bounds__(256) split_signal_kernel(const KParams p,
+                                                           unsigned short *__restrict__ dst) {
+  const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 >= p.xs_clip_stride) return;
+  const int c = blockIdx.y;
+  const float *x = p.x + (long long)c * p.x_clip_stride;
+  float v[4];
+  if (i0 + 4 <= p.n_samples) {
+    const f32x4u t = *reinterpret_cast<const f32x4u *>(x + i0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = t[e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long long i = i0 + e;
+      float t = 0.f;
+      if (i < p.n_samples) {
+        t = x[i];
+      } else if (i >= p.xs_edge_off && i - p.xs_edge_off < p.edge_clip_stride) {
+        const long long j = i - p.xs_edge_off;  // as edge_fill_kernel
+        const long long q = (p.edge_mode == EDGE_FULL || j < p.edge_ll)
+                                ? j - p.pad
+                                : (long long)p.t_r0 * p.hop - p.pad + (j - p.edge_ll);
+        if (q >= -(long long)p.pad && q < (long long)p.n_samples + p.pad)
+          t = fetch_sample(p.x, (long long)c * p.x_clip_stride, (int)q, p.n_samples, p.pad_mode,
+                           true);
+      }
+      v[e] = t;
+    }
+  }
+  u16x4 h, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    unsigned hi, lo;
+    bf16_split(v[e], hi, lo);
+    h[e] = (unsigned short)hi;
+    l[e] = (unsigned short)lo;
+  }
+  unsigned short *o = dst + (long long)c * p.xs_clip_stride + i0;
+  *reinterpret_cast<u16x4 *>(o) = h;
+  *reinterpret_cast<u16x4 *>(o + p.xs_plane) = l;
+}
+
+template <int WM, int WN, int MR, int NR, bool MASKED>
+__device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int wg_index,
+                                                   const int wg_count) {
+  constexpr int NW = WM * WN;
+  constexpr int NT = NW * 64;
+  constexpr int BM = WM * MR * 32;
+  constexpr int BN = WN * NR * 32;
+  constexpr int MT = WM * MR;
+  constexpr int ROWB = KC * 2;        // bytes of one row of one plane in a stage
+  constexpr int A_PL = BM * ROWB;     // bytes of one A plane
+  constexpr int X_PL = BN * ROWB;
+  constexpr int STAGE = 2 * A_PL + 2 * X_PL;
+  constexpr int AJ = BM / (16 * NW);  // DMA instructions per wave, per plane, per stage
+  constexpr int XJ = BN / (16 * NW);
+  static_assert(BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "DMA geometry");
+  typedef __attribute__((address_space(1))) const void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned char *sStage = smem_raw;  // [2][STAGE]
+  long long *sColOff = reinterpret_cast<long long *>(smem_raw + 2 * STAGE);  // [BN]
+  int *sTileLo = reinterpret_cast<int *>(sColOff + BN);
+  int *sTileHi = sTileLo + MT;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN;
+  const int wn = wave % WN;
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+  const int row16 = lane >> 2;                    // DMA: row inside a 16-row piece
+  const int cg = (lane & 3) ^ ((lane >> 4) & 3);  // DMA: global chunk that lands in slot lane & 3
+
+  // ---- XCD-aware tile order (as framed_gemm_body)
+  int tile;
+  {
+    const int nwg = wg_count, b = wg_index;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = b & 7, idx = b >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tile_m, tile_n;
+  {
+    const int G = p.n_group;
+    const int per_group = G * p.n_tiles_m;
+    const int full = (p.n_tiles_n / G) * per_group;
+    if (tile < full) {
+      const int g = tile / per_group;
+      const int rest = tile - g * per_group;
+      tile_m = rest / G;
+      tile_n = g * G + (rest - tile_m * G);
+    } else {
+      const int Gt = p.n_tiles_n % G;
+      const int rest = tile - full;
+      tile_m = rest / Gt;
+      tile_n = (p.n_tiles_n / G) * G + (rest - tile_m * Gt);
+    }
+  }
+  const int m0 = tile_m * BM;
+  const long long n0 = (long long)tile_n * BN;
+  const bool cplx = p.a_im != nullptr;
+  const int rpb = cplx ? 2 : 1;
+
+  // ---- per-frame element offsets into the split signal, per-row-tile K ranges
+  for (int j = tid; j < BN; j += NT) {
+    long long col = n0 + j;
+    if (col >= p.n_cols) col = 0;  // unused column: any valid frame, its results are not stored
+    const int c = (int)(col / p.n_frames);
+    const int t = (int)(col - (long long)c * p.n_frames);
+    const long long in_clip = t < p.n_left ? p.xs_edge_off + (long long)t * p.hop
+                              : t >= p.t_r0
+                                  ? p.xs_edge_off + p.edge_ll + (long long)(t - p.t_r0) * p.hop
+                                  : (long long)t * p.hop - p.pad;
+    sColOff[j] = (long long)c * p.xs_clip_stride + in_clip;
+  }
+  if (tid < MT) {
+    const int row_lo = m0 + tid * 32;
+    int lo = 0, hi = 0;
+    const int bin_lo = row_lo / rpb;
+    int bin_hi = (row_lo + 32 + rpb - 1) / rpb;
+    bin_hi = bin_hi < p.n_bins ? bin_hi : p.n_bins;
+    if (bin_lo < bin_hi) {
+      if (p.row_support) {
+        lo = p.K;
+        hi = 0;
+        for (int b = bin_lo; b < bin_hi; ++b) {
+          const int s = p.row_support[2 * b], e = p.row_support[2 * b + 1];
+          if (e > s) {
+            lo = s < lo ? s : lo;
+            hi = e > hi ? e : hi;
+          }
+        }
+        lo = lo < 0 ? 0 : lo;
+        hi = hi > p.K ? p.K : hi;
+        if (hi <= lo) lo = hi = 0;
+      } else {
+        hi = p.K;
+      }
+    }
+    sTileLo[tid] = lo;
+    sTileHi[tid] = hi;
+  }
+  __syncthreads();
+
+  int tlo[MT], thi[MT];
+  int kb = p.K, ke = 0;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    tlo[i] = __builtin_amdgcn_readfirstlane(sTileLo[i]);
+    thi[i] = __builtin_amdgcn_readfirstlane(sTileHi[i]);
+    if (thi[i] > tlo[i]) {
+      kb = tlo[i] < kb ? tlo[i] : kb;
+      ke = thi[i] > ke ? thi[i] : ke;
+    }
+  }
+  kb = kb & ~(KC - 1);
+  const int nstages = ke > kb ? (ke - kb + KC - 1) / KC : 0;  // Ks covers the last partial stage
+  auto stage_mask = [&](int kc) __attribute__((always_inline)) -> unsigned {
+    if (!MASKED) return (1u << MT) - 1u;
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+      if (thi[i] > kc && tlo[i] < kc + KC) m |= 1u << i;
+    return m;
+  };
+
+  // ---- DMA source pointers (hi planes; lo = + plane distance), one per 16-row piece
+  const unsigned short *aptr[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int row = m0 + (j * NW + wave) * 16 + row16;
+    int bin = cplx ? (row >> 1) : row;
+    bin = bin < p.n_bins ? bin : p.n_bins - 1;  // rows past the end feed unused accumulators
+    const long long comp = (cplx && (row & 1)) ? 2 * p.as_plane : 0;
+    aptr[j] = p.as + comp + (long long)bin * p.Ks + 8 * cg;
+  }
+  const unsigned short *xptr[XJ];
+#pragma unroll
+  for (int j = 0; j < XJ; ++j) xptr[j] = p.xs + sColOff[(j * NW + wave) * 16 + row16] + 8 * cg;
+
+  auto dma_stage = [&](int kc, int buf, unsigned am) __attribute__((always_inline)) {
+    unsigned char *st = sStage + buf * STAGE;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      // 16-row piece j*NW + wave lies in row tile (j*NW + wave) / 2; an inactive row tile is
+      // all zeros in this stage and is not multiplied: fetch one hot row instead
+      const bool on = !MASKED || ((am >> ((j * NW + wave) >> 1)) & 1u);
+      const unsigned short *src = on ? aptr[j] + kc : p.as + 8 * cg;
+      unsigned char *d = st + (j * NW + wave) * 16 * ROWB;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)d, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + p.as_plane), (lptr_t)(d + A_PL), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+      const unsigned short *src = xptr[j] + kc;
+      unsigned char *d = st + 2 * A_PL + (j * NW + wave) * 16 * ROWB;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)d, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + p.xs_plane), (lptr_t)(d + X_PL), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[MR][NR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int n = 0; n < NR; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+
+  // One K stage: two 16-deep MFMA steps.  Lane (li, lh) supplies row li of a 32-row tile and
+  // taps 8*lh .. 8*lh+7 of the step: one ds_read_b128 per (tile, plane).
+  auto mfma_stage = [&](int buf, unsigned mask) __attribute__((always_inline)) {
+    const unsigned char *st = sStage + buf * STAGE;
+    const unsigned char *a_base = st + ((wm * MR) * 32 + li) * ROWB;
+    const unsigned char *x_base = st + 2 * A_PL + ((wn * NR) * 32 + li) * ROWB;
+    const int fsw = (li >> 2) & 3;
+    const unsigned wmask = MASKED ? (mask >> (wm * MR)) : ~0u;
+    bf16x8 ah[2][MR], al[2][MR], xh[2][NR], xl[2][NR];
+    auto load_frags = [&](int q, int slot) __attribute__((always_inline)) {
+      const int off = 16 * ((2 * q + lh) ^ fsw);
+#pragma unroll
+      for (int m = 0; m < MR; ++m) {
+        ah[slot][m] = *reinterpret_cast<const bf16x8 *>(a_base + m * 32 * ROWB + off);
+        al[slot][m] = *reinterpret_cast<const bf16x8 *>(a_base + A_PL + m * 32 * ROWB + off);
+      }
+#pragma unroll
+      for (int n = 0; n < NR; ++n) {
+        xh[slot][n] = *reinterpret_cast<const bf16x8 *>(x_base + n * 32 * ROWB + off);
+        xl[slot][n] = *reinterpret_cast<const bf16x8 *>(x_base + X_PL + n * 32 * ROWB + off);
+      }
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int q = 0; q < KC / 16; ++q) {
+      if (q + 1 < KC / 16) load_frags(q + 1, (q + 1) & 1);  // prefetch under the MFMAs
+      const int s = q & 1;
+      // small terms first; each accumulator is revisited only after MR*NR - 1 other MFMAs
+#pragma unroll
+      for (int term = 0; term < 3; ++term) {
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+          if ((!MASKED || ((wmask >> m) & 1u)) && !(p.debug & 16)) {
+#pragma unroll
+            for (int n = 0; n < NR; ++n) {
+              const bf16x8 a = term == 0 ? al[s][m] : ah[s][m];
+              const bf16x8 x = term == 1 ? xl[s][n] : xh[s][n];
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, x, acc[m][n], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  };
+
+  // ---- K loop: stage c+1 is DMA'd into the other buffer while stage c is multiplied; the
+  // barrier at the end of the iteration (carrying the vmcnt(0)) publishes it.
+  if (nstages > 0) {
+    dma_stage(kb, 0, stage_mask(kb));
+    __syncthreads();
+    for (int c = 0; c < nstages; ++c) {
+      const int buf = c & 1;
+      const int kc = kb + c * KC;
+      // debug bits (benchmark ablations, results are wrong): 1 no DMA in the loop, 16 no MFMAs,
+      // 4 no barrier
+      if (c + 1 < nstages && !(p.debug & 1)) dma_stage(kc + KC, buf ^ 1, stage_mask(kc + KC));
+      mfma_stage(buf, stage_mask(kc));
+      if (!(p.debug & 4)) __syncthreads();
+    }
+  }
+
+  // ---- epilogue (frames innermost), as framed_gemm_body: one 32x32 tile at a time through a
+  // wave-private LDS patch.  Accumulator element e of lane (li, lh) is
+  // D[row = (e&3) + 8*(e>>2) + 4*lh][col = li].
+  constexpr int LDC = 33;
+  float *sC = reinterpret_cast<float *>(smem_raw) + wave * (32 * LDC);
+  const int E = epilogue_width(p.epilogue);
+#pragma unroll 1
+  for (int ti = 0; ti < MR * NR; ++ti) {
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int n = 0; n < NR; ++n)
+        if (ti == m * NR + n) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            sC[((e & 3) + 8 * (e >> 2) + 4 * lh) * LDC + li] = acc[m][n][e];
+        }
+    __syncthreads();
+    const int tm = ti / NR, tn = ti - tm * NR;
+    const int row_base = m0 + (wm * MR + tm) * 32;
+    const long long col = n0 + (wn * NR + tn) * 32 + li;
+    const bool col_ok = col < p.n_cols;
+    int c = 0, t = 0;
+    if (col_ok) {
+      c = (int)(col / p.n_frames);
+      t = (int)(col - (long long)c * p.n_frames);
+    }
+    float *obase = p.out + (long long)c * p.out_clip_stride + (long long)t * E;
+    if (cplx) {
+#pragma unroll 1
+      for (int it = 0; it < 8; ++it) {
+        const int rl = 2 * (2 * it + lh);  // even local row: re; rl + 1: im
+        const int bin = (row_base + rl) >> 1;
+        if (col_ok && bin < p.n_bins) {
+          float re = sC[rl * LDC + li];
+          float im = p.im_sign * sC[(rl + 1) * LDC + li];
+          if (p.row_scale) {
+            const float sc = p.row_scale[bin];
+            re *= sc;
+            im *= sc;
+          }
+          epilogue_store(p, obase + (long long)(p.out_row_offset + bin) * p.out_row_stride, re, im);
+        }
+      }
+    } else {
+#pragma unroll 1
+      for (int it = 0; it < 16; ++it) {
+        const int rl = 2 * it + lh;
+        const int row = row_base + rl;
+        if (col_ok && row < p.n_bins) {
+          float v = sC[rl * LDC + li];
+          if (p.row_scale) v *= p.row_scale[row];
+          obase[(long long)(p.out_row_offset + row) * p.out_row_stride] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int WM, int WN, int MR, int NR, bool MASKED>
+__global__ void __launch_bounds__(WM *WN * 64) framed_bf16x3_kernel(const KParams p) {
+  framed_bf16x3_body<WM, WN, MR, NR, MASKED>(p, blockIdx.x, gridDim.x);
+}

@@ -94,6 +94,14 @@ struct KParams {
   int n_tiles_n;
   int n_group;  // frame tiles crossed with all row tiles before advancing (L2 blocking)
   int debug;    // ablation bits (benchmarking only), see framed_gemm_kernel
+  // MISPEC_PREC_BF16X3 operands (framed_bf16x3.inl)
+  const unsigned short *xs;  // hi plane of the split signal: per clip [waveform | edge spans]
+  long long xs_clip_stride;  // elements per clip slot (multiple of 8)
+  long long xs_plane;        // hi -> lo plane distance, elements
+  long long xs_edge_off;     // start of the edge spans inside a clip slot
+  const unsigned short *as;  // split basis planes [re_hi | re_lo | im_hi | im_lo], each (n_bins, Ks)
+  long long as_plane;
+  int Ks;  // taps per split basis row (K rounded up to 32, zero filled)
 };
 
 // ---------------------------------------------------------------------------------
@@ -773,6 +781,8 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
   framed_gemm_body<WM, WN, MR, NR, BMODE, AMODE, MASKED, GLDS>(p, blockIdx.x, gridDim.x);
 }
 
+#include "framed_bf16x3.inl"
+
 // Several independent contractions of the same tile shape in one launch (the octaves of
 // CQT2010v2 / VQT: each is a short-K, few-hundred-workgroup problem that cannot fill the chip on
 // its own).  Workgroups [first[i], first[i+1]) belong to problem i.
@@ -1195,6 +1205,121 @@ int launch_framed(const KParams &p, int tile, hipStream_t stream) {
   return launch_tile(r, auto_tile(rem_rows, false), stream);
 }
 
+// ---------------------------------------------------------------------------------
+// MISPEC_PREC_BF16X3 host side
+// ---------------------------------------------------------------------------------
+inline long long round_up_ll(long long v, long long m) { return (v + m - 1) / m * m; }
+
+struct SplitPlan {
+  long long edge_bytes;  // fp32 edge spans (leftover rows run on the fp32 kernel), 256-aligned
+  long long ls;          // waveform region of a clip slot, elements
+  long long slot;        // clip slot, elements
+  long long bytes;       // both planes
+};
+
+SplitPlan plan_split(const KParams &p, const EdgePlan &e) {
+  SplitPlan sp{};
+  sp.edge_bytes = round_up_ll(e.stride * p.n_clips * (long long)sizeof(float), 256);
+  sp.ls = round_up_ll(p.n_samples, 8);
+  sp.slot = round_up_ll(sp.ls + e.stride, 8);
+  sp.bytes = 2 * sp.slot * p.n_clips * (long long)sizeof(unsigned short);
+  return sp;
+}
+
+long long basis_split_bytes(int n_bins, int kernel, bool has_im) {
+  return (has_im ? 4LL : 2LL) * n_bins * round_up_kc(kernel) * (long long)sizeof(unsigned short);
+}
+
+// does the bf16x3 kernel cover this problem?  (else it runs in fp32, which is always acceptable)
+bool bf16x3_ok(const mispec_framed_gemm_args *a, const KParams &p) {
+  if (a->precision != MISPEC_PREC_BF16X3 || !a->basis_split) return false;
+  if (a->basis_split_bytes < basis_split_bytes(p.n_bins, p.K, p.a_im != nullptr)) return false;
+  if ((p.hop & 1) || (p.pad & 1)) return false;  // frames must start at even element offsets
+  const int rows = p.n_bins * (p.a_im ? 2 : 1);
+  return rows > 128;  // narrower problems: the 256-row tile would be mostly empty
+}
+
+template <int WM, int WN, int MR, int NR, bool MASKED>
+int launch_bf16x3_cfg(KParams p, hipStream_t stream) {
+  constexpr int BM = WM * MR * 32;
+  constexpr int BN = WN * NR * 32;
+  constexpr size_t smem = 2 * (2 * BM + 2 * BN) * (KC * 2) + BN * sizeof(long long) +
+                          2 * WM * MR * sizeof(int);
+  static_assert(smem <= 160 * 1024, "LDS budget");
+  const int rows = p.n_bins * (p.a_im ? 2 : 1);
+  p.n_tiles_m = (rows + BM - 1) / BM;
+  const long long tn = (p.n_cols + BN - 1) / BN;
+  if (tn * p.n_tiles_m > 0x7fffffffLL) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
+  p.n_tiles_n = (int)tn;
+  // one workgroup per CU, 32 CUs per XCD: cross all row tiles with ~32 / n_tiles_m frame tiles
+  int g = (32 + p.n_tiles_m / 2) / p.n_tiles_m;
+  if (g < 1) g = 1;
+  if (g > p.n_tiles_n) g = p.n_tiles_n;
+  p.n_group = g;
+  const long long grid = tn * p.n_tiles_m;
+  if (grid == 0) return MISPEC_OK;
+  auto kern = framed_bf16x3_kernel<WM, WN, MR, NR, MASKED>;
+  static std::atomic<unsigned long long> configured{0};
+  int rc = configure_lds(kern, smem, configured);
+  if (rc != MISPEC_OK) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WM * WN * 64), smem, stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+
+// split the waveform + edge spans into the second part of the workspace and attach it to p
+int setup_split(KParams &p, const mispec_framed_gemm_args *a, hipStream_t stream) {
+  const EdgePlan e = plan_edges(p.n_samples, p.K, p.hop, p.pad, p.n_frames);
+  const SplitPlan sp = plan_split(p, e);
+  if (!a->workspace || a->workspace_bytes < sp.edge_bytes + sp.bytes)
+    return fail(MISPEC_E_INVALID,
+                "workspace too small: size it with the *_workspace_bytes query%s");
+  unsigned short *xs = reinterpret_cast<unsigned short *>(static_cast<char *>(a->workspace) +
+                                                          sp.edge_bytes);
+  p.xs = xs;
+  p.xs_clip_stride = sp.slot;
+  p.xs_plane = sp.slot * p.n_clips;
+  p.xs_edge_off = sp.ls;
+  p.Ks = round_up_kc(p.K);
+  p.as = static_cast<const unsigned short *>(a->basis_split);
+  p.as_plane = (long long)p.n_bins * p.Ks;
+  const unsigned gx = (unsigned)((sp.slot + 1023) / 1024);
+  hipLaunchKernelGGL(split_signal_kernel, dim3(gx, (unsigned)p.n_clips), dim3(256), 0, stream, p,
+                     xs);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail(MISPEC_E_HIP, "signal split launch: %s", hipGetErrorString(err));
+  return MISPEC_OK;
+}
+
+int launch_framed_bf16x3(const KParams &p, int tile, hipStream_t stream) {
+  const int rpb = p.a_im ? 2 : 1;
+  const bool masked = p.row_support != nullptr;
+  // whole 256-row blocks on the bf16 pipe; a leftover block joins them when it is at least a
+  // quarter full (or carries supports), else its rows (the Nyquist bin of an n_fft/2+1 STFT)
+  // run on the narrow fp32 kernel
+  const int bins_per_wg = 256 / rpb;
+  int main_bins = (p.n_bins / bins_per_wg) * bins_per_wg;
+  if (masked || (p.n_bins - main_bins) * rpb > 64) main_bins = p.n_bins;
+  KParams q = p;
+  q.n_bins = main_bins;
+  int rc;
+  if (tile == MISPEC_TILE_256x256)  // one wave per SIMD, 128x128 per wave
+    rc = masked ? launch_bf16x3_cfg<2, 2, 4, 4, true>(q, stream)
+                : launch_bf16x3_cfg<2, 2, 4, 4, false>(q, stream);
+  else  // two waves per SIMD, 64x128 per wave
+    rc = masked ? launch_bf16x3_cfg<4, 2, 2, 4, true>(q, stream)
+                : launch_bf16x3_cfg<4, 2, 2, 4, false>(q, stream);
+  if (rc != MISPEC_OK || main_bins == p.n_bins) return rc;
+  KParams r = p;
+  r.n_bins = p.n_bins - main_bins;
+  r.a_re = p.a_re + (long long)main_bins * p.a_row_stride;
+  if (p.a_im) r.a_im = p.a_im + (long long)main_bins * p.a_row_stride;
+  if (p.row_scale) r.row_scale = p.row_scale + main_bins;
+  r.out_row_offset = p.out_row_offset + main_bins;
+  return launch_framed(r, MISPEC_TILE_AUTO, stream);
+}
+
 // attach the edge workspace to p and enqueue the fill pre-pass
 int setup_edges(KParams &p, void *workspace, long long workspace_bytes, hipStream_t stream) {
   const EdgePlan e = plan_edges(p.n_samples, p.K, p.hop, p.pad, p.n_frames);
@@ -1271,6 +1396,9 @@ int fill_params(const mispec_framed_gemm_args *a, KParams &p) {
   p.out_row_stride = a->out_row_stride;
   p.out_row_offset = a->out_row_offset;
   p.debug = a->reserved;
+  if (a->precision != MISPEC_PREC_F32 && a->precision != MISPEC_PREC_BF16X3)
+    return fail(MISPEC_E_INVALID, "bad precision%s");
+  if (a->reserved2 != 0) return fail(MISPEC_E_INVALID, "reserved2 must be 0%s");
   return MISPEC_OK;
 }
 
@@ -1324,6 +1452,10 @@ int64_t mispec_framed_gemm_workspace_bytes(const mispec_framed_gemm_args *args) 
   int rc = fill_params(args, p);
   if (rc != MISPEC_OK) return rc;
   const EdgePlan e = plan_edges(p.n_samples, p.K, p.hop, p.pad, p.n_frames);
+  if (bf16x3_ok(args, p)) {
+    const SplitPlan sp = plan_split(p, e);
+    return sp.edge_bytes + sp.bytes;
+  }
   return e.stride * p.n_clips * (int64_t)sizeof(float);
 }
 
@@ -1334,7 +1466,35 @@ int mispec_framed_gemm_f32(const mispec_framed_gemm_args *args, void *stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   rc = setup_edges(p, args->workspace, args->workspace_bytes, s);
   if (rc != MISPEC_OK) return rc;
+  if (bf16x3_ok(args, p)) {
+    rc = setup_split(p, args, s);
+    if (rc != MISPEC_OK) return rc;
+    return launch_framed_bf16x3(p, args->tile, s);
+  }
   return launch_framed(p, args->tile, s);
+}
+
+int64_t mispec_basis_split_bytes(int32_t n_bins, int32_t kernel, int32_t has_im) {
+  if (n_bins <= 0 || kernel <= 0) return fail(MISPEC_E_INVALID, "non-positive size%s");
+  return basis_split_bytes(n_bins, kernel, has_im != 0);
+}
+
+int mispec_split_basis_bf16(const float *basis_re, const float *basis_im,
+                            int64_t basis_row_stride, int32_t n_bins, int32_t kernel, void *dst,
+                            int64_t dst_bytes, void *stream) {
+  if (!basis_re || !dst) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
+  if (n_bins <= 0 || kernel <= 0) return fail(MISPEC_E_INVALID, "non-positive size%s");
+  if (dst_bytes < basis_split_bytes(n_bins, kernel, basis_im != nullptr))
+    return fail(MISPEC_E_INVALID, "dst too small: size it with mispec_basis_split_bytes%s");
+  const int ks = round_up_kc(kernel);
+  hipLaunchKernelGGL(split_basis_kernel, dim3((unsigned)((ks + 255) / 256), (unsigned)n_bins,
+                                              basis_im ? 2u : 1u),
+                     dim3(256), 0, static_cast<hipStream_t>(stream), basis_re, basis_im,
+                     (long long)basis_row_stride, n_bins, kernel, ks,
+                     static_cast<unsigned short *>(dst));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "basis split launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
 }
 
 int mispec_framed_gemm_group_f32(const mispec_framed_gemm_args *args, int32_t n, void *stream) {

@@ -5,18 +5,74 @@ stream and device); every FLOP of the hot path is issued by the HIP kernels.  Th
 no CPU / eager fallback: CPU tensors raise, a missing extension raises.
 """
 import ctypes
+import os
+import weakref
 
 import torch
 
 from . import _abi
 from ._abi import (  # noqa: F401  (re-exported for the feature modules)
     EPI_COMPLEX, EPI_MAGNITUDE, EPI_PHASE_ATAN2, EPI_PHASE_COSSIN, EPI_POWER, EPI_REAL,
-    PAD_NONE, PAD_REFLECT, PAD_ZERO, TILE_AUTO,
+    PAD_NONE, PAD_REFLECT, PAD_ZERO, PREC_BF16X3, PREC_F32, TILE_AUTO,
 )
 from .basis import decimated_length
 
 # benchmarking / bring-up only: OR-ed into the ablation bits of every framed_gemm call
-_ENV_DEBUG = int(__import__("os").environ.get("MISPEC_DEBUG", "0"), 0)
+_ENV_DEBUG = int(os.environ.get("MISPEC_DEBUG", "0"), 0)
+
+# Arithmetic of the framed contraction (include/mispec.h, MISPEC_PREC_*):
+#   "fp32"   fp32 MFMA, bit-for-bit an fmaf chain like the reference's conv1d (default)
+#   "bf16x3" split-bf16 operands on the 16x faster bf16 MFMA, fp32 accumulate: ~5e-6 of the
+#            spectrum peak, inside the 1e-4 bar; problems it does not cover run in fp32
+_PRECISIONS = {"fp32": PREC_F32, "bf16x3": PREC_BF16X3}
+_default_precision = os.environ.get("MISPEC_PRECISION", "fp32")
+
+
+def set_precision(name):
+    """Process-wide default for modules whose ``precision`` attribute is None."""
+    global _default_precision
+    if name not in _PRECISIONS:
+        raise ValueError("precision must be one of %s" % sorted(_PRECISIONS))
+    _default_precision = name
+
+
+def get_precision():
+    return _default_precision
+
+
+def resolve_precision(name=None):
+    name = name or _default_precision
+    if name not in _PRECISIONS:
+        raise ValueError("precision must be one of %s, got %r" % (sorted(_PRECISIONS), name))
+    return name
+
+
+class DerivedCache:
+    """A tensor derived from a module's basis buffers (kernel supports, split-bf16 planes),
+    rebuilt whenever the buffers are replaced or modified in place (``load_state_dict``,
+    ``.to``, an optimiser step).  An entry is valid only while the SAME tensor objects
+    (weak references, so a new tensor that reuses a freed address can never alias) still have
+    the ``_version`` they were built from.
+
+    One entry per device: ``nn.DataParallel`` replicas share this object and call from one
+    host thread per GPU, so entries are only ever replaced whole (no torn state)."""
+
+    def __init__(self):
+        self._entries = {}
+
+    def get(self, sources, build, extra=None):
+        sources = tuple(sources)
+        dev = sources[0].device
+        vers = tuple(s._version for s in sources)
+        hit = self._entries.get(dev)
+        if hit is not None:
+            refs, hvers, hextra, val = hit
+            if (hextra == extra and hvers == vers and len(refs) == len(sources)
+                    and all(r() is s for r, s in zip(refs, sources))):
+                return val
+        val = build()
+        self._entries[dev] = (tuple(weakref.ref(s) for s in sources), vers, extra, val)
+        return val
 
 _PAD_MODES = {"constant": PAD_ZERO, "reflect": PAD_REFLECT, None: PAD_NONE}
 
@@ -94,7 +150,7 @@ def n_frames(length, kernel, hop, pad):
 def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign=-1.0,
                  eps=0.0, power=2.0, row_scale=None, row_support=None, out=None,
                  out_rows_total=None, out_row_offset=0, tile=TILE_AUTO, _debug=0,
-                 need_workspace=True):
+                 need_workspace=True, precision=None, basis_split=None):
     """Validate one framed-contraction problem and fill its C argument block.
     Returns (args, out, device, keepalive tensors)."""
     dev = _require_device(x, basis_re, basis_im, row_scale, row_support, out)
@@ -154,6 +210,13 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
     a.out_row_offset = int(out_row_offset)
     a.reserved = int(_debug) | _ENV_DEBUG
     keep = [x, wr, wi, row_scale, row_support]
+    if resolve_precision(precision) == "bf16x3" and need_workspace:
+        if basis_split is None:  # uncached: callers with a persistent basis pass it in
+            basis_split = split_basis(wr, wi)
+        a.precision = PREC_BF16X3
+        a.basis_split = basis_split.data_ptr()
+        a.basis_split_bytes = basis_split.numel() * basis_split.element_size()
+        keep.append(basis_split)
     if need_workspace:
         need = _abi.load().mispec_framed_gemm_workspace_bytes(ctypes.byref(a))
         if need < 0:
@@ -166,12 +229,34 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
     return a, out, dev, keep
 
 
+def split_basis(basis_re, basis_im):
+    """(hi, lo) bf16 planes of a basis for ``precision="bf16x3"`` (mispec_split_basis_bf16)."""
+    dev = _require_device(basis_re, basis_im)
+    wr = _rows(basis_re, "basis_re")
+    wi = _rows(basis_im, "basis_im") if basis_im is not None else None
+    if wi is not None and (wi.shape != wr.shape or wi.stride(0) != wr.stride(0)):
+        raise RuntimeError("real / imaginary bases must have identical shape and layout")
+    lib = _abi.load()
+    F, K = wr.shape
+    need = lib.mispec_basis_split_bytes(F, K, 1 if wi is not None else 0)
+    if need < 0:
+        _abi.check(int(need))
+    dst = torch.empty(need // 2, dtype=torch.int16, device=dev)
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _abi.check(lib.mispec_split_basis_bf16(
+            wr.data_ptr(), wi.data_ptr() if wi is not None else None, wr.stride(0), F, K,
+            dst.data_ptr(), need, ctypes.c_void_p(stream)))
+    return dst
+
+
 def framed_gemm(x, basis_re, basis_im, *, reference_kernel=False, **kw):
     """``out[b, row_offset + f, t(, 0:2)]`` <- epilogue(sum_n x_pad[b, t*hop + n] * basis[f, n]).
 
     Keyword arguments: hop, pad, pad_mode (``PAD_*``), epilogue (``EPI_*``), im_sign, eps, power,
     row_scale, row_support, out (pre-allocated (B, rows_total, T[, 2]) tensor: octave assembly /
-    all-gather slices write in place), out_rows_total, out_row_offset, tile."""
+    all-gather slices write in place), out_rows_total, out_row_offset, tile, precision ("fp32" /
+    "bf16x3" / None = process default), basis_split (cached ``split_basis`` result)."""
     a, out, dev, _keep = _framed_args(x, basis_re, basis_im, need_workspace=not reference_kernel,
                                       **kw)
     lib = _abi.load()

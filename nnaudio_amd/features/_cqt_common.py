@@ -39,19 +39,13 @@ def normalisation_scale(lenghts, normalization_type, extra=1.0):
 
 class SupportCache:
     """[start, stop) of the non-zero taps of every kernel row, recomputed whenever the
-    kernel tensors are replaced or modified in place (``load_state_dict``, ``.to``).
-
-    One entry per device: ``nn.DataParallel`` replicas share this object and call from one
-    host thread per GPU, so entries are only ever replaced whole (no torn key/value pair)."""
+    kernel tensors are replaced or modified in place (see ``engine.DerivedCache``)."""
 
     def __init__(self):
-        self._entries = {}
+        self._cache = engine.DerivedCache()
 
-    def get(self, real, imag):
-        key = (real.data_ptr(), real._version, imag.data_ptr(), imag._version)
-        hit = self._entries.get(real.device)
-        if hit is not None and hit[0] == key:
-            return hit[1]
+    @staticmethod
+    def _build(real, imag):
         nz = (real.reshape(real.shape[0], -1) != 0) | (imag.reshape(imag.shape[0], -1) != 0)
         K = nz.shape[1]
         idx = torch.arange(K, device=nz.device)
@@ -60,9 +54,10 @@ class SupportCache:
         start = big.min(dim=1).values
         stop = small.max(dim=1).values
         start = torch.minimum(start, stop)
-        val = torch.stack((start, stop), 1).to(torch.int32).contiguous()
-        self._entries[real.device] = (key, val)
-        return val
+        return torch.stack((start, stop), 1).to(torch.int32).contiguous()
+
+    def get(self, real, imag):
+        return self._cache.get((real, imag), lambda: self._build(real, imag))
 
 
 def octave_recursion(x, banks, lenghts, hop, n_bins, lowpass, downsample_factor, pad_mode,
@@ -127,7 +122,8 @@ def octave_recursion(x, banks, lenghts, hop, n_bins, lowpass, downsample_factor,
         launches.append((xd, kr_i, ki_i, dict(
             hop=hop, pad=pad, pad_mode=mode, epilogue=epi, im_sign=-1.0,
             eps=1e-8 if trainable else 0.0, row_scale=scale[row0:row0 + rows].contiguous(),
-            row_support=sup, out=out, out_rows_total=n_bins, out_row_offset=row0)))
+            row_support=sup, out=out, out_rows_total=n_bins, out_row_offset=row0,
+            precision="fp32")))
     engine.framed_gemm_group(launches)
     return out
 

@@ -73,6 +73,8 @@ class CQT1992v2(nn.Module):
         imag = torch.tensor(bank.imag).unsqueeze(1)
         _register_kernels(self, real, imag, trainable)
         self._support = SupportCache()
+        self.precision = None  # None: nnaudio_amd.get_precision(); "fp32" / "bf16x3"
+        self._split = engine.DerivedCache()
         if verbose:
             print("CQT kernels created, time used = {:.4f} seconds".format(time() - start))
 
@@ -96,10 +98,15 @@ class CQT1992v2(nn.Module):
             return None
         sup = None if self.trainable else self._support.get(self.cqt_kernels_real,
                                                             self.cqt_kernels_imag)
+        precision = engine.resolve_precision(self.precision)
+        split = None
+        if precision == "bf16x3":
+            kr, ki = self.cqt_kernels_real, self.cqt_kernels_imag
+            split = self._split.get((kr, ki), lambda: engine.split_basis(kr, ki))
         return engine.framed_gemm(
             x, self.cqt_kernels_real, self.cqt_kernels_imag, hop=self.hop_length, pad=pad,
             pad_mode=mode, epilogue=epi, im_sign=-1.0, eps=1e-8 if self.trainable else 0.0,
-            row_scale=scale, row_support=sup,
+            row_scale=scale, row_support=sup, precision=precision, basis_split=split,
         )
 
 

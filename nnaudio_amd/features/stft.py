@@ -96,6 +96,10 @@ class STFT(nn.Module):
             self.register_buffer("wsin", wsin)
             self.register_buffer("wcos", wcos)
         self.register_buffer("window_mask", win.unsqueeze(0).unsqueeze(-1))
+        # not a constructor argument (the signature stays the reference's): set the attribute,
+        # or nnaudio_amd.set_precision(...), to "bf16x3" for the split-bf16 matrix pipe
+        self.precision = None
+        self._split = engine.DerivedCache()
 
         if verbose:
             print("STFT kernels created, time used = {:.4f} seconds".format(time() - start))
@@ -121,9 +125,15 @@ class STFT(nn.Module):
         wsin, wcos = self.wsin, self.wcos
         if self.freq_bins is not None:
             wsin, wcos = wsin[: self.freq_bins], wcos[: self.freq_bins]
+        precision = engine.resolve_precision(self.precision)
+        split = None
+        if precision == "bf16x3":
+            split = self._split.get((self.wcos, self.wsin),
+                                    lambda: engine.split_basis(wcos, wsin), extra=self.freq_bins)
         return engine.framed_gemm(
             x, wcos, wsin, hop=self.stride, pad=pad, pad_mode=mode, epilogue=epilogue,
             im_sign=-1.0, eps=1e-8 if self.trainable else 0.0, power=power,
+            precision=precision, basis_split=split,
         )
 
     def forward(self, x, output_format=None):

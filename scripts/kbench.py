@@ -53,6 +53,45 @@ def stft():
         print("stft cfg2 %s: %.3f ms" % (fmt, ms))
 
 
+def bf16():
+    """precision="bf16x3": error against the fp32 kernel and timings of both wave layouts."""
+    B, L = 64, 441000
+    x = torch.randn(B, L, device=DEV)
+    m = features.STFT(n_fft=2048, hop_length=512, output_format="Magnitude", verbose=False).to(DEV)
+    flops = 2.0 * 2050 * 2048 * B * 862
+    ref = m(x)
+    split = engine.split_basis(m.wcos, m.wsin)
+    kw = dict(hop=512, pad=1024, pad_mode=2, epilogue=engine.EPI_MAGNITUDE, precision="bf16x3",
+              basis_split=split)
+    split1k = engine.split_basis(m.wcos[:1024], m.wsin[:1024])
+    kw1k = dict(hop=512, pad=1024, pad_mode=2, epilogue=engine.EPI_MAGNITUDE, precision="bf16x3")
+    for tile, what in ((0, "8 waves 64x128"), (9, "4 waves 128x128")):
+        y = engine.framed_gemm(x, m.wcos, m.wsin, tile=tile, **kw)
+        err = float((y - ref).abs().max() / ref.abs().max())
+        ms = timeit(lambda: engine.framed_gemm(x, m.wcos, m.wsin, tile=tile, **kw))
+        print("stft cfg2 bf16x3 [%s]: %.3f ms  %.1f TF-equivalent (%.1f%% of 833), max err %.2e of peak"
+              % (what, ms, flops / ms / 1e9, flops / ms / 1e9 / 8.33, err))
+        ms = timeit(lambda: engine.framed_gemm(x, m.wcos[:1024], m.wsin[:1024], tile=tile, hop=512, pad=1024,
+                                               pad_mode=2, epilogue=engine.EPI_MAGNITUDE, precision="bf16x3"))
+        print("   1024 bins incl. uncached basis split: %.3f ms" % ms)
+    for dbg, what in ((0, "full"), (1, "no DMA in loop"), (16, "no MFMA"), (4, "no barrier"), (5, "no DMA, no barrier"), (17, "no DMA no MFMA: frag reads + barrier")):
+        ms = timeit(lambda: engine.framed_gemm(x, m.wcos[:1024], m.wsin[:1024], tile=0, _debug=dbg,
+                                               basis_split=split1k, **kw1k))
+        print("   ablate[%-36s] 1024 bins: %.3f ms" % (what, ms))
+    m.precision = "bf16x3"
+    for fmt in ("Magnitude", "Complex", "Phase"):
+        ms = timeit(lambda: m(x, output_format=fmt))
+        print("stft cfg2 bf16x3 module %s: %.3f ms" % (fmt, ms))
+    c = features.CQT1992v2(sr=44100, hop_length=512, n_bins=84, verbose=False).to(DEV)
+    ref = c(x)
+    ms0 = timeit(lambda: c(x), n=5, w=2)
+    c.precision = "bf16x3"
+    y = c(x)
+    ms = timeit(lambda: c(x), n=5, w=2)
+    print("cqt1992v2 84 bins: fp32 %.3f ms, bf16x3 %.3f ms, max err %.2e of peak"
+          % (ms0, ms, float((y - ref).abs().max() / ref.abs().max())))
+
+
 def mel():
     B, L = 256, 110250
     x = torch.randn(B, L, device=DEV)
@@ -109,7 +148,7 @@ def cqt2010():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["all"]
     torch.manual_seed(0)
-    for name, fn in (("stft", stft), ("mel", mel), ("cqt", cqt), ("cqt2010", cqt2010)):
+    for name, fn in (("stft", stft), ("bf16", bf16), ("mel", mel), ("cqt", cqt), ("cqt2010", cqt2010)):
         if "all" in which or name in which:
             t0 = time.time()
             fn()

@@ -406,3 +406,161 @@ def test_cfg5_cqt2010v2_vqt_full_length():
     lhs = c(x - 3.0 * x2)
     rhs = yc - 3.0 * c(x2)
     assert (lhs - rhs).abs().max().item() <= 1e-4 * rhs.abs().max().item()
+
+
+# ---------------------------------------------------------------------------------------
+# precision="bf16x3": split-bf16 operands on the bf16 MFMA (include/mispec.h MISPEC_PREC_BF16X3)
+# Same parity bar as the fp32 path; measured error is ~5e-6 of the peak.
+# ---------------------------------------------------------------------------------------
+@pytest.fixture
+def bf16x3():
+    import nnaudio_amd
+
+    old = nnaudio_amd.get_precision()
+    nnaudio_amd.set_precision("bf16x3")
+    yield
+    nnaudio_amd.set_precision(old)
+
+
+def _np_bf16_split(v):
+    """numpy restatement of bf16_split (framed_bf16x3.inl): round-to-nearest-even hi, then lo."""
+    def rne(a):
+        u = a.astype(np.float32).view(np.uint32).astype(np.uint64)
+        return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF).astype(np.uint16)
+
+    hi = rne(v)
+    hf = (hi.astype(np.uint32) << 16).view(np.float32)
+    lo = rne(v.astype(np.float32) - hf)
+    return hi, lo
+
+
+@pytest.mark.parametrize("F,K,has_im", [(5, 70, True), (33, 256, True), (12, 31, False)])
+def test_split_basis_is_bit_exact(F, K, has_im):
+    from nnaudio_amd import engine
+
+    rng = np.random.default_rng(F * 1000 + K)
+    re = (rng.standard_normal((F, K)) * 10.0 ** rng.integers(-6, 3, (F, 1))).astype(np.float32)
+    im = rng.standard_normal((F, K)).astype(np.float32) if has_im else None
+    re[0, :3] = [0.0, -0.0, 1.0]
+    got = engine.split_basis(torch.as_tensor(re).to(DEV),
+                             torch.as_tensor(im).to(DEV) if has_im else None)
+    torch.cuda.synchronize()
+    Ks = (K + 31) // 32 * 32
+    planes = got.cpu().numpy().view(np.uint16).reshape(4 if has_im else 2, F, Ks)
+    for z, src in enumerate([re, im] if has_im else [re]):
+        hi, lo = _np_bf16_split(src)
+        assert np.array_equal(planes[2 * z][:, :K], hi)
+        assert np.array_equal(planes[2 * z + 1][:, :K], lo)
+        assert not planes[2 * z][:, K:].any() and not planes[2 * z + 1][:, K:].any()
+        # hi + lo carries >= 16 significant bits of the fp32 value
+        back = ((hi.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+                + (lo.astype(np.uint32) << 16).view(np.float32).astype(np.float64))
+        assert np.abs(back - src).max() <= 2.0 ** -16 * np.abs(src).max()
+
+
+@pytest.mark.parametrize("name", [n for n in _golden.case_names(forward_only=True)
+                                  if n.split("_")[0] in ("stft", "mel", "gamma", "cqt1992v2")])
+def test_case_bf16x3_matches_reference_and_oracle(golden, bf16x3, name):
+    case = golden.cases[name]
+    x = golden.inputs[case["input"]]
+    ref = golden.forward[name]
+    y = run(build_module(case, DEV), x, **case["fwd"])
+    assert y.dtype == np.float32 and list(y.shape) == case["out_shape"]
+    orc = oracle_forward(build_module(case), case, x)
+    if is_phase(case):
+        mcase = dict(case, ctor=dict(case["ctor"], output_format="Magnitude"), fwd={})
+        mag = oracle_forward(build_module(mcase), mcase, x)
+        assert_phase_parity(y, ref, mag, what=name + " vs reference")
+        assert_phase_parity(y, orc, mag, what=name + " vs oracle")
+    else:
+        assert_parity(y, ref, rel=1e-4, what=name + " vs reference")
+        assert_parity(y, orc, rel=1e-4, what=name + " vs oracle")
+
+
+@pytest.mark.parametrize("shape", [  # (B, L, bins, K, hop, pad, mode): 256-row blocks, edges, tails
+    (3, 9000, 128, 512, 128, 256, 2),    # exactly one full row block
+    (2, 7001, 257, 512, 64, 256, 1),     # 2 blocks + Nyquist bin on the fp32 kernel
+    (1, 5000, 200, 300, 50, 150, 2),     # K % 32 != 0, partial second block on bf16
+    (2, 4096, 160, 1024, 256, 0, 0),     # center=False
+    (5, 1500, 130, 1024, 32, 512, 2),    # short clips: every frame touches the padding
+    (2, 6000, 140, 512, 63, 256, 2),     # odd hop: not covered, must run (exactly) in fp32
+])
+@pytest.mark.parametrize("support", [False, True])
+def test_bf16x3_kernel_shapes(shape, support):
+    from nnaudio_amd import engine
+
+    B, L, F, K, hop, pad, mode = shape
+    rng = np.random.default_rng(B * 100000 + L)
+    x = rng.standard_normal((B, L)).astype(np.float32)
+    wr = rng.standard_normal((F, K)).astype(np.float32)
+    wi = rng.standard_normal((F, K)).astype(np.float32)
+    sup = None
+    if support:  # centred supports that shrink with the row index, like a CQT bank
+        half = np.linspace(K // 2, 8, F).astype(np.int64)
+        lo, hi = K // 2 - half, K // 2 + half
+        keep = (np.arange(K)[None, :] >= lo[:, None]) & (np.arange(K)[None, :] < hi[:, None])
+        wr, wi = (wr * keep).astype(np.float32), (wi * keep).astype(np.float32)
+        sup = torch.as_tensor(np.stack([lo, hi], 1).astype(np.int32)).to(DEV)
+    re, im = _np_framed(x, wr, wi, hop, pad, mode)
+    ref = np.stack((re, im), -1)
+    kw = dict(hop=hop, pad=pad, pad_mode=mode, epilogue=engine.EPI_COMPLEX, row_support=sup)
+    xd, wrd, wid = (torch.as_tensor(a).to(DEV) for a in (x, wr, wi))
+    y = engine.framed_gemm(xd, wrd, wid, precision="bf16x3", **kw)
+    y32 = engine.framed_gemm(xd, wrd, wid, precision="fp32", **kw)
+    torch.cuda.synchronize()
+    assert_parity(y.cpu().numpy(), ref, rel=1e-4, what="bf16x3 %s" % (shape,))
+    if hop % 2:
+        assert torch.equal(y, y32)  # fell back to the fp32 kernel
+    else:
+        assert not torch.equal(y, y32)  # really took the bf16 pipe
+
+
+def test_bf16x3_split_cache_follows_the_basis(bf16x3):
+    """The cached split planes must be rebuilt when the basis changes in place or is replaced."""
+    from nnaudio_amd import features
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 8000, generator=g).to(DEV)
+    m = features.STFT(n_fft=512, hop_length=128, output_format="Magnitude", verbose=False).to(DEV)
+    y0 = m(x)
+    assert m(x).data_ptr() != y0.data_ptr() and torch.equal(m(x), y0)
+    with torch.no_grad():
+        m.wcos.mul_(2.0)
+        m.wsin.mul_(2.0)
+    y1 = m(x)
+    assert torch.allclose(y1, 2.0 * y0, rtol=1e-6, atol=0.0)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd["wcos"] *= 0.25
+    sd["wsin"] *= 0.25
+    m.load_state_dict(sd)
+    assert torch.allclose(m(x), 0.5 * y0, rtol=1e-6, atol=0.0)
+    m2 = m.to("cpu").to(DEV)  # fresh tensors at possibly recycled addresses
+    assert torch.allclose(m2(x), 0.5 * y0, rtol=1e-6, atol=0.0)
+
+
+def test_bf16x3_cfg2_full_size_sampled():
+    from nnaudio_amd import features
+    from oracle import spectral_oracle as O
+
+    B, L = 64, 441000
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn(B, L, generator=g)
+    m = features.STFT(n_fft=2048, hop_length=512, window="hann", output_format="Complex",
+                      verbose=False).to(DEV)
+    m.precision = "bf16x3"
+    xd = x.to(DEV)
+    y = m(xd)
+    assert tuple(y.shape) == (64, 1025, 862, 2)
+    rng = np.random.default_rng(1)
+    cb, ct = _sample_cols(rng, B, 862, 96)
+    ct[:8] = [0, 1, 2, 3, 858, 859, 860, 861]
+    re, im = O.sampled_complex(x.numpy(), m.wcos.cpu().numpy(), m.wsin.cpu().numpy(), cb, ct,
+                               512, 1024, "reflect")
+    got = y[torch.as_tensor(cb), :, torch.as_tensor(ct)].cpu().numpy()
+    peak = max(np.abs(re).max(), np.abs(im).max())
+    err = max(np.abs(got[..., 0] - re).max(), np.abs(got[..., 1] - im).max())
+    assert err <= 1e-4 * peak
+    assert err <= 2e-5 * peak  # the split's own budget (measured 4e-6): catches a lost term
+    m.precision = "fp32"
+    y32 = m(xd)
+    assert (y - y32).abs().max().item() <= 2e-5 * y32.abs().max().item()

@@ -116,13 +116,16 @@ __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int w
   constexpr int BM = WM * MR * 32;
   constexpr int BN = WN * NR * 32;
   constexpr int MT = WM * MR;
-  constexpr int ROWB = KC * 2;        // bytes of one row of one plane in a stage
-  constexpr int A_PL = BM * ROWB;     // bytes of one A plane
+  constexpr int ROWB = KC * 2;  // bytes of one row of one plane in a stage
+  // one DMA instruction moves 16 rows; every wave issues the same number of them, so a narrow
+  // A tile is padded to 16*NW rows (the extra rows re-read the last basis row, never multiplied)
+  constexpr int BMA = BM < 16 * NW ? 16 * NW : BM;
+  constexpr int A_PL = BMA * ROWB;  // bytes of one A plane
   constexpr int X_PL = BN * ROWB;
   constexpr int STAGE = 2 * A_PL + 2 * X_PL;
-  constexpr int AJ = BM / (16 * NW);  // DMA instructions per wave, per plane, per stage
+  constexpr int AJ = BMA / (16 * NW);  // DMA instructions per wave, per plane, per stage
   constexpr int XJ = BN / (16 * NW);
-  static_assert(BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "DMA geometry");
+  static_assert(BMA % (16 * NW) == 0 && BN % (16 * NW) == 0, "DMA geometry");
   typedef __attribute__((address_space(1))) const void *gptr_t;
   typedef __attribute__((address_space(3))) void *lptr_t;
 
@@ -255,7 +258,7 @@ __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int w
     for (int j = 0; j < AJ; ++j) {
       // 16-row piece j*NW + wave lies in row tile (j*NW + wave) / 2; an inactive row tile is
       // all zeros in this stage and is not multiplied: fetch one hot row instead
-      const bool on = !MASKED || ((am >> ((j * NW + wave) >> 1)) & 1u);
+      const bool on = !MASKED || (j * NW + wave) >= 2 * MT || ((am >> ((j * NW + wave) >> 1)) & 1u);
       const unsigned short *src = on ? aptr[j] + kc : p.as + 8 * cg;
       unsigned char *d = st + (j * NW + wave) * 16 * ROWB;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)d, 16, 0, 0);
@@ -278,65 +281,104 @@ __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int w
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
 
-  // One K stage: two 16-deep MFMA steps.  Lane (li, lh) supplies row li of a 32-row tile and
-  // taps 8*lh .. 8*lh+7 of the step: one ds_read_b128 per (tile, plane).
-  auto mfma_stage = [&](int buf, unsigned mask) __attribute__((always_inline)) {
+  // A K stage is two 16-deep MFMA steps.  Lane (li, lh) supplies row li of a 32-row tile and
+  // taps 8*lh .. 8*lh+7 of the step: one ds_read_b128 per (tile, plane) and step.
+  const int fsw = (li >> 2) & 3;
+  const int a_off = ((wm * MR) * 32 + li) * ROWB;
+  const int x_off = 2 * A_PL + ((wn * NR) * 32 + li) * ROWB;
+  bf16x8 ah[2][MR], al[2][MR], xh[2][NR], xl[2][NR];  // slot = step of the stage
+  auto load_frags = [&](int buf, int q) __attribute__((always_inline)) {
     const unsigned char *st = sStage + buf * STAGE;
-    const unsigned char *a_base = st + ((wm * MR) * 32 + li) * ROWB;
-    const unsigned char *x_base = st + 2 * A_PL + ((wn * NR) * 32 + li) * ROWB;
-    const int fsw = (li >> 2) & 3;
+    const int off = 16 * ((2 * q + lh) ^ fsw);
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      ah[q][m] = *reinterpret_cast<const bf16x8 *>(st + a_off + m * 32 * ROWB + off);
+      al[q][m] = *reinterpret_cast<const bf16x8 *>(st + a_off + A_PL + m * 32 * ROWB + off);
+    }
+#pragma unroll
+    for (int n = 0; n < NR; ++n) {
+      xh[q][n] = *reinterpret_cast<const bf16x8 *>(st + x_off + n * 32 * ROWB + off);
+      xl[q][n] = *reinterpret_cast<const bf16x8 *>(st + x_off + X_PL + n * 32 * ROWB + off);
+    }
+  };
+  // the 3 * MR * NR MFMAs of one step; small terms first, and each accumulator is revisited
+  // only after MR*NR - 1 other MFMAs
+  auto mfma_step = [&](int q, unsigned mask) __attribute__((always_inline)) {
     const unsigned wmask = MASKED ? (mask >> (wm * MR)) : ~0u;
-    bf16x8 ah[2][MR], al[2][MR], xh[2][NR], xl[2][NR];
-    auto load_frags = [&](int q, int slot) __attribute__((always_inline)) {
-      const int off = 16 * ((2 * q + lh) ^ fsw);
+#pragma unroll
+    for (int term = 0; term < 3; ++term) {
 #pragma unroll
       for (int m = 0; m < MR; ++m) {
-        ah[slot][m] = *reinterpret_cast<const bf16x8 *>(a_base + m * 32 * ROWB + off);
-        al[slot][m] = *reinterpret_cast<const bf16x8 *>(a_base + A_PL + m * 32 * ROWB + off);
-      }
+        if (!MASKED || ((wmask >> m) & 1u)) {
 #pragma unroll
-      for (int n = 0; n < NR; ++n) {
-        xh[slot][n] = *reinterpret_cast<const bf16x8 *>(x_base + n * 32 * ROWB + off);
-        xl[slot][n] = *reinterpret_cast<const bf16x8 *>(x_base + X_PL + n * 32 * ROWB + off);
-      }
-    };
-    load_frags(0, 0);
-#pragma unroll
-    for (int q = 0; q < KC / 16; ++q) {
-      if (q + 1 < KC / 16) load_frags(q + 1, (q + 1) & 1);  // prefetch under the MFMAs
-      const int s = q & 1;
-      // small terms first; each accumulator is revisited only after MR*NR - 1 other MFMAs
-#pragma unroll
-      for (int term = 0; term < 3; ++term) {
-#pragma unroll
-        for (int m = 0; m < MR; ++m) {
-          if ((!MASKED || ((wmask >> m) & 1u)) && !(p.debug & 16)) {
-#pragma unroll
-            for (int n = 0; n < NR; ++n) {
-              const bf16x8 a = term == 0 ? al[s][m] : ah[s][m];
-              const bf16x8 x = term == 1 ? xl[s][n] : xh[s][n];
-              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, x, acc[m][n], 0, 0, 0);
-            }
+          for (int n = 0; n < NR; ++n) {
+            const bf16x8 a = term == 0 ? al[q][m] : ah[q][m];
+            const bf16x8 x = term == 1 ? xl[q][n] : xh[q][n];
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, x, acc[m][n], 0, 0, 0);
           }
         }
       }
     }
   };
+  // scheduling hints for one half stage: spread N_DS LDS reads and N_VM LDS-DMA loads evenly
+  // through its N_MFMA MFMAs instead of leaving them in front of an idle matrix pipe
+  auto interleave = [&](auto n_mfma_tag, auto n_ds_tag, auto n_vm_tag) __attribute__((always_inline)) {
+    constexpr int NM = decltype(n_mfma_tag)::value;
+    constexpr int ND = decltype(n_ds_tag)::value;
+    constexpr int NV = decltype(n_vm_tag)::value;
+    // the reads are consumed right after this half: have them issued over its first 3/4 so
+    // that their latency is covered by the remaining MFMAs
+    constexpr int NMD = NM - NM / 4;
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+      if ((i + 1) * NV / NM != i * NV / NM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      if (i < NMD && (i + 1) * ND / NMD != i * ND / NMD)
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+  };
+  using std::integral_constant;
+  typedef integral_constant<int, 3 * MR * NR> n_mfma;       // MFMAs per step
+  typedef integral_constant<int, 2 * (MR + NR)> n_reads;    // fragment reads per step
+  typedef integral_constant<int, 2 * (AJ + XJ)> n_dma;      // DMA instructions per stage
+  typedef integral_constant<int, 0> none;
 
-  // ---- K loop: stage c+1 is DMA'd into the other buffer while stage c is multiplied; the
-  // barrier at the end of the iteration (carrying the vmcnt(0)) publishes it.
+  // ---- K loop.  One barrier per stage, placed between its two steps:
+  //   first half  : MFMAs of step 0 (fragments already in registers) while the step-1 fragments
+  //                 of this stage are read from buffer b
+  //   barrier     : every wave has read all it needs from buffer b, and stage c+1 (DMA'd a whole
+  //                 stage earlier) has landed in buffer b^1
+  //   second half : MFMAs of step 1 while stage c+2 is DMA'd into buffer b and the step-0
+  //                 fragments of stage c+1 are read from buffer b^1
+  // so neither the LDS latency nor the DMA issue ever sits in front of an idle matrix pipe.
+  // DMA / NEXT: whether stages c+2 / c+1 exist (compile time: no control flow inside a half).
+  auto stage_iter = [&](int c, auto dma_tag, auto next_tag) __attribute__((always_inline)) {
+    constexpr bool DMA = decltype(dma_tag)::value;
+    constexpr bool NEXT = decltype(next_tag)::value;
+    const int buf = c & 1;
+    const int kc = kb + c * KC;
+    const unsigned mask = stage_mask(kc);
+    load_frags(buf, 1);
+    mfma_step(0, mask);
+    if (!MASKED) interleave(n_mfma{}, n_reads{}, none{});
+    __syncthreads();
+    if (DMA) dma_stage(kc + 2 * KC, buf, stage_mask(kc + 2 * KC));
+    if (NEXT) load_frags(buf ^ 1, 0);
+    mfma_step(1, mask);
+    if (!MASKED)
+      interleave(n_mfma{}, integral_constant<int, NEXT ? n_reads::value : 0>{},
+                 integral_constant<int, DMA ? n_dma::value : 0>{});
+  };
   if (nstages > 0) {
     dma_stage(kb, 0, stage_mask(kb));
     __syncthreads();
-    for (int c = 0; c < nstages; ++c) {
-      const int buf = c & 1;
-      const int kc = kb + c * KC;
-      // debug bits (benchmark ablations, results are wrong): 1 no DMA in the loop, 16 no MFMAs,
-      // 4 no barrier
-      if (c + 1 < nstages && !(p.debug & 1)) dma_stage(kc + KC, buf ^ 1, stage_mask(kc + KC));
-      mfma_stage(buf, stage_mask(kc));
-      if (!(p.debug & 4)) __syncthreads();
-    }
+    if (nstages > 1) dma_stage(kb + KC, 1, stage_mask(kb + KC));
+    load_frags(0, 0);
+    int c = 0;
+    for (; c + 2 < nstages; ++c) stage_iter(c, integral_constant<bool, true>{}, integral_constant<bool, true>{});
+    if (c + 1 < nstages) stage_iter(c++, integral_constant<bool, false>{}, integral_constant<bool, true>{});
+    stage_iter(c, integral_constant<bool, false>{}, integral_constant<bool, false>{});
+    __syncthreads();  // every wave is done with the stage buffers (the epilogue reuses them)
   }
 
   // ---- epilogue (frames innermost), as framed_gemm_body: one 32x32 tile at a time through a
@@ -402,4 +444,16 @@ __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int w
 template <int WM, int WN, int MR, int NR, bool MASKED>
 __global__ void __launch_bounds__(WM *WN * 64) framed_bf16x3_kernel(const KParams p) {
   framed_bf16x3_body<WM, WN, MR, NR, MASKED>(p, blockIdx.x, gridDim.x);
+}
+
+// Dense basis whose row count is not a multiple of 256 (the n_fft/2+1 bins of an STFT): the
+// leftover rows run as narrow 32- or 64-row workgroups in the tail of the main grid, where
+// they fill the CUs the last partial round of 256x256 tiles leaves idle.
+template <int RMR>
+__global__ void __launch_bounds__(512) framed_bf16x3_pair_kernel(const KParams pm, const KParams pr,
+                                                                  const int n_main) {
+  if ((int)blockIdx.x < n_main)
+    framed_bf16x3_body<4, 2, 2, 4, false>(pm, blockIdx.x, n_main);
+  else
+    framed_bf16x3_body<1, 8, RMR, 1, false>(pr, blockIdx.x - n_main, gridDim.x - n_main);
 }

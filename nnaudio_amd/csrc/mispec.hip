@@ -1221,7 +1221,8 @@ SplitPlan plan_split(const KParams &p, const EdgePlan &e) {
   SplitPlan sp{};
   sp.edge_bytes = round_up_ll(e.stride * p.n_clips * (long long)sizeof(float), 256);
   sp.ls = round_up_ll(p.n_samples, 8);
-  sp.slot = round_up_ll(sp.ls + e.stride, 8);
+  // 128-byte slots: with the usual power-of-two hop / pad every frame then starts on a cache line
+  sp.slot = round_up_ll(sp.ls + e.stride, 64);
   sp.bytes = 2 * sp.slot * p.n_clips * (long long)sizeof(unsigned short);
   return sp;
 }
@@ -1239,24 +1240,39 @@ bool bf16x3_ok(const mispec_framed_gemm_args *a, const KParams &p) {
   return rows > 128;  // narrower problems: the 256-row tile would be mostly empty
 }
 
-template <int WM, int WN, int MR, int NR, bool MASKED>
-int launch_bf16x3_cfg(KParams p, hipStream_t stream) {
+template <int WM, int WN, int MR, int NR>
+constexpr size_t bf16x3_smem() {
+  constexpr int NW = WM * WN;
   constexpr int BM = WM * MR * 32;
   constexpr int BN = WN * NR * 32;
-  constexpr size_t smem = 2 * (2 * BM + 2 * BN) * (KC * 2) + BN * sizeof(long long) +
-                          2 * WM * MR * sizeof(int);
-  static_assert(smem <= 160 * 1024, "LDS budget");
+  constexpr int BMA = BM < 16 * NW ? 16 * NW : BM;
+  return 2 * (2 * BMA + 2 * BN) * (KC * 2) + BN * sizeof(long long) + 2 * WM * MR * sizeof(int);
+}
+
+// fill the tiling fields of p for a bf16x3 tile shape; returns the number of workgroups (or < 0)
+template <int WM, int WN, int MR, int NR>
+long long prepare_bf16x3(KParams &p) {
+  constexpr int BM = WM * MR * 32;
+  constexpr int BN = WN * NR * 32;
   const int rows = p.n_bins * (p.a_im ? 2 : 1);
   p.n_tiles_m = (rows + BM - 1) / BM;
   const long long tn = (p.n_cols + BN - 1) / BN;
-  if (tn * p.n_tiles_m > 0x7fffffffLL) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
+  if (tn * p.n_tiles_m > 0x7fffffffLL) return -1;
   p.n_tiles_n = (int)tn;
   // one workgroup per CU, 32 CUs per XCD: cross all row tiles with ~32 / n_tiles_m frame tiles
   int g = (32 + p.n_tiles_m / 2) / p.n_tiles_m;
   if (g < 1) g = 1;
   if (g > p.n_tiles_n) g = p.n_tiles_n;
   p.n_group = g;
-  const long long grid = tn * p.n_tiles_m;
+  return tn * p.n_tiles_m;
+}
+
+template <int WM, int WN, int MR, int NR, bool MASKED>
+int launch_bf16x3_cfg(KParams p, hipStream_t stream) {
+  constexpr size_t smem = bf16x3_smem<WM, WN, MR, NR>();
+  static_assert(smem <= 160 * 1024, "LDS budget");
+  const long long grid = prepare_bf16x3<WM, WN, MR, NR>(p);
+  if (grid < 0) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
   if (grid == 0) return MISPEC_OK;
   auto kern = framed_bf16x3_kernel<WM, WN, MR, NR, MASKED>;
   static std::atomic<unsigned long long> configured{0};
@@ -1292,6 +1308,17 @@ int setup_split(KParams &p, const mispec_framed_gemm_args *a, hipStream_t stream
   return MISPEC_OK;
 }
 
+// the rows [first_bin, n_bins) of a problem as a problem of its own
+KParams leftover_rows(const KParams &p, int first_bin) {
+  KParams r = p;
+  r.n_bins = p.n_bins - first_bin;
+  r.a_re = p.a_re + (long long)first_bin * p.a_row_stride;
+  if (p.a_im) r.a_im = p.a_im + (long long)first_bin * p.a_row_stride;
+  if (p.row_scale) r.row_scale = p.row_scale + first_bin;
+  r.out_row_offset = p.out_row_offset + first_bin;
+  return r;
+}
+
 int launch_framed_bf16x3(const KParams &p, int tile, hipStream_t stream) {
   const int rpb = p.a_im ? 2 : 1;
   const bool masked = p.row_support != nullptr;
@@ -1304,6 +1331,40 @@ int launch_framed_bf16x3(const KParams &p, int tile, hipStream_t stream) {
   KParams q = p;
   q.n_bins = main_bins;
   int rc;
+  if (tile == MISPEC_TILE_AUTO && !masked && main_bins > 0 && main_bins < p.n_bins &&
+      !(p.debug & 0x2000)) {
+    // one launch: 256x256 workgroups + narrow ones for the leftover rows in the grid's tail
+    KParams r = leftover_rows(p, main_bins);
+    r.as = p.as + (long long)main_bins * p.Ks;  // same planes, first leftover bin
+    const int rem_rows = r.n_bins * rpb;
+    const long long gm = prepare_bf16x3<4, 2, 2, 4>(q);
+    const long long gr = rem_rows <= 32 ? prepare_bf16x3<1, 8, 1, 1>(r) : prepare_bf16x3<1, 8, 2, 1>(r);
+    if (gm < 0 || gr < 0 || gm + gr > 0x7fffffffLL)
+      return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
+    constexpr size_t sm_main = bf16x3_smem<4, 2, 2, 4>();
+    constexpr size_t sm_r1 = bf16x3_smem<1, 8, 1, 1>();
+    constexpr size_t sm_r2 = bf16x3_smem<1, 8, 2, 1>();
+    constexpr size_t smem = sm_main > sm_r2 ? (sm_main > sm_r1 ? sm_main : sm_r1)
+                                            : (sm_r2 > sm_r1 ? sm_r2 : sm_r1);
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    const dim3 grid((unsigned)(gm + gr));
+    if (rem_rows <= 32) {
+      auto kern = framed_bf16x3_pair_kernel<1>;
+      static std::atomic<unsigned long long> configured{0};
+      rc = configure_lds(kern, smem, configured);
+      if (rc != MISPEC_OK) return rc;
+      hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, q, r, (int)gm);
+    } else {
+      auto kern = framed_bf16x3_pair_kernel<2>;
+      static std::atomic<unsigned long long> configured{0};
+      rc = configure_lds(kern, smem, configured);
+      if (rc != MISPEC_OK) return rc;
+      hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, q, r, (int)gm);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return MISPEC_OK;
+  }
   if (tile == MISPEC_TILE_256x256)  // one wave per SIMD, 128x128 per wave
     rc = masked ? launch_bf16x3_cfg<2, 2, 4, 4, true>(q, stream)
                 : launch_bf16x3_cfg<2, 2, 4, 4, false>(q, stream);
@@ -1311,13 +1372,7 @@ int launch_framed_bf16x3(const KParams &p, int tile, hipStream_t stream) {
     rc = masked ? launch_bf16x3_cfg<4, 2, 2, 4, true>(q, stream)
                 : launch_bf16x3_cfg<4, 2, 2, 4, false>(q, stream);
   if (rc != MISPEC_OK || main_bins == p.n_bins) return rc;
-  KParams r = p;
-  r.n_bins = p.n_bins - main_bins;
-  r.a_re = p.a_re + (long long)main_bins * p.a_row_stride;
-  if (p.a_im) r.a_im = p.a_im + (long long)main_bins * p.a_row_stride;
-  if (p.row_scale) r.row_scale = p.row_scale + main_bins;
-  r.out_row_offset = p.out_row_offset + main_bins;
-  return launch_framed(r, MISPEC_TILE_AUTO, stream);
+  return launch_framed(leftover_rows(p, main_bins), MISPEC_TILE_AUTO, stream);
 }
 
 // attach the edge workspace to p and enqueue the fill pre-pass

@@ -74,7 +74,7 @@ def bf16():
         ms = timeit(lambda: engine.framed_gemm(x, m.wcos[:1024], m.wsin[:1024], tile=tile, hop=512, pad=1024,
                                                pad_mode=2, epilogue=engine.EPI_MAGNITUDE, precision="bf16x3"))
         print("   1024 bins incl. uncached basis split: %.3f ms" % ms)
-    for dbg, what in ((0, "full"), (1, "no DMA in loop"), (16, "no MFMA"), (4, "no barrier"), (5, "no DMA, no barrier"), (17, "no DMA no MFMA: frag reads + barrier")):
+    for dbg, what in ((0, "full"),):
         ms = timeit(lambda: engine.framed_gemm(x, m.wcos[:1024], m.wsin[:1024], tile=0, _debug=dbg,
                                                basis_split=split1k, **kw1k))
         print("   ablate[%-36s] 1024 bins: %.3f ms" % (what, ms))

@@ -27,12 +27,48 @@ def build(force=False, verbose=True):
             and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps)):
         return OUT
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-I", INC, SRC, "-o", OUT + ".tmp"]
+           "-Rpass-analysis=kernel-resource-usage", "-I", INC, SRC, "-o", OUT + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    remarks, other = resource_usage(res.stderr)
+    if other.strip():
+        sys.stderr.write(other)
+    if res.returncode != 0:
+        raise subprocess.CalledProcessError(res.returncode, cmd)
+    # The MFMA kernels feed LDS with global_load_lds and pace it with s_waitcnt vmcnt: a build of
+    # the bf16x3 kernel that spilled (scratch loads inside its K loop, which count on the same
+    # vmcnt) produced run-to-run different results on the MI355X.  Refuse such a build.
+    spilled = {k: v for k, v in remarks.items() if k.startswith("framed_") and v > 0}
+    if spilled:
+        raise RuntimeError("kernels using LDS-direct loads must not use scratch: %s" % spilled)
     os.replace(OUT + ".tmp", OUT)
     return OUT
+
+
+def resource_usage(stderr):
+    """Split hipcc's stderr into {kernel: scratch bytes per lane} (from the
+    -Rpass-analysis=kernel-resource-usage remarks) and everything else."""
+    import re
+
+    usage, other, name = {}, [], None
+    for line in stderr.splitlines(True):
+        if "[-Rpass-analysis=kernel-resource-usage]" not in line:
+            # source echo lines that follow a remark ("  797 | __global__ ..." / "      | ^")
+            if name is not None and (re.match(r"\s+(\d+\s+)?\|", line)
+                                     or line.startswith("In file included from")):
+                continue
+            other.append(line)
+            continue
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            continue
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and name:
+            short = re.sub(r"^_ZN12_GLOBAL__N_1\d+", "", name)
+            usage[short] = int(m.group(1))
+    return usage, "".join(other)
 
 
 if __name__ == "__main__":

@@ -381,63 +381,118 @@ __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int w
     __syncthreads();  // every wave is done with the stage buffers (the epilogue reuses them)
   }
 
-  // ---- epilogue (frames innermost), as framed_gemm_body: one 32x32 tile at a time through a
-  // wave-private LDS patch.  Accumulator element e of lane (li, lh) is
-  // D[row = (e&3) + 8*(e>>2) + 4*lh][col = li].
-  constexpr int LDC = 33;
-  float *sC = reinterpret_cast<float *>(smem_raw) + wave * (32 * LDC);
+  // ---- epilogue.  Accumulator element e of lane (li, lh) is
+  // D[row = (e&3) + 8*(e>>2) + 4*lh][col = li]: with interleaved (re, im) rows a lane holds both
+  // parts of 8 bins of a 32x32 tile (elements e, e+1 for even e), so Complex / Magnitude / Power
+  // are formed and stored from registers, frames innermost (32 consecutive frames per half wave).
   const int E = epilogue_width(p.epilogue);
-#pragma unroll 1
-  for (int ti = 0; ti < MR * NR; ++ti) {
+  const bool direct = cplx && (p.epilogue == MISPEC_EPI_COMPLEX || p.epilogue == MISPEC_EPI_MAGNITUDE ||
+                               p.epilogue == MISPEC_EPI_POWER);
+  if (direct) {
+    // one column block (32 frames) at a time: a single output pointer is live beside the
+    // accumulators (this kernel must not spill: see the note on scratch in mispec.hip)
+    auto store_all = [&](auto epi_tag) __attribute__((always_inline)) {
+      constexpr int EPI = decltype(epi_tag)::value;
 #pragma unroll
-    for (int m = 0; m < MR; ++m)
-#pragma unroll
-      for (int n = 0; n < NR; ++n)
-        if (ti == m * NR + n) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e)
-            sC[((e & 3) + 8 * (e >> 2) + 4 * lh) * LDC + li] = acc[m][n][e];
+      for (int n = 0; n < NR; ++n) {
+        const long long col = n0 + (wn * NR + n) * 32 + li;
+        const bool col_ok = col < p.n_cols;
+        int c = 0, t = 0;
+        if (col_ok) {
+          c = (int)(col / p.n_frames);
+          t = (int)(col - (long long)c * p.n_frames);
         }
-    __syncthreads();
-    const int tm = ti / NR, tn = ti - tm * NR;
-    const int row_base = m0 + (wm * MR + tm) * 32;
-    const long long col = n0 + (wn * NR + tn) * 32 + li;
-    const bool col_ok = col < p.n_cols;
-    int c = 0, t = 0;
-    if (col_ok) {
-      c = (int)(col / p.n_frames);
-      t = (int)(col - (long long)c * p.n_frames);
-    }
-    float *obase = p.out + (long long)c * p.out_clip_stride + (long long)t * E;
-    if (cplx) {
-#pragma unroll 1
-      for (int it = 0; it < 8; ++it) {
-        const int rl = 2 * (2 * it + lh);  // even local row: re; rl + 1: im
-        const int bin = (row_base + rl) >> 1;
-        if (col_ok && bin < p.n_bins) {
-          float re = sC[rl * LDC + li];
-          float im = p.im_sign * sC[(rl + 1) * LDC + li];
-          if (p.row_scale) {
-            const float sc = p.row_scale[bin];
-            re *= sc;
-            im *= sc;
+        float *obase = p.out + (long long)c * p.out_clip_stride + (long long)t * E +
+                       (long long)p.out_row_offset * p.out_row_stride;
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+          const int bin0 = ((m0 + (wm * MR + m) * 32) >> 1) + 2 * lh;
+#pragma unroll
+          for (int e2 = 0; e2 < 8; ++e2) {
+            const int bin = bin0 + (e2 & 1) + 4 * (e2 >> 1);
+            if (col_ok && bin < p.n_bins) {
+              const float sc = p.row_scale ? p.row_scale[bin] : 1.f;
+              const float re = acc[m][n][2 * e2] * sc;
+              const float im = p.im_sign * acc[m][n][2 * e2 + 1] * sc;
+              float *dst = obase + (long long)bin * p.out_row_stride;
+              if (EPI == MISPEC_EPI_COMPLEX) {
+                *reinterpret_cast<float2 *>(dst) = make_float2(re, im);
+              } else if (EPI == MISPEC_EPI_MAGNITUDE) {
+                dst[0] = sqrtf(re * re + im * im + p.eps);
+              } else {
+                epilogue_store(p, dst, re, im);  // MISPEC_EPI_POWER
+              }
+            }
+            // keep the 8*MR*NR store groups in program order: hoisting all their address
+            // arithmetic above the first store costs more registers than the kernel has
+            __builtin_amdgcn_sched_barrier(0);
           }
-          epilogue_store(p, obase + (long long)(p.out_row_offset + bin) * p.out_row_stride, re, im);
         }
       }
-    } else {
+    };
+    if (p.epilogue == MISPEC_EPI_COMPLEX)
+      store_all(std::integral_constant<int, MISPEC_EPI_COMPLEX>{});
+    else if (p.epilogue == MISPEC_EPI_MAGNITUDE)
+      store_all(std::integral_constant<int, MISPEC_EPI_MAGNITUDE>{});
+    else
+      store_all(std::integral_constant<int, MISPEC_EPI_POWER>{});
+  } else {
+    // phase epilogues / real bases: one 32x32 tile at a time through a wave-private LDS patch
+    // (a single code instance of the transcendental epilogues), as framed_gemm_body
+    constexpr int LDC = 33;
+    float *sC = reinterpret_cast<float *>(smem_raw) + wave * (32 * LDC);
 #pragma unroll 1
-      for (int it = 0; it < 16; ++it) {
-        const int rl = 2 * it + lh;
-        const int row = row_base + rl;
-        if (col_ok && row < p.n_bins) {
-          float v = sC[rl * LDC + li];
-          if (p.row_scale) v *= p.row_scale[row];
-          obase[(long long)(p.out_row_offset + row) * p.out_row_stride] = v;
+    for (int ti = 0; ti < MR * NR; ++ti) {
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int n = 0; n < NR; ++n)
+          if (ti == m * NR + n) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+              sC[((e & 3) + 8 * (e >> 2) + 4 * lh) * LDC + li] = acc[m][n][e];
+          }
+      __syncthreads();
+      const int tm = ti / NR, tn = ti - tm * NR;
+      const int row_base = m0 + (wm * MR + tm) * 32;
+      const long long col = n0 + (wn * NR + tn) * 32 + li;
+      const bool col_ok = col < p.n_cols;
+      int c = 0, t = 0;
+      if (col_ok) {
+        c = (int)(col / p.n_frames);
+        t = (int)(col - (long long)c * p.n_frames);
+      }
+      float *obase = p.out + (long long)c * p.out_clip_stride + (long long)t * E;
+      if (cplx) {
+#pragma unroll 1
+        for (int it = 0; it < 8; ++it) {
+          const int rl = 2 * (2 * it + lh);  // even local row: re; rl + 1: im
+          const int bin = (row_base + rl) >> 1;
+          if (col_ok && bin < p.n_bins) {
+            float re = sC[rl * LDC + li];
+            float im = p.im_sign * sC[(rl + 1) * LDC + li];
+            if (p.row_scale) {
+              const float sc = p.row_scale[bin];
+              re *= sc;
+              im *= sc;
+            }
+            epilogue_store(p, obase + (long long)(p.out_row_offset + bin) * p.out_row_stride, re, im);
+          }
+        }
+      } else {
+#pragma unroll 1
+        for (int it = 0; it < 16; ++it) {
+          const int rl = 2 * it + lh;
+          const int row = row_base + rl;
+          if (col_ok && row < p.n_bins) {
+            float v = sC[rl * LDC + li];
+            if (p.row_scale) v *= p.row_scale[row];
+            obase[(long long)(p.out_row_offset + row) * p.out_row_stride] = v;
+          }
         }
       }
+      __syncthreads();
     }
-    __syncthreads();
   }
 }
 

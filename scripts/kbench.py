@@ -65,7 +65,7 @@ def bf16():
               basis_split=split)
     split1k = engine.split_basis(m.wcos[:1024], m.wsin[:1024])
     kw1k = dict(hop=512, pad=1024, pad_mode=2, epilogue=engine.EPI_MAGNITUDE, precision="bf16x3")
-    for tile, what in ((0, "8 waves 64x128"), (9, "4 waves 128x128")):
+    for tile, what in ((0, "8 waves 64x128"),):
         y = engine.framed_gemm(x, m.wcos, m.wsin, tile=tile, **kw)
         err = float((y - ref).abs().max() / ref.abs().max())
         ms = timeit(lambda: engine.framed_gemm(x, m.wcos, m.wsin, tile=tile, **kw))

@@ -389,32 +389,40 @@ __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int w
   const bool direct = cplx && (p.epilogue == MISPEC_EPI_COMPLEX || p.epilogue == MISPEC_EPI_MAGNITUDE ||
                                p.epilogue == MISPEC_EPI_POWER);
   if (direct) {
-    // one column block (32 frames) at a time: a single output pointer is live beside the
-    // accumulators (this kernel must not spill: see the note on scratch in mispec.hip)
+    // Row-major store order: the NR column blocks of a row (NR*32 consecutive frames, one
+    // contiguous run of the output) are written back to back, so that L2 sees whole lines.
+    // Only the first block's (clip, frame) is kept; block n is 32*n frames further along the
+    // flat frame axis, i.e. in the same clip or (per lane) a later one.
+    const long long col0 = n0 + (wn * NR) * 32 + li;
+    int c0 = 0, t0 = 0;
+    {
+      const long long cc = col0 < p.n_cols ? col0 : 0;
+      c0 = (int)(cc / p.n_frames);
+      t0 = (int)(cc - (long long)c0 * p.n_frames);
+    }
+    float *const orow = p.out + (long long)p.out_row_offset * p.out_row_stride;
     auto store_all = [&](auto epi_tag) __attribute__((always_inline)) {
       constexpr int EPI = decltype(epi_tag)::value;
 #pragma unroll
-      for (int n = 0; n < NR; ++n) {
-        const long long col = n0 + (wn * NR + n) * 32 + li;
-        const bool col_ok = col < p.n_cols;
-        int c = 0, t = 0;
-        if (col_ok) {
-          c = (int)(col / p.n_frames);
-          t = (int)(col - (long long)c * p.n_frames);
-        }
-        float *obase = p.out + (long long)c * p.out_clip_stride + (long long)t * E +
-                       (long long)p.out_row_offset * p.out_row_stride;
+      for (int m = 0; m < MR; ++m) {
+        const int bin0 = ((m0 + (wm * MR + m) * 32) >> 1) + 2 * lh;
 #pragma unroll
-        for (int m = 0; m < MR; ++m) {
-          const int bin0 = ((m0 + (wm * MR + m) * 32) >> 1) + 2 * lh;
+        for (int e2 = 0; e2 < 8; ++e2) {
+          const int bin = bin0 + (e2 & 1) + 4 * (e2 >> 1);
+          const bool bin_ok = bin < p.n_bins;
+          const float sc = (p.row_scale && bin_ok) ? p.row_scale[bin] : 1.f;
+          float *const obin = orow + (long long)bin * p.out_row_stride;
 #pragma unroll
-          for (int e2 = 0; e2 < 8; ++e2) {
-            const int bin = bin0 + (e2 & 1) + 4 * (e2 >> 1);
-            if (col_ok && bin < p.n_bins) {
-              const float sc = p.row_scale ? p.row_scale[bin] : 1.f;
+          for (int n = 0; n < NR; ++n) {
+            int c = c0, t = t0 + 32 * n;
+            while (t >= p.n_frames) {
+              t -= p.n_frames;
+              ++c;
+            }
+            if (bin_ok && col0 + 32 * n < p.n_cols) {
               const float re = acc[m][n][2 * e2] * sc;
               const float im = p.im_sign * acc[m][n][2 * e2 + 1] * sc;
-              float *dst = obase + (long long)bin * p.out_row_stride;
+              float *dst = obin + (long long)c * p.out_clip_stride + (long long)t * E;
               if (EPI == MISPEC_EPI_COMPLEX) {
                 *reinterpret_cast<float2 *>(dst) = make_float2(re, im);
               } else if (EPI == MISPEC_EPI_MAGNITUDE) {
@@ -423,10 +431,10 @@ __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int w
                 epilogue_store(p, dst, re, im);  // MISPEC_EPI_POWER
               }
             }
-            // keep the 8*MR*NR store groups in program order: hoisting all their address
-            // arithmetic above the first store costs more registers than the kernel has
-            __builtin_amdgcn_sched_barrier(0);
           }
+          // keep the 8*MR row groups in program order: hoisting all their address arithmetic
+          // above the first store costs more registers than the kernel has (it must not spill)
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     };

@@ -10,10 +10,17 @@ The batch shards across ranks as independent clips (nnaudio_amd.dist); computing
 collective, so the timed region has none; the RCCL all-gather that reassembles the output
 tensor is timed separately and reported on stderr / in "extra" (never in `value`).
 
+The step runs with ``--precision bf16x3`` by default: fp32 operands split into bf16 (hi, lo)
+pairs, three bf16 MFMAs per product, fp32 accumulate (include/mispec.h MISPEC_PREC_BF16X3;
+~5e-6 of the spectrum peak, same 1e-4 parity tests as the fp32 path).  The fp32-MFMA path
+(the modules' default) is timed in the same run and reported under "paths".
+
 Rank 0 prints ONE JSON line: metric = spectrogram frames/s (whole job), plus
-  "roofline":     the framed-GEMM kernel against the fp32 MFMA peak (157.3 TFLOP/s) --
-                  algorithmic flops per launch / average launch duration (HIP events on the
-                  launch stream) -- and its HBM-roofline fraction on algorithmic bytes;
+  "roofline":     the framed-GEMM kernel against the dense MFMA peak of the arithmetic used
+                  (bf16 2500 TFLOP/s, or fp32 157.3) -- ALGORITHMIC flops per launch (2 flop
+                  per tap of the dense contraction, whatever the split executes) / average
+                  launch duration (HIP events on the launch stream) -- and its HBM-roofline
+                  fraction on algorithmic bytes;
   "cpu_baseline": the numpy port of the reference algorithm (oracle/, float32 BLAS) timed on
                   this host on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -31,7 +38,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA = 157.3e12  # FLOP/s, MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
+PEAK_BF16_MFMA = 2.5e15   # FLOP/s dense, MI355X_MICROARCH.md (v_mfma_f32_32x32x16_bf16)
 PEAK_HBM = 8.0e12         # B/s spec
+PEAK = {"fp32": PEAK_F32_MFMA, "bf16x3": PEAK_BF16_MFMA}
+MFMAS_PER_PRODUCT = {"fp32": 1, "bf16x3": 3}
 
 
 def log(*a):
@@ -148,6 +158,8 @@ def main():
     ap.add_argument("--workload", default="stft", choices=["stft", "mel", "cqt", "cqt2010"])
     ap.add_argument("--extras", type=int, default=1, help="also time CQT84 / Mel / gather (untimed region)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32"],
+                    help="arithmetic of the timed step (the other path is reported under 'paths')")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -171,38 +183,66 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    import nnaudio_amd
+    from nnaudio_amd import engine
+
     module, make_input, meta = workload(args.workload, device)
     x = make_input(rank)
-    wall, dev_s = timed_steps(module, x, args.steps, args.warmup, sync)
-    t = torch.tensor([wall, dev_s], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall, dev_s = float(t[0]), float(t[1])
+
+    def run_path(precision, steps, warmup):
+        """Time `steps` forwards in one arithmetic; whole-job numbers (max over ranks)."""
+        nnaudio_amd.set_precision(precision)
+        wall, dev_s = timed_steps(module, x, steps, warmup, sync)
+        t = torch.tensor([wall, dev_s], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, dev_s = float(t[0]), float(t[1])
+        res = {"frames_per_s": meta["frames"] * world * steps / wall, "ms_per_step": wall / steps * 1e3,
+               "step_device_ms": dev_s / steps * 1e3,
+               "algorithmic_tflops": meta["flops"] / (dev_s / steps) / 1e12,
+               "mfma_frac": meta["flops"] / (dev_s / steps) / PEAK[precision],
+               "hbm_frac_on_algorithmic_bytes": meta["bytes"] / (dev_s / steps) / PEAK_HBM}
+        return wall, dev_s, res
+
+    def dominant_kernel(precision):
+        """STFT: the main contraction alone (1024 of the 1025 bins: whole 128- / 256-row blocks;
+        the Nyquist bin and the pre-passes are other kernels), events on the launch stream."""
+        wc, ws = module.wcos[:1024], module.wsin[:1024]
+        split = engine.split_basis(wc, ws) if precision == "bf16x3" else None
+
+        class _M:
+            def __call__(self, _):
+                return engine.framed_gemm(x, wc, ws, hop=512, pad=1024, pad_mode=engine.PAD_REFLECT,
+                                          epilogue=engine.EPI_MAGNITUDE, precision=precision,
+                                          basis_split=split)
+
+        _, d = timed_steps(_M(), x, args.steps, 2, sync)
+        fl = 2.0 * 2048 * 2048 * meta["frames"]
+        per = d / args.steps
+        name = ("framed_bf16x3_kernel<4,2,2,4,unmasked> (v_mfma_f32_32x32x16_bf16) + split_signal_kernel"
+                if precision == "bf16x3" else
+                "framed_gemm_kernel<2,2,2,2,framed,rows,unmasked> (v_mfma_f32_32x32x2_f32)")
+        return {"name": name, "avg_ms": per * 1e3, "algorithmic_flops": fl,
+                "tflops": fl / per / 1e12, "frac_of_peak": fl / per / PEAK[precision],
+                "executed_mfma_tflops": MFMAS_PER_PRODUCT[precision] * fl / per / 1e12,
+                "executed_frac_of_peak": MFMAS_PER_PRODUCT[precision] * fl / per / PEAK[precision]}
+
+    prec = args.precision
+    other = "fp32" if prec == "bf16x3" else "bf16x3"
+    wall, dev_s, primary = run_path(prec, args.steps, args.warmup)
+    paths = {prec: primary}
+    dominant = None
+    if args.workload == "stft":
+        dominant = dominant_kernel(prec)
+    if args.extras:
+        _, _, paths[other] = run_path(other, max(3, args.steps // 2), 2)
+        if args.workload == "stft":
+            paths[other]["dominant_kernel"] = dominant_kernel(other)
+    nnaudio_amd.set_precision(prec)
 
     frames_total = meta["frames"] * world * args.steps
     kern_s = dev_s / args.steps
     achieved = meta["flops"] / kern_s
-    dominant = None
-    if args.workload == "stft":
-        # the dominant kernel alone (1024 of the 1025 bins; the Nyquist bin and the edge-span
-        # pre-pass are separate small launches), timed with events on the launch stream
-        from nnaudio_amd import engine
-
-        def main_only():
-            return engine.framed_gemm(x, module.wcos[:1024], module.wsin[:1024], hop=512, pad=1024,
-                                      pad_mode=engine.PAD_REFLECT, epilogue=engine.EPI_MAGNITUDE,
-                                      tile=1)
-
-        class _M:
-            def __call__(self, _):
-                return main_only()
-
-        _, d_main = timed_steps(_M(), x, args.steps, 2, sync)
-        fl = 2.0 * 2048 * 2048 * meta["frames"]
-        dominant = {"name": "framed_gemm_kernel<2,2,2,2,framed,rows,unmasked>",
-                    "avg_ms": d_main / args.steps * 1e3, "algorithmic_flops": fl,
-                    "tflops": fl / (d_main / args.steps) / 1e12,
-                    "frac_of_peak": fl / (d_main / args.steps) / PEAK_F32_MFMA}
     out = {
         "metric": "spectrogram frames/sec",
         "value": frames_total / wall,
@@ -214,24 +254,32 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "bf16x3" if prec == "bf16x3" else "f32",
         "data": "synthetic",
         "config": {"workload": meta["tag"], "global_batch": meta["B"] * world,
                    "clip_samples": meta["L"], "frames_per_clip": meta["T"],
+                   "precision": ("bf16x3: fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per "
+                                 "product, fp32 accumulate (err ~5e-6 of peak, 1e-4 parity bar)"
+                                 if prec == "bf16x3" else "fp32 MFMA, fp32 accumulate"),
                    "parallelism": "batch-sharded x%d, no data-path collective" % world},
-        "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_F32_MFMA / 1e12,
-                     "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA, "traffic": None,
-                     "kernel": "framed_gemm_kernel<2,2,2,2,framed,rows,unmasked> (v_mfma_f32_32x32x2_f32)"
-                               " + Nyquist-bin launch + edge-span pre-pass = one step",
+        "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK[prec] / 1e12,
+                     "unit": "TFLOP/s", "frac": achieved / PEAK[prec], "traffic": None,
+                     "kernel": "one step = pre-passes + main contraction + Nyquist-bin tiles; "
+                               "achieved = algorithmic flops (2 per tap of the dense contraction) / "
+                               "step device time; the bf16x3 path executes 3 MFMA flops per "
+                               "algorithmic flop (executed_frac)",
+                     "executed_frac": MFMAS_PER_PRODUCT[prec] * achieved / PEAK[prec],
                      "step_device_ms": kern_s * 1e3, "dominant_kernel": dominant,
                      "algorithmic_flops_per_launch": meta["flops"],
                      "algorithmic_bytes_per_launch": meta["bytes"],
                      "hbm_frac_on_algorithmic_bytes": meta["bytes"] / kern_s / PEAK_HBM},
+        "paths": paths,
     }
     traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(traffic_file) and args.workload == "stft":
         try:
-            out["roofline"]["traffic"] = json.load(open(traffic_file))["stft_cfg2_bytes_per_launch"]
+            out["roofline"]["traffic"] = json.load(open(traffic_file))[
+                "stft_cfg2_bytes_per_launch" + ("_bf16x3" if prec == "bf16x3" else "")]
         except Exception:
             pass
 
@@ -253,7 +301,8 @@ def main():
                 w2, d2 = float(tt[0]), float(tt[1])
                 extra[name] = {"workload": me2["tag"], "frames_per_s": me2["frames"] * world * n2 / w2,
                                "ms_per_step": w2 / n2 * 1e3,
-                               "mfma_frac": me2["flops"] / (d2 / n2) / PEAK_F32_MFMA,
+                               "precision": prec,
+                               "mfma_frac": me2["flops"] / (d2 / n2) / PEAK[prec],
                                "hbm_frac_on_algorithmic_bytes": me2["bytes"] / (d2 / n2) / PEAK_HBM}
                 del m2, x2
                 torch.cuda.empty_cache()

@@ -30,7 +30,7 @@ for f in find("*counter_collection.csv"):
         agg[k][r.get("Counter_Name")] += float(r.get("Counter_Value", 0) or 0)
         cnt[(k, r.get("Counter_Name"))] += 1
     for k, d in agg.items():
-        if "framed_gemm" not in k:
+        if "framed_" not in k and "split_signal" not in k:
             continue
         print("  kernel:", k)
         for c, v in sorted(d.items()):
@@ -43,7 +43,7 @@ try:
     dom, dur, best = None, None, -1.0
     for f in find("*kernel_stats.csv"):
         for r in csv.DictReader(open(f)):
-            if "framed_gemm" in r.get("Name", "") and float(r["TotalDurationNs"]) > best:
+            if "framed_" in r.get("Name", "") and float(r["TotalDurationNs"]) > best:
                 best = float(r["TotalDurationNs"])
                 dom, dur = r["Name"], float(r["AverageNs"]) * 1e-9
     vals = {}
@@ -66,6 +66,10 @@ try:
             for k in ("SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS"):
                 if k in vals:
                     print("  %-34s: %.1f %% of wave cycles" % (k, 100 * vals[k] / w))
+        if "SQ_INSTS_VALU_MFMA_MOPS_BF16" in vals or "SQ_INSTS_VALU_MFMA_MOPS_F32" in vals:
+            for k in ("SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_VALU_MFMA_MOPS_F32"):
+                if k in vals:
+                    print("  %-34s: %.4g per dispatch" % (k, vals[k]))
         if "FETCH_SIZE" in vals:
             print("  FETCH_SIZE (KB) per dispatch      : %.4g  (x2 on gfx950 for 16B/lane streams -> %.1f MB read)" % (vals["FETCH_SIZE"], 2 * vals["FETCH_SIZE"] * 1024 / 1e6))
         if "WRITE_SIZE" in vals:

@@ -15,9 +15,11 @@
 // Operands (all bf16, prepared by the two pre-pass kernels below):
 //   basis : planes [re_hi | re_lo | im_hi | im_lo], each (n_bins, Ks), Ks = K rounded up to 32
 //           with zero taps -> no K-tail handling; split once per basis (cached by the caller)
-//   signal: planes [hi | lo], each (n_clips, S): a clip slot = [waveform, Ls | padded edge
-//           spans]: every frame is a plain run of >= Ks elements at an EVEN element offset
-//           (hop and pad even), so 16-byte LDS-direct pieces start 4-byte aligned.
+//   signal: planes [hi | lo], each (n_clips, S): a clip slot holds the PADDED clip (what the
+//           reference materialises with nn.ReflectionPad1d / ConstantPad1d, stft.py:279-289)
+//           followed by zeros: frame t is the plain run  slot[t*hop .. t*hop + Ks)  at an EVEN
+//           element offset (hop even), so 16-byte LDS-direct pieces start 4-byte aligned and
+//           there is no edge handling anywhere in the contraction.
 //
 // Workgroup = WM x WN waves, wave tile MR x NR MFMA tiles of 32x32, K stage = 32 taps.
 // LDS stage = [A_hi | A_lo | X_hi | X_lo], rows of 64 B (32 bf16), double buffered, filled by
@@ -63,35 +65,28 @@ __global__ void __launch_bounds__(256) split_basis_kernel(const float *__restric
   dst[(2 * z + 1) * plane + o] = (unsigned short)lo;
 }
 
-// waveform + padded edge spans of every clip -> (hi, lo) planes.  One thread = 4 consecutive
-// elements of a clip slot (S % 8 == 0).  grid (ceil(S/1024), n_clips)
+// padded clips -> (hi, lo) planes.  One thread = 4 consecutive elements of a clip slot
+// (S % 8 == 0); element i of a slot is the padded signal at position i - pad, zero beyond it.
+// grid (ceil(S/1024), n_clips)
 __global__ void __launch_bounds__(256) split_signal_kernel(const KParams p,
                                                            unsigned short *__restrict__ dst) {
   const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i0 >= p.xs_clip_stride) return;
   const int c = blockIdx.y;
   const float *x = p.x + (long long)c * p.x_clip_stride;
+  const long long q0 = i0 - p.pad;  // signal position of the first element
   float v[4];
-  if (i0 + 4 <= p.n_samples) {
-    const f32x4u t = *reinterpret_cast<const f32x4u *>(x + i0);
+  if (q0 >= 0 && q0 + 4 <= p.n_samples) {
+    const f32x4u t = *reinterpret_cast<const f32x4u *>(x + q0);
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = t[e];
   } else {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const long long i = i0 + e;
+      const long long q = q0 + e;
       float t = 0.f;
-      if (i < p.n_samples) {
-        t = x[i];
-      } else if (i >= p.xs_edge_off && i - p.xs_edge_off < p.edge_clip_stride) {
-        const long long j = i - p.xs_edge_off;  // as edge_fill_kernel
-        const long long q = (p.edge_mode == EDGE_FULL || j < p.edge_ll)
-                                ? j - p.pad
-                                : (long long)p.t_r0 * p.hop - p.pad + (j - p.edge_ll);
-        if (q >= -(long long)p.pad && q < (long long)p.n_samples + p.pad)
-          t = fetch_sample(p.x, (long long)c * p.x_clip_stride, (int)q, p.n_samples, p.pad_mode,
-                           true);
-      }
+      if (q >= -(long long)p.pad && q < (long long)p.n_samples + p.pad)
+        t = fetch_sample(p.x, (long long)c * p.x_clip_stride, (int)q, p.n_samples, p.pad_mode, true);
       v[e] = t;
     }
   }
@@ -181,11 +176,7 @@ __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int w
     if (col >= p.n_cols) col = 0;  // unused column: any valid frame, its results are not stored
     const int c = (int)(col / p.n_frames);
     const int t = (int)(col - (long long)c * p.n_frames);
-    const long long in_clip = t < p.n_left ? p.xs_edge_off + (long long)t * p.hop
-                              : t >= p.t_r0
-                                  ? p.xs_edge_off + p.edge_ll + (long long)(t - p.t_r0) * p.hop
-                                  : (long long)t * p.hop - p.pad;
-    sColOff[j] = (long long)c * p.xs_clip_stride + in_clip;
+    sColOff[j] = (long long)c * p.xs_clip_stride + (long long)t * p.hop;
   }
   if (tid < MT) {
     const int row_lo = m0 + tid * 32;

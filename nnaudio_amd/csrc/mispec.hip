@@ -95,10 +95,9 @@ struct KParams {
   int n_group;  // frame tiles crossed with all row tiles before advancing (L2 blocking)
   int debug;    // ablation bits (benchmarking only), see framed_gemm_kernel
   // MISPEC_PREC_BF16X3 operands (framed_bf16x3.inl)
-  const unsigned short *xs;  // hi plane of the split signal: per clip [waveform | edge spans]
-  long long xs_clip_stride;  // elements per clip slot (multiple of 8)
+  const unsigned short *xs;  // hi plane of the split signal: one slot per clip, the padded clip
+  long long xs_clip_stride;  // elements per clip slot (multiple of 64)
   long long xs_plane;        // hi -> lo plane distance, elements
-  long long xs_edge_off;     // start of the edge spans inside a clip slot
   const unsigned short *as;  // split basis planes [re_hi | re_lo | im_hi | im_lo], each (n_bins, Ks)
   long long as_plane;
   int Ks;  // taps per split basis row (K rounded up to 32, zero filled)
@@ -1211,8 +1210,7 @@ int launch_framed(const KParams &p, int tile, hipStream_t stream) {
 inline long long round_up_ll(long long v, long long m) { return (v + m - 1) / m * m; }
 
 struct SplitPlan {
-  long long edge_bytes;  // fp32 edge spans (leftover rows run on the fp32 kernel), 256-aligned
-  long long ls;          // waveform region of a clip slot, elements
+  long long edge_bytes;  // fp32 edge spans (leftover rows may run on the fp32 kernel), 256-aligned
   long long slot;        // clip slot, elements
   long long bytes;       // both planes
 };
@@ -1220,9 +1218,11 @@ struct SplitPlan {
 SplitPlan plan_split(const KParams &p, const EdgePlan &e) {
   SplitPlan sp{};
   sp.edge_bytes = round_up_ll(e.stride * p.n_clips * (long long)sizeof(float), 256);
-  sp.ls = round_up_ll(p.n_samples, 8);
-  // 128-byte slots: with the usual power-of-two hop / pad every frame then starts on a cache line
-  sp.slot = round_up_ll(sp.ls + e.stride, 64);
+  // the padded clip, and room for one hop past the last frame (rows the hop-periodic kernel
+  // reads beyond it); 128-byte slots: with a power-of-two hop every frame starts on a cache line
+  const long long padded = (long long)p.n_samples + 2LL * p.pad;
+  const long long reach = (long long)(p.n_frames - 1) * p.hop + round_up_kc(p.K) + p.hop;
+  sp.slot = round_up_ll(padded > reach ? padded : reach, 64);
   sp.bytes = 2 * sp.slot * p.n_clips * (long long)sizeof(unsigned short);
   return sp;
 }
@@ -1235,7 +1235,7 @@ long long basis_split_bytes(int n_bins, int kernel, bool has_im) {
 bool bf16x3_ok(const mispec_framed_gemm_args *a, const KParams &p) {
   if (a->precision != MISPEC_PREC_BF16X3 || !a->basis_split) return false;
   if (a->basis_split_bytes < basis_split_bytes(p.n_bins, p.K, p.a_im != nullptr)) return false;
-  if ((p.hop & 1) || (p.pad & 1)) return false;  // frames must start at even element offsets
+  if (p.hop & 1) return false;  // frames must start at even element offsets
   const int rows = p.n_bins * (p.a_im ? 2 : 1);
   return rows > 128;  // narrower problems: the 256-row tile would be mostly empty
 }
@@ -1296,7 +1296,6 @@ int setup_split(KParams &p, const mispec_framed_gemm_args *a, hipStream_t stream
   p.xs = xs;
   p.xs_clip_stride = sp.slot;
   p.xs_plane = sp.slot * p.n_clips;
-  p.xs_edge_off = sp.ls;
   p.Ks = round_up_kc(p.K);
   p.as = static_cast<const unsigned short *>(a->basis_split);
   p.as_plane = (long long)p.n_bins * p.Ks;

@@ -103,6 +103,145 @@ __global__ void __launch_bounds__(256) split_signal_kernel(const KParams p,
   *reinterpret_cast<u16x4 *>(o + p.xs_plane) = l;
 }
 
+// ---------------------------------------------------------------------------------
+// Epilogue shared by the bf16x3 kernels: pointwise epilogue on the wave's MR x NR accumulator
+// tiles and the (batch, bin, frame[,2]) store.  (m0, n0) = first basis row / first flat frame
+// column of the workgroup tile; smem_raw = the workgroup's LDS (free at this point).
+// ---------------------------------------------------------------------------------
+template <int WM, int WN, int MR, int NR>
+__device__ __forceinline__ void bf16x3_epilogue(const KParams &p, f32x16 (&acc)[MR][NR], const int m0,
+                                                const long long n0, unsigned char *smem_raw) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN;
+  const int wn = wave % WN;
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+  const bool cplx = p.a_im != nullptr;
+  // ---- epilogue.  Accumulator element e of lane (li, lh) is
+  // D[row = (e&3) + 8*(e>>2) + 4*lh][col = li]: with interleaved (re, im) rows a lane holds both
+  // parts of 8 bins of a 32x32 tile (elements e, e+1 for even e), so Complex / Magnitude / Power
+  // are formed and stored from registers, frames innermost (32 consecutive frames per half wave).
+  const int E = epilogue_width(p.epilogue);
+  const bool direct = cplx && (p.epilogue == MISPEC_EPI_COMPLEX || p.epilogue == MISPEC_EPI_MAGNITUDE ||
+                               p.epilogue == MISPEC_EPI_POWER);
+  if (direct) {
+    // Row-major store order: the NR column blocks of a row (NR*32 consecutive frames, one
+    // contiguous run of the output) are written back to back, so that L2 sees whole lines.
+    // Only the first block's (clip, frame) is kept; block n is 32*n frames further along the
+    // flat frame axis, i.e. in the same clip or (per lane) a later one.
+    const long long col0 = n0 + (wn * NR) * 32 + li;
+    int c0 = 0, t0 = 0;
+    {
+      const long long cc = col0 < p.n_cols ? col0 : 0;
+      c0 = (int)(cc / p.n_frames);
+      t0 = (int)(cc - (long long)c0 * p.n_frames);
+    }
+    float *const orow = p.out + (long long)p.out_row_offset * p.out_row_stride;
+    auto store_all = [&](auto epi_tag) __attribute__((always_inline)) {
+      constexpr int EPI = decltype(epi_tag)::value;
+#pragma unroll
+      for (int m = 0; m < MR; ++m) {
+        const int bin0 = ((m0 + (wm * MR + m) * 32) >> 1) + 2 * lh;
+#pragma unroll
+        for (int e2 = 0; e2 < 8; ++e2) {
+          const int bin = bin0 + (e2 & 1) + 4 * (e2 >> 1);
+          const bool bin_ok = bin < p.n_bins;
+          const float sc = (p.row_scale && bin_ok) ? p.row_scale[bin] : 1.f;
+          float *const obin = orow + (long long)bin * p.out_row_stride;
+#pragma unroll
+          for (int n = 0; n < NR; ++n) {
+            int c = c0, t = t0 + 32 * n;
+            while (t >= p.n_frames) {
+              t -= p.n_frames;
+              ++c;
+            }
+            if (bin_ok && col0 + 32 * n < p.n_cols) {
+              const float re = acc[m][n][2 * e2] * sc;
+              const float im = p.im_sign * acc[m][n][2 * e2 + 1] * sc;
+              float *dst = obin + (long long)c * p.out_clip_stride + (long long)t * E;
+              if (EPI == MISPEC_EPI_COMPLEX) {
+                *reinterpret_cast<float2 *>(dst) = make_float2(re, im);
+              } else if (EPI == MISPEC_EPI_MAGNITUDE) {
+                dst[0] = sqrtf(re * re + im * im + p.eps);
+              } else {
+                epilogue_store(p, dst, re, im);  // MISPEC_EPI_POWER
+              }
+            }
+          }
+          // keep the 8*MR row groups in program order: hoisting all their address arithmetic
+          // above the first store costs more registers than the kernel has (it must not spill)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
+    if (p.epilogue == MISPEC_EPI_COMPLEX)
+      store_all(std::integral_constant<int, MISPEC_EPI_COMPLEX>{});
+    else if (p.epilogue == MISPEC_EPI_MAGNITUDE)
+      store_all(std::integral_constant<int, MISPEC_EPI_MAGNITUDE>{});
+    else
+      store_all(std::integral_constant<int, MISPEC_EPI_POWER>{});
+  } else {
+    // phase epilogues / real bases: one 32x32 tile at a time through a wave-private LDS patch
+    // (a single code instance of the transcendental epilogues), as framed_gemm_body
+    constexpr int LDC = 33;
+    float *sC = reinterpret_cast<float *>(smem_raw) + wave * (32 * LDC);
+#pragma unroll 1
+    for (int ti = 0; ti < MR * NR; ++ti) {
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int n = 0; n < NR; ++n)
+          if (ti == m * NR + n) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+              sC[((e & 3) + 8 * (e >> 2) + 4 * lh) * LDC + li] = acc[m][n][e];
+          }
+      __syncthreads();
+      const int tm = ti / NR, tn = ti - tm * NR;
+      const int row_base = m0 + (wm * MR + tm) * 32;
+      const long long col = n0 + (wn * NR + tn) * 32 + li;
+      const bool col_ok = col < p.n_cols;
+      int c = 0, t = 0;
+      if (col_ok) {
+        c = (int)(col / p.n_frames);
+        t = (int)(col - (long long)c * p.n_frames);
+      }
+      float *obase = p.out + (long long)c * p.out_clip_stride + (long long)t * E;
+      if (cplx) {
+#pragma unroll 1
+        for (int it = 0; it < 8; ++it) {
+          const int rl = 2 * (2 * it + lh);  // even local row: re; rl + 1: im
+          const int bin = (row_base + rl) >> 1;
+          if (col_ok && bin < p.n_bins) {
+            float re = sC[rl * LDC + li];
+            float im = p.im_sign * sC[(rl + 1) * LDC + li];
+            if (p.row_scale) {
+              const float sc = p.row_scale[bin];
+              re *= sc;
+              im *= sc;
+            }
+            epilogue_store(p, obase + (long long)(p.out_row_offset + bin) * p.out_row_stride, re, im);
+          }
+        }
+      } else {
+#pragma unroll 1
+        for (int it = 0; it < 16; ++it) {
+          const int rl = 2 * it + lh;
+          const int row = row_base + rl;
+          if (col_ok && row < p.n_bins) {
+            float v = sC[rl * LDC + li];
+            if (p.row_scale) v *= p.row_scale[row];
+            obase[(long long)(p.out_row_offset + row) * p.out_row_stride] = v;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 template <int WM, int WN, int MR, int NR, bool MASKED>
 __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int wg_index,
                                                    const int wg_count) {
@@ -372,127 +511,7 @@ __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int w
     __syncthreads();  // every wave is done with the stage buffers (the epilogue reuses them)
   }
 
-  // ---- epilogue.  Accumulator element e of lane (li, lh) is
-  // D[row = (e&3) + 8*(e>>2) + 4*lh][col = li]: with interleaved (re, im) rows a lane holds both
-  // parts of 8 bins of a 32x32 tile (elements e, e+1 for even e), so Complex / Magnitude / Power
-  // are formed and stored from registers, frames innermost (32 consecutive frames per half wave).
-  const int E = epilogue_width(p.epilogue);
-  const bool direct = cplx && (p.epilogue == MISPEC_EPI_COMPLEX || p.epilogue == MISPEC_EPI_MAGNITUDE ||
-                               p.epilogue == MISPEC_EPI_POWER);
-  if (direct) {
-    // Row-major store order: the NR column blocks of a row (NR*32 consecutive frames, one
-    // contiguous run of the output) are written back to back, so that L2 sees whole lines.
-    // Only the first block's (clip, frame) is kept; block n is 32*n frames further along the
-    // flat frame axis, i.e. in the same clip or (per lane) a later one.
-    const long long col0 = n0 + (wn * NR) * 32 + li;
-    int c0 = 0, t0 = 0;
-    {
-      const long long cc = col0 < p.n_cols ? col0 : 0;
-      c0 = (int)(cc / p.n_frames);
-      t0 = (int)(cc - (long long)c0 * p.n_frames);
-    }
-    float *const orow = p.out + (long long)p.out_row_offset * p.out_row_stride;
-    auto store_all = [&](auto epi_tag) __attribute__((always_inline)) {
-      constexpr int EPI = decltype(epi_tag)::value;
-#pragma unroll
-      for (int m = 0; m < MR; ++m) {
-        const int bin0 = ((m0 + (wm * MR + m) * 32) >> 1) + 2 * lh;
-#pragma unroll
-        for (int e2 = 0; e2 < 8; ++e2) {
-          const int bin = bin0 + (e2 & 1) + 4 * (e2 >> 1);
-          const bool bin_ok = bin < p.n_bins;
-          const float sc = (p.row_scale && bin_ok) ? p.row_scale[bin] : 1.f;
-          float *const obin = orow + (long long)bin * p.out_row_stride;
-#pragma unroll
-          for (int n = 0; n < NR; ++n) {
-            int c = c0, t = t0 + 32 * n;
-            while (t >= p.n_frames) {
-              t -= p.n_frames;
-              ++c;
-            }
-            if (bin_ok && col0 + 32 * n < p.n_cols) {
-              const float re = acc[m][n][2 * e2] * sc;
-              const float im = p.im_sign * acc[m][n][2 * e2 + 1] * sc;
-              float *dst = obin + (long long)c * p.out_clip_stride + (long long)t * E;
-              if (EPI == MISPEC_EPI_COMPLEX) {
-                *reinterpret_cast<float2 *>(dst) = make_float2(re, im);
-              } else if (EPI == MISPEC_EPI_MAGNITUDE) {
-                dst[0] = sqrtf(re * re + im * im + p.eps);
-              } else {
-                epilogue_store(p, dst, re, im);  // MISPEC_EPI_POWER
-              }
-            }
-          }
-          // keep the 8*MR row groups in program order: hoisting all their address arithmetic
-          // above the first store costs more registers than the kernel has (it must not spill)
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    };
-    if (p.epilogue == MISPEC_EPI_COMPLEX)
-      store_all(std::integral_constant<int, MISPEC_EPI_COMPLEX>{});
-    else if (p.epilogue == MISPEC_EPI_MAGNITUDE)
-      store_all(std::integral_constant<int, MISPEC_EPI_MAGNITUDE>{});
-    else
-      store_all(std::integral_constant<int, MISPEC_EPI_POWER>{});
-  } else {
-    // phase epilogues / real bases: one 32x32 tile at a time through a wave-private LDS patch
-    // (a single code instance of the transcendental epilogues), as framed_gemm_body
-    constexpr int LDC = 33;
-    float *sC = reinterpret_cast<float *>(smem_raw) + wave * (32 * LDC);
-#pragma unroll 1
-    for (int ti = 0; ti < MR * NR; ++ti) {
-#pragma unroll
-      for (int m = 0; m < MR; ++m)
-#pragma unroll
-        for (int n = 0; n < NR; ++n)
-          if (ti == m * NR + n) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-              sC[((e & 3) + 8 * (e >> 2) + 4 * lh) * LDC + li] = acc[m][n][e];
-          }
-      __syncthreads();
-      const int tm = ti / NR, tn = ti - tm * NR;
-      const int row_base = m0 + (wm * MR + tm) * 32;
-      const long long col = n0 + (wn * NR + tn) * 32 + li;
-      const bool col_ok = col < p.n_cols;
-      int c = 0, t = 0;
-      if (col_ok) {
-        c = (int)(col / p.n_frames);
-        t = (int)(col - (long long)c * p.n_frames);
-      }
-      float *obase = p.out + (long long)c * p.out_clip_stride + (long long)t * E;
-      if (cplx) {
-#pragma unroll 1
-        for (int it = 0; it < 8; ++it) {
-          const int rl = 2 * (2 * it + lh);  // even local row: re; rl + 1: im
-          const int bin = (row_base + rl) >> 1;
-          if (col_ok && bin < p.n_bins) {
-            float re = sC[rl * LDC + li];
-            float im = p.im_sign * sC[(rl + 1) * LDC + li];
-            if (p.row_scale) {
-              const float sc = p.row_scale[bin];
-              re *= sc;
-              im *= sc;
-            }
-            epilogue_store(p, obase + (long long)(p.out_row_offset + bin) * p.out_row_stride, re, im);
-          }
-        }
-      } else {
-#pragma unroll 1
-        for (int it = 0; it < 16; ++it) {
-          const int rl = 2 * it + lh;
-          const int row = row_base + rl;
-          if (col_ok && row < p.n_bins) {
-            float v = sC[rl * LDC + li];
-            if (p.row_scale) v *= p.row_scale[row];
-            obase[(long long)(p.out_row_offset + row) * p.out_row_stride] = v;
-          }
-        }
-      }
-      __syncthreads();
-    }
-  }
+  bf16x3_epilogue<WM, WN, MR, NR>(p, acc, m0, n0, smem_raw);
 }
 
 template <int WM, int WN, int MR, int NR, bool MASKED>

@@ -101,6 +101,10 @@ struct KParams {
   const unsigned short *as;  // split basis planes [re_hi | re_lo | im_hi | im_lo], each (n_bins, Ks)
   long long as_plane;
   int Ks;  // taps per split basis row (K rounded up to 32, zero filled)
+  // hop-periodic K order (framed_bf16x3_slab.inl)
+  int n_super;    // C = ceil(Ks / hop)
+  int slab_rows;  // rows of one slab buffer (>= BN + 2*(C-1), multiple of 16)
+  int slab_nbuf;  // 1 or 2 slab buffers
 };
 
 // ---------------------------------------------------------------------------------
@@ -781,6 +785,7 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
 }
 
 #include "framed_bf16x3.inl"
+#include "framed_bf16x3_slab.inl"
 
 // Several independent contractions of the same tile shape in one launch (the octaves of
 // CQT2010v2 / VQT: each is a short-K, few-hundred-workgroup problem that cannot fill the chip on
@@ -1284,6 +1289,47 @@ int launch_bf16x3_cfg(KParams p, hipStream_t stream) {
   return MISPEC_OK;
 }
 
+// ---- hop-periodic (slab) variant: applicability, LDS budget, launch
+template <int WM, int WN, int MR, int NR>
+bool plan_slab(KParams &p, size_t &smem) {
+  constexpr int BM = WM * MR * 32;
+  constexpr int BN = WN * NR * 32;
+  if (p.debug & 0x4000) return false;  // benchmarking: force the staged kernel
+  if (p.hop % KC != 0 || p.Ks < 2 * p.hop || p.n_frames < BN) return false;
+  const int C = (p.Ks + p.hop - 1) / p.hop;
+  const int rows = (BN + 2 * (C - 1) + 15) / 16 * 16;
+  if (rows > SLAB_MAX_ROWS) return false;
+  const size_t a = 2 * 2 * (size_t)BM * (KC * 2);
+  const size_t slab = 2 * (size_t)rows * (KC * 2);
+  const size_t tables = rows * sizeof(long long) + BN * sizeof(int) + 2 * WM * MR * sizeof(int);
+  const size_t lds = 160 * 1024;
+  int nbuf = 2;
+  if (a + 2 * slab + tables > lds) nbuf = 1;
+  if (a + nbuf * slab + tables > lds) return false;
+  if (p.debug & 0x8000) nbuf = 1;  // benchmarking: single slab buffer
+  p.n_super = C;
+  p.slab_rows = rows;
+  p.slab_nbuf = nbuf;
+  smem = a + nbuf * slab + tables;
+  return true;
+}
+
+template <int WM, int WN, int MR, int NR, bool MASKED>
+int launch_bf16x3_slab_cfg(KParams p, size_t smem, hipStream_t stream) {
+  const long long grid = prepare_bf16x3<WM, WN, MR, NR>(p);
+  if (grid < 0) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
+  if (grid == 0) return MISPEC_OK;
+  auto kern = framed_bf16x3_slab_kernel<WM, WN, MR, NR, MASKED>;
+  // the LDS request varies with K / hop: raise the kernel's limit to the device maximum once
+  static std::atomic<unsigned long long> configured{0};
+  int rc = configure_lds(kern, 160 * 1024, configured);
+  if (rc != MISPEC_OK) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WM * WN * 64), smem, stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+
 // split the waveform + edge spans into the second part of the workspace and attach it to p
 int setup_split(KParams &p, const mispec_framed_gemm_args *a, hipStream_t stream) {
   const EdgePlan e = plan_edges(p.n_samples, p.K, p.hop, p.pad, p.n_frames);
@@ -1336,38 +1382,45 @@ int launch_framed_bf16x3(const KParams &p, int tile, hipStream_t stream) {
     KParams r = leftover_rows(p, main_bins);
     r.as = p.as + (long long)main_bins * p.Ks;  // same planes, first leftover bin
     const int rem_rows = r.n_bins * rpb;
+    size_t sm_main = bf16x3_smem<4, 2, 2, 4>();
+    const bool slab = false;  // dense 256x256 slab tiles do not fit in 256 VGPRs
     const long long gm = prepare_bf16x3<4, 2, 2, 4>(q);
     const long long gr = rem_rows <= 32 ? prepare_bf16x3<1, 8, 1, 1>(r) : prepare_bf16x3<1, 8, 2, 1>(r);
     if (gm < 0 || gr < 0 || gm + gr > 0x7fffffffLL)
       return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
-    constexpr size_t sm_main = bf16x3_smem<4, 2, 2, 4>();
-    constexpr size_t sm_r1 = bf16x3_smem<1, 8, 1, 1>();
-    constexpr size_t sm_r2 = bf16x3_smem<1, 8, 2, 1>();
-    constexpr size_t smem = sm_main > sm_r2 ? (sm_main > sm_r1 ? sm_main : sm_r1)
-                                            : (sm_r2 > sm_r1 ? sm_r2 : sm_r1);
-    static_assert(smem <= 160 * 1024, "LDS budget");
+    const size_t sm_rem = rem_rows <= 32 ? bf16x3_smem<1, 8, 1, 1>() : bf16x3_smem<1, 8, 2, 1>();
+    const size_t smem = sm_main > sm_rem ? sm_main : sm_rem;
     const dim3 grid((unsigned)(gm + gr));
+    rc = MISPEC_OK;
+#define MISPEC_LAUNCH_PAIR(KERN)                                                              \
+  {                                                                                           \
+    auto kern = KERN;                                                                         \
+    static std::atomic<unsigned long long> configured{0};                                     \
+    rc = configure_lds(kern, 160 * 1024, configured);                                         \
+    if (rc == MISPEC_OK) hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, q, r, (int)gm); \
+  }
     if (rem_rows <= 32) {
-      auto kern = framed_bf16x3_pair_kernel<1>;
-      static std::atomic<unsigned long long> configured{0};
-      rc = configure_lds(kern, smem, configured);
-      if (rc != MISPEC_OK) return rc;
-      hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, q, r, (int)gm);
+      MISPEC_LAUNCH_PAIR(framed_bf16x3_pair_kernel<1>)
     } else {
-      auto kern = framed_bf16x3_pair_kernel<2>;
-      static std::atomic<unsigned long long> configured{0};
-      rc = configure_lds(kern, smem, configured);
-      if (rc != MISPEC_OK) return rc;
-      hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, q, r, (int)gm);
+      MISPEC_LAUNCH_PAIR(framed_bf16x3_pair_kernel<2>)
     }
+#undef MISPEC_LAUNCH_PAIR
+    if (rc != MISPEC_OK) return rc;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
     return MISPEC_OK;
   }
-  // 256x256 workgroups of 8 waves (two per SIMD, 64x128 per wave).  A 4-wave layout with
-  // 128x128 per wave (accumulators in AGPRs) measured 8 % slower and does not fit without scratch.
-  rc = masked ? launch_bf16x3_cfg<4, 2, 2, 4, true>(q, stream)
-              : launch_bf16x3_cfg<4, 2, 2, 4, false>(q, stream);
+  // Bases with supports (CQT banks): the hop-periodic (slab) kernel when the shape allows, on
+  // 192x256 tiles of 2x4 waves (96x64 per wave).  Waves w and w+4 share a SIMD, i.e. every SIMD
+  // hosts one wave of each row half, so K stages in which only the long low-frequency kernels
+  // are active still load all four matrix pipes evenly.  Otherwise the staged kernel: 256x256 workgroups of 8 waves (two per SIMD, 64x128 per wave; a 4-wave
+  // layout with 128x128 per wave measured 8 % slower and does not fit without scratch).
+  size_t sm = 0;
+  if (masked && plan_slab<2, 4, 3, 2>(q, sm))
+    rc = launch_bf16x3_slab_cfg<2, 4, 3, 2, true>(q, sm, stream);
+  else
+    rc = masked ? launch_bf16x3_cfg<4, 2, 2, 4, true>(q, stream)
+                : launch_bf16x3_cfg<4, 2, 2, 4, false>(q, stream);
   if (rc != MISPEC_OK || main_bins == p.n_bins) return rc;
   return launch_framed(leftover_rows(p, main_bins), MISPEC_TILE_AUTO, stream);
 }

@@ -484,8 +484,13 @@ def test_case_bf16x3_matches_reference_and_oracle(golden, bf16x3, name):
     (2, 4096, 160, 1024, 256, 0, 0),     # center=False
     (5, 1500, 130, 1024, 32, 512, 2),    # short clips: every frame touches the padding
     (2, 6000, 140, 512, 63, 256, 2),     # odd hop: not covered, must run (exactly) in fp32
+    # n_frames >= 256 and hop % 32 == 0: with supports these take the hop-periodic (slab) kernel
+    (3, 40000, 90, 1024, 128, 512, 2),   # 313 frames per clip: tiles straddle clip boundaries
+    (2, 33000, 100, 2048, 64, 1024, 1),  # C = 32 super-stages, zero padding
+    (1, 70000, 70, 300, 96, 150, 2),     # K % 32 != 0, hop = 3 sub-stages, C = 4
+    (2, 20000, 84, 512, 64, 0, 0),       # center=False
 ])
-@pytest.mark.parametrize("support", [False, True])
+@pytest.mark.parametrize("support", [False, True, "narrow", "single-buffer"])
 def test_bf16x3_kernel_shapes(shape, support):
     from nnaudio_amd import engine
 
@@ -495,8 +500,10 @@ def test_bf16x3_kernel_shapes(shape, support):
     wr = rng.standard_normal((F, K)).astype(np.float32)
     wi = rng.standard_normal((F, K)).astype(np.float32)
     sup = None
+    dbg = 0x8000 if support == "single-buffer" else 0  # slab kernel with one slab buffer
     if support:  # centred supports that shrink with the row index, like a CQT bank
-        half = np.linspace(K // 2, 8, F).astype(np.int64)
+        widest = min(K // 2, 40) if support == "narrow" else K // 2  # narrow: < one hop of taps
+        half = np.linspace(widest, 8, F).astype(np.int64)
         lo, hi = K // 2 - half, K // 2 + half
         keep = (np.arange(K)[None, :] >= lo[:, None]) & (np.arange(K)[None, :] < hi[:, None])
         wr, wi = (wr * keep).astype(np.float32), (wi * keep).astype(np.float32)
@@ -505,7 +512,7 @@ def test_bf16x3_kernel_shapes(shape, support):
     ref = np.stack((re, im), -1)
     kw = dict(hop=hop, pad=pad, pad_mode=mode, epilogue=engine.EPI_COMPLEX, row_support=sup)
     xd, wrd, wid = (torch.as_tensor(a).to(DEV) for a in (x, wr, wi))
-    y = engine.framed_gemm(xd, wrd, wid, precision="bf16x3", **kw)
+    y = engine.framed_gemm(xd, wrd, wid, precision="bf16x3", _debug=dbg, **kw)
     y32 = engine.framed_gemm(xd, wrd, wid, precision="fp32", **kw)
     torch.cuda.synchronize()
     assert_parity(y.cpu().numpy(), ref, rel=1e-4, what="bf16x3 %s" % (shape,))

@@ -105,6 +105,7 @@ struct KParams {
   int n_super;    // C = ceil(Ks / hop)
   int slab_rows;  // rows of one slab buffer (>= BN + 2*(C-1), multiple of 16)
   int slab_nbuf;  // 1 or 2 slab buffers
+  int row_split;  // framed_bf16x3_narrow: workgroups per frame tile (each takes every row_split-th row tile)
 };
 
 // ---------------------------------------------------------------------------------
@@ -786,6 +787,8 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
 
 #include "framed_bf16x3.inl"
 #include "framed_bf16x3_slab.inl"
+#include "framed_bf16x3_packed.inl"
+#include "framed_bf16x3_narrow.inl"
 
 // Several independent contractions of the same tile shape in one launch (the octaves of
 // CQT2010v2 / VQT: each is a short-K, few-hundred-workgroup problem that cannot fill the chip on
@@ -1330,6 +1333,40 @@ int launch_bf16x3_slab_cfg(KParams p, size_t smem, hipStream_t stream) {
   return MISPEC_OK;
 }
 
+int launch_bf16x3_narrow(KParams p, size_t smem, hipStream_t stream) {
+  if (prepare_bf16x3<1, 8, 1, 1>(p) < 0) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
+  smem += 2 * 64 * sizeof(int);  // per-sub-stage j ranges (hop / 32 <= 64 sub-stages)
+  // one workgroup per frame tile walks all its row tiles (equal work per workgroup); when the
+  // frame tiles alone cannot fill the 256 CUs the row tiles are dealt out to more workgroups
+  int split = p.n_tiles_n > 0 ? 256 / p.n_tiles_n : 1;
+  split = split < 1 ? 1 : (split > p.n_tiles_m ? p.n_tiles_m : split);
+  p.row_split = split;
+  const long long grid = (long long)p.n_tiles_n * split;
+  if (grid == 0) return MISPEC_OK;
+  auto kern = framed_bf16x3_narrow_kernel;
+  static std::atomic<unsigned long long> configured{0};
+  int rc = configure_lds(kern, 160 * 1024, configured);
+  if (rc != MISPEC_OK) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+
+int launch_bf16x3_packed(KParams p, size_t smem, hipStream_t stream) {
+  const long long grid = prepare_bf16x3<2, 4, 3, 2>(p);
+  if (grid < 0) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
+  if (grid == 0) return MISPEC_OK;
+  auto kern = framed_bf16x3_packed_kernel;
+  static std::atomic<unsigned long long> configured{0};
+  int rc = configure_lds(kern, 160 * 1024, configured);
+  if (rc != MISPEC_OK) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+
 // split the waveform + edge spans into the second part of the workspace and attach it to p
 int setup_split(KParams &p, const mispec_framed_gemm_args *a, hipStream_t stream) {
   const EdgePlan e = plan_edges(p.n_samples, p.K, p.hop, p.pad, p.n_frames);
@@ -1416,8 +1453,10 @@ int launch_framed_bf16x3(const KParams &p, int tile, hipStream_t stream) {
   // are active still load all four matrix pipes evenly.  Otherwise the staged kernel: 256x256 workgroups of 8 waves (two per SIMD, 64x128 per wave; a 4-wave
   // layout with 128x128 per wave measured 8 % slower and does not fit without scratch).
   size_t sm = 0;
-  if (masked && plan_slab<2, 4, 3, 2>(q, sm))
-    rc = launch_bf16x3_slab_cfg<2, 4, 3, 2, true>(q, sm, stream);
+  if (masked && q.hop <= 64 * KC && plan_slab<2, 4, 3, 2>(q, sm))
+    rc = (p.debug & 0x20000)   ? launch_bf16x3_slab_cfg<2, 4, 3, 2, true>(q, sm, stream)
+         : (p.debug & 0x40000) ? launch_bf16x3_packed(q, sm, stream)
+                               : launch_bf16x3_narrow(q, sm, stream);
   else
     rc = masked ? launch_bf16x3_cfg<4, 2, 2, 4, true>(q, stream)
                 : launch_bf16x3_cfg<4, 2, 2, 4, false>(q, stream);

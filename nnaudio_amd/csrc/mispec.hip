@@ -787,7 +787,6 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
 
 #include "framed_bf16x3.inl"
 #include "framed_bf16x3_slab.inl"
-#include "framed_bf16x3_packed.inl"
 #include "framed_bf16x3_narrow.inl"
 
 // Several independent contractions of the same tile shape in one launch (the octaves of
@@ -1353,20 +1352,6 @@ int launch_bf16x3_narrow(KParams p, size_t smem, hipStream_t stream) {
   return MISPEC_OK;
 }
 
-int launch_bf16x3_packed(KParams p, size_t smem, hipStream_t stream) {
-  const long long grid = prepare_bf16x3<2, 4, 3, 2>(p);
-  if (grid < 0) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
-  if (grid == 0) return MISPEC_OK;
-  auto kern = framed_bf16x3_packed_kernel;
-  static std::atomic<unsigned long long> configured{0};
-  int rc = configure_lds(kern, 160 * 1024, configured);
-  if (rc != MISPEC_OK) return rc;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, stream, p);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
-  return MISPEC_OK;
-}
-
 // split the waveform + edge spans into the second part of the workspace and attach it to p
 int setup_split(KParams &p, const mispec_framed_gemm_args *a, hipStream_t stream) {
   const EdgePlan e = plan_edges(p.n_samples, p.K, p.hop, p.pad, p.n_frames);
@@ -1447,16 +1432,14 @@ int launch_framed_bf16x3(const KParams &p, int tile, hipStream_t stream) {
     if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
     return MISPEC_OK;
   }
-  // Bases with supports (CQT banks): the hop-periodic (slab) kernel when the shape allows, on
-  // 192x256 tiles of 2x4 waves (96x64 per wave).  Waves w and w+4 share a SIMD, i.e. every SIMD
-  // hosts one wave of each row half, so K stages in which only the long low-frequency kernels
-  // are active still load all four matrix pipes evenly.  Otherwise the staged kernel: 256x256 workgroups of 8 waves (two per SIMD, 64x128 per wave; a 4-wave
+  // Bases with supports (CQT banks): the hop-periodic narrow-tile kernel when the shape allows
+  // (framed_bf16x3_narrow.inl; debug bit 0x20000 selects its predecessor with 192x256 masked
+  // tiles, framed_bf16x3_slab.inl, for A/B measurements).  Otherwise the staged kernel: 256x256 workgroups of 8 waves (two per SIMD, 64x128 per wave; a 4-wave
   // layout with 128x128 per wave measured 8 % slower and does not fit without scratch).
   size_t sm = 0;
   if (masked && q.hop <= 64 * KC && plan_slab<2, 4, 3, 2>(q, sm))
-    rc = (p.debug & 0x20000)   ? launch_bf16x3_slab_cfg<2, 4, 3, 2, true>(q, sm, stream)
-         : (p.debug & 0x40000) ? launch_bf16x3_packed(q, sm, stream)
-                               : launch_bf16x3_narrow(q, sm, stream);
+    rc = (p.debug & 0x20000) ? launch_bf16x3_slab_cfg<2, 4, 3, 2, true>(q, sm, stream)  // A/B runs
+                             : launch_bf16x3_narrow(q, sm, stream);
   else
     rc = masked ? launch_bf16x3_cfg<4, 2, 2, 4, true>(q, stream)
                 : launch_bf16x3_cfg<4, 2, 2, 4, false>(q, stream);

@@ -366,7 +366,8 @@ def test_cfg3_mel_full_size_sampled():
     assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
 
 
-def test_cfg4_cqt1992v2_full_size_sampled():
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_cfg4_cqt1992v2_full_size_sampled(precision):
     from nnaudio_amd import features
     from oracle import spectral_oracle as O
 
@@ -374,6 +375,7 @@ def test_cfg4_cqt1992v2_full_size_sampled():
     x = torch.randn(B, L, generator=torch.Generator().manual_seed(2))
     m = features.CQT1992v2(sr=44100, hop_length=512, fmin=32.70, n_bins=84, bins_per_octave=12,
                            output_format="Complex", verbose=False).to(DEV)
+    m.precision = precision  # bf16x3: the hop-periodic narrow-tile kernel, 64 super-stages
     y = m(x.to(DEV))
     assert tuple(y.shape) == (16, 84, 862, 2)
     rng = np.random.default_rng(2)

@@ -185,6 +185,17 @@ int mispec_filterbank_f32(const float *fb, int32_t n_filters, int32_t n_freq,
                           float *out, void *stream);
 
 /*
+ * power_to_db of MFCC (mel.py:263-279), per clip c over its `clip_elems` values (n_mels * n_frames):
+ *   l   = 10*log10(max(spec, amin)) - 10*log10(max(amin, ref))
+ *   out = top_db < 0 ? l : max(l, max_over_clip(l) - top_db)
+ * `out` may alias `spec`.  workspace: n_clips * 4 bytes (per-clip maxima).  The discrete cosine
+ * transform that follows (mel.py:281-307) is mispec_filterbank_f32 with the DCT-II matrix.
+ */
+int mispec_power_to_db_f32(const float *spec, int32_t n_clips, int64_t clip_elems, float amin,
+                           float ref, float top_db, float *out, void *workspace,
+                           int64_t workspace_bytes, void *stream);
+
+/*
  * Strided FIR decimation  y[c, i] = sum_{n<n_taps} taps[n] * x[c, i*stride + n - pad]
  * with zeros outside the signal (F.conv1d(x, taps, stride, padding=pad),
  * utils.py:98-99 where pad = (n_taps-1)//2).  n_out = (n_samples + 2*pad - n_taps)/stride + 1.

@@ -30,6 +30,7 @@ EXPORTS = (
     "mispec_basis_split_bytes",
     "mispec_split_basis_bf16",
     "mispec_filterbank_f32",
+    "mispec_power_to_db_f32",
     "mispec_fir_decimate_f32",
     "mispec_fir_decimate_workspace_bytes",
 )
@@ -120,6 +121,11 @@ def load():
     lib.mispec_filterbank_f32.argtypes = [
         ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
         ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+    ]
+    lib.mispec_power_to_db_f32.restype = ctypes.c_int
+    lib.mispec_power_to_db_f32.argtypes = [
+        ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_float,
+        ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
     ]
     lib.mispec_fir_decimate_f32.restype = ctypes.c_int
     lib.mispec_fir_decimate_f32.argtypes = [

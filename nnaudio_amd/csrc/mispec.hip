@@ -1212,6 +1212,46 @@ int launch_framed(const KParams &p, int tile, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------
+// power_to_db (MFCC, mel.py:263-279): HBM-bound pointwise pass with a per-clip maximum
+// ---------------------------------------------------------------------------------
+// per-clip maximum of max(spec, amin) (> 0: unsigned compare on the float bits is monotonic)
+__global__ void __launch_bounds__(256) clip_max_kernel(const float *__restrict__ spec,
+                                                       long long clip_elems, float amin,
+                                                       unsigned *__restrict__ wmax) {
+  const int c = blockIdx.y;
+  const float *s = spec + (long long)c * clip_elems;
+  float m = amin;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < clip_elems;
+       i += (long long)gridDim.x * 256)
+    m = fmaxf(m, s[i]);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+  if ((threadIdx.x & 63) == 0) atomicMax(&wmax[c], __float_as_uint(m));
+}
+
+__global__ void __launch_bounds__(256) clear_u32_kernel(unsigned *__restrict__ w, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) w[i] = 0u;
+}
+
+__global__ void __launch_bounds__(256) power_to_db_kernel(const float *__restrict__ spec,
+                                                          long long clip_elems, float amin,
+                                                          float ref, float top_db,
+                                                          const unsigned *__restrict__ wmax,
+                                                          float *__restrict__ out) {
+  const int c = blockIdx.y;
+  const long long base = (long long)c * clip_elems;
+  const float off = 10.0f * log10f(fmaxf(amin, ref));
+  float floor_db = -INFINITY;
+  if (top_db >= 0.f) floor_db = (10.0f * log10f(__uint_as_float(wmax[c])) - off) - top_db;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < clip_elems;
+       i += (long long)gridDim.x * 256) {
+    const float l = 10.0f * log10f(fmaxf(spec[base + i], amin)) - off;
+    out[base + i] = fmaxf(l, floor_db);
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // MISPEC_PREC_BF16X3 host side
 // ---------------------------------------------------------------------------------
 inline long long round_up_ll(long long v, long long m) { return (v + m - 1) / m * m; }
@@ -1658,6 +1698,30 @@ int mispec_framed_gemm_f32_ref(const mispec_framed_gemm_args *args, void *stream
   if (blocks > 0x7fffffffLL) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
   hipLaunchKernelGGL(framed_gemm_ref_kernel, dim3((unsigned)blocks), dim3(256), 0,
                      static_cast<hipStream_t>(stream), p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+
+int mispec_power_to_db_f32(const float *spec, int32_t n_clips, int64_t clip_elems, float amin,
+                           float ref, float top_db, float *out, void *workspace,
+                           int64_t workspace_bytes, void *stream) {
+  if (!spec || !out) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
+  if (n_clips <= 0 || clip_elems <= 0) return fail(MISPEC_E_INVALID, "non-positive size%s");
+  if (!(amin > 0.f)) return fail(MISPEC_E_INVALID, "amin must be strictly positive%s");
+  if (!workspace || workspace_bytes < (int64_t)n_clips * 4)
+    return fail(MISPEC_E_INVALID, "workspace too small: n_clips * 4 bytes%s");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  unsigned *wmax = static_cast<unsigned *>(workspace);
+  long long bx = (clip_elems + 256 * 8 - 1) / (256 * 8);  // ~8 elements per thread
+  bx = bx < 1 ? 1 : (bx > 1024 ? 1024 : bx);
+  const dim3 grid((unsigned)bx, (unsigned)n_clips);
+  if (top_db >= 0.f) {
+    hipLaunchKernelGGL(clear_u32_kernel, dim3((n_clips + 255) / 256), dim3(256), 0, s, wmax, n_clips);
+    hipLaunchKernelGGL(clip_max_kernel, grid, dim3(256), 0, s, spec, (long long)clip_elems, amin, wmax);
+  }
+  hipLaunchKernelGGL(power_to_db_kernel, grid, dim3(256), 0, s, spec, (long long)clip_elems, amin,
+                     fabsf(ref), top_db, wmax, out);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
   return MISPEC_OK;

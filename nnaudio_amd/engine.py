@@ -313,6 +313,27 @@ def filterbank(fb, spec):
     return out
 
 
+def power_to_db(spec, amin, ref, top_db):
+    """librosa-style power_to_db with a per-clip maximum (mel.py:263-279); (B, M, T) -> same."""
+    dev = _require_device(spec)
+    spec = _f32(spec, "spectrogram").contiguous()
+    if spec.dim() < 2:
+        raise RuntimeError("power_to_db expects (batch, ...)")
+    if top_db is not None and top_db < 0:
+        raise ValueError("top_db must be non-negative")
+    B = spec.shape[0]
+    out = torch.empty_like(spec)
+    ws = torch.empty(B, dtype=torch.int32, device=dev)
+    lib = _abi.load()
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _abi.check(lib.mispec_power_to_db_f32(
+            spec.data_ptr(), B, spec[0].numel(), float(amin), float(ref),
+            -1.0 if top_db is None else float(top_db), out.data_ptr(), ws.data_ptr(), B * 4,
+            ctypes.c_void_p(stream)))
+    return out
+
+
 def fir_decimate(x, taps, stride):
     """conv1d(x, taps, stride=stride, padding=(len-1)//2)  [utils.py:73-124] -> (B, n_out)."""
     dev = _require_device(x, taps)

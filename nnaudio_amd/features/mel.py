@@ -10,8 +10,8 @@ import torch
 import torch.nn as nn
 
 from .. import engine
-from ..basis import mel_filterbank
-from ..utils import broadcast_dim
+from ..basis import dct_ortho_matrix, mel_filterbank
+from ..utils import ParameterError, broadcast_dim
 from .stft import STFT
 
 
@@ -88,3 +88,38 @@ class MelSpectrogram(nn.Module):
         return "Mel filter banks size = {}, trainable_mel={}".format(
             (*self.mel_basis.shape,), self.trainable_mel, self.trainable_STFT
         )
+
+
+class MFCC(nn.Module):
+    """Mel-frequency cepstral coefficients: ``MelSpectrogram`` -> ``power_to_db`` (per-clip
+    ``top_db`` floor) -> orthonormal DCT-II over the mel axis -> first ``n_mfcc`` rows.
+    Same constructor, buffers (``amin``, ``ref``, ``melspec_layer.*``) and output
+    ``(batch, n_mfcc, frames)`` as the reference (mel.py:197-329).  The DCT runs as the same planar
+    contraction kernel as the mel filterbank, with the (n_mfcc, n_mels) cosine matrix the
+    reference evaluates through an FFT."""
+
+    def __init__(self, sr=22050, n_mfcc=20, norm="ortho", verbose=True, ref=1.0, amin=1e-10,
+                 top_db=80.0, **kwargs):
+        super().__init__()
+        self.melspec_layer = MelSpectrogram(sr=sr, verbose=verbose, **kwargs)
+        self.m_mfcc = n_mfcc
+        if amin <= 0:
+            raise ParameterError("amin must be strictly positive")
+        self.register_buffer("amin", torch.tensor([amin]))
+        self.register_buffer("ref", torch.abs(torch.tensor([ref])))
+        self.top_db = top_db
+        self.n_mfcc = n_mfcc
+        n_mels = self.melspec_layer.mel_basis.shape[0]
+        # derived constant, not part of the reference's state_dict
+        self.register_buffer("_dct_basis", torch.from_numpy(dct_ortho_matrix(min(n_mfcc, n_mels), n_mels)),
+                             persistent=False)
+
+    def forward(self, x):
+        spec = self.melspec_layer(x)
+        if self.top_db is not None and self.top_db < 0:
+            raise ParameterError("top_db must be non-negative")
+        db = engine.power_to_db(spec, float(self.amin), float(self.ref), self.top_db)
+        return engine.filterbank(self._dct_basis, db)
+
+    def extra_repr(self) -> str:
+        return "n_mfcc = {}".format((self.n_mfcc))

@@ -13,3 +13,9 @@ def broadcast_dim(x):
     else:
         raise ValueError("Only support input with shape = (batch, len) or shape = (len)")
     return x
+
+
+class ParameterError(NameError):
+    """Raised for invalid MFCC parameters.  The reference raises ``ParameterError`` without ever
+    defining it (mel.py:255, 273), i.e. the caller sees a ``NameError``; deriving from it keeps
+    ``except NameError`` handlers working while giving the error a meaningful name."""

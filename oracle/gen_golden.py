@@ -212,6 +212,15 @@ def main():
     # buffers-only cases at the BASELINE sizes (forward too big to store)
     case("bufonly_stft_cfg2", "STFT", dict(n_fft=2048, hop_length=512, window="hann"), None,
          attrs=stft_attrs)
+    # MFCC: mel -> power_to_db -> DCT-II
+    case("mfcc_default", "MFCC", dict(), "x_1s22k", attrs=("n_mfcc", "top_db"))
+    case("mfcc_13_of_40", "MFCC",
+         dict(sr=16000, n_mfcc=13, n_fft=512, n_mels=40, hop_length=160), "x_short")
+    case("mfcc_no_topdb_ref2", "MFCC",
+         dict(sr=16000, n_mfcc=20, n_fft=512, n_mels=64, hop_length=128, top_db=None, ref=2.0,
+              amin=1e-6), "x_short")
+    case("mfcc_sines_topdb40", "MFCC",
+         dict(sr=22050, n_mfcc=24, n_fft=1024, n_mels=80, hop_length=256, top_db=40.0), "x_sines")
     case("bufonly_cqt_testgrid", "CQT1992v2",
          dict(sr=44100, fmin=55, n_bins=207, bins_per_octave=24), None, attrs=cqt_attrs)
     case("bufonly_gamma_44k", "Gammatonegram", dict(sr=44100, n_fft=2048, n_bins=64), None)

@@ -315,3 +315,34 @@ def sampled_complex(x, basis_re, basis_im, clips, frames_idx, hop, pad, mode):
     wi = np.asarray(basis_im, dtype=np.float64).reshape(basis_im.shape[0], -1)
     fr = gather_frames(x, clips, frames_idx, wr.shape[1], hop, pad, mode)
     return fr @ wr.T, -(fr @ wi.T)
+
+
+def power_to_db(S, amin=1e-10, ref=1.0, top_db=80.0):
+    """MFCC._power_to_db [mel.py:263-279]: 10*log10(max(S, amin)) - 10*log10(max(amin, |ref|)),
+    floored at (per-clip maximum - top_db)."""
+    S = np.asarray(S, dtype=np.float64)
+    log_spec = 10.0 * np.log10(np.maximum(S, amin)) - 10.0 * np.log10(max(amin, abs(ref)))
+    if top_db is not None:
+        if top_db < 0:
+            raise ValueError("top_db must be non-negative")
+        bmax = log_spec.reshape(log_spec.shape[0], -1).max(axis=1)[:, None, None]
+        log_spec = np.maximum(log_spec, bmax - top_db)
+    return log_spec
+
+
+def dct_ortho(x):
+    """MFCC._dct(x, norm="ortho") [mel.py:281-307] over axis 1 of (B, N, T): the orthonormal
+    DCT-II, written as the explicit cosine sum the reference evaluates through an FFT."""
+    x = np.asarray(x, dtype=np.float64)
+    N = x.shape[1]
+    n = np.arange(N)[None, :]
+    k = np.arange(N)[:, None]
+    D = np.cos(np.pi * (2 * n + 1) * k / (2.0 * N)) * np.sqrt(2.0 / N)
+    D[0] *= np.sqrt(0.5)
+    return np.einsum("kn,bnt->bkt", D, x)
+
+
+def mfcc(x, wsin, wcos, hop, mel_basis, n_mfcc, amin=1e-10, ref=1.0, top_db=80.0, **mel_kw):
+    """MFCC.forward [mel.py:309-326]."""
+    mel = filterbank_spectrogram(x, wsin, wcos, hop, mel_basis, **mel_kw).astype(np.float64)
+    return dct_ortho(power_to_db(mel, amin, ref, top_db))[:, :n_mfcc, :].astype(np.float32)

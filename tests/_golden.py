@@ -74,6 +74,12 @@ def oracle_forward(mod, case, x):
             x, sd["stft.wsin"], sd["stft.wcos"], mod.stride, fbk, power=ctor.get("power", 2.0),
             center=ctor.get("center", True), pad_mode=ctor.get("pad_mode", "reflect"),
             trainable_stft=ctor.get("trainable_STFT", False))
+    if cls == "MFCC":
+        ml = mod.melspec_layer
+        return O.mfcc(x, sd["melspec_layer.stft.wsin"], sd["melspec_layer.stft.wcos"], ml.stride,
+                      sd["melspec_layer.mel_basis"], mod.n_mfcc, amin=float(sd["amin"][0]),
+                      ref=float(sd["ref"][0]), top_db=mod.top_db, power=ctor.get("power", 2.0),
+                      center=ctor.get("center", True), pad_mode=ctor.get("pad_mode", "reflect"))
     fmt = fmt or "Magnitude"
     if cls in ("CQT1992v2", "CQT"):
         return O.cqt1992v2(x, sd["cqt_kernels_real"], sd["cqt_kernels_imag"], sd["lenghts"],

@@ -461,7 +461,7 @@ def test_split_basis_is_bit_exact(F, K, has_im):
 
 
 @pytest.mark.parametrize("name", [n for n in _golden.case_names(forward_only=True)
-                                  if n.split("_")[0] in ("stft", "mel", "gamma", "cqt1992v2")])
+                                  if n.split("_")[0] in ("stft", "mel", "gamma", "cqt1992v2", "mfcc")])
 def test_case_bf16x3_matches_reference_and_oracle(golden, bf16x3, name):
     case = golden.cases[name]
     x = golden.inputs[case["input"]]
@@ -573,3 +573,24 @@ def test_bf16x3_cfg2_full_size_sampled():
     m.precision = "fp32"
     y32 = m(xd)
     assert (y - y32).abs().max().item() <= 2e-5 * y32.abs().max().item()
+
+
+def test_mfcc_power_to_db_and_errors():
+    """power_to_db against the numpy restatement incl. the per-clip top_db floor, in place, and
+    the reference's parameter errors (mel.py:255, 273)."""
+    from nnaudio_amd import engine, features
+    from oracle import spectral_oracle as O
+
+    rng = np.random.default_rng(5)
+    S = (rng.random((3, 40, 57)) ** 8 * np.array([1.0, 1e3, 1e-6])[:, None, None]).astype(np.float32)
+    S[0, 0, 0] = 0.0
+    Sd = torch.as_tensor(S).to(DEV)
+    for amin, ref, top_db in ((1e-10, 1.0, 80.0), (1e-6, 2.0, None), (1e-10, 1.0, 0.0)):
+        got = engine.power_to_db(Sd, amin, ref, top_db).cpu().numpy()
+        want = O.power_to_db(S, amin, ref, top_db)
+        assert np.abs(got - want).max() <= 1e-4, (amin, ref, top_db)
+    with pytest.raises(NameError):
+        features.MFCC(amin=0.0, verbose=False)
+    m = features.MFCC(sr=16000, n_fft=512, n_mels=40, top_db=-1.0, verbose=False).to(DEV)
+    with pytest.raises(NameError):
+        m(torch.zeros(1, 4000, device=DEV))

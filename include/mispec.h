@@ -185,6 +185,25 @@ int mispec_filterbank_f32(const float *fb, int32_t n_filters, int32_t n_freq,
                           float *out, void *stream);
 
 /*
+ * Inverse STFT (STFTBase.inverse_stft, stft.py:15-63), two steps:
+ *
+ *  1. frames[c, t, n] = sum_{k<n_freq} spec[c,k,t,0]*basis[n, k] + spec[c,k,t,1]*basis[n, n_freq+k]
+ *     spec is the (n_clips, n_freq, n_frames, 2) complex spectrogram; basis is (n_fft, 2*n_freq):
+ *     [cos part | -sin part] of kernel_cos_inv / kernel_sin_inv, with the mirrored bins of a
+ *     one-sided spectrum folded in (extend_fbins, utils.py:63-70) -- built by the caller from the
+ *     module's buffers.  frames is (n_clips, n_frames, n_fft), n innermost.
+ *  2. y[c, i] = (sum_t frames[c,t,n]*window[n]/n_fft) / sum_t window[n]^2,  n = i + start - t*hop,
+ *     the sums over the frames that cover sample i + start; the division is skipped where the
+ *     window sum is <= 1e-10 (stft.py:41-51).  start = n_fft/2 when centred, out_len = trimmed
+ *     length.  out rows are out_clip_stride elements apart.
+ */
+int mispec_istft_frames_f32(const float *spec, int32_t n_clips, int32_t n_freq, int32_t n_frames,
+                            const float *basis, int32_t n_fft, float *frames, void *stream);
+int mispec_overlap_add_f32(const float *frames, int32_t n_clips, int32_t n_frames, int32_t n_fft,
+                           const float *window, int32_t hop, int32_t start, float *out,
+                           int64_t out_clip_stride, int32_t out_len, void *stream);
+
+/*
  * power_to_db of MFCC (mel.py:263-279), per clip c over its `clip_elems` values (n_mels * n_frames):
  *   l   = 10*log10(max(spec, amin)) - 10*log10(max(amin, ref))
  *   out = top_db < 0 ? l : max(l, max_over_clip(l) - top_db)

@@ -31,6 +31,8 @@ EXPORTS = (
     "mispec_split_basis_bf16",
     "mispec_filterbank_f32",
     "mispec_power_to_db_f32",
+    "mispec_istft_frames_f32",
+    "mispec_overlap_add_f32",
     "mispec_fir_decimate_f32",
     "mispec_fir_decimate_workspace_bytes",
 )
@@ -121,6 +123,17 @@ def load():
     lib.mispec_filterbank_f32.argtypes = [
         ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
         ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+    ]
+    lib.mispec_istft_frames_f32.restype = ctypes.c_int
+    lib.mispec_istft_frames_f32.argtypes = [
+        ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+        ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+    ]
+    lib.mispec_overlap_add_f32.restype = ctypes.c_int
+    lib.mispec_overlap_add_f32.argtypes = [
+        ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+        ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+        ctypes.c_void_p,
     ]
     lib.mispec_power_to_db_f32.restype = ctypes.c_int
     lib.mispec_power_to_db_f32.argtypes = [

@@ -46,7 +46,8 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 constexpr int KC = 32;   // K depth of one LDS stage
 constexpr int LDT = 36;  // LDS row stride in floats: 16-B aligned rows, conflict-free ds_read_b128
 
-enum { BMODE_FRAMED = 0, BMODE_PLANAR = 1 };
+// BMODE_PLANAR_T: planar operand, output stored rows-innermost (frame-major): the iSTFT frames
+enum { BMODE_FRAMED = 0, BMODE_PLANAR = 1, BMODE_PLANAR_T = 2 };
 enum { AMODE_ROWS = 0, AMODE_TOEPLITZ = 1 };
 enum { STORE_FRAMES_INNER = 0, STORE_ROWS_INNER = 1 };
 enum { EDGE_NONE = 0, EDGE_SPANS = 1, EDGE_FULL = 2 };
@@ -56,6 +57,10 @@ struct KParams {
   const float *x;
   long long x_clip_stride;
   long long x_k_stride;  // planar mode: distance between successive k
+  int x_col_stride;      // planar mode: distance between successive columns (frames); 0 = 1
+  int k_split;           // planar mode: k >= k_split reads element (k - k_split) of a second
+  int k_split_off;       //   operand starting k_split_off elements further (0 = no split)
+  int out_frame_stride;  // rows-innermost store: elements between successive frames
   int n_clips;
   int n_samples;
   int hop;
@@ -277,7 +282,8 @@ __device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_
   constexpr int B_STAGE = (BMODE == BMODE_FRAMED) ? BN * LROW : KC * BN;
   constexpr int PPASS = KC * BN / NT;  // planar mode: scalar elements per thread
   static_assert(BMODE == BMODE_FRAMED || NT % BN == 0 || BN % NT == 0, "planar loader shape");
-  constexpr int STORE_MODE = (AMODE == AMODE_TOEPLITZ) ? STORE_ROWS_INNER : STORE_FRAMES_INNER;
+  constexpr int STORE_MODE = (AMODE == AMODE_TOEPLITZ || BMODE == BMODE_PLANAR_T) ? STORE_ROWS_INNER
+                                                                               : STORE_FRAMES_INNER;
   // planar loader: which (k row, column) a thread moves in pass ps
   constexpr int KPP = (NT >= BN) ? NT / BN : 1;
   constexpr int JPP = (NT >= BN) ? 1 : BN / NT;
@@ -341,8 +347,9 @@ __device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_
     if (col >= p.n_cols) col = 0;  // unused column: any valid frame, its results are not stored
     const int c = (int)(col / p.n_frames);
     const int t = (int)(col - (long long)c * p.n_frames);
-    sColPtr[j] = (BMODE == BMODE_FRAMED) ? frame_ptr(p, c, t)
-                                         : p.x + (long long)c * p.x_clip_stride + t;
+    sColPtr[j] = (BMODE == BMODE_FRAMED)
+                     ? frame_ptr(p, c, t)
+                     : p.x + (long long)c * p.x_clip_stride + (long long)t * (p.x_col_stride ? p.x_col_stride : 1);
   }
   if (tid < MT) {
     const int row_lo = m0 + tid * 32;
@@ -432,7 +439,7 @@ __device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_
 
   f32x4v ra[APASS];
   f32x4v rb[(BMODE == BMODE_FRAMED) ? BPASS : 1];
-  float rp[(BMODE == BMODE_PLANAR) ? PPASS : 1];
+  float rp[(BMODE != BMODE_FRAMED) ? PPASS : 1];
   unsigned toep_bits = 0;  // Toeplitz A: which of the 4*APASS loaded taps are inside the band
 
   // ---- stage loads: no control flow, every address is valid memory by construction.
@@ -448,7 +455,9 @@ __device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_
         const int kl = (NT >= BN) ? ps * KPP + tid / BN : ps / JPP;
         int kk = kc + kl;
         kk = kk < p.K ? kk : p.K - 1;  // K tail: any finite value, the A side is zero there
-        rp[ps] = bptr[ps][(long long)kk * p.x_k_stride];
+        long long ko = (long long)kk * p.x_k_stride;
+        if (p.k_split && kk >= p.k_split) ko = (long long)(kk - p.k_split) * p.x_k_stride + p.k_split_off;
+        rp[ps] = bptr[ps][ko];
       }
     }
   };
@@ -730,7 +739,7 @@ __device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_
         if (col < p.n_cols && row < p.n_bins) {
           const int c = (int)(col / p.n_frames);
           const int t = (int)(col - (long long)c * p.n_frames);
-          const long long o = (long long)t * 32 + row;
+          const long long o = (long long)t * p.out_frame_stride + row;
           float v = sC[li * LDC + cl];
           if (p.row_scale) v *= p.row_scale[row];
           if (o < p.out_len) p.out[(long long)c * p.out_clip_stride + o] = v;
@@ -1212,6 +1221,39 @@ int launch_framed(const KParams &p, int tile, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------
+// iSTFT overlap-add (stft.py:33-54, utils.py:43-57): frames (clip, t, n) -> waveform
+//   y[c, i] = (sum_t frames[c, t, n] * win[n] / N) / wss,   n = i + start - t*hop in [0, N),
+//   wss = sum_t win[n]^2 over the same t (division skipped where wss <= 1e-10)
+// One thread per output sample: a gather over the <= ceil(N/hop) frames covering it (no atomics,
+// fixed summation order); consecutive lanes read consecutive n of the same frame.
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) overlap_add_kernel(const float *__restrict__ frames,
+                                                          const float *__restrict__ win, int N,
+                                                          int hop, int n_frames, int start,
+                                                          int out_len, float *__restrict__ out,
+                                                          long long out_clip_stride) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= out_len) return;
+  const int c = blockIdx.y;
+  const long long pos = (long long)i + start;  // position in the un-trimmed overlap-add signal
+  int t_hi = (int)(pos / hop);
+  t_hi = t_hi < n_frames - 1 ? t_hi : n_frames - 1;
+  long long t_lo_num = pos - N + 1;
+  int t_lo = t_lo_num <= 0 ? 0 : (int)((t_lo_num + hop - 1) / hop);
+  const float *f = frames + (long long)c * n_frames * N;
+  const float inv_n = 1.0f / (float)N;
+  float acc = 0.f, wss = 0.f;
+  for (int t = t_lo; t <= t_hi; ++t) {
+    const int n = (int)(pos - (long long)t * hop);
+    const float w = win[n];
+    acc += f[(long long)t * N + n] * w * inv_n;
+    wss += w * w;
+  }
+  if (wss > 1e-10f) acc /= wss;
+  out[(long long)c * out_clip_stride + i] = acc;
+}
+
+// ---------------------------------------------------------------------------------
 // power_to_db (MFCC, mel.py:263-279): HBM-bound pointwise pass with a per-clip maximum
 // ---------------------------------------------------------------------------------
 // per-clip maximum of max(spec, amin) (> 0: unsigned compare on the float bits is monotonic)
@@ -1603,6 +1645,7 @@ int fir_params(KParams &p, const float *x, int64_t x_clip_stride, int32_t n_clip
   p.out_clip_stride = y_clip_stride;
   p.out_row_stride = 0;
   p.out_len = n_out;
+  p.out_frame_stride = 32;
   return MISPEC_OK;
 }
 
@@ -1698,6 +1741,61 @@ int mispec_framed_gemm_f32_ref(const mispec_framed_gemm_args *args, void *stream
   if (blocks > 0x7fffffffLL) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
   hipLaunchKernelGGL(framed_gemm_ref_kernel, dim3((unsigned)blocks), dim3(256), 0,
                      static_cast<hipStream_t>(stream), p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+
+int mispec_istft_frames_f32(const float *spec, int32_t n_clips, int32_t n_freq, int32_t n_frames,
+                            const float *basis, int32_t n_fft, float *frames, void *stream) {
+  if (!spec || !basis || !frames) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
+  if (n_clips <= 0 || n_freq <= 0 || n_frames <= 0 || n_fft <= 0)
+    return fail(MISPEC_E_INVALID, "non-positive size%s");
+  KParams p;
+  memset(&p, 0, sizeof(p));
+  // K axis = [re of bins 0..F-1 | im of bins 0..F-1]; element (k, t, c) of a clip of the
+  // interleaved (F, T, 2) spectrogram sits at k*2T + 2t + c
+  p.x = spec;
+  p.x_clip_stride = (long long)n_freq * n_frames * 2;
+  p.x_k_stride = 2LL * n_frames;
+  p.x_col_stride = 2;
+  p.k_split = n_freq;
+  p.k_split_off = 1;
+  p.n_clips = n_clips;
+  p.n_samples = n_frames;
+  p.hop = 1;
+  p.n_frames = n_frames;
+  p.n_cols = (long long)n_clips * n_frames;
+  p.a_re = basis;
+  p.a_im = nullptr;
+  p.a_row_stride = 2LL * n_freq;
+  p.n_bins = n_fft;
+  p.K = 2 * n_freq;
+  p.epilogue = MISPEC_EPI_REAL;
+  p.im_sign = 1.f;
+  p.out = frames;
+  p.out_clip_stride = (long long)n_frames * n_fft;
+  p.out_frame_stride = n_fft;
+  p.out_len = (int)((long long)n_frames * n_fft > 0x7fffffffLL ? 0x7fffffff : n_frames * n_fft);
+  if ((long long)n_frames * n_fft > 0x7fffffffLL)
+    return fail(MISPEC_E_UNSUPPORTED, "frames of one clip overflow int32%s");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n_fft <= 32) return launch_cfg<1, 4, 1, 2, BMODE_PLANAR_T, AMODE_ROWS, false>(p, s);
+  if (n_fft <= 64) return launch_cfg<1, 4, 2, 2, BMODE_PLANAR_T, AMODE_ROWS, false>(p, s);
+  return launch_cfg<2, 2, 2, 2, BMODE_PLANAR_T, AMODE_ROWS, false>(p, s);
+}
+
+int mispec_overlap_add_f32(const float *frames, int32_t n_clips, int32_t n_frames, int32_t n_fft,
+                           const float *window, int32_t hop, int32_t start, float *out,
+                           int64_t out_clip_stride, int32_t out_len, void *stream) {
+  if (!frames || !window || !out) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
+  if (n_clips <= 0 || n_frames <= 0 || n_fft <= 0 || hop <= 0 || out_len <= 0 || start < 0)
+    return fail(MISPEC_E_INVALID, "non-positive size%s");
+  if ((long long)start + out_len > (long long)(n_frames - 1) * hop + n_fft)
+    return fail(MISPEC_E_INVALID, "output range exceeds the overlap-add signal%s");
+  hipLaunchKernelGGL(overlap_add_kernel, dim3((unsigned)((out_len + 255) / 256), (unsigned)n_clips),
+                     dim3(256), 0, static_cast<hipStream_t>(stream), frames, window, n_fft, hop,
+                     n_frames, start, out_len, out, (long long)out_clip_stride);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
   return MISPEC_OK;

@@ -313,6 +313,55 @@ def filterbank(fb, spec):
     return out
 
 
+def istft_basis(kernel_cos, kernel_sin, n_freq, onesided):
+    """(n_fft, 2*n_freq) contraction basis of the inverse STFT from the module's inverse kernels
+    (n_fft, 1, n_fft, 1): [cos | -sin], with the mirrored upper bins of a one-sided spectrum
+    (extend_fbins, utils.py:63-70: conjugates of bins F-2 .. 1) folded onto bins 1 .. F-2."""
+    C = kernel_cos.reshape(kernel_cos.shape[0], -1)
+    S = kernel_sin.reshape(kernel_sin.shape[0], -1)
+    N = C.shape[1]
+    if not onesided:
+        if n_freq != N:
+            raise RuntimeError("a two-sided spectrogram needs n_fft = %d frequency bins, got %d" % (N, n_freq))
+        return torch.cat((C, -S), 1).contiguous()
+    if 2 * n_freq - 2 != N:
+        raise RuntimeError(
+            "a one-sided spectrogram needs n_fft // 2 + 1 = %d frequency bins, got %d" % (N // 2 + 1, n_freq))
+    Ce, Se = C[:, :n_freq].clone(), S[:, :n_freq].clone()
+    mirror = torch.arange(N - 1, N - n_freq + 1, -1, device=C.device)  # N-1 .. N-(F-2) <-> bins 1 .. F-2
+    Ce[:, 1:n_freq - 1] += C[:, mirror]
+    Se[:, 1:n_freq - 1] -= S[:, mirror]
+    return torch.cat((Ce, -Se), 1).contiguous()
+
+
+def istft(spec, basis, window, hop, start, out_len):
+    """Inverse STFT of a (B, F, T, 2) spectrogram with an ``istft_basis``: frame synthesis
+    (planar contraction kernel, frames stored sample-innermost) + windowed overlap-add with
+    window-sum-square normalisation (stft.py:15-63) -> (B, out_len)."""
+    dev = _require_device(spec, basis, window)
+    spec = _f32(spec, "spectrogram").contiguous()
+    basis = _f32(basis, "basis").contiguous()
+    window = _f32(window, "window").reshape(-1).contiguous()
+    B, F, T, two = spec.shape
+    N = basis.shape[0]
+    if two != 2 or basis.shape[1] != 2 * F or window.numel() != N:
+        raise RuntimeError("istft: spectrogram %s, basis %s, window %s do not fit together"
+                           % (tuple(spec.shape), tuple(basis.shape), tuple(window.shape)))
+    frames = torch.empty((B, T, N), dtype=torch.float32, device=dev)
+    out = torch.empty((B, max(int(out_len), 0)), dtype=torch.float32, device=dev)
+    if out.numel() == 0:
+        return out
+    lib = _abi.load()
+    with torch.cuda.device(dev):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _abi.check(lib.mispec_istft_frames_f32(spec.data_ptr(), B, F, T, basis.data_ptr(), N,
+                                               frames.data_ptr(), stream))
+        _abi.check(lib.mispec_overlap_add_f32(frames.data_ptr(), B, T, N, window.data_ptr(), int(hop),
+                                              int(start), out.data_ptr(), out.stride(0), out.shape[1],
+                                              stream))
+    return out
+
+
 def power_to_db(spec, amin, ref, top_db):
     """librosa-style power_to_db with a per-clip maximum (mel.py:263-279); (B, M, T) -> same."""
     dev = _require_device(spec)

@@ -15,6 +15,36 @@ from ..basis import fourier_basis
 from ..utils import broadcast_dim
 
 
+def _inverse_stft(mod, X, kernel_cos, kernel_sin, onesided, length):
+    """STFTBase.inverse_stft (stft.py:15-63) for ``STFT.inverse`` and ``iSTFT.forward``.
+    (``refresh_win`` needs no state here: the window sum is evaluated inside the overlap-add
+    kernel for whatever number of frames the input has.)"""
+    engine.grad_guard(mod, X)
+    if not hasattr(mod, "_inv_basis"):
+        mod._inv_basis = engine.DerivedCache()
+    F = X.shape[1]
+    basis = mod._inv_basis.get(
+        (kernel_cos, kernel_sin),
+        lambda: engine.istft_basis(kernel_cos, kernel_sin, F, onesided), extra=(F, bool(onesided)))
+    wdtype = mod.window_mask.dtype
+    window = mod.window_mask.reshape(-1).to(torch.float32)
+    if window.numel() != mod.n_fft:
+        raise RuntimeError(
+            "The size of tensor a (%d) must match the size of tensor b (%d) at non-singleton "
+            "dimension 1" % (mod.n_fft, window.numel()))
+    T = X.shape[2]
+    full = mod.n_fft + mod.stride * (T - 1)
+    pad = mod.pad_amount if mod.center else 0
+    if length is None:
+        start, out_len = pad, full - 2 * pad
+    else:
+        start, out_len = pad, min(int(length), full - pad)
+    y = engine.istft(X, basis, window, mod.stride, start, out_len)
+    # the reference multiplies the float32 frames by its window buffer: the iSTFT class keeps a
+    # float64 window (stft.py:489-493) and therefore returns float64 waveforms
+    return y if wdtype == torch.float32 else y.to(wdtype)
+
+
 class STFT(nn.Module):
     """Short-time Fourier transform of ``(len,)``, ``(batch, len)`` or ``(batch, 1, len)``
     float32 waveforms.
@@ -155,11 +185,66 @@ class STFT(nn.Module):
             raise NameError(
                 "Please activate the iSTFT module by setting `iSTFT=True` if you want to use `inverse`"
             )
-        raise NotImplementedError(
-            "inverse STFT is outside this build's hot path (SURVEY.md 8f, rank 2)"
+        assert X.dim() == 4, (
+            "Inverse iSTFT only works for complex number,"
+            "make sure our tensor is in the shape of (batch, freq_bins, timesteps, 2)."
+            "\nIf you have a magnitude spectrogram, please consider using Griffin-Lim."
         )
+        return _inverse_stft(self, X, self.kernel_cos_inv, self.kernel_sin_inv, onesided, length)
 
     def extra_repr(self) -> str:
         return "n_fft={}, Fourier Kernel size={}, iSTFT={}, trainable={}".format(
             self.n_fft, (*self.wsin.shape,), self.iSTFT, self.trainable
         )
+
+
+class iSTFT(nn.Module):
+    """Spectrogram ``(batch, freq_bins, frames, 2)`` -> waveform; same constructor, buffers
+    (``kernel_sin``, ``kernel_cos`` of shape ``(n_fft, 1, n_fft, 1)``, ``window_mask``) and
+    ``forward(X, onesided=False, length=None, refresh_win=None)`` as the reference
+    (stft.py:364-546)."""
+
+    def __init__(self, n_fft=2048, win_length=None, freq_bins=None, hop_length=None, window="hann",
+                 freq_scale="no", center=True, fmin=50, fmax=6000, sr=22050,
+                 trainable_kernels=False, trainable_window=False, verbose=True, refresh_win=True):
+        super().__init__()
+        if win_length is None:
+            win_length = n_fft
+        if hop_length is None:
+            hop_length = int(win_length // 4)
+        self.n_fft = n_fft
+        self.win_length = win_length
+        self.stride = hop_length
+        self.center = center
+        self.pad_amount = self.n_fft // 2
+        self.refresh_win = refresh_win
+        self.trainable = trainable_kernels or trainable_window
+        start = time()
+        ksin, kcos, _, _, _ = fourier_basis(
+            n_fft, win_length=win_length, freq_bins=n_fft, window=window, freq_scale=freq_scale,
+            fmin=fmin, fmax=fmax, sr=sr, verbose=False)
+        # the inverse kernels are not windowed; the window is applied to the synthesised frames
+        from scipy.signal import get_window
+
+        window_mask = torch.tensor(get_window(window, int(win_length), fftbins=True)).unsqueeze(0).unsqueeze(-1)
+        ksin = torch.tensor(ksin, dtype=torch.float).unsqueeze(-1)
+        kcos = torch.tensor(kcos, dtype=torch.float).unsqueeze(-1)
+        if trainable_kernels:
+            self.register_parameter("kernel_sin", nn.Parameter(ksin, requires_grad=True))
+            self.register_parameter("kernel_cos", nn.Parameter(kcos, requires_grad=True))
+        else:
+            self.register_buffer("kernel_sin", ksin)
+            self.register_buffer("kernel_cos", kcos)
+        if trainable_window:
+            self.register_parameter("window_mask", nn.Parameter(window_mask, requires_grad=True))
+        else:
+            self.register_buffer("window_mask", window_mask)
+        if verbose:
+            print("iSTFT kernels created, time used = {:.4f} seconds".format(time() - start))
+
+    def forward(self, X, onesided=False, length=None, refresh_win=None):
+        assert X.dim() == 4, (
+            "Inverse iSTFT only works for complex number,"
+            "make sure our tensor is in the shape of (batch, freq_bins, timesteps, 2)"
+        )
+        return _inverse_stft(self, X, self.kernel_cos, self.kernel_sin, onesided, length)

@@ -73,13 +73,24 @@ def main():
         [np.sin(2 * np.pi * 440 * t) + 0.5 * np.sin(2 * np.pi * 3520 * t + 1.0),
          np.sin(2 * np.pi * 55 * t) * np.cos(2 * np.pi * 3 * t)]
     ).astype(np.float32)
+    # spectrograms for the inverse transforms: the reference's own STFT of x_short
+    with torch.no_grad():
+        xs = torch.from_numpy(inputs["x_short"])
+        X512 = R.STFT(n_fft=512, hop_length=128, verbose=False)(xs)
+        inputs["X_512_128"] = X512.numpy()
+        inputs["X_512_128_full"] = torch.cat(
+            (X512, torch.stack((X512[:, 1:-1, :, 0].flip(1), -X512[:, 1:-1, :, 1].flip(1)), -1)), 1).numpy()
+        inputs["X_256_64_nocenter"] = R.STFT(n_fft=256, hop_length=64, center=False, verbose=False)(xs).numpy()
+        inputs["X_512_100_hamming"] = R.STFT(n_fft=512, hop_length=100, window="hamming",
+                                             verbose=False)(xs).numpy()
     np.savez_compressed(os.path.join(OUT, "inputs.npz"), **inputs)
 
     # ---- (3) cases -----------------------------------------------------------
     C = []
 
-    def case(name, cls, ctor, x, fwd=None, attrs=()):
-        C.append(dict(name=name, cls=cls, ctor=ctor, input=x, fwd=fwd or {}, attrs=list(attrs)))
+    def case(name, cls, ctor, x, fwd=None, attrs=(), method="forward"):
+        C.append(dict(name=name, cls=cls, ctor=ctor, input=x, fwd=fwd or {}, attrs=list(attrs),
+                      method=method))
 
     stft_attrs = ("stride", "n_fft", "freq_bins", "pad_amount", "win_length")
     # STFT: cfg1 + the reference test grid flavours (tests/parameters.py) + odd corners
@@ -221,6 +232,20 @@ def main():
               amin=1e-6), "x_short")
     case("mfcc_sines_topdb40", "MFCC",
          dict(sr=22050, n_mfcc=24, n_fft=1024, n_mels=80, hop_length=256, top_db=40.0), "x_sines")
+    # inverse STFT: STFT.inverse and the iSTFT class
+    case("istft_inverse_default", "STFT", dict(n_fft=512, hop_length=128, iSTFT=True), "X_512_128",
+         method="inverse")
+    case("istft_inverse_length", "STFT", dict(n_fft=512, hop_length=128, iSTFT=True), "X_512_128",
+         fwd=dict(length=8000), method="inverse")
+    case("istft_inverse_twosided", "STFT", dict(n_fft=512, hop_length=128, iSTFT=True),
+         "X_512_128_full", fwd=dict(onesided=False, length=7000), method="inverse")
+    case("istft_inverse_nocenter", "STFT", dict(n_fft=256, hop_length=64, center=False, iSTFT=True),
+         "X_256_64_nocenter", method="inverse")
+    case("istft_class_onesided", "iSTFT", dict(n_fft=512, hop_length=128), "X_512_128",
+         fwd=dict(onesided=True))
+    case("istft_class_twosided", "iSTFT", dict(n_fft=512, hop_length=128), "X_512_128_full")
+    case("istft_class_hamming_len", "iSTFT", dict(n_fft=512, hop_length=100, window="hamming"),
+         "X_512_100_hamming", fwd=dict(onesided=True, length=8000))
     case("bufonly_cqt_testgrid", "CQT1992v2",
          dict(sr=44100, fmin=55, n_bins=207, bins_per_octave=24), None, attrs=cqt_attrs)
     case("bufonly_gamma_44k", "Gammatonegram", dict(sr=44100, n_fft=2048, n_bins=64), None)
@@ -233,6 +258,8 @@ def main():
             warnings.simplefilter("ignore")
             mod = getattr(R, c["cls"])(verbose=False, **c["ctor"])
         entry = dict(name=c["name"], cls=c["cls"], ctor=c["ctor"], fwd=c["fwd"], input=c["input"])
+        if c["method"] != "forward":
+            entry["method"] = c["method"]
         # attributes users read
         at = {}
         for a in c["attrs"]:
@@ -264,7 +291,7 @@ def main():
             x = torch.from_numpy(inputs[c["input"]])
             with torch.no_grad(), warnings.catch_warnings():
                 warnings.simplefilter("ignore")
-                y = mod(x, **c["fwd"])
+                y = getattr(mod, c["method"])(x, **c["fwd"]) if c["method"] != "forward" else mod(x, **c["fwd"])
             y = y.detach().cpu().numpy()
             fwd_store[c["name"]] = y
             entry["out_shape"] = list(y.shape)

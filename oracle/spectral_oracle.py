@@ -346,3 +346,37 @@ def mfcc(x, wsin, wcos, hop, mel_basis, n_mfcc, amin=1e-10, ref=1.0, top_db=80.0
     """MFCC.forward [mel.py:309-326]."""
     mel = filterbank_spectrogram(x, wsin, wcos, hop, mel_basis, **mel_kw).astype(np.float64)
     return dct_ortho(power_to_db(mel, amin, ref, top_db))[:, :n_mfcc, :].astype(np.float32)
+
+
+def extend_fbins(X):
+    """utils.py:63-70: append the conjugates of bins F-2 .. 1 above a one-sided spectrum."""
+    upper = X[:, 1:-1][:, ::-1].copy()
+    upper[..., 1] = -upper[..., 1]
+    return np.concatenate((X, upper), axis=1)
+
+
+def istft(X, kernel_cos, kernel_sin, window, n_fft, hop, center=True, onesided=True, length=None):
+    """STFTBase.inverse_stft [stft.py:15-63]: frame synthesis with the (n_fft, 1, n_fft, 1)
+    inverse kernels, window / n_fft, overlap-add, division by the window sum of squares where it
+    exceeds 1e-10, trimming."""
+    X = np.asarray(X, dtype=np.float64)
+    if onesided:
+        X = extend_fbins(X)
+    C = np.asarray(kernel_cos, dtype=np.float64).reshape(kernel_cos.shape[0], -1)
+    S = np.asarray(kernel_sin, dtype=np.float64).reshape(kernel_sin.shape[0], -1)
+    w = np.asarray(window, dtype=np.float64).reshape(-1)
+    real = np.einsum("nk,bkt->bnt", C, X[..., 0]) - np.einsum("nk,bkt->bnt", S, X[..., 1])
+    real = real * w[None, :, None] / n_fft
+    B, N, T = real.shape
+    full = N + hop * (T - 1)
+    y = np.zeros((B, full))
+    wss = np.zeros(full)
+    for t in range(T):
+        y[:, t * hop:t * hop + N] += real[:, :, t]
+        wss[t * hop:t * hop + N] += w ** 2
+    nz = wss > 1e-10
+    y[:, nz] /= wss[nz]
+    pad = n_fft // 2
+    if length is None:
+        return y[:, pad:full - pad] if center else y
+    return y[:, pad:pad + length] if center else y[:, :length]

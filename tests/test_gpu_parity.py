@@ -27,10 +27,11 @@ def _need_gpu():
     _abi.load()  # fail loudly if the extension is not built
 
 
-def run(mod, x, **fwd):
+def run(mod, x, _method="forward", **fwd):
     with torch.no_grad(), warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        y = mod(torch.as_tensor(x).to(DEV), **fwd)
+        fn = mod if _method == "forward" else getattr(mod, _method)
+        y = fn(torch.as_tensor(x).to(DEV), **fwd)
     torch.cuda.synchronize()
     return y.cpu().numpy()
 
@@ -44,9 +45,16 @@ def test_case_matches_reference_and_oracle(golden, name):
     x = golden.inputs[case["input"]]
     ref = golden.forward[name]
     mod = build_module(case, DEV)
-    y = run(mod, x, **case["fwd"])
-    assert y.dtype == np.float32 and list(y.shape) == case["out_shape"]
+    y = run(mod, x, _method=case.get("method", "forward"), **case["fwd"])
+    assert y.dtype == ref.dtype and list(y.shape) == case["out_shape"]
     orc = oracle_forward(build_module(case), case, x)
+    if _golden.is_inverse(case):
+        # compare where the overlap-add is conditioned (see _golden.well_conditioned)
+        y_r, _ = _golden.well_conditioned(case, mod, x, y, ref)
+        y_o, _ = _golden.well_conditioned(case, mod, x, y, orc)
+        assert_parity(y_r, ref, rel=1e-4, what=name + " vs reference")
+        assert_parity(y_o, orc, rel=1e-4, what=name + " vs oracle")
+        return
     if is_phase(case):
         mcase = dict(case, ctor=dict(case["ctor"], output_format="Magnitude"), fwd={})
         mag = oracle_forward(build_module(mcase), mcase, x)
@@ -594,3 +602,25 @@ def test_mfcc_power_to_db_and_errors():
     m = features.MFCC(sr=16000, n_fft=512, n_mels=40, top_db=-1.0, verbose=False).to(DEV)
     with pytest.raises(NameError):
         m(torch.zeros(1, 4000, device=DEV))
+
+
+def test_stft_istft_round_trip():
+    """reference tests/test_stft.py:28-54: inverse(STFT(x)) == x on randn(4, 16000), for the
+    hop lengths the reference's parameter grid uses, through STFT.inverse and the iSTFT class."""
+    from nnaudio_amd import features
+
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(4, 16000, generator=g).to(DEV)
+    for n_fft, hop, window in ((2048, 512, "hann"), (1024, 128, "hann"), (512, 100, "hamming")):
+        fwd = features.STFT(n_fft=n_fft, hop_length=hop, window=window, iSTFT=True, verbose=False).to(DEV)
+        X = fwd(x, output_format="Complex")
+        y = fwd.inverse(X, length=x.shape[1])
+        assert y.dtype == torch.float32 and tuple(y.shape) == (4, 16000)
+        assert torch.allclose(y, x, rtol=1e-5, atol=1e-3)  # the reference's own tolerance
+        assert (y - x).abs().max().item() <= 2e-5
+        inv = features.iSTFT(n_fft=n_fft, hop_length=hop, window=window, verbose=False).to(DEV)
+        y2 = inv(X, onesided=True, length=x.shape[1])
+        assert y2.dtype == torch.float64  # float64 window buffer, as in the reference
+        assert (y2.float() - x).abs().max().item() <= 2e-5
+    with pytest.raises(NameError):
+        features.STFT(n_fft=512, verbose=False).to(DEV).inverse(X)

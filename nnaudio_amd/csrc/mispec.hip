@@ -14,16 +14,30 @@
 //         with the padded edge spans, so that EVERY frame is a contiguous run of memory and
 //         the K loop contains no control flow around its loads.
 //
-// The contraction runs on the matrix cores with v_mfma_f32_32x32x2_f32 (fp32 in, fp32
-// accumulate: bit-for-bit an fmaf chain, so the 1e-4 parity bar is met with ~1e-6),
-// 64-wide wavefronts, 32-deep K stages double-buffered through LDS and software-pipelined
-// two stages ahead in registers, and the magnitude / power / phase / complex epilogue applied
-// to the accumulators before a (batch, bin, frame[,2]) store with frames innermost.
+// This file: the fp32 path.  The contraction runs on the matrix cores with
+// v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate: bit-for-bit an fmaf chain, so the 1e-4 parity
+// bar is met with ~1e-6), 64-wide wavefronts, 32-deep K stages double-buffered through LDS and
+// filled by LDS-direct loads, and the magnitude / power / phase / complex epilogue applied to the
+// accumulators before a (batch, bin, frame[,2]) store with frames innermost.
 //
 // Variants of the same template:
 //   * A as a banded Toeplitz matrix of FIR taps  -> strided decimation (utils.py:73-124)
-//   * Bop read from a planar (clip, k, t) tensor -> filterbank matmul  (mel.py:188)
+//   * Bop read from a planar (clip, k, t) tensor -> filterbank matmul  (mel.py:188), MFCC's DCT,
+//                                                   inverse-STFT frame synthesis (stft.py:15-63)
 //   * per-row [start, stop) supports             -> CQT kernels skip their zero taps
+//
+// The bf16x3 path (MISPEC_PREC_BF16X3: fp32 operands split into bf16 pairs, three
+// v_mfma_f32_32x32x16_bf16 per product) lives in framed_bf16x3.inl (staged 256x256 kernel, split
+// pre-passes, shared epilogue), framed_bf16x3_slab.inl (hop-periodic K order) and
+// framed_bf16x3_narrow.inl (32-row tiles with super-stage packing for CQT banks), all included
+// below; the host side of both paths, the small pointwise kernels (power_to_db, overlap-add) and
+// the extern "C" entry points are at the end of this file.
+//
+// `reserved` of mispec_framed_gemm_args carries benchmark-only ablation bits ("debug" below;
+// results are WRONG for bits 1-16): 1 no global loads in the K loop, 2 no LDS stores, 4 no barrier,
+// 8 no fragment reads, 16 no MFMAs, 0x100 frame-tile-fastest tile order, 0x800 register-staged
+// instead of LDS-direct loads, 0x2000 no pair launch, 0x4000 bf16x3: staged kernel instead of the
+// hop-periodic ones, 0x8000 one slab buffer, 0x20000 masked 192x256 slab tiles instead of narrow tiles.
 //
 #include <hip/hip_runtime.h>
 

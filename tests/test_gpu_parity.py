@@ -374,18 +374,20 @@ def test_cfg3_mel_full_size_sampled():
     assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
-def test_cfg4_cqt1992v2_full_size_sampled(precision):
+@pytest.mark.parametrize("precision,B", [("fp32", 16), ("bf16x3", 16), ("bf16x3", 64)])
+def test_cfg4_cqt1992v2_full_size_sampled(precision, B):
     from nnaudio_amd import features
     from oracle import spectral_oracle as O
 
-    B, L = 16, 441000  # one rank's shard of cfg4 (128 clips over 8 GPUs)
+    # B = 16: one rank's shard of cfg4 (128 clips over 8 GPUs); B = 64: the bench's CQT84 batch,
+    # where the frame tiles alone fill the chip and every workgroup walks all its row tiles
+    L = 441000
     x = torch.randn(B, L, generator=torch.Generator().manual_seed(2))
     m = features.CQT1992v2(sr=44100, hop_length=512, fmin=32.70, n_bins=84, bins_per_octave=12,
                            output_format="Complex", verbose=False).to(DEV)
     m.precision = precision  # bf16x3: the hop-periodic narrow-tile kernel, 64 super-stages
     y = m(x.to(DEV))
-    assert tuple(y.shape) == (16, 84, 862, 2)
+    assert tuple(y.shape) == (B, 84, 862, 2)
     rng = np.random.default_rng(2)
     cb, ct = _sample_cols(rng, B, 862, 24)
     ct[:6] = [0, 1, 30, 840, 860, 861]

@@ -185,6 +185,63 @@ int mispec_filterbank_f32(const float *fb, int32_t n_filters, int32_t n_freq,
                           float *out, void *stream);
 
 /*
+ * Planar contraction  out[c, m, j] = sum_{k<K} a[m, k] * X(c, k, j)   (the kernel behind the
+ * filterbank, MFCC's DCT and the inverse-STFT frame synthesis, exposed for the backward pass).
+ * X(c, k, j) = x[c*x_clip_stride + koff(k) + j*x_col_stride] with
+ *   koff(k) = k_offsets[k]                                  when k_offsets != NULL,
+ *           = (k - k_split)*x_k_stride + k_split_off        when k_split != 0 and k >= k_split,
+ *           = k*x_k_stride                                  otherwise.
+ * Output element (c, m, j) goes to out + c*out_clip_stride + m*out_row_stride + j, or, with
+ * rows_inner != 0, to out + c*out_clip_stride + j*out_col_stride + m (m innermost).
+ */
+typedef struct mispec_planar_args {
+  uint32_t struct_size;
+  int32_t rows_inner;
+  const float *a;          /* (m, k) rows a_row_stride apart                     */
+  int64_t a_row_stride;
+  int32_t m;
+  int32_t k;
+  const float *x;
+  int64_t x_clip_stride;
+  int64_t x_k_stride;
+  int32_t x_col_stride;    /* 0 means 1                                          */
+  int32_t k_split;
+  int64_t k_split_off;
+  const int64_t *k_offsets; /* optional (k,) element offsets                      */
+  int32_t n_clips;
+  int32_t n_cols;          /* columns j per clip                                 */
+  float *out;
+  int64_t out_clip_stride;
+  int64_t out_row_stride;  /* rows_inner == 0                                    */
+  int64_t out_col_stride;  /* rows_inner != 0                                    */
+} mispec_planar_args;
+int mispec_contract_planar_f32(const mispec_planar_args *args, void *stream);
+
+/*
+ * Backward of the framed contraction (trainable bases: stft.py:238-242, cqt.py:698-702,
+ * mel.py:158-161).  With (u, v) = (s*acc_re, s*im_sign*acc_im) -- what MISPEC_EPI_COMPLEX stores,
+ * s = row_scale -- and out = E(u, v):
+ *   mispec_framed_epilogue_bwd_f32: (grad_out, z = (u, v) as (B, F, T, 2)) -> g, laid out
+ *       (2, F, B, T): g[0] = dL/dacc_re, g[1] = dL/dacc_im;
+ *   d basis  = mispec_contract_planar_f32(a = g as (2F, B*T), x = padded signal, k_offsets =
+ *       frame starts from mispec_frame_offsets_i64, columns = taps);
+ *   d frames = mispec_contract_planar_f32(a = [basis_re^T | basis_im^T], x = g, rows_inner),
+ *   d signal = mispec_overlap_add_f32(window = NULL: plain overlap-add) then
+ *       mispec_unpad_adjoint_f32 (mirrored positions of reflect padding folded back).
+ * mispec_pad_signal_f32 materialises the (n_clips, n_samples + 2*pad) padded signal.
+ */
+int mispec_pad_signal_f32(const float *x, int64_t x_clip_stride, int32_t n_clips, int32_t n_samples,
+                          int32_t pad, int32_t pad_mode, float *out, void *stream);
+int mispec_unpad_adjoint_f32(const float *dxp, int32_t n_clips, int32_t n_samples, int32_t pad,
+                             int32_t pad_mode, float *dx, int64_t dx_clip_stride, void *stream);
+int mispec_frame_offsets_i64(int64_t *k_offsets, int32_t n_clips, int32_t n_frames,
+                             int64_t clip_stride, int32_t hop, void *stream);
+int mispec_framed_epilogue_bwd_f32(const float *grad_out, const float *z, int32_t n_clips,
+                                   int32_t n_bins, int32_t n_frames, int32_t epilogue, float eps,
+                                   float power, float im_sign, const float *row_scale, float *g,
+                                   void *stream);
+
+/*
  * Inverse STFT (STFTBase.inverse_stft, stft.py:15-63), two steps:
  *
  *  1. frames[c, t, n] = sum_{k<n_freq} spec[c,k,t,0]*basis[n, k] + spec[c,k,t,1]*basis[n, n_freq+k]
@@ -195,7 +252,8 @@ int mispec_filterbank_f32(const float *fb, int32_t n_filters, int32_t n_freq,
  *  2. y[c, i] = (sum_t frames[c,t,n]*window[n]/n_fft) / sum_t window[n]^2,  n = i + start - t*hop,
  *     the sums over the frames that cover sample i + start; the division is skipped where the
  *     window sum is <= 1e-10 (stft.py:41-51).  start = n_fft/2 when centred, out_len = trimmed
- *     length.  out rows are out_clip_stride elements apart.
+ *     length.  out rows are out_clip_stride elements apart.  window == NULL: plain overlap-add
+ *     (no window, no 1/n_fft, no normalisation): the adjoint of framing, used by the backward pass.
  */
 int mispec_istft_frames_f32(const float *spec, int32_t n_clips, int32_t n_freq, int32_t n_frames,
                             const float *basis, int32_t n_fft, float *frames, void *stream);

@@ -31,6 +31,11 @@ EXPORTS = (
     "mispec_split_basis_bf16",
     "mispec_filterbank_f32",
     "mispec_power_to_db_f32",
+    "mispec_contract_planar_f32",
+    "mispec_pad_signal_f32",
+    "mispec_unpad_adjoint_f32",
+    "mispec_frame_offsets_i64",
+    "mispec_framed_epilogue_bwd_f32",
     "mispec_istft_frames_f32",
     "mispec_overlap_add_f32",
     "mispec_fir_decimate_f32",
@@ -74,6 +79,32 @@ class FramedGemmArgs(ctypes.Structure):
         ("reserved2", ctypes.c_int32),
         ("basis_split", ctypes.c_void_p),
         ("basis_split_bytes", ctypes.c_int64),
+    ]
+
+
+class PlanarArgs(ctypes.Structure):
+    """struct mispec_planar_args"""
+
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32),
+        ("rows_inner", ctypes.c_int32),
+        ("a", ctypes.c_void_p),
+        ("a_row_stride", ctypes.c_int64),
+        ("m", ctypes.c_int32),
+        ("k", ctypes.c_int32),
+        ("x", ctypes.c_void_p),
+        ("x_clip_stride", ctypes.c_int64),
+        ("x_k_stride", ctypes.c_int64),
+        ("x_col_stride", ctypes.c_int32),
+        ("k_split", ctypes.c_int32),
+        ("k_split_off", ctypes.c_int64),
+        ("k_offsets", ctypes.c_void_p),
+        ("n_clips", ctypes.c_int32),
+        ("n_cols", ctypes.c_int32),
+        ("out", ctypes.c_void_p),
+        ("out_clip_stride", ctypes.c_int64),
+        ("out_row_stride", ctypes.c_int64),
+        ("out_col_stride", ctypes.c_int64),
     ]
 
 
@@ -123,6 +154,29 @@ def load():
     lib.mispec_filterbank_f32.argtypes = [
         ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
         ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+    ]
+    lib.mispec_contract_planar_f32.restype = ctypes.c_int
+    lib.mispec_contract_planar_f32.argtypes = [ctypes.POINTER(PlanarArgs), ctypes.c_void_p]
+    lib.mispec_pad_signal_f32.restype = ctypes.c_int
+    lib.mispec_pad_signal_f32.argtypes = [
+        ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+        ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+    ]
+    lib.mispec_unpad_adjoint_f32.restype = ctypes.c_int
+    lib.mispec_unpad_adjoint_f32.argtypes = [
+        ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+        ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+    ]
+    lib.mispec_frame_offsets_i64.restype = ctypes.c_int
+    lib.mispec_frame_offsets_i64.argtypes = [
+        ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32,
+        ctypes.c_void_p,
+    ]
+    lib.mispec_framed_epilogue_bwd_f32.restype = ctypes.c_int
+    lib.mispec_framed_epilogue_bwd_f32.argtypes = [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+        ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_void_p,
     ]
     lib.mispec_istft_frames_f32.restype = ctypes.c_int
     lib.mispec_istft_frames_f32.argtypes = [

@@ -73,8 +73,9 @@ struct KParams {
   long long x_k_stride;  // planar mode: distance between successive k
   int x_col_stride;      // planar mode: distance between successive columns (frames); 0 = 1
   int k_split;           // planar mode: k >= k_split reads element (k - k_split) of a second
-  int k_split_off;       //   operand starting k_split_off elements further (0 = no split)
+  long long k_split_off; //   operand starting k_split_off elements further (0 = no split)
   int out_frame_stride;  // rows-innermost store: elements between successive frames
+  const long long *k_offsets;  // planar mode: element offset of every k (overrides x_k_stride)
   int n_clips;
   int n_samples;
   int hop;
@@ -471,6 +472,7 @@ __device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_
         kk = kk < p.K ? kk : p.K - 1;  // K tail: any finite value, the A side is zero there
         long long ko = (long long)kk * p.x_k_stride;
         if (p.k_split && kk >= p.k_split) ko = (long long)(kk - p.k_split) * p.x_k_stride + p.k_split_off;
+        if (p.k_offsets) ko = p.k_offsets[kk];
         rp[ps] = bptr[ps][ko];
       }
     }
@@ -1257,14 +1259,125 @@ __global__ void __launch_bounds__(256) overlap_add_kernel(const float *__restric
   const float *f = frames + (long long)c * n_frames * N;
   const float inv_n = 1.0f / (float)N;
   float acc = 0.f, wss = 0.f;
-  for (int t = t_lo; t <= t_hi; ++t) {
-    const int n = (int)(pos - (long long)t * hop);
-    const float w = win[n];
-    acc += f[(long long)t * N + n] * w * inv_n;
-    wss += w * w;
+  if (win) {
+    for (int t = t_lo; t <= t_hi; ++t) {
+      const int n = (int)(pos - (long long)t * hop);
+      const float w = win[n];
+      acc += f[(long long)t * N + n] * w * inv_n;
+      wss += w * w;
+    }
+    if (wss > 1e-10f) acc /= wss;
+  } else {  // plain overlap-add (adjoint of framing)
+    for (int t = t_lo; t <= t_hi; ++t) acc += f[(long long)t * N + (int)(pos - (long long)t * hop)];
   }
-  if (wss > 1e-10f) acc /= wss;
   out[(long long)c * out_clip_stride + i] = acc;
+}
+
+// ---------------------------------------------------------------------------------
+// Backward of the framed contraction (trainable bases, stft.py:238-242 / cqt.py:698-702; SURVEY 8f
+// rank 3).  With acc_re/acc_im the contraction sums, s the per-bin scale and
+//   (u, v) = (s*acc_re, s*im_sign*acc_im)   -- what MISPEC_EPI_COMPLEX stores --
+// the pointwise epilogue is out = E(u, v).  The backward pass is
+//   1. framed_epilogue_bwd_kernel:  (grad_out, u, v) -> G = (dL/dacc_re, dL/dacc_im), laid out
+//      (2, F, B, T) so that a row (component, bin) is contiguous over the flat frame axis;
+//   2. d basis = G x frames^T  and  d frames = basis^T x G: the planar contraction kernel
+//      (mispec_contract_planar_f32), frames read from the padded signal through a k-offset table;
+//   3. d signal = overlap-add of d frames (overlap_add_kernel, no window) folded back through the
+//      padding (unpad_adjoint_kernel).
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pad_signal_kernel(const KParams p, float *__restrict__ out) {
+  const long long Lp = (long long)p.n_samples + 2LL * p.pad;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= Lp) return;
+  const int c = blockIdx.y;
+  out[(long long)c * Lp + i] = fetch_sample(p.x, (long long)c * p.x_clip_stride, (int)(i - p.pad),
+                                            p.n_samples, p.pad_mode, true);
+}
+
+// dx[c, i] = dxp[c, i + pad] + the padded positions that mirror onto sample i (reflect)
+__global__ void __launch_bounds__(256) unpad_adjoint_kernel(const float *__restrict__ dxp, int L,
+                                                            int pad, int pad_mode,
+                                                            float *__restrict__ dx,
+                                                            long long dx_clip_stride) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= L) return;
+  const int c = blockIdx.y;
+  const float *g = dxp + (long long)c * (L + 2LL * pad);
+  float v = g[i + pad];
+  if (pad_mode == MISPEC_PAD_REFLECT) {
+    if (i >= 1 && i <= pad) v += g[pad - i];                          // position -i
+    if (i <= L - 2 && i >= L - 1 - pad) v += g[pad + 2 * L - 2 - i];  // position 2L-2-i
+  }
+  dx[(long long)c * dx_clip_stride + i] = v;
+}
+
+__global__ void __launch_bounds__(256) frame_offsets_kernel(long long *__restrict__ koff, int n_clips,
+                                                            int n_frames, long long clip_stride,
+                                                            int hop) {
+  const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (k >= (long long)n_clips * n_frames) return;
+  const int c = (int)(k / n_frames);
+  const int t = (int)(k - (long long)c * n_frames);
+  koff[k] = (long long)c * clip_stride + (long long)t * hop;
+}
+
+__global__ void __launch_bounds__(256) framed_epilogue_bwd_kernel(
+    const float *__restrict__ go, const float *__restrict__ z, int n_clips, int n_bins, int n_frames,
+    int epilogue, float eps, float power, float im_sign, const float *__restrict__ row_scale,
+    float *__restrict__ g) {
+  const long long total = (long long)n_clips * n_bins * n_frames;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int t = (int)(i % n_frames);
+  const long long bf = i / n_frames;
+  const int f = (int)(bf % n_bins);
+  const int c = (int)(bf / n_bins);
+  const float u = z[2 * i], v = z[2 * i + 1];
+  float gu = 0.f, gv = 0.f;
+  const float r2 = u * u + v * v;
+  switch (epilogue) {
+    case MISPEC_EPI_COMPLEX:
+      gu = go[2 * i];
+      gv = go[2 * i + 1];
+      break;
+    case MISPEC_EPI_MAGNITUDE: {
+      const float y = sqrtf(r2 + eps);
+      if (y > 0.f) {
+        gu = go[i] * u / y;
+        gv = go[i] * v / y;
+      }
+    } break;
+    case MISPEC_EPI_POWER: {
+      // y = sqrt(s)^p, s = u^2 + v^2 + eps:  dy/du = p * s^(p/2 - 1) * u
+      const float s0 = r2 + eps;
+      if (s0 > 0.f) {
+        const float k = power * powf(s0, 0.5f * power - 1.0f) * go[i];
+        gu = k * u;
+        gv = k * v;
+      }
+    } break;
+    case MISPEC_EPI_PHASE_ATAN2:
+      if (r2 > 0.f) {
+        gu = -go[i] * v / r2;
+        gv = go[i] * u / r2;
+      }
+      break;
+    case MISPEC_EPI_PHASE_COSSIN:
+      if (r2 > 0.f) {
+        const float r3 = r2 * sqrtf(r2);
+        const float g0 = go[2 * i], g1 = go[2 * i + 1];
+        gu = (g0 * v * v - g1 * u * v) / r3;
+        gv = (g1 * u * u - g0 * u * v) / r3;
+      }
+      break;
+    default:
+      break;
+  }
+  const float sc = row_scale ? row_scale[f] : 1.f;
+  const long long plane = (long long)n_bins * n_clips * n_frames;
+  const long long o = ((long long)f * n_clips + c) * n_frames + t;
+  g[o] = sc * gu;
+  g[plane + o] = sc * im_sign * gv;
 }
 
 // ---------------------------------------------------------------------------------
@@ -1760,6 +1873,119 @@ int mispec_framed_gemm_f32_ref(const mispec_framed_gemm_args *args, void *stream
   return MISPEC_OK;
 }
 
+int mispec_contract_planar_f32(const mispec_planar_args *a, void *stream) {
+  if (!a) return fail(MISPEC_E_INVALID, "args is NULL%s");
+  if (a->struct_size != sizeof(mispec_planar_args))
+    return fail(MISPEC_E_INVALID, "struct_size mismatch (ABI skew)%s");
+  if (!a->a || !a->x || !a->out) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
+  if (a->m <= 0 || a->k <= 0 || a->n_clips <= 0 || a->n_cols <= 0)
+    return fail(MISPEC_E_INVALID, "non-positive size%s");
+  if ((long long)a->n_clips * a->n_cols > 0x7fffffffLL)
+    return fail(MISPEC_E_UNSUPPORTED, "column count overflows int32%s");
+  KParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = a->x;
+  p.x_clip_stride = a->x_clip_stride;
+  p.x_k_stride = a->x_k_stride;
+  p.x_col_stride = a->x_col_stride;
+  p.k_split = a->k_split;
+  p.k_split_off = a->k_split_off;
+  p.k_offsets = reinterpret_cast<const long long *>(a->k_offsets);
+  p.n_clips = a->n_clips;
+  p.n_samples = a->n_cols;
+  p.hop = 1;
+  p.n_frames = a->n_cols;
+  p.n_cols = (long long)a->n_clips * a->n_cols;
+  p.a_re = a->a;
+  p.a_im = nullptr;
+  p.a_row_stride = a->a_row_stride;
+  p.n_bins = a->m;
+  p.K = a->k;
+  p.epilogue = MISPEC_EPI_REAL;
+  p.im_sign = 1.f;
+  p.out = a->out;
+  p.out_clip_stride = a->out_clip_stride;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (a->rows_inner) {
+    if ((long long)a->n_cols * a->out_col_stride > 0x7fffffffLL)
+      return fail(MISPEC_E_UNSUPPORTED, "one clip of the output overflows int32%s");
+    p.out_frame_stride = (int)a->out_col_stride;
+    p.out_len = (int)((long long)(a->n_cols - 1) * a->out_col_stride + a->m);
+    if (a->m <= 32) return launch_cfg<1, 4, 1, 2, BMODE_PLANAR_T, AMODE_ROWS, false>(p, s);
+    if (a->m <= 64) return launch_cfg<1, 4, 2, 2, BMODE_PLANAR_T, AMODE_ROWS, false>(p, s);
+    return launch_cfg<2, 2, 2, 2, BMODE_PLANAR_T, AMODE_ROWS, false>(p, s);
+  }
+  p.out_row_stride = a->out_row_stride;
+  if (a->m <= 32) return launch_cfg<1, 4, 1, 2, BMODE_PLANAR, AMODE_ROWS, false>(p, s);
+  if (a->m <= 64) return launch_cfg<1, 4, 2, 2, BMODE_PLANAR, AMODE_ROWS, false>(p, s);
+  return launch_cfg<2, 2, 2, 2, BMODE_PLANAR, AMODE_ROWS, false>(p, s);
+}
+
+int mispec_pad_signal_f32(const float *x, int64_t x_clip_stride, int32_t n_clips, int32_t n_samples,
+                          int32_t pad, int32_t pad_mode, float *out, void *stream) {
+  if (!x || !out) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
+  if (n_clips <= 0 || n_samples <= 0 || pad < 0) return fail(MISPEC_E_INVALID, "non-positive size%s");
+  if (pad_mode < MISPEC_PAD_NONE || pad_mode > MISPEC_PAD_REFLECT || (pad_mode == MISPEC_PAD_NONE && pad))
+    return fail(MISPEC_E_INVALID, "bad pad_mode%s");
+  if (pad_mode == MISPEC_PAD_REFLECT && pad >= n_samples)
+    return fail(MISPEC_E_INVALID, "reflect padding needs pad < n_samples%s");
+  KParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = x;
+  p.x_clip_stride = x_clip_stride;
+  p.n_samples = n_samples;
+  p.pad = pad;
+  p.pad_mode = pad_mode;
+  const long long lp = (long long)n_samples + 2LL * pad;
+  hipLaunchKernelGGL(pad_signal_kernel, dim3((unsigned)((lp + 255) / 256), (unsigned)n_clips), dim3(256),
+                     0, static_cast<hipStream_t>(stream), p, out);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+
+int mispec_unpad_adjoint_f32(const float *dxp, int32_t n_clips, int32_t n_samples, int32_t pad,
+                             int32_t pad_mode, float *dx, int64_t dx_clip_stride, void *stream) {
+  if (!dxp || !dx) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
+  if (n_clips <= 0 || n_samples <= 0 || pad < 0) return fail(MISPEC_E_INVALID, "non-positive size%s");
+  hipLaunchKernelGGL(unpad_adjoint_kernel, dim3((unsigned)((n_samples + 255) / 256), (unsigned)n_clips),
+                     dim3(256), 0, static_cast<hipStream_t>(stream), dxp, n_samples, pad, pad_mode, dx,
+                     (long long)dx_clip_stride);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+
+int mispec_frame_offsets_i64(int64_t *k_offsets, int32_t n_clips, int32_t n_frames, int64_t clip_stride,
+                             int32_t hop, void *stream) {
+  if (!k_offsets) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
+  if (n_clips <= 0 || n_frames <= 0 || hop <= 0) return fail(MISPEC_E_INVALID, "non-positive size%s");
+  const long long n = (long long)n_clips * n_frames;
+  hipLaunchKernelGGL(frame_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), reinterpret_cast<long long *>(k_offsets), n_clips,
+                     n_frames, (long long)clip_stride, hop);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+
+int mispec_framed_epilogue_bwd_f32(const float *grad_out, const float *z, int32_t n_clips, int32_t n_bins,
+                                   int32_t n_frames, int32_t epilogue, float eps, float power,
+                                   float im_sign, const float *row_scale, float *g, void *stream) {
+  if (!grad_out || !z || !g) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
+  if (n_clips <= 0 || n_bins <= 0 || n_frames <= 0) return fail(MISPEC_E_INVALID, "non-positive size%s");
+  if (epilogue < MISPEC_EPI_COMPLEX || epilogue > MISPEC_EPI_PHASE_COSSIN)
+    return fail(MISPEC_E_INVALID, "bad epilogue%s");
+  const long long total = (long long)n_clips * n_bins * n_frames;
+  if ((total + 255) / 256 > 0x7fffffffLL) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
+  hipLaunchKernelGGL(framed_epilogue_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), grad_out, z, n_clips, n_bins, n_frames, epilogue,
+                     eps, power, im_sign, row_scale, g);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+
 int mispec_istft_frames_f32(const float *spec, int32_t n_clips, int32_t n_freq, int32_t n_frames,
                             const float *basis, int32_t n_fft, float *frames, void *stream) {
   if (!spec || !basis || !frames) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
@@ -1802,7 +2028,7 @@ int mispec_istft_frames_f32(const float *spec, int32_t n_clips, int32_t n_freq, 
 int mispec_overlap_add_f32(const float *frames, int32_t n_clips, int32_t n_frames, int32_t n_fft,
                            const float *window, int32_t hop, int32_t start, float *out,
                            int64_t out_clip_stride, int32_t out_len, void *stream) {
-  if (!frames || !window || !out) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
+  if (!frames || !out) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
   if (n_clips <= 0 || n_frames <= 0 || n_fft <= 0 || hop <= 0 || out_len <= 0 || start < 0)
     return fail(MISPEC_E_INVALID, "non-positive size%s");
   if ((long long)start + out_len > (long long)(n_frames - 1) * hop + n_fft)

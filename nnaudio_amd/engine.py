@@ -416,13 +416,166 @@ def pad_mode_id(name):
     return _PAD_MODES[name]
 
 
+# ---------------------------------------------------------------------------------------
+# backward of the framed contraction (include/mispec.h "Backward of ...")
+# ---------------------------------------------------------------------------------------
+def contract_planar(a, x, *, k, n_clips, n_cols, x_clip_stride, x_k_stride=0, x_col_stride=1,
+                    k_split=0, k_split_off=0, k_offsets=None, out=None, rows_inner=False):
+    """out[c, m, j] = sum_k a[m, k] * X(c, k, j) (mispec_contract_planar_f32); ``a`` is (m, k)."""
+    dev = _require_device(a, x, k_offsets, out)
+    a = _f32(a, "a")
+    if a.dim() != 2 or a.stride(1) != 1 or a.shape[1] != k:
+        raise RuntimeError("a must be (m, k) with unit inner stride")
+    m = a.shape[0]
+    if out is None:
+        shape = (n_clips, n_cols, m) if rows_inner else (n_clips, m, n_cols)
+        out = torch.empty(shape, dtype=torch.float32, device=dev)
+    pa = _abi.PlanarArgs()
+    pa.struct_size = ctypes.sizeof(_abi.PlanarArgs)
+    pa.rows_inner = 1 if rows_inner else 0
+    pa.a, pa.a_row_stride, pa.m, pa.k = a.data_ptr(), a.stride(0), m, int(k)
+    pa.x, pa.x_clip_stride, pa.x_k_stride = x.data_ptr(), int(x_clip_stride), int(x_k_stride)
+    pa.x_col_stride, pa.k_split, pa.k_split_off = int(x_col_stride), int(k_split), int(k_split_off)
+    pa.k_offsets = k_offsets.data_ptr() if k_offsets is not None else None
+    pa.n_clips, pa.n_cols = int(n_clips), int(n_cols)
+    pa.out, pa.out_clip_stride = out.data_ptr(), out.stride(0)
+    pa.out_row_stride = n_cols
+    pa.out_col_stride = m
+    with torch.cuda.device(dev):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _abi.check(_abi.load().mispec_contract_planar_f32(ctypes.byref(pa), stream))
+    return out
+
+
+class _FramedGemmFn(torch.autograd.Function):
+    """Autograd wrapper of ``framed_gemm`` for trainable bases / differentiable inputs."""
+
+    @staticmethod
+    def forward(ctx, x, basis_re, basis_im, kw):
+        ctx.kw = dict(kw)
+        ctx.save_for_backward(x, basis_re, basis_im)
+        return framed_gemm(x, basis_re, basis_im, **kw)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, basis_re, basis_im = ctx.saved_tensors
+        kw = ctx.kw
+        lib = _abi.load()
+        dev = x.device
+        xs = _signal(x.detach())
+        wr = _rows(basis_re.detach(), "basis_re")
+        wi = _rows(basis_im.detach(), "basis_im")
+        B, L = xs.shape
+        F, K = wr.shape
+        hop, pad, pad_mode = int(kw["hop"]), int(kw["pad"]), int(kw["pad_mode"])
+        scale = kw.get("row_scale")
+        im_sign = float(kw.get("im_sign", -1.0))
+        # (u, v): the Complex epilogue of the same contraction, in the exact fp32 arithmetic
+        zkw = dict(kw, epilogue=EPI_COMPLEX, precision="fp32", row_support=None, out=None,
+                   out_rows_total=None, out_row_offset=0)
+        zkw.pop("basis_split", None)
+        z = framed_gemm(xs, wr, wi, **zkw)
+        T = z.shape[2]
+        go = _f32(grad_out, "grad_output").contiguous()
+        g = torch.empty((2, F, B, T), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _abi.check(lib.mispec_framed_epilogue_bwd_f32(
+                go.data_ptr(), z.data_ptr(), B, F, T, int(kw["epilogue"]), float(kw.get("eps", 0.0)),
+                float(kw.get("power", 2.0)), im_sign,
+                scale.data_ptr() if scale is not None else None, g.data_ptr(), stream))
+        del z
+        gx = gre = gim = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            Lp = L + 2 * pad
+            xp = torch.empty((B, Lp), dtype=torch.float32, device=dev)
+            koff = torch.empty(B * T, dtype=torch.int64, device=dev)
+            with torch.cuda.device(dev):
+                _abi.check(lib.mispec_pad_signal_f32(xs.data_ptr(), xs.stride(0), B, L, pad, pad_mode,
+                                                     xp.data_ptr(), stream))
+                _abi.check(lib.mispec_frame_offsets_i64(koff.data_ptr(), B, T, Lp, hop, stream))
+            # d basis[row, n] = sum_{(b,t)} g[row, (b,t)] * xp[b, t*hop + n]
+            dw = contract_planar(g.reshape(2 * F, B * T), xp, k=B * T, n_clips=1, n_cols=K,
+                                 x_clip_stride=0, k_offsets=koff)[0]
+            gre = dw[:F].reshape(basis_re.shape)
+            gim = dw[F:].reshape(basis_im.shape)
+        if ctx.needs_input_grad[0]:
+            # d frames[b, t, n] = sum_f g_re[f,b,t]*w_re[f,n] + g_im[f,b,t]*w_im[f,n]
+            bt = torch.cat((wr.t(), wi.t()), 1).contiguous()  # (K, 2F)
+            frames = contract_planar(bt, g, k=2 * F, n_clips=B, n_cols=T, x_clip_stride=T,
+                                     x_k_stride=B * T, k_split=F, k_split_off=F * B * T,
+                                     rows_inner=True)  # (B, T, K)
+            Lp = L + 2 * pad
+            dxp = torch.empty((B, Lp), dtype=torch.float32, device=dev)
+            dx = torch.empty((B, L), dtype=torch.float32, device=dev)
+            cover = (T - 1) * hop + K  # samples the frames reach; the rest of the padded signal gets 0
+            with torch.cuda.device(dev):
+                if cover < Lp:
+                    dxp.zero_()
+                _abi.check(lib.mispec_overlap_add_f32(frames.data_ptr(), B, T, K, None, hop, 0,
+                                                      dxp.data_ptr(), dxp.stride(0), min(cover, Lp),
+                                                      stream))
+                _abi.check(lib.mispec_unpad_adjoint_f32(dxp.data_ptr(), B, L, pad, pad_mode,
+                                                        dx.data_ptr(), dx.stride(0), stream))
+            gx = dx.reshape(x.shape)
+        return gx, gre, gim, None
+
+
+class _FilterbankFn(torch.autograd.Function):
+    """Autograd wrapper of ``filterbank`` (mel / gammatone reduction, mel.py:188)."""
+
+    @staticmethod
+    def forward(ctx, fb, spec):
+        ctx.save_for_backward(fb, spec)
+        return filterbank(fb, spec)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        fb, spec = ctx.saved_tensors
+        fb, spec = fb.detach(), spec.detach().contiguous()
+        go = _f32(grad_out, "grad_output").contiguous()
+        B, F, T = spec.shape
+        M = fb.shape[0]
+        gfb = gspec = None
+        if ctx.needs_input_grad[1]:
+            gspec = filterbank(fb.t().contiguous(), go)  # fb^T (F, M) x (B, M, T)
+        if ctx.needs_input_grad[0]:
+            # d fb[m, f] = sum_{(b,t)} g[b, m, t] * spec[b, f, t]
+            dev = spec.device
+            koff = torch.empty(B * T, dtype=torch.int64, device=dev)
+            with torch.cuda.device(dev):
+                stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                _abi.check(_abi.load().mispec_frame_offsets_i64(koff.data_ptr(), B, T, F * T, 1, stream))
+            gm = go.permute(1, 0, 2).reshape(M, B * T).contiguous()
+            gfb = contract_planar(gm, spec, k=B * T, n_clips=1, n_cols=F, x_clip_stride=0,
+                                  x_col_stride=T, k_offsets=koff)[0].reshape(fb.shape)
+        return gfb, gspec
+
+
+def filterbank_autograd(fb, spec):
+    if torch.is_grad_enabled() and (fb.requires_grad or spec.requires_grad):
+        return _FilterbankFn.apply(fb, spec)
+    return filterbank(fb, spec)
+
+
+def framed_gemm_autograd(x, basis_re, basis_im, **kw):
+    """``framed_gemm`` that records a graph when the input or the bases require gradients."""
+    if torch.is_grad_enabled() and (x.requires_grad or basis_re.requires_grad
+                                    or (basis_im is not None and basis_im.requires_grad)):
+        if basis_im is None:
+            raise NotImplementedError("backward of a real contraction is not implemented")
+        return _FramedGemmFn.apply(x, basis_re, basis_im, kw)
+    return framed_gemm(x, basis_re, basis_im, **kw)
+
+
 def grad_guard(module, x):
-    """The HIP path is forward-only this round: refuse to silently drop a graph."""
+    """Modules without a backward pass (CQT2010v2 / VQT octave recursion, MFCC's dB + DCT stage,
+    the inverse STFT): refuse to silently drop a graph."""
     if torch.is_grad_enabled() and (
         x.requires_grad or any(p.requires_grad for p in module.parameters())
     ):
         raise NotImplementedError(
-            "%s: backward through the HIP kernels is not implemented yet (trainable bases / "
-            "requires_grad inputs). Call under torch.no_grad() for inference."
+            "%s: backward through this module's HIP kernels is not implemented yet (trainable "
+            "bases / requires_grad inputs). Call under torch.no_grad() for inference."
             % type(module).__name__
         )

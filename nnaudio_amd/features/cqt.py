@@ -81,7 +81,6 @@ class CQT1992v2(nn.Module):
     def forward(self, x, output_format=None, normalization_type="librosa"):
         output_format = output_format or self.output_format
         x = broadcast_dim(x)
-        engine.grad_guard(self, x)
         if self.center:
             if self.pad_mode == "constant":
                 mode = engine.PAD_ZERO
@@ -103,7 +102,7 @@ class CQT1992v2(nn.Module):
         if precision == "bf16x3":
             kr, ki = self.cqt_kernels_real, self.cqt_kernels_imag
             split = self._split.get((kr, ki), lambda: engine.split_basis(kr, ki))
-        return engine.framed_gemm(
+        return engine.framed_gemm_autograd(
             x, self.cqt_kernels_real, self.cqt_kernels_imag, hop=self.hop_length, pad=pad,
             pad_mode=mode, epilogue=epi, im_sign=-1.0, eps=1e-8 if self.trainable else 0.0,
             row_scale=scale, row_support=sup, precision=precision, basis_split=split,

@@ -74,10 +74,9 @@ class Gammatonegram(nn.Module):
 
     def forward(self, x):
         x = broadcast_dim(x)
-        engine.grad_guard(self, x)
         self.stft.num_samples = x.shape[-1]
         spec = self.stft._spectrum(x, engine.EPI_POWER, power=self.power)
-        return engine.filterbank(self.gammatone_basis, spec)
+        return engine.filterbank_autograd(self.gammatone_basis, spec)
 
     def extra_repr(self) -> str:
         return "Gammatone filter banks size = {}, trainable_bins={}".format(

@@ -79,10 +79,9 @@ class MelSpectrogram(nn.Module):
 
     def forward(self, x):
         x = broadcast_dim(x)
-        engine.grad_guard(self, x)
         self.stft.num_samples = x.shape[-1]
         spec = self.stft._spectrum(x, engine.EPI_POWER, power=self.power)
-        return engine.filterbank(self.mel_basis, spec)
+        return engine.filterbank_autograd(self.mel_basis, spec)
 
     def extra_repr(self) -> str:
         return "Mel filter banks size = {}, trainable_mel={}".format(
@@ -115,6 +114,7 @@ class MFCC(nn.Module):
                              persistent=False)
 
     def forward(self, x):
+        engine.grad_guard(self, x)  # no backward through power_to_db / the DCT yet
         spec = self.melspec_layer(x)
         if self.top_db is not None and self.top_db < 0:
             raise ParameterError("top_db must be non-negative")

@@ -160,7 +160,7 @@ class STFT(nn.Module):
         if precision == "bf16x3":
             split = self._split.get((self.wcos, self.wsin),
                                     lambda: engine.split_basis(wcos, wsin), extra=self.freq_bins)
-        return engine.framed_gemm(
+        return engine.framed_gemm_autograd(
             x, wcos, wsin, hop=self.stride, pad=pad, pad_mode=mode, epilogue=epilogue,
             im_sign=-1.0, eps=1e-8 if self.trainable else 0.0, power=power,
             precision=precision, basis_split=split,
@@ -171,7 +171,6 @@ class STFT(nn.Module):
         output_format = output_format or self.output_format
         self.num_samples = x.shape[-1]
         x = broadcast_dim(x)
-        engine.grad_guard(self, x)
         if output_format == "Magnitude":
             return self._spectrum(x, engine.EPI_MAGNITUDE)
         if output_format == "Complex":

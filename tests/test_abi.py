@@ -39,20 +39,22 @@ def test_args_struct_layout_matches_header(tmp_path):
     gcc = shutil.which("gcc")
     if gcc is None:
         pytest.skip("no C compiler")
-    fields = [f[0] for f in _abi.FramedGemmArgs._fields_]
-    prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "mispec.h"', 'int main(void){',
-            'printf("%zu\\n", sizeof(mispec_framed_gemm_args));']
-    for f in fields:
-        prog.append('printf("%%zu\\n", offsetof(mispec_framed_gemm_args, %s));' % f)
-    prog.append("return 0;}")
-    src = tmp_path / "layout.c"
-    src.write_text("\n".join(prog))
-    exe = tmp_path / "layout"
-    subprocess.check_call([gcc, "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
-    vals = [int(v) for v in subprocess.check_output([str(exe)]).split()]
-    assert vals[0] == ctypes.sizeof(_abi.FramedGemmArgs)
-    for f, off in zip(fields, vals[1:]):
-        assert getattr(_abi.FramedGemmArgs, f).offset == off, f
+    for cname, mirror in (("mispec_framed_gemm_args", _abi.FramedGemmArgs),
+                          ("mispec_planar_args", _abi.PlanarArgs)):
+        fields = [f[0] for f in mirror._fields_]
+        prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "mispec.h"', 'int main(void){',
+                'printf("%%zu\\n", sizeof(%s));' % cname]
+        for f in fields:
+            prog.append('printf("%%zu\\n", offsetof(%s, %s));' % (cname, f))
+        prog.append("return 0;}")
+        src = tmp_path / ("layout_%s.c" % cname)
+        src.write_text("\n".join(prog))
+        exe = tmp_path / ("layout_%s" % cname)
+        subprocess.check_call([gcc, "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+        vals = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+        assert vals[0] == ctypes.sizeof(mirror)
+        for f, off in zip(fields, vals[1:]):
+            assert getattr(mirror, f).offset == off, (cname, f)
 
 
 def test_invalid_arguments_are_rejected_without_a_gpu():
@@ -84,9 +86,10 @@ def test_cpu_tensors_fail_loudly():
 def test_trainable_needs_no_grad():
     from nnaudio_amd import features
 
-    m = features.STFT(n_fft=64, hop_length=16, trainable=True, verbose=False)
+    # CQT2010v2 / VQT (octave recursion) have no backward pass yet: they must refuse to drop a graph
+    m = features.CQT2010v2(sr=8000, fmin=220, n_bins=12, trainable=True, verbose=False)
     with pytest.raises(NotImplementedError):
-        m(torch.zeros(1, 256))
+        m(torch.zeros(1, 4096))
 
 
 def test_legacy_import_shim_warns():

@@ -626,3 +626,124 @@ def test_stft_istft_round_trip():
         assert (y2.float() - x).abs().max().item() <= 2e-5
     with pytest.raises(NameError):
         features.STFT(n_fft=512, verbose=False).to(DEV).inverse(X)
+
+
+# ---------------------------------------------------------------------------------------
+# backward: trainable bases and differentiable inputs, against torch autograd
+# on a plain conv1d restatement of the reference's forward (fp32, same device)
+# ---------------------------------------------------------------------------------------
+def _torch_framed(x, w_re, w_im, hop, pad, mode):
+    import torch.nn.functional as F
+
+    xp = x[:, None, :]
+    if pad:
+        xp = F.pad(xp, (pad, pad), mode="reflect" if mode == "reflect" else "constant")
+    return F.conv1d(xp, w_re, stride=hop), F.conv1d(xp, w_im, stride=hop)
+
+
+def _grad_close(got, want, what, rel=2e-4):
+    assert got is not None, what
+    err = (got - want).abs().max().item()
+    ref = want.abs().max().item()
+    assert err <= rel * ref, "%s: max|d|=%.3e vs %.3e" % (what, err, ref)
+
+
+@pytest.mark.parametrize("fmt", ["Magnitude", "Complex", "Phase"])
+@pytest.mark.parametrize("pad_mode,center", [("reflect", True), ("constant", True), ("reflect", False)])
+def test_backward_stft(fmt, pad_mode, center):
+    from nnaudio_amd import features
+
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(3, 6000, generator=g).to(DEV).requires_grad_(True)
+    m = features.STFT(n_fft=512, hop_length=160, trainable=True, output_format=fmt, pad_mode=pad_mode,
+                      center=center, verbose=False).to(DEV)
+    y = m(x)
+    w = torch.randn(y.shape, generator=g).to(DEV)
+    if fmt == "Phase":
+        # d atan2 ~ 1/|z|^2: weight only bins that carry energy, or fp32 noise in either
+        # implementation dominates the comparison
+        mag = m(x.detach(), output_format="Magnitude").detach()
+        w = w * (mag > 0.25 * mag.mean())
+    (y * w).sum().backward()
+    got = x.grad.clone(), m.wcos.grad.clone(), m.wsin.grad.clone()
+
+    x2 = x.detach().clone().requires_grad_(True)
+    wc, ws = m.wcos.detach().clone().requires_grad_(True), m.wsin.detach().clone().requires_grad_(True)
+    re, im = _torch_framed(x2, wc, ws, 160, 256 if center else 0, pad_mode)
+    if fmt == "Magnitude":
+        y2 = torch.sqrt(re ** 2 + im ** 2 + 1e-8)
+    elif fmt == "Complex":
+        y2 = torch.stack((re, -im), -1)
+    else:
+        y2 = torch.atan2(-im + 0.0, re)
+    if fmt != "Phase":  # (phase values: +pi / -pi at the real-valued DC / Nyquist bins)
+        assert (y - y2).abs().max().item() <= 1e-4 * max(1.0, y2.abs().max().item())
+    (y2 * w).sum().backward()
+    _grad_close(got[0], x2.grad, "d x")
+    _grad_close(got[1], wc.grad, "d wcos")
+    _grad_close(got[2], ws.grad, "d wsin")
+
+
+@pytest.mark.parametrize("fmt", ["Magnitude", "Complex", "Phase"])
+def test_backward_cqt1992v2(fmt):
+    from nnaudio_amd import features
+
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(2, 9000, generator=g).to(DEV).requires_grad_(True)
+    m = features.CQT1992v2(sr=8000, fmin=110, n_bins=36, hop_length=128, trainable=True,
+                           output_format=fmt, verbose=False).to(DEV)
+    y = m(x)
+    w = torch.randn(y.shape, generator=g).to(DEV)
+    (y * w).sum().backward()
+    got = x.grad.clone(), m.cqt_kernels_real.grad.clone(), m.cqt_kernels_imag.grad.clone()
+
+    x2 = x.detach().clone().requires_grad_(True)
+    kr = m.cqt_kernels_real.detach().clone().requires_grad_(True)
+    ki = m.cqt_kernels_imag.detach().clone().requires_grad_(True)
+    re, im = _torch_framed(x2, kr, ki, 128, m.kernel_width // 2, "reflect")
+    s = torch.sqrt(m.lenghts.view(-1, 1))
+    re, im = re * s, -im * s
+    if fmt == "Magnitude":
+        y2 = torch.sqrt(re ** 2 + im ** 2 + 1e-8)
+    elif fmt == "Complex":
+        y2 = torch.stack((re, im), -1)
+    else:
+        a = torch.atan2(im, re)
+        y2 = torch.stack((torch.cos(a), torch.sin(a)), -1)
+    (y2 * w).sum().backward()
+    _grad_close(got[0], x2.grad, "d x")
+    _grad_close(got[1], kr.grad, "d cqt_kernels_real")
+    _grad_close(got[2], ki.grad, "d cqt_kernels_imag")
+
+
+def test_backward_mel_and_frozen_front_end():
+    from nnaudio_amd import features
+
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(3, 5000, generator=g).to(DEV)
+    m = features.MelSpectrogram(sr=16000, n_fft=512, n_mels=40, hop_length=128, power=2.0,
+                                trainable_mel=True, trainable_STFT=True, verbose=False).to(DEV)
+    y = m(x)
+    w = torch.randn(y.shape, generator=g).to(DEV)
+    (y * w).sum().backward()
+    wc = m.stft.wcos.detach().clone().requires_grad_(True)
+    ws = m.stft.wsin.detach().clone().requires_grad_(True)
+    mb = m.mel_basis.detach().clone().requires_grad_(True)
+    re, im = _torch_framed(x, wc, ws, 128, 256, "reflect")
+    y2 = torch.matmul(mb, torch.sqrt(re ** 2 + im ** 2 + 1e-8) ** 2.0)
+    (y2 * w).sum().backward()
+    _grad_close(m.mel_basis.grad, mb.grad, "d mel_basis")
+    _grad_close(m.stft.wcos.grad, wc.grad, "d wcos")
+    _grad_close(m.stft.wsin.grad, ws.grad, "d wsin")
+    # a frozen front-end inside a training graph: gradient w.r.t. the waveform only
+    f = features.STFT(n_fft=256, hop_length=64, output_format="Magnitude", verbose=False).to(DEV)
+    xg = x.clone().requires_grad_(True)
+    f(xg).sum().backward()
+    x3 = x.clone().requires_grad_(True)
+    re, im = _torch_framed(x3, f.wcos, f.wsin, 64, 128, "reflect")
+    torch.sqrt(re ** 2 + im ** 2).sum().backward()
+    _grad_close(xg.grad, x3.grad, "d x (frozen STFT)")
+    # modules without a backward pass refuse instead of dropping the graph
+    q = features.CQT2010v2(sr=8000, fmin=220, n_bins=12, trainable=True, verbose=False).to(DEV)
+    with pytest.raises(NotImplementedError):
+        q(x)

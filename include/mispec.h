@@ -283,6 +283,13 @@ int mispec_fir_decimate_f32(const float *x, int64_t x_clip_stride, int32_t n_cli
                             int32_t n_out, void *workspace, int64_t workspace_bytes,
                             void *stream);
 
+/* Adjoint of mispec_fir_decimate_f32 with respect to the signal (backward of the octave
+ * recursion): dx[c, m] = sum_i dy[c, i] * taps[m + pad - i*stride], dx is (n_clips, n_samples). */
+int mispec_fir_decimate_bwd_f32(const float *dy, int64_t dy_clip_stride, int32_t n_clips,
+                                int32_t n_out, const float *taps, int32_t n_taps, int32_t stride,
+                                int32_t pad, float *dx, int64_t dx_clip_stride, int32_t n_samples,
+                                void *stream);
+
 /* Scratch bytes mispec_fir_decimate_f32 needs (zero-padded clip edges); negative = error. */
 int64_t mispec_fir_decimate_workspace_bytes(int32_t n_clips, int32_t n_samples, int32_t n_taps,
                                             int32_t stride, int32_t pad, int32_t n_out);

@@ -40,6 +40,7 @@ EXPORTS = (
     "mispec_overlap_add_f32",
     "mispec_fir_decimate_f32",
     "mispec_fir_decimate_workspace_bytes",
+    "mispec_fir_decimate_bwd_f32",
 )
 
 
@@ -193,6 +194,12 @@ def load():
     lib.mispec_power_to_db_f32.argtypes = [
         ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_float,
         ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+    ]
+    lib.mispec_fir_decimate_bwd_f32.restype = ctypes.c_int
+    lib.mispec_fir_decimate_bwd_f32.argtypes = [
+        ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+        ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64,
+        ctypes.c_int32, ctypes.c_void_p,
     ]
     lib.mispec_fir_decimate_f32.restype = ctypes.c_int
     lib.mispec_fir_decimate_f32.argtypes = [

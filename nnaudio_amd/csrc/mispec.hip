@@ -1380,6 +1380,28 @@ __global__ void __launch_bounds__(256) framed_epilogue_bwd_kernel(
   g[plane + o] = sc * im_sign * gv;
 }
 
+// adjoint of the strided FIR  y[i] = sum_n taps[n] * x[i*stride + n - pad]  (zero outside):
+//   dx[m] = sum_i dy[i] * taps[m + pad - i*stride]     (a gather: <= ceil(n_taps/stride) terms)
+__global__ void __launch_bounds__(256) fir_decimate_bwd_kernel(const float *__restrict__ dy,
+                                                               long long dy_clip_stride, int n_out,
+                                                               const float *__restrict__ taps,
+                                                               int n_taps, int stride, int pad, int L,
+                                                               float *__restrict__ dx,
+                                                               long long dx_clip_stride) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= L) return;
+  const int c = blockIdx.y;
+  const long long q = (long long)m + pad;  // tap index of output 0 at this sample
+  long long lo_num = q - n_taps + 1;
+  int i_lo = lo_num <= 0 ? 0 : (int)((lo_num + stride - 1) / stride);
+  int i_hi = (int)(q / stride);
+  i_hi = i_hi < n_out - 1 ? i_hi : n_out - 1;
+  const float *g = dy + (long long)c * dy_clip_stride;
+  float acc = 0.f;
+  for (int i = i_lo; i <= i_hi; ++i) acc += g[i] * taps[(int)(q - (long long)i * stride)];
+  dx[(long long)c * dx_clip_stride + m] = acc;
+}
+
 // ---------------------------------------------------------------------------------
 // power_to_db (MFCC, mel.py:263-279): HBM-bound pointwise pass with a per-clip maximum
 // ---------------------------------------------------------------------------------
@@ -1981,6 +2003,20 @@ int mispec_framed_epilogue_bwd_f32(const float *grad_out, const float *z, int32_
   hipLaunchKernelGGL(framed_epilogue_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), grad_out, z, n_clips, n_bins, n_frames, epilogue,
                      eps, power, im_sign, row_scale, g);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+
+int mispec_fir_decimate_bwd_f32(const float *dy, int64_t dy_clip_stride, int32_t n_clips, int32_t n_out,
+                                const float *taps, int32_t n_taps, int32_t stride, int32_t pad,
+                                float *dx, int64_t dx_clip_stride, int32_t n_samples, void *stream) {
+  if (!dy || !taps || !dx) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
+  if (n_clips <= 0 || n_out <= 0 || n_taps <= 0 || stride <= 0 || pad < 0 || n_samples <= 0)
+    return fail(MISPEC_E_INVALID, "non-positive size%s");
+  hipLaunchKernelGGL(fir_decimate_bwd_kernel, dim3((unsigned)((n_samples + 255) / 256), (unsigned)n_clips),
+                     dim3(256), 0, static_cast<hipStream_t>(stream), dy, (long long)dy_clip_stride, n_out,
+                     taps, n_taps, stride, pad, n_samples, dx, (long long)dx_clip_stride);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
   return MISPEC_OK;

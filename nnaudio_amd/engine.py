@@ -558,6 +558,43 @@ def filterbank_autograd(fb, spec):
     return filterbank(fb, spec)
 
 
+class _FirDecimateFn(torch.autograd.Function):
+    """Autograd wrapper of ``fir_decimate`` (gradient w.r.t. the signal; the anti-alias taps are
+    fixed buffers in the reference, cqt.py:947-954)."""
+
+    @staticmethod
+    def forward(ctx, x, taps, stride):
+        ctx.save_for_backward(taps)
+        ctx.stride, ctx.shape = int(stride), tuple(x.shape)
+        return fir_decimate(x, taps, stride)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (taps,) = ctx.saved_tensors
+        taps = _f32(taps.detach(), "filter").reshape(-1).contiguous()
+        go = _f32(grad_out, "grad_output").contiguous()
+        B, n_out = go.shape
+        L = ctx.shape[-1]
+        nt = taps.numel()
+        dx = torch.empty((B, L), dtype=torch.float32, device=go.device)
+        with torch.cuda.device(go.device):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(go.device).cuda_stream)
+            _abi.check(_abi.load().mispec_fir_decimate_bwd_f32(
+                go.data_ptr(), go.stride(0), B, n_out, taps.data_ptr(), nt, ctx.stride, (nt - 1) // 2,
+                dx.data_ptr(), dx.stride(0), L, stream))
+        return dx.reshape(ctx.shape), None, None
+
+
+def fir_decimate_autograd(x, taps, stride):
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _FirDecimateFn.apply(x, taps, stride)
+    return fir_decimate(x, taps, stride)
+
+
+def needs_grad(module, x):
+    return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in module.parameters()))
+
+
 def framed_gemm_autograd(x, basis_re, basis_im, **kw):
     """``framed_gemm`` that records a graph when the input or the bases require gradients."""
     if torch.is_grad_enabled() and (x.requires_grad or basis_re.requires_grad

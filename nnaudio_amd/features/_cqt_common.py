@@ -61,7 +61,7 @@ class SupportCache:
 
 
 def octave_recursion(x, banks, lenghts, hop, n_bins, lowpass, downsample_factor, pad_mode,
-                     output_format, normalization_type, trainable, supports=None):
+                     output_format, normalization_type, trainable, supports=None, graph=False):
     """Top-down octave loop.  ``banks[i] = (real_i, imag_i)`` (i = 0: top octave); each octave
     halves the signal with the anti-alias FIR kernel and halves the hop, and its framed
     contraction writes straight into its row block of the final ``(B, n_bins, T[, 2])``
@@ -78,10 +78,11 @@ def octave_recursion(x, banks, lenghts, hop, n_bins, lowpass, downsample_factor,
     xd = x
     T_ref = None
     launches = []  # the per-octave contractions are independent: one grouped launch at the end
+    blocks = []    # graph=True (training): per-octave outputs through autograd, concatenated
     for i, (kr, ki) in enumerate(banks):
         if i > 0:
             hop = hop // 2
-            xd = engine.fir_decimate(xd, lowpass, 2)
+            xd = engine.fir_decimate_autograd(xd, lowpass, 2) if graph else engine.fir_decimate(xd, lowpass, 2)
         K = kr.shape[-1]
         L = xd.shape[-1]
         pad = K // 2
@@ -119,17 +120,27 @@ def octave_recursion(x, banks, lenghts, hop, n_bins, lowpass, downsample_factor,
         sup = None
         if supports is not None and not trainable:
             sup = supports[i].get(kr, ki)[first:].contiguous()
+        if graph:
+            # the reference's own structure (cqt.py:1091-1105): one contraction per octave, rows
+            # concatenated with the lowest octave first
+            blocks.append((row0, engine.framed_gemm_autograd(
+                xd, kr_i, ki_i, hop=hop, pad=pad, pad_mode=mode, epilogue=epi, im_sign=-1.0,
+                eps=1e-8 if trainable else 0.0, row_scale=scale[row0:row0 + rows].contiguous(),
+                precision="fp32")))
+            continue
         launches.append((xd, kr_i, ki_i, dict(
             hop=hop, pad=pad, pad_mode=mode, epilogue=epi, im_sign=-1.0,
             eps=1e-8 if trainable else 0.0, row_scale=scale[row0:row0 + rows].contiguous(),
             row_support=sup, out=out, out_rows_total=n_bins, out_row_offset=row0,
             precision="fp32")))
+    if graph:
+        return torch.cat([b for _, b in sorted(blocks, key=lambda rb: rb[0])], 1)
     engine.framed_gemm_group(launches)
     return out
 
 
 def early_decimate(x, taps, factor):
-    return engine.fir_decimate(x, taps, int(factor))
+    return engine.fir_decimate_autograd(x, taps, int(factor))
 
 
 __all__ = ["output_epilogue", "normalisation_scale", "SupportCache", "octave_recursion",

@@ -202,7 +202,7 @@ class CQT2010v2(nn.Module):
     def forward(self, x, output_format=None, normalization_type="librosa"):
         output_format = output_format or self.output_format
         x = broadcast_dim(x)
-        engine.grad_guard(self, x)
+        graph = engine.needs_grad(self, x)
         if self.pad_mode not in ("constant", "reflect"):
             raise AttributeError("'CQT2010v2' object has no attribute 'padding'")
         if self.earlydownsample:
@@ -211,7 +211,7 @@ class CQT2010v2(nn.Module):
         return octave_recursion(
             x, banks, self.lenghts, self.hop_length, self.n_bins, self.lowpass_filter,
             self.downsample_factor, self.pad_mode, output_format, normalization_type,
-            self.trainable, supports=[self._support] * self.n_octaves,
+            self.trainable, supports=[self._support] * self.n_octaves, graph=graph,
         )
 
 

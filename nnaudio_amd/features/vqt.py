@@ -125,7 +125,7 @@ class VQT(nn.Module):
     def forward(self, x, output_format=None, normalization_type="librosa"):
         output_format = output_format or self.output_format
         x = broadcast_dim(x)
-        engine.grad_guard(self, x)
+        graph = engine.needs_grad(self, x)
         if self.pad_mode not in ("constant", "reflect"):
             raise UnboundLocalError("local variable 'my_padding' referenced before assignment")
         if self.earlydownsample:
@@ -138,5 +138,5 @@ class VQT(nn.Module):
         return octave_recursion(
             x, banks, self.lenghts, self.hop_length, self.n_bins, self.lowpass_filter,
             self.downsample_factor, self.pad_mode, output_format, normalization_type,
-            self.trainable, supports=self._supports,
+            self.trainable, supports=self._supports, graph=graph,
         )

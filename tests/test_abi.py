@@ -86,8 +86,8 @@ def test_cpu_tensors_fail_loudly():
 def test_trainable_needs_no_grad():
     from nnaudio_amd import features
 
-    # CQT2010v2 / VQT (octave recursion) have no backward pass yet: they must refuse to drop a graph
-    m = features.CQT2010v2(sr=8000, fmin=220, n_bins=12, trainable=True, verbose=False)
+    # MFCC's dB + DCT stage has no backward pass yet: it must refuse to drop a graph
+    m = features.MFCC(sr=8000, n_fft=256, n_mels=20, n_mfcc=8, trainable_mel=True, verbose=False)
     with pytest.raises(NotImplementedError):
         m(torch.zeros(1, 4096))
 

@@ -744,6 +744,65 @@ def test_backward_mel_and_frozen_front_end():
     torch.sqrt(re ** 2 + im ** 2).sum().backward()
     _grad_close(xg.grad, x3.grad, "d x (frozen STFT)")
     # modules without a backward pass refuse instead of dropping the graph
-    q = features.CQT2010v2(sr=8000, fmin=220, n_bins=12, trainable=True, verbose=False).to(DEV)
+    q = features.MFCC(sr=16000, n_fft=512, n_mels=40, trainable_mel=True, verbose=False).to(DEV)
     with pytest.raises(NotImplementedError):
         q(x)
+
+
+@pytest.mark.parametrize("cls,fmt", [("CQT2010v2", "Magnitude"), ("CQT2010v2", "Complex"),
+                                     ("VQT", "Magnitude")])
+def test_backward_octave_recursion(cls, fmt):
+    """CQT2010v2 (trainable top-octave kernels) / VQT (differentiable input) against torch autograd
+    on the reference's own structure: early down-sampling, per-octave conv1d pair, decimation by
+    the anti-alias FIR, cat, bottom cut, scaling (cqt.py:1070-1139, vqt.py:143-215)."""
+    import torch.nn.functional as F
+
+    from nnaudio_amd import features
+
+    g = torch.Generator().manual_seed(24)
+    x = torch.randn(2, 12000, generator=g).to(DEV).requires_grad_(True)
+    kw = dict(sr=16000, fmin=110, n_bins=40, hop_length=256, output_format=fmt, verbose=False)
+    if cls == "CQT2010v2":
+        m = features.CQT2010v2(trainable=True, **kw).to(DEV)
+        params = [m.cqt_kernels_real, m.cqt_kernels_imag]
+    else:
+        m = features.VQT(gamma=5, **kw).to(DEV)
+        params = []
+    y = m(x)
+    w = torch.randn(y.shape, generator=g).to(DEV)
+    (y * w).sum().backward()
+    got = [x.grad.clone()] + [p.grad.clone() for p in params]
+
+    x2 = x.detach().clone().requires_grad_(True)
+    p2 = [p.detach().clone().requires_grad_(True) for p in params]
+
+    def fir(sig, taps, stride):
+        return F.conv1d(sig, taps, stride=stride, padding=(taps.shape[-1] - 1) // 2)
+
+    def octave(sig, kr, ki, hop):
+        pad = kr.shape[-1] // 2
+        sp = F.pad(sig, (pad, pad), mode="reflect")
+        return torch.stack((F.conv1d(sp, kr, stride=hop), -F.conv1d(sp, ki, stride=hop)), -1)
+
+    sig = x2[:, None, :]
+    if m.earlydownsample and m.early_downsample_filter is not None:
+        sig = fir(sig, m.early_downsample_filter, int(m.downsample_factor))
+    hop = m.hop_length
+    banks = ([(p2[0], p2[1])] * m.n_octaves if cls == "CQT2010v2" else
+             [(getattr(m, "cqt_kernels_real_%d" % i), getattr(m, "cqt_kernels_imag_%d" % i))
+              for i in range(m.n_octaves)])
+    C = octave(sig, banks[0][0], banks[0][1], hop)
+    for i in range(1, m.n_octaves):
+        hop //= 2
+        sig = fir(sig, m.lowpass_filter, 2)
+        C = torch.cat((octave(sig, banks[i][0], banks[i][1], hop), C), 1)
+    C = C[:, -m.n_bins:] * m.downsample_factor * torch.sqrt(m.lenghts.view(-1, 1, 1))
+    if fmt == "Magnitude":
+        y2 = torch.sqrt(C.pow(2).sum(-1) + (1e-8 if cls == "CQT2010v2" else 0.0))
+    else:
+        y2 = C
+    assert (y - y2).abs().max().item() <= 1e-4 * y2.abs().max().item()
+    (y2 * w).sum().backward()
+    _grad_close(got[0], x2.grad, "d x")
+    for a, b, name in zip(got[1:], p2, ("d cqt_kernels_real", "d cqt_kernels_imag")):
+        _grad_close(a, b.grad, name)

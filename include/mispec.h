@@ -223,9 +223,8 @@ int mispec_contract_planar_f32(const mispec_planar_args *args, void *stream);
  * s = row_scale -- and out = E(u, v):
  *   mispec_framed_epilogue_bwd_f32: (grad_out, z = (u, v) as (B, F, T, 2)) -> g, laid out
  *       (2, F, B, T): g[0] = dL/dacc_re, g[1] = dL/dacc_im;
- *   d basis  = mispec_contract_planar_f32(a = g as (2F, B*T), x = padded signal, k_offsets =
- *       frame starts from mispec_frame_offsets_i64, columns = taps);
- *   d frames = mispec_contract_planar_f32(a = [basis_re^T | basis_im^T], x = g, rows_inner),
+ *   d basis and d frames: two more framed contractions (see mispec_frames_transpose_f32 below; or
+ *       mispec_contract_planar_f32 with a k-offset table from mispec_frame_offsets_i64);
  *   d signal = mispec_overlap_add_f32(window = NULL: plain overlap-add) then
  *       mispec_unpad_adjoint_f32 (mirrored positions of reflect padding folded back).
  * mispec_pad_signal_f32 materialises the (n_clips, n_samples + 2*pad) padded signal.
@@ -239,7 +238,16 @@ int mispec_frame_offsets_i64(int64_t *k_offsets, int32_t n_clips, int32_t n_fram
 int mispec_framed_epilogue_bwd_f32(const float *grad_out, const float *z, int32_t n_clips,
                                    int32_t n_bins, int32_t n_frames, int32_t epilogue, float eps,
                                    float power, float im_sign, const float *row_scale, float *g,
-                                   void *stream);
+                                   float *gt, void *stream);
+/* g (2, F, B, T) and / or gt (B, T, 2F) (one frame's gradient vector contiguous, [re | im]): with
+ * mispec_frames_transpose_f32 (xt[n, (c,t)] = xpad[c, t*hop + n], the frame matrix tap-major)
+ * both backward contractions become calls of the framed MFMA kernel itself:
+ *   d basis    = framed(signal = xt flat,  basis = g as (2F, B*T), hop = kernel = B*T, real)
+ *   d frames^T = framed(signal = gt flat,  basis = [re^T | im^T] (K, 2F), hop = kernel = 2F, real)
+ * and d signal = mispec_overlap_add_f32 on the tap-major d frames (window NULL, start = -1 - s). */
+int mispec_frames_transpose_f32(const float *xpad, int64_t clip_stride, int32_t n_clips,
+                                int32_t n_frames, int32_t hop, int32_t kernel, float *xt,
+                                void *stream);
 
 /*
  * Inverse STFT (STFTBase.inverse_stft, stft.py:15-63), two steps:

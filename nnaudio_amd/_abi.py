@@ -36,6 +36,7 @@ EXPORTS = (
     "mispec_unpad_adjoint_f32",
     "mispec_frame_offsets_i64",
     "mispec_framed_epilogue_bwd_f32",
+    "mispec_frames_transpose_f32",
     "mispec_istft_frames_f32",
     "mispec_overlap_add_f32",
     "mispec_fir_decimate_f32",
@@ -177,7 +178,12 @@ def load():
     lib.mispec_framed_epilogue_bwd_f32.argtypes = [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
         ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p,
-        ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+    ]
+    lib.mispec_frames_transpose_f32.restype = ctypes.c_int
+    lib.mispec_frames_transpose_f32.argtypes = [
+        ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+        ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
     ]
     lib.mispec_istft_frames_f32.restype = ctypes.c_int
     lib.mispec_istft_frames_f32.argtypes = [

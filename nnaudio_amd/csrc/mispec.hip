@@ -1247,10 +1247,24 @@ __global__ void __launch_bounds__(256) overlap_add_kernel(const float *__restric
                                                           const float *__restrict__ win, int N,
                                                           int hop, int n_frames, int start,
                                                           int out_len, float *__restrict__ out,
-                                                          long long out_clip_stride) {
+                                                          long long out_clip_stride,
+                                                          long long frames_t_cols) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= out_len) return;
   const int c = blockIdx.y;
+  if (frames_t_cols) {
+    // plain overlap-add of frames stored tap-major: frames[n, (c,t)], frames_t_cols = n_clips*T
+    const long long pos = (long long)i + start;
+    int t_hi = (int)(pos / hop);
+    t_hi = t_hi < n_frames - 1 ? t_hi : n_frames - 1;
+    const long long t_lo_num = pos - N + 1;
+    const int t_lo = t_lo_num <= 0 ? 0 : (int)((t_lo_num + hop - 1) / hop);
+    float acc = 0.f;
+    for (int t = t_lo; t <= t_hi; ++t)
+      acc += frames[(pos - (long long)t * hop) * frames_t_cols + (long long)c * n_frames + t];
+    out[(long long)c * out_clip_stride + i] = acc;
+    return;
+  }
   const long long pos = (long long)i + start;  // position in the un-trimmed overlap-add signal
   int t_hi = (int)(pos / hop);
   t_hi = t_hi < n_frames - 1 ? t_hi : n_frames - 1;
@@ -1311,6 +1325,36 @@ __global__ void __launch_bounds__(256) unpad_adjoint_kernel(const float *__restr
   dx[(long long)c * dx_clip_stride + i] = v;
 }
 
+// Frame matrix, transposed: xt[n, (c,t)] = xp[c, t*hop + n]  (n < N taps; (c,t) the flat frame
+// axis).  32x32 tiles through LDS: reads run along n (contiguous in xp), writes along t.
+__global__ void __launch_bounds__(256) frames_transpose_kernel(const float *__restrict__ xp,
+                                                               long long clip_stride, int n_frames,
+                                                               int hop, int N, long long n_cols,
+                                                               float *__restrict__ xt) {
+  __shared__ float tile[32][33];
+  const long long col0 = (long long)blockIdx.x * 32;  // flat frame index
+  const int n0 = blockIdx.y * 32;
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int r = ly; r < 32; r += 8) {
+    const long long col = col0 + r;
+    float v = 0.f;
+    if (col < n_cols && n0 + lx < N) {
+      const int c = (int)(col / n_frames);
+      const int t = (int)(col - (long long)c * n_frames);
+      v = xp[(long long)c * clip_stride + (long long)t * hop + n0 + lx];
+    }
+    tile[r][lx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = ly; r < 32; r += 8) {
+    const int n = n0 + r;
+    const long long col = col0 + lx;
+    if (n < N && col < n_cols) xt[(long long)n * n_cols + col] = tile[lx][r];
+  }
+}
+
 __global__ void __launch_bounds__(256) frame_offsets_kernel(long long *__restrict__ koff, int n_clips,
                                                             int n_frames, long long clip_stride,
                                                             int hop) {
@@ -1324,7 +1368,7 @@ __global__ void __launch_bounds__(256) frame_offsets_kernel(long long *__restric
 __global__ void __launch_bounds__(256) framed_epilogue_bwd_kernel(
     const float *__restrict__ go, const float *__restrict__ z, int n_clips, int n_bins, int n_frames,
     int epilogue, float eps, float power, float im_sign, const float *__restrict__ row_scale,
-    float *__restrict__ g) {
+    float *__restrict__ g, float *__restrict__ gt) {
   const long long total = (long long)n_clips * n_bins * n_frames;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
@@ -1376,8 +1420,15 @@ __global__ void __launch_bounds__(256) framed_epilogue_bwd_kernel(
   const float sc = row_scale ? row_scale[f] : 1.f;
   const long long plane = (long long)n_bins * n_clips * n_frames;
   const long long o = ((long long)f * n_clips + c) * n_frames + t;
-  g[o] = sc * gu;
-  g[plane + o] = sc * im_sign * gv;
+  if (g) {
+    g[o] = sc * gu;
+    g[plane + o] = sc * im_sign * gv;
+  }
+  if (gt) {  // (B, T, 2F): one frame's gradient vector contiguous, [re bins | im bins]
+    const long long ot = ((long long)c * n_frames + t) * (2LL * n_bins) + f;
+    gt[ot] = sc * gu;
+    gt[ot + n_bins] = sc * im_sign * gv;
+  }
 }
 
 // adjoint of the strided FIR  y[i] = sum_n taps[n] * x[i*stride + n - pad]  (zero outside):
@@ -1991,10 +2042,25 @@ int mispec_frame_offsets_i64(int64_t *k_offsets, int32_t n_clips, int32_t n_fram
   return MISPEC_OK;
 }
 
+int mispec_frames_transpose_f32(const float *xpad, int64_t clip_stride, int32_t n_clips,
+                                int32_t n_frames, int32_t hop, int32_t kernel, float *xt, void *stream) {
+  if (!xpad || !xt) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
+  if (n_clips <= 0 || n_frames <= 0 || hop <= 0 || kernel <= 0)
+    return fail(MISPEC_E_INVALID, "non-positive size%s");
+  const long long cols = (long long)n_clips * n_frames;
+  hipLaunchKernelGGL(frames_transpose_kernel, dim3((unsigned)((cols + 31) / 32), (unsigned)((kernel + 31) / 32)),
+                     dim3(256), 0, static_cast<hipStream_t>(stream), xpad, (long long)clip_stride, n_frames,
+                     hop, kernel, cols, xt);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+
 int mispec_framed_epilogue_bwd_f32(const float *grad_out, const float *z, int32_t n_clips, int32_t n_bins,
                                    int32_t n_frames, int32_t epilogue, float eps, float power,
-                                   float im_sign, const float *row_scale, float *g, void *stream) {
-  if (!grad_out || !z || !g) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
+                                   float im_sign, const float *row_scale, float *g, float *gt,
+                                   void *stream) {
+  if (!grad_out || !z || (!g && !gt)) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
   if (n_clips <= 0 || n_bins <= 0 || n_frames <= 0) return fail(MISPEC_E_INVALID, "non-positive size%s");
   if (epilogue < MISPEC_EPI_COMPLEX || epilogue > MISPEC_EPI_PHASE_COSSIN)
     return fail(MISPEC_E_INVALID, "bad epilogue%s");
@@ -2002,7 +2068,7 @@ int mispec_framed_epilogue_bwd_f32(const float *grad_out, const float *z, int32_
   if ((total + 255) / 256 > 0x7fffffffLL) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
   hipLaunchKernelGGL(framed_epilogue_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), grad_out, z, n_clips, n_bins, n_frames, epilogue,
-                     eps, power, im_sign, row_scale, g);
+                     eps, power, im_sign, row_scale, g, gt);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
   return MISPEC_OK;
@@ -2064,6 +2130,13 @@ int mispec_istft_frames_f32(const float *spec, int32_t n_clips, int32_t n_freq, 
 int mispec_overlap_add_f32(const float *frames, int32_t n_clips, int32_t n_frames, int32_t n_fft,
                            const float *window, int32_t hop, int32_t start, float *out,
                            int64_t out_clip_stride, int32_t out_len, void *stream) {
+  // start < 0 (with window == NULL) flags tap-major frames (n_fft, n_clips*n_frames); the
+  // overlap-add then starts at sample -(start + 1)
+  const bool transposed = start < 0;
+  if (transposed) {
+    if (window) return fail(MISPEC_E_INVALID, "tap-major frames need window == NULL%s");
+    start = -(start + 1);
+  }
   if (!frames || !out) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
   if (n_clips <= 0 || n_frames <= 0 || n_fft <= 0 || hop <= 0 || out_len <= 0 || start < 0)
     return fail(MISPEC_E_INVALID, "non-positive size%s");
@@ -2071,7 +2144,8 @@ int mispec_overlap_add_f32(const float *frames, int32_t n_clips, int32_t n_frame
     return fail(MISPEC_E_INVALID, "output range exceeds the overlap-add signal%s");
   hipLaunchKernelGGL(overlap_add_kernel, dim3((unsigned)((out_len + 255) / 256), (unsigned)n_clips),
                      dim3(256), 0, static_cast<hipStream_t>(stream), frames, window, n_fft, hop,
-                     n_frames, start, out_len, out, (long long)out_clip_stride);
+                     n_frames, start < 0 ? 0 : start, out_len, out, (long long)out_clip_stride,
+                     transposed ? (long long)n_clips * n_frames : 0LL);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
   return MISPEC_OK;

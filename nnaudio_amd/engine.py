@@ -477,42 +477,55 @@ class _FramedGemmFn(torch.autograd.Function):
         z = framed_gemm(xs, wr, wi, **zkw)
         T = z.shape[2]
         go = _f32(grad_out, "grad_output").contiguous()
-        g = torch.empty((2, F, B, T), dtype=torch.float32, device=dev)
+        need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        need_x = ctx.needs_input_grad[0]
+        # G = (dL/dacc_re, dL/dacc_im): bin-major (2, F, B, T) for d basis, frame-major
+        # (B, T, 2F) for d signal -- the layouts in which each is the "basis" / the "signal" of
+        # another framed contraction on the MFMA kernel
+        g = torch.empty((2, F, B, T), dtype=torch.float32, device=dev) if need_w else None
+        gt = torch.empty((B, T, 2 * F), dtype=torch.float32, device=dev) if need_x else None
         with torch.cuda.device(dev):
             stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             _abi.check(lib.mispec_framed_epilogue_bwd_f32(
                 go.data_ptr(), z.data_ptr(), B, F, T, int(kw["epilogue"]), float(kw.get("eps", 0.0)),
                 float(kw.get("power", 2.0)), im_sign,
-                scale.data_ptr() if scale is not None else None, g.data_ptr(), stream))
+                scale.data_ptr() if scale is not None else None,
+                g.data_ptr() if g is not None else None, gt.data_ptr() if gt is not None else None,
+                stream))
         del z
         gx = gre = gim = None
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            Lp = L + 2 * pad
+        Lp = L + 2 * pad
+        BT = B * T
+        if need_w:
+            # d basis[row, n] = sum_{(b,t)} g[row, (b,t)] * xp[b, t*hop + n]: with the frame matrix
+            # stored tap-major (xt[n, (b,t)]) this is the framed contraction of the "signal" xt
+            # (frame n = its row n: hop = kernel = B*T) with the "basis" g
             xp = torch.empty((B, Lp), dtype=torch.float32, device=dev)
-            koff = torch.empty(B * T, dtype=torch.int64, device=dev)
+            xt = torch.empty((K, BT), dtype=torch.float32, device=dev)
             with torch.cuda.device(dev):
                 _abi.check(lib.mispec_pad_signal_f32(xs.data_ptr(), xs.stride(0), B, L, pad, pad_mode,
                                                      xp.data_ptr(), stream))
-                _abi.check(lib.mispec_frame_offsets_i64(koff.data_ptr(), B, T, Lp, hop, stream))
-            # d basis[row, n] = sum_{(b,t)} g[row, (b,t)] * xp[b, t*hop + n]
-            dw = contract_planar(g.reshape(2 * F, B * T), xp, k=B * T, n_clips=1, n_cols=K,
-                                 x_clip_stride=0, k_offsets=koff)[0]
+                _abi.check(lib.mispec_frames_transpose_f32(xp.data_ptr(), Lp, B, T, hop, K,
+                                                           xt.data_ptr(), stream))
+            dw = framed_gemm(xt.reshape(1, K * BT), g.reshape(2 * F, BT), None, hop=BT, pad=0,
+                             pad_mode=PAD_NONE, epilogue=EPI_REAL, im_sign=1.0, precision="fp32")[0]
             gre = dw[:F].reshape(basis_re.shape)
             gim = dw[F:].reshape(basis_im.shape)
-        if ctx.needs_input_grad[0]:
-            # d frames[b, t, n] = sum_f g_re[f,b,t]*w_re[f,n] + g_im[f,b,t]*w_im[f,n]
+            del xp, xt
+        if need_x:
+            # d frames[(b,t), n] = sum_f g_re*w_re[f,n] + g_im*w_im[f,n]: the framed contraction of
+            # the "signal" gt (frame (b,t) = its row: hop = kernel = 2F) with the "basis"
+            # [w_re^T | w_im^T]; the result comes out tap-major (K, B*T)
             bt = torch.cat((wr.t(), wi.t()), 1).contiguous()  # (K, 2F)
-            frames = contract_planar(bt, g, k=2 * F, n_clips=B, n_cols=T, x_clip_stride=T,
-                                     x_k_stride=B * T, k_split=F, k_split_off=F * B * T,
-                                     rows_inner=True)  # (B, T, K)
-            Lp = L + 2 * pad
+            ft = framed_gemm(gt.reshape(1, BT * 2 * F), bt, None, hop=2 * F, pad=0, pad_mode=PAD_NONE,
+                             epilogue=EPI_REAL, im_sign=1.0, precision="fp32")[0]  # (K, BT)
             dxp = torch.empty((B, Lp), dtype=torch.float32, device=dev)
             dx = torch.empty((B, L), dtype=torch.float32, device=dev)
             cover = (T - 1) * hop + K  # samples the frames reach; the rest of the padded signal gets 0
             with torch.cuda.device(dev):
                 if cover < Lp:
                     dxp.zero_()
-                _abi.check(lib.mispec_overlap_add_f32(frames.data_ptr(), B, T, K, None, hop, 0,
+                _abi.check(lib.mispec_overlap_add_f32(ft.data_ptr(), B, T, K, None, hop, -1,
                                                       dxp.data_ptr(), dxp.stride(0), min(cover, Lp),
                                                       stream))
                 _abi.check(lib.mispec_unpad_adjoint_f32(dxp.data_ptr(), B, L, pad, pad_mode,

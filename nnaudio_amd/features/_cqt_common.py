@@ -61,13 +61,15 @@ class SupportCache:
 
 
 def octave_recursion(x, banks, lenghts, hop, n_bins, lowpass, downsample_factor, pad_mode,
-                     output_format, normalization_type, trainable, supports=None, graph=False):
+                     output_format, normalization_type, trainable, supports=None, graph=False,
+                     scale=None, im_sign=-1.0):
     """Top-down octave loop.  ``banks[i] = (real_i, imag_i)`` (i = 0: top octave); each octave
     halves the signal with the anti-alias FIR kernel and halves the hop, and its framed
     contraction writes straight into its row block of the final ``(B, n_bins, T[, 2])``
     tensor (the reference's growing ``torch.cat`` is gone)."""
     epi = output_epilogue(output_format)
-    scale = normalisation_scale(lenghts, normalization_type, downsample_factor)
+    if scale is None:
+        scale = normalisation_scale(lenghts, normalization_type, downsample_factor)
     if epi is None:
         return None
     n_oct = len(banks)
@@ -124,12 +126,12 @@ def octave_recursion(x, banks, lenghts, hop, n_bins, lowpass, downsample_factor,
             # the reference's own structure (cqt.py:1091-1105): one contraction per octave, rows
             # concatenated with the lowest octave first
             blocks.append((row0, engine.framed_gemm_autograd(
-                xd, kr_i, ki_i, hop=hop, pad=pad, pad_mode=mode, epilogue=epi, im_sign=-1.0,
+                xd, kr_i, ki_i, hop=hop, pad=pad, pad_mode=mode, epilogue=epi, im_sign=im_sign,
                 eps=1e-8 if trainable else 0.0, row_scale=scale[row0:row0 + rows].contiguous(),
                 precision="fp32")))
             continue
         launches.append((xd, kr_i, ki_i, dict(
-            hop=hop, pad=pad, pad_mode=mode, epilogue=epi, im_sign=-1.0,
+            hop=hop, pad=pad, pad_mode=mode, epilogue=epi, im_sign=im_sign,
             eps=1e-8 if trainable else 0.0, row_scale=scale[row0:row0 + rows].contiguous(),
             row_support=sup, out=out, out_rows_total=n_bins, out_row_offset=row0,
             precision="fp32")))

@@ -246,6 +246,19 @@ def main():
     case("istft_class_twosided", "iSTFT", dict(n_fft=512, hop_length=128), "X_512_128_full")
     case("istft_class_hamming_len", "iSTFT", dict(n_fft=512, hop_length=100, window="hamming"),
          "X_512_100_hamming", fwd=dict(onesided=True, length=8000))
+    # frequency-domain CQT variants
+    for fmt in ("Magnitude", "Complex", "Phase"):
+        case("cqt1992_fd_%s" % fmt.lower(), "CQT1992",
+             dict(sr=22050, fmin=220, n_bins=48, hop_length=256, output_format=fmt), "x_1s22k")
+    case("cqt1992_fd_wrap_constpad", "CQT1992",
+         dict(sr=16000, fmin=110, n_bins=36, hop_length=128, pad_mode="constant"), "x_short",
+         fwd=dict(normalization_type="wrap"))
+    for fmt in ("Magnitude", "Complex", "Phase"):
+        case("cqt2010_fd_%s" % fmt.lower(), "CQT2010",
+             dict(sr=22050, fmin=55, n_bins=60, output_format=fmt), "x_1s22k")
+    case("cqt2010_fd_noearly_conv", "CQT2010",
+         dict(sr=16000, fmin=110, n_bins=40, hop_length=256, earlydownsample=False), "x_short",
+         fwd=dict(normalization_type="convolutional"))
     case("bufonly_cqt_testgrid", "CQT1992v2",
          dict(sr=44100, fmin=55, n_bins=207, bins_per_octave=24), None, attrs=cqt_attrs)
     case("bufonly_gamma_44k", "Gammatonegram", dict(sr=44100, n_fft=2048, n_bins=64), None)
@@ -256,7 +269,12 @@ def main():
     for c in C:
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            mod = getattr(R, c["cls"])(verbose=False, **c["ctor"])
+            import contextlib
+            import io
+
+            with contextlib.redirect_stdout(io.StringIO()):  # CQT1992 has no `verbose` switch
+                kwv = {} if c["cls"] == "CQT1992" else {"verbose": False}
+                mod = getattr(R, c["cls"])(**kwv, **c["ctor"])
         entry = dict(name=c["name"], cls=c["cls"], ctor=c["ctor"], fwd=c["fwd"], input=c["input"])
         if c["method"] != "forward":
             entry["method"] = c["method"]

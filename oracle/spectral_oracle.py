@@ -380,3 +380,79 @@ def istft(X, kernel_cos, kernel_sin, window, n_fft, hop, center=True, onesided=T
     if length is None:
         return y[:, pad:full - pad] if center else y
     return y[:, pad:pad + length] if center else y[:, :length]
+
+
+def _complex_kernel_product(kr, ki, fr, fi):
+    """complex_mul (utils.py:175-203): (kr + j ki) @ (fr + j fi) over the frequency axis."""
+    kr = np.asarray(kr, dtype=np.float64)
+    ki = np.asarray(ki, dtype=np.float64)
+    return (np.einsum("kf,bft->bkt", kr, fr) - np.einsum("kf,bft->bkt", ki, fi),
+            np.einsum("kf,bft->bkt", kr, fi) + np.einsum("kf,bft->bkt", ki, fr))
+
+
+def _freq_domain_cqt(x, wsin, wcos, kr, ki, hop, pad_mode, center=True, warn_fallback=False):
+    """get_cqt_complex2 with STFT kernels (utils.py:524-559) / the body of CQT1992.forward
+    (cqt.py:204-221): un-windowed STFT of size K, then the complex kernel product."""
+    wsin = np.asarray(wsin).reshape(wsin.shape[0], -1)
+    wcos = np.asarray(wcos).reshape(wcos.shape[0], -1)
+    K = wsin.shape[-1]
+    if center:
+        if warn_fallback and pad_mode == "reflect" and K // 2 >= x.shape[-1]:
+            xp = pad_signal(x, K // 2, "constant")
+        else:
+            xp = pad_signal(x, K // 2, pad_mode)
+    else:
+        xp = x
+    fr = correlate_strided(xp, wcos, hop, np.float64)
+    fi = correlate_strided(xp, wsin, hop, np.float64)
+    return _complex_kernel_product(kr, ki, fr, fi)
+
+
+def _cqt_freq_norm(lenghts, width, normalization_type):
+    lenghts = np.asarray(lenghts, dtype=np.float64)
+    if normalization_type == "librosa":
+        return np.sqrt(lenghts) / width
+    if normalization_type == "convolutional":
+        return np.ones_like(lenghts)
+    if normalization_type == "wrap":
+        return np.full_like(lenghts, 2.0 / width)
+    raise ValueError("The normalization_type %r is not part of our current options." % normalization_type)
+
+
+def cqt1992(x, wsin, wcos, kr, ki, lenghts, hop, center=True, pad_mode="reflect",
+            output_format="Magnitude", normalization_type="librosa"):
+    """CQT1992.forward [cqt.py:189-254]."""
+    x = broadcast_dim(x)
+    re, im = _freq_domain_cqt(x, wsin, wcos, kr, ki, hop, pad_mode, center)
+    s = _cqt_freq_norm(lenghts, np.asarray(wsin).shape[-1], normalization_type)[None, :, None]
+    if output_format == "Magnitude":
+        return np.sqrt((re * s) ** 2 + (im * s) ** 2).astype(np.float32)
+    if output_format == "Complex":
+        return np.stack((re * s, -im * s), -1).astype(np.float32)
+    a = np.arctan2(im, re)  # the reference takes the phase of the un-negated, un-normalised pair
+    return np.stack((np.cos(a), np.sin(a)), -1).astype(np.float32)
+
+
+def cqt2010(x, wsin, wcos, kr, ki, lenghts, hop, n_bins, n_octaves, lowpass, early_taps=None,
+            downsample_factor=1, pad_mode="reflect", output_format="Magnitude",
+            normalization_type="librosa"):
+    """CQT2010.forward [cqt.py:481-555]."""
+    x = broadcast_dim(x)
+    if early_taps is not None:
+        x = fir_decimate(x, early_taps, int(downsample_factor))
+    blocks = []
+    xd = x
+    for i in range(n_octaves):
+        if i > 0:
+            hop = hop // 2
+            xd = fir_decimate(xd, lowpass, 2)
+        re, im = _freq_domain_cqt(xd, wsin, wcos, kr, ki, hop, pad_mode, True, warn_fallback=True)
+        blocks.insert(0, np.stack((re, im), -1))
+    C = np.concatenate(blocks, 1)[:, -n_bins:]
+    C = C * _cqt_freq_norm(lenghts, np.asarray(wsin).shape[-1], normalization_type)[None, :, None, None]
+    if output_format == "Magnitude":
+        return np.sqrt((C ** 2).sum(-1)).astype(np.float32)
+    if output_format == "Complex":
+        return C.astype(np.float32)
+    a = np.arctan2(C[..., 1], C[..., 0])
+    return np.stack((np.cos(a), np.sin(a)), -1).astype(np.float32)

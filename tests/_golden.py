@@ -44,7 +44,12 @@ def build_module(case, device=None):
 
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        mod = getattr(features, case["cls"])(verbose=False, **case["ctor"])
+        import contextlib
+        import io
+
+        with contextlib.redirect_stdout(io.StringIO()):  # CQT1992 has no `verbose` switch
+            kwv = {} if case["cls"] == "CQT1992" else {"verbose": False}
+            mod = getattr(features, case["cls"])(**kwv, **case["ctor"])
     if device is not None:
         mod = mod.to(device)
     return mod
@@ -87,6 +92,19 @@ def oracle_forward(mod, case, x):
                       ref=float(sd["ref"][0]), top_db=mod.top_db, power=ctor.get("power", 2.0),
                       center=ctor.get("center", True), pad_mode=ctor.get("pad_mode", "reflect"))
     fmt = fmt or "Magnitude"
+    if cls == "CQT1992":
+        return O.cqt1992(x, sd["wsin"], sd["wcos"], sd["cqt_kernels_real"], sd["cqt_kernels_imag"],
+                         sd["lenghts"], mod.hop_length, center=ctor.get("center", True),
+                         pad_mode=ctor.get("pad_mode", "reflect"), output_format=fmt,
+                         normalization_type=norm)
+    if cls == "CQT2010":
+        early = sd.get("early_downsample_filter") if mod.earlydownsample else None
+        return O.cqt2010(x, sd["wsin"], sd["wcos"], sd["cqt_kernels_real"], sd["cqt_kernels_imag"],
+                         sd["lenghts"], mod.hop_length, mod.n_bins, mod.n_octaves,
+                         sd["lowpass_filter"], early_taps=early,
+                         downsample_factor=mod.downsample_factor,
+                         pad_mode=ctor.get("pad_mode", "reflect"), output_format=fmt,
+                         normalization_type=norm)
     if cls in ("CQT1992v2", "CQT"):
         return O.cqt1992v2(x, sd["cqt_kernels_real"], sd["cqt_kernels_imag"], sd["lenghts"],
                            mod.hop_length, center=ctor.get("center", True),

@@ -280,6 +280,13 @@ int mispec_power_to_db_f32(const float *spec, int32_t n_clips, int64_t clip_elem
                            float ref, float top_db, float *out, void *workspace,
                            int64_t workspace_bytes, void *stream);
 
+/* Backward of mispec_power_to_db_f32 with respect to spec: elements above the per-clip floor pass
+ * grad_out * 10 / (ln 10 * spec) (0 where spec <= amin); the floored ones hand their gradient to
+ * the clip maximum.  workspace: n_clips * 8 bytes. */
+int mispec_power_to_db_bwd_f32(const float *spec, const float *grad_out, int32_t n_clips,
+                               int64_t clip_elems, float amin, float top_db, float *grad_spec,
+                               void *workspace, int64_t workspace_bytes, void *stream);
+
 /*
  * Strided FIR decimation  y[c, i] = sum_{n<n_taps} taps[n] * x[c, i*stride + n - pad]
  * with zeros outside the signal (F.conv1d(x, taps, stride, padding=pad),

@@ -31,6 +31,7 @@ EXPORTS = (
     "mispec_split_basis_bf16",
     "mispec_filterbank_f32",
     "mispec_power_to_db_f32",
+    "mispec_power_to_db_bwd_f32",
     "mispec_contract_planar_f32",
     "mispec_pad_signal_f32",
     "mispec_unpad_adjoint_f32",
@@ -195,6 +196,11 @@ def load():
         ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
         ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
         ctypes.c_void_p,
+    ]
+    lib.mispec_power_to_db_bwd_f32.restype = ctypes.c_int
+    lib.mispec_power_to_db_bwd_f32.argtypes = [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float,
+        ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
     ]
     lib.mispec_power_to_db_f32.restype = ctypes.c_int
     lib.mispec_power_to_db_f32.argtypes = [

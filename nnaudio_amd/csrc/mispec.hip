@@ -1493,6 +1493,47 @@ __global__ void __launch_bounds__(256) power_to_db_kernel(const float *__restric
   }
 }
 
+// power_to_db backward.  Elements above the per-clip floor pass their gradient through the
+// logarithm; the floored ones hand theirs to the clip maximum (out = max(l, max(l) - top_db)).
+__global__ void __launch_bounds__(256) power_to_db_floor_sum_kernel(
+    const float *__restrict__ spec, const float *__restrict__ go, long long clip_elems, float amin,
+    float top_db, const unsigned *__restrict__ wmax, float *__restrict__ wsum) {
+  const int c = blockIdx.y;
+  const long long base = (long long)c * clip_elems;
+  const float lmax = 10.0f * log10f(__uint_as_float(wmax[c]));
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < clip_elems;
+       i += (long long)gridDim.x * 256) {
+    const float l = 10.0f * log10f(fmaxf(spec[base + i], amin));
+    if (l < lmax - top_db) acc += go[base + i];
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+  if ((threadIdx.x & 63) == 0 && acc != 0.f) atomicAdd(&wsum[c], acc);
+}
+
+__global__ void __launch_bounds__(256) power_to_db_bwd_kernel(
+    const float *__restrict__ spec, const float *__restrict__ go, long long clip_elems, float amin,
+    float top_db, const unsigned *__restrict__ wmax, const float *__restrict__ wsum,
+    float *__restrict__ gs) {
+  const int c = blockIdx.y;
+  const long long base = (long long)c * clip_elems;
+  const float smax = top_db >= 0.f ? __uint_as_float(wmax[c]) : 0.f;
+  const float lmax = top_db >= 0.f ? 10.0f * log10f(smax) : 0.f;
+  const float k = 4.3429448190325175f;  // 10 / ln(10)
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < clip_elems;
+       i += (long long)gridDim.x * 256) {
+    const float sv = spec[base + i];
+    float g = go[base + i];
+    if (top_db >= 0.f) {
+      const float sc = fmaxf(sv, amin);
+      if (10.0f * log10f(sc) < lmax - top_db) g = 0.f;
+      if (sc == smax) g += wsum[c];
+    }
+    gs[base + i] = sv > amin ? g * k / sv : 0.f;
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // MISPEC_PREC_BF16X3 host side
 // ---------------------------------------------------------------------------------
@@ -2170,6 +2211,33 @@ int mispec_power_to_db_f32(const float *spec, int32_t n_clips, int64_t clip_elem
   }
   hipLaunchKernelGGL(power_to_db_kernel, grid, dim3(256), 0, s, spec, (long long)clip_elems, amin,
                      fabsf(ref), top_db, wmax, out);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+
+int mispec_power_to_db_bwd_f32(const float *spec, const float *grad_out, int32_t n_clips,
+                               int64_t clip_elems, float amin, float top_db, float *grad_spec,
+                               void *workspace, int64_t workspace_bytes, void *stream) {
+  if (!spec || !grad_out || !grad_spec) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
+  if (n_clips <= 0 || clip_elems <= 0) return fail(MISPEC_E_INVALID, "non-positive size%s");
+  if (!(amin > 0.f)) return fail(MISPEC_E_INVALID, "amin must be strictly positive%s");
+  if (!workspace || workspace_bytes < (int64_t)n_clips * 8)
+    return fail(MISPEC_E_INVALID, "workspace too small: n_clips * 8 bytes%s");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  unsigned *wmax = static_cast<unsigned *>(workspace);
+  float *wsum = reinterpret_cast<float *>(wmax + n_clips);
+  long long bx = (clip_elems + 256 * 8 - 1) / (256 * 8);
+  bx = bx < 1 ? 1 : (bx > 1024 ? 1024 : bx);
+  const dim3 grid((unsigned)bx, (unsigned)n_clips);
+  if (top_db >= 0.f) {
+    hipLaunchKernelGGL(clear_u32_kernel, dim3((2 * n_clips + 255) / 256), dim3(256), 0, s, wmax, 2 * n_clips);
+    hipLaunchKernelGGL(clip_max_kernel, grid, dim3(256), 0, s, spec, (long long)clip_elems, amin, wmax);
+    hipLaunchKernelGGL(power_to_db_floor_sum_kernel, grid, dim3(256), 0, s, spec, grad_out,
+                       (long long)clip_elems, amin, top_db, wmax, wsum);
+  }
+  hipLaunchKernelGGL(power_to_db_bwd_kernel, grid, dim3(256), 0, s, spec, grad_out, (long long)clip_elems,
+                     amin, top_db, wmax, wsum, grad_spec);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
   return MISPEC_OK;

@@ -383,6 +383,38 @@ def power_to_db(spec, amin, ref, top_db):
     return out
 
 
+class _PowerToDbFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, spec, amin, ref, top_db):
+        ctx.save_for_backward(spec)
+        ctx.meta = (float(amin), top_db)
+        return power_to_db(spec, amin, ref, top_db)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (spec,) = ctx.saved_tensors
+        spec = _f32(spec.detach(), "spectrogram").contiguous()
+        go = _f32(grad_out, "grad_output").contiguous()
+        amin, top_db = ctx.meta
+        B = spec.shape[0]
+        gs = torch.empty_like(spec)
+        ws = torch.empty(2 * B, dtype=torch.int32, device=spec.device)
+        with torch.cuda.device(spec.device):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(spec.device).cuda_stream)
+            _abi.check(_abi.load().mispec_power_to_db_bwd_f32(
+                spec.data_ptr(), go.data_ptr(), B, spec[0].numel(), amin,
+                -1.0 if top_db is None else float(top_db), gs.data_ptr(), ws.data_ptr(), 8 * B, stream))
+        return gs, None, None, None
+
+
+def power_to_db_autograd(spec, amin, ref, top_db):
+    if torch.is_grad_enabled() and spec.requires_grad:
+        if top_db is not None and top_db < 0:
+            raise ValueError("top_db must be non-negative")
+        return _PowerToDbFn.apply(spec, amin, ref, top_db)
+    return power_to_db(spec, amin, ref, top_db)
+
+
 def fir_decimate(x, taps, stride):
     """conv1d(x, taps, stride=stride, padding=(len-1)//2)  [utils.py:73-124] -> (B, n_out)."""
     dev = _require_device(x, taps)

@@ -114,12 +114,11 @@ class MFCC(nn.Module):
                              persistent=False)
 
     def forward(self, x):
-        engine.grad_guard(self, x)  # no backward through power_to_db / the DCT yet
         spec = self.melspec_layer(x)
         if self.top_db is not None and self.top_db < 0:
             raise ParameterError("top_db must be non-negative")
-        db = engine.power_to_db(spec, float(self.amin), float(self.ref), self.top_db)
-        return engine.filterbank(self._dct_basis, db)
+        db = engine.power_to_db_autograd(spec, float(self.amin), float(self.ref), self.top_db)
+        return engine.filterbank_autograd(self._dct_basis, db)
 
     def extra_repr(self) -> str:
         return "n_mfcc = {}".format((self.n_mfcc))

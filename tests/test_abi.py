@@ -86,10 +86,10 @@ def test_cpu_tensors_fail_loudly():
 def test_trainable_needs_no_grad():
     from nnaudio_amd import features
 
-    # MFCC's dB + DCT stage has no backward pass yet: it must refuse to drop a graph
-    m = features.MFCC(sr=8000, n_fft=256, n_mels=20, n_mfcc=8, trainable_mel=True, verbose=False)
+    # the inverse STFT has no backward pass yet: it must refuse to drop a graph
+    m = features.iSTFT(n_fft=64, hop_length=16, trainable_kernels=True, verbose=False)
     with pytest.raises(NotImplementedError):
-        m(torch.zeros(1, 4096))
+        m(torch.zeros(1, 33, 8, 2))
 
 
 def test_legacy_import_shim_warns():

@@ -744,9 +744,37 @@ def test_backward_mel_and_frozen_front_end():
     torch.sqrt(re ** 2 + im ** 2).sum().backward()
     _grad_close(xg.grad, x3.grad, "d x (frozen STFT)")
     # modules without a backward pass refuse instead of dropping the graph
-    q = features.MFCC(sr=16000, n_fft=512, n_mels=40, trainable_mel=True, verbose=False).to(DEV)
+    q = features.iSTFT(n_fft=64, hop_length=16, trainable_kernels=True, verbose=False).to(DEV)
     with pytest.raises(NotImplementedError):
-        q(x)
+        q(torch.zeros(1, 33, 8, 2, device=DEV))
+
+
+@pytest.mark.parametrize("top_db", [80.0, 20.0, None])
+def test_backward_mfcc(top_db):
+    from nnaudio_amd import features
+
+    g = torch.Generator().manual_seed(25)
+    x = torch.randn(3, 6000, generator=g).to(DEV)
+    m = features.MFCC(sr=16000, n_mfcc=13, n_fft=512, n_mels=40, hop_length=160, top_db=top_db,
+                      trainable_mel=True, trainable_STFT=True, verbose=False).to(DEV)
+    y = m(x)
+    w = torch.randn(y.shape, generator=g).to(DEV)
+    (y * w).sum().backward()
+    ml = m.melspec_layer
+    wc = ml.stft.wcos.detach().clone().requires_grad_(True)
+    ws = ml.stft.wsin.detach().clone().requires_grad_(True)
+    mb = ml.mel_basis.detach().clone().requires_grad_(True)
+    re, im = _torch_framed(x, wc, ws, 160, 256, "reflect")
+    S = torch.matmul(mb, torch.sqrt(re ** 2 + im ** 2 + 1e-8) ** 2.0)
+    L = 10.0 * torch.log10(torch.max(S, m.amin)) - 10.0 * torch.log10(torch.max(m.amin, m.ref))
+    if top_db is not None:
+        L = torch.max(L, L.flatten(1).max(1)[0][:, None, None] - top_db)
+    y2 = torch.matmul(m._dct_basis, L)
+    assert (y - y2).abs().max().item() <= 1e-4 * y2.abs().max().item()
+    (y2 * w).sum().backward()
+    _grad_close(ml.mel_basis.grad, mb.grad, "d mel_basis", rel=5e-4)
+    _grad_close(ml.stft.wcos.grad, wc.grad, "d wcos", rel=5e-4)
+    _grad_close(ml.stft.wsin.grad, ws.grad, "d wsin", rel=5e-4)
 
 
 @pytest.mark.parametrize("cls,fmt", [("CQT2010v2", "Magnitude"), ("CQT2010v2", "Complex"),

@@ -280,6 +280,15 @@ int mispec_power_to_db_f32(const float *spec, int32_t n_clips, int64_t clip_elem
                            float ref, float top_db, float *out, void *workspace,
                            int64_t workspace_bytes, void *stream);
 
+/* Backward of mispec_overlap_add_f32 (windowed form) w.r.t. the frame sum:
+ *   u[c, p] = grad_out[c, p - start] / (n_fft * wss[p])  for p in [start, start + out_len), else 0
+ * over the un-trimmed axis p in [0, (n_frames-1)*hop + n_fft); u is (n_clips, that length).  The
+ * gradient of the spectrogram is then mispec_framed_gemm_f32 of u (no padding) with the
+ * window-weighted transposed synthesis basis. */
+int mispec_istft_grad_signal_f32(const float *grad_out, int64_t grad_clip_stride, int32_t n_clips,
+                                 int32_t n_frames, int32_t n_fft, const float *window, int32_t hop,
+                                 int32_t start, int32_t out_len, float *u, void *stream);
+
 /* Backward of mispec_power_to_db_f32 with respect to spec: elements above the per-clip floor pass
  * grad_out * 10 / (ln 10 * spec) (0 where spec <= amin); the floored ones hand their gradient to
  * the clip maximum.  workspace: n_clips * 8 bytes. */

@@ -30,6 +30,7 @@ EXPORTS = (
     "mispec_basis_split_bytes",
     "mispec_split_basis_bf16",
     "mispec_filterbank_f32",
+    "mispec_istft_grad_signal_f32",
     "mispec_power_to_db_f32",
     "mispec_power_to_db_bwd_f32",
     "mispec_contract_planar_f32",
@@ -195,6 +196,12 @@ def load():
     lib.mispec_overlap_add_f32.argtypes = [
         ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
         ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+        ctypes.c_void_p,
+    ]
+    lib.mispec_istft_grad_signal_f32.restype = ctypes.c_int
+    lib.mispec_istft_grad_signal_f32.argtypes = [
+        ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+        ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
         ctypes.c_void_p,
     ]
     lib.mispec_power_to_db_bwd_f32.restype = ctypes.c_int

@@ -1287,6 +1287,34 @@ __global__ void __launch_bounds__(256) overlap_add_kernel(const float *__restric
   out[(long long)c * out_clip_stride + i] = acc;
 }
 
+// Adjoint of the windowed overlap-add w.r.t. its (window-weighted) frame sum: the gradient of the
+// trimmed waveform scattered back onto the un-trimmed overlap-add axis and divided by N * wss,
+//   u[c, p] = grad_out[c, p - start] / (N * wss[p])   for p in [start, start + out_len), else 0.
+// d frames[c, t, n] = win[n] * u[c, t*hop + n], so d spectrogram is the framed contraction of u
+// with the window-weighted transposed synthesis basis.
+__global__ void __launch_bounds__(256) istft_grad_signal_kernel(
+    const float *__restrict__ go, long long go_clip_stride, const float *__restrict__ win, int N,
+    int hop, int n_frames, int start, int out_len, float *__restrict__ u, long long full) {
+  const long long pos = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (pos >= full) return;
+  const int c = blockIdx.y;
+  float v = 0.f;
+  if (pos >= start && pos < (long long)start + out_len) {
+    int t_hi = (int)(pos / hop);
+    t_hi = t_hi < n_frames - 1 ? t_hi : n_frames - 1;
+    const long long t_lo_num = pos - N + 1;
+    const int t_lo = t_lo_num <= 0 ? 0 : (int)((t_lo_num + hop - 1) / hop);
+    float wss = 0.f;
+    for (int t = t_lo; t <= t_hi; ++t) {
+      const float w = win[(int)(pos - (long long)t * hop)];
+      wss += w * w;
+    }
+    v = go[(long long)c * go_clip_stride + (pos - start)] / (float)N;
+    if (wss > 1e-10f) v /= wss;
+  }
+  u[(long long)c * full + pos] = v;
+}
+
 // ---------------------------------------------------------------------------------
 // Backward of the framed contraction (trainable bases, stft.py:238-242 / cqt.py:698-702; SURVEY 8f
 // rank 3).  With acc_re/acc_im the contraction sums, s the per-bin scale and
@@ -2187,6 +2215,23 @@ int mispec_overlap_add_f32(const float *frames, int32_t n_clips, int32_t n_frame
                      dim3(256), 0, static_cast<hipStream_t>(stream), frames, window, n_fft, hop,
                      n_frames, start < 0 ? 0 : start, out_len, out, (long long)out_clip_stride,
                      transposed ? (long long)n_clips * n_frames : 0LL);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+
+int mispec_istft_grad_signal_f32(const float *grad_out, int64_t grad_clip_stride, int32_t n_clips,
+                                 int32_t n_frames, int32_t n_fft, const float *window, int32_t hop,
+                                 int32_t start, int32_t out_len, float *u, void *stream) {
+  if (!grad_out || !window || !u) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
+  if (n_clips <= 0 || n_frames <= 0 || n_fft <= 0 || hop <= 0 || out_len <= 0 || start < 0)
+    return fail(MISPEC_E_INVALID, "non-positive size%s");
+  const long long full = (long long)(n_frames - 1) * hop + n_fft;
+  if ((long long)start + out_len > full)
+    return fail(MISPEC_E_INVALID, "output range exceeds the overlap-add signal%s");
+  hipLaunchKernelGGL(istft_grad_signal_kernel, dim3((unsigned)((full + 255) / 256), (unsigned)n_clips),
+                     dim3(256), 0, static_cast<hipStream_t>(stream), grad_out, (long long)grad_clip_stride,
+                     window, n_fft, hop, n_frames, start, out_len, u, full);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
   return MISPEC_OK;

@@ -362,6 +362,65 @@ def istft(spec, basis, window, hop, start, out_len):
     return out
 
 
+class _IstftFn(torch.autograd.Function):
+    """Autograd wrapper of ``istft`` (gradients w.r.t. the spectrogram and the synthesis basis;
+    the window is a fixed buffer here)."""
+
+    @staticmethod
+    def forward(ctx, spec, basis, window, hop, start, out_len):
+        ctx.save_for_backward(spec, basis, window)
+        ctx.meta = (int(hop), int(start), int(out_len))
+        return istft(spec, basis, window, hop, start, out_len)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        spec, basis, window = ctx.saved_tensors
+        hop, start, out_len = ctx.meta
+        dev = spec.device
+        spec = _f32(spec.detach(), "spectrogram").contiguous()
+        basis = _f32(basis.detach(), "basis").contiguous()
+        window = _f32(window.detach(), "window").reshape(-1).contiguous()
+        go = _f32(grad_out, "grad_output").contiguous()
+        B, F, T, _ = spec.shape
+        N = basis.shape[0]
+        full = (T - 1) * hop + N
+        lib = _abi.load()
+        u = torch.empty((B, full), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _abi.check(lib.mispec_istft_grad_signal_f32(go.data_ptr(), go.stride(0), B, T, N,
+                                                        window.data_ptr(), hop, start, out_len,
+                                                        u.data_ptr(), stream))
+        gspec = gbasis = None
+        if ctx.needs_input_grad[0]:
+            # d X[b, c, t] = sum_n basis[n, c] * win[n] * u[b, t*hop + n]: the forward framed
+            # contraction of u with the window-weighted transposed synthesis basis
+            bw = (basis * window[:, None]).t().contiguous()  # (2F, N)
+            gspec = framed_gemm(u, bw[:F], bw[F:], hop=hop, pad=0, pad_mode=PAD_NONE,
+                                epilogue=EPI_COMPLEX, im_sign=1.0, precision="fp32")
+        if ctx.needs_input_grad[1]:
+            # d basis[n, c] = win[n] * sum_{(b,t)} u[b, t*hop + n] * X[b, c, t]: as in
+            # _FramedGemmFn, the framed contraction of the tap-major frame matrix of u with X
+            BT = B * T
+            ut = torch.empty((N, BT), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _abi.check(lib.mispec_frames_transpose_f32(u.data_ptr(), full, B, T, hop, N,
+                                                           ut.data_ptr(), stream))
+            g = spec.permute(3, 1, 0, 2).reshape(2 * F, BT).contiguous()
+            dw = framed_gemm(ut.reshape(1, N * BT), g, None, hop=BT, pad=0, pad_mode=PAD_NONE,
+                             epilogue=EPI_REAL, im_sign=1.0, precision="fp32")[0]  # (2F, N)
+            gbasis = (dw.t() * window[:, None]).contiguous()
+        return gspec, gbasis, None, None, None, None
+
+
+def istft_autograd(spec, basis, window, hop, start, out_len):
+    if torch.is_grad_enabled() and (spec.requires_grad or basis.requires_grad):
+        if window.requires_grad:
+            raise NotImplementedError("the inverse STFT has no backward pass for a trainable window")
+        return _IstftFn.apply(spec, basis, window, hop, start, out_len)
+    return istft(spec, basis, window, hop, start, out_len)
+
+
 def power_to_db(spec, amin, ref, top_db):
     """librosa-style power_to_db with a per-clip maximum (mel.py:263-279); (B, M, T) -> same."""
     dev = _require_device(spec)

@@ -19,13 +19,19 @@ def _inverse_stft(mod, X, kernel_cos, kernel_sin, onesided, length):
     """STFTBase.inverse_stft (stft.py:15-63) for ``STFT.inverse`` and ``iSTFT.forward``.
     (``refresh_win`` needs no state here: the window sum is evaluated inside the overlap-add
     kernel for whatever number of frames the input has.)"""
-    engine.grad_guard(mod, X)
-    if not hasattr(mod, "_inv_basis"):
-        mod._inv_basis = engine.DerivedCache()
     F = X.shape[1]
-    basis = mod._inv_basis.get(
-        (kernel_cos, kernel_sin),
-        lambda: engine.istft_basis(kernel_cos, kernel_sin, F, onesided), extra=(F, bool(onesided)))
+    graph = torch.is_grad_enabled()
+    if graph and mod.window_mask.requires_grad:
+        raise NotImplementedError(
+            "the inverse STFT has no backward pass for a trainable window; run it under torch.no_grad()")
+    if graph and (kernel_cos.requires_grad or kernel_sin.requires_grad):
+        basis = engine.istft_basis(kernel_cos, kernel_sin, F, onesided)  # differentiable torch indexing
+    else:
+        if not hasattr(mod, "_inv_basis"):
+            mod._inv_basis = engine.DerivedCache()
+        basis = mod._inv_basis.get(
+            (kernel_cos, kernel_sin),
+            lambda: engine.istft_basis(kernel_cos, kernel_sin, F, onesided), extra=(F, bool(onesided)))
     wdtype = mod.window_mask.dtype
     window = mod.window_mask.reshape(-1).to(torch.float32)
     if window.numel() != mod.n_fft:
@@ -39,7 +45,7 @@ def _inverse_stft(mod, X, kernel_cos, kernel_sin, onesided, length):
         start, out_len = pad, full - 2 * pad
     else:
         start, out_len = pad, min(int(length), full - pad)
-    y = engine.istft(X, basis, window, mod.stride, start, out_len)
+    y = engine.istft_autograd(X, basis, window, mod.stride, start, out_len)
     # the reference multiplies the float32 frames by its window buffer: the iSTFT class keeps a
     # float64 window (stft.py:489-493) and therefore returns float64 waveforms
     return y if wdtype == torch.float32 else y.to(wdtype)

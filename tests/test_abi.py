@@ -86,8 +86,8 @@ def test_cpu_tensors_fail_loudly():
 def test_trainable_needs_no_grad():
     from nnaudio_amd import features
 
-    # the inverse STFT has no backward pass yet: it must refuse to drop a graph
-    m = features.iSTFT(n_fft=64, hop_length=16, trainable_kernels=True, verbose=False)
+    # no backward pass for a trainable synthesis window: it must refuse to drop a graph
+    m = features.iSTFT(n_fft=64, hop_length=16, trainable_window=True, verbose=False)
     with pytest.raises(NotImplementedError):
         m(torch.zeros(1, 33, 8, 2))
 

@@ -744,9 +744,45 @@ def test_backward_mel_and_frozen_front_end():
     torch.sqrt(re ** 2 + im ** 2).sum().backward()
     _grad_close(xg.grad, x3.grad, "d x (frozen STFT)")
     # modules without a backward pass refuse instead of dropping the graph
-    q = features.iSTFT(n_fft=64, hop_length=16, trainable_kernels=True, verbose=False).to(DEV)
+    q = features.iSTFT(n_fft=64, hop_length=16, trainable_window=True, verbose=False).to(DEV)
     with pytest.raises(NotImplementedError):
         q(torch.zeros(1, 33, 8, 2, device=DEV))
+
+
+@pytest.mark.parametrize("onesided,length", [(True, None), (False, None), (True, 3000)])
+def test_backward_istft(onesided, length):
+    """d spectrogram and d synthesis kernels of the inverse STFT against torch autograd on a
+    fold-based restatement."""
+    from nnaudio_amd import engine, features
+
+    n_fft, hop, T, B = 256, 64, 50, 3
+    F = n_fft // 2 + 1 if onesided else n_fft
+    g = torch.Generator().manual_seed(27)
+    X = torch.randn(B, F, T, 2, generator=g).to(DEV).requires_grad_(True)
+    m = features.iSTFT(n_fft=n_fft, hop_length=hop, trainable_kernels=True, verbose=False).to(DEV)
+    y = m(X, onesided=onesided, length=length)
+    w = torch.randn(y.shape, generator=g, dtype=torch.float64).to(DEV)
+    (y * w).sum().backward()
+
+    X2 = X.detach().clone().requires_grad_(True)
+    kc = m.kernel_cos.detach().clone().requires_grad_(True)
+    ks = m.kernel_sin.detach().clone().requires_grad_(True)
+    basis = engine.istft_basis(kc, ks, F, onesided)
+    win = m.window_mask.reshape(-1).float()
+    Xp = torch.cat((X2[..., 0], X2[..., 1]), 1)
+    frames = torch.einsum("nc,bct->bnt", basis, Xp) * win[None, :, None] / n_fft
+    full = (T - 1) * hop + n_fft
+    fold = lambda f: torch.nn.functional.fold(f, (1, full), (1, n_fft), stride=(1, hop)).reshape(-1, full)
+    wss = fold((win ** 2)[None, :, None].expand(1, n_fft, T))
+    yf = fold(frames) / torch.where(wss > 1e-10, wss, torch.ones_like(wss))
+    pad = n_fft // 2
+    y2 = yf[:, pad:full - pad] if length is None else yf[:, pad:pad + length]
+    assert y2.shape == y.shape
+    assert (y.float() - y2).abs().max().item() <= 1e-4 * y2.abs().max().item()
+    (y2 * w.float()).sum().backward()
+    _grad_close(X.grad, X2.grad, "d spectrogram", rel=5e-4)
+    _grad_close(m.kernel_cos.grad, kc.grad, "d kernel_cos", rel=5e-4)
+    _grad_close(m.kernel_sin.grad, ks.grad, "d kernel_sin", rel=5e-4)
 
 
 @pytest.mark.parametrize("top_db", [80.0, 20.0, None])

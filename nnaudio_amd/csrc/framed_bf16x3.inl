@@ -242,6 +242,181 @@ __device__ __forceinline__ void bf16x3_epilogue(const KParams &p, f32x16 (&acc)[
   }
 }
 
+// ---------------------------------------------------------------------------------
+// Epilogue of the dense staged kernel ("planar" accumulators).  The dense kernel multiplies
+// frames x basis (MFMA operands swapped) and lays a complex basis out as 32 re rows followed by
+// the 32 im rows of the same bins, so that
+//   acc[0][n][e] = re, acc[1][n][e] = im   of bin (m0/2 + 32*wm + li)
+//   at flat frame n0 + 32*(wn*NR + n) + 8*(e>>2) + 4*lh + (e&3):
+// a lane owns both parts of one bin and four consecutive frames per register quad.  Complex /
+// Magnitude / Power (and real bases) are formed in registers, transposed through a wave-private
+// LDS patch and stored with 16-byte stores that cover whole 512-byte row segments.
+// ---------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int WM, int WN, int NR>
+__device__ __forceinline__ void bf16x3_epilogue_planar(const KParams &p, f32x16 (&acc)[2][NR], const int m0,
+                                                       const long long n0, unsigned char *smem_raw) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN;
+  const int wn = wave % WN;
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+  const bool cplx = p.a_im != nullptr;
+  const int E = epilogue_width(p.epilogue);
+  float *const orow = p.out + (long long)p.out_row_offset * p.out_row_stride;
+  // POWER: |z|^2 and |z| directly; other exponents take the generic path below
+  const bool pow_sq = p.epilogue == MISPEC_EPI_POWER && p.power == 2.0f && p.eps == 0.f;
+  const bool pow_1 = p.epilogue == MISPEC_EPI_POWER && p.power == 1.0f;
+  const bool direct = !cplx || p.epilogue == MISPEC_EPI_COMPLEX || p.epilogue == MISPEC_EPI_MAGNITUDE ||
+                      pow_sq || pow_1;
+  if (direct) {
+    // The final values go through a wave-private LDS patch [32 rows][NR*32 frames' worth of
+    // floats] (ds_write_b128 by (bin, frame quad), ds_read_b128 by (row, 4 consecutive floats)),
+    // so that one store instruction writes whole rows of the wave's tile: 64/LPR rows x
+    // NR*128 bytes.  KIND: 0 real basis (pass = row tile m: rows m0 + 32*(2*wm + m) ..),
+    // 1 Complex (pass = half of the wave's frames), 2 sqrt(|z|^2 + eps), 3 |z|^2.
+    constexpr int RS = NR * 32 + 4;  // patch row stride in floats (16-byte rows, banks spread)
+    constexpr int LPR = NR * 8;      // lanes per patch row when every lane reads 4 floats
+    float *const P = reinterpret_cast<float *>(smem_raw) + wave * (32 * RS);
+    const int lr = lane / LPR, lc = lane % LPR;
+    auto store_all = [&](auto kind_tag) __attribute__((always_inline)) {
+      constexpr int KIND = decltype(kind_tag)::value;
+      constexpr int W = KIND == 1 ? 2 : 1;     // floats per frame
+      constexpr int NPASS = KIND <= 1 ? 2 : 1;
+      constexpr int FP = NR * 32 / W;          // frames per pass
+      constexpr int FPL = 4 / W;               // frames per lane in the read phase
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        {
+          const int bin = KIND == 0 ? m0 + (wm * 2 + ps) * 32 + li : (m0 >> 1) + wm * 32 + li;
+          const float sc = (p.row_scale && bin < p.n_bins) ? p.row_scale[bin] : 1.f;
+          const float sci = sc * p.im_sign;
+#pragma unroll
+          for (int n = 0; n < NR; ++n) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              if (KIND == 1 && (32 * n + 8 * g) / FP != ps) continue;
+              float v[4 * W];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const float re = acc[KIND == 0 ? ps : 0][n][4 * g + i] * sc;
+                const float im = KIND == 0 ? 0.f : acc[1][n][4 * g + i] * sci;
+                if (KIND == 0) v[i] = re;
+                if (KIND == 1) {
+                  v[2 * i] = re;
+                  v[2 * i + 1] = im;
+                }
+                if (KIND == 2) v[i] = sqrtf(re * re + im * im + p.eps);
+                if (KIND == 3) v[i] = re * re + im * im;
+              }
+              const int f = 32 * n + 8 * g + 4 * lh - (KIND == 1 ? ps * FP : 0);  // frame in the pass
+              float *d = P + li * RS + f * W;
+#pragma unroll
+              for (int h = 0; h < W; ++h) {
+                f32x4 q = {v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
+                *reinterpret_cast<f32x4 *>(d + 4 * h) = q;
+              }
+            }
+          }
+        }
+        // rows back out: lane (lr, lc) handles floats 4*lc .. 4*lc+3 of rows lr, lr + 64/LPR, ..
+        const long long col = n0 + (wn * NR) * 32 + (KIND == 1 ? ps * FP : 0) + lc * FPL;
+        const bool col_ok = col < p.n_cols;
+        int c = 0, t = 0;
+        if (col_ok) {
+          c = (int)(col / p.n_frames);
+          t = (int)(col - (long long)c * p.n_frames);
+        }
+        const bool fast = col_ok && t + FPL - 1 < p.n_frames;  // the lane's frames lie in one clip
+        const int bin0 = KIND == 0 ? m0 + (wm * 2 + ps) * 32 : (m0 >> 1) + wm * 32;
+        float *const obase = orow + (long long)c * p.out_clip_stride + (long long)t * W;
+#pragma unroll 4
+        for (int r = lr; r < 32; r += 64 / LPR) {
+          const int bin = bin0 + r;
+          if (col_ok && bin < p.n_bins) {
+            const f32x4 q = *reinterpret_cast<const f32x4 *>(P + r * RS + 4 * lc);
+            float *dst = obase + (long long)bin * p.out_row_stride;
+            if (fast) {
+              *reinterpret_cast<f32x4u *>(dst) = q;
+            } else {  // straddles a clip boundary or the end of the batch
+#pragma unroll
+              for (int f = 0; f < FPL; ++f) {
+                int cc = c, tt = t + f;
+                while (tt >= p.n_frames) {
+                  tt -= p.n_frames;
+                  ++cc;
+                }
+                if (col + f < p.n_cols) {
+                  float *d1 = orow + (long long)bin * p.out_row_stride + (long long)cc * p.out_clip_stride +
+                              (long long)tt * W;
+#pragma unroll
+                  for (int h = 0; h < W; ++h) d1[h] = q[W * f + h];
+                }
+              }
+            }
+          }
+        }
+      }
+    };
+    if (!cplx)
+      store_all(std::integral_constant<int, 0>{});
+    else if (p.epilogue == MISPEC_EPI_COMPLEX)
+      store_all(std::integral_constant<int, 1>{});
+    else if (pow_sq)
+      store_all(std::integral_constant<int, 3>{});
+    else
+      store_all(std::integral_constant<int, 2>{});  // Magnitude, Power with exponent 1
+    return;
+  }
+  // phase epilogues, general exponents: one (re, im) tile pair at a time through wave-private LDS patches indexed
+  // [bin][frame] (a single code instance of the transcendental epilogues), frames innermost
+  constexpr int LDC = 33;
+  float *sRe = reinterpret_cast<float *>(smem_raw) + wave * (2 * 32 * LDC);
+  float *sIm = sRe + 32 * LDC;
+#pragma unroll 1
+  for (int tn = 0; tn < NR; ++tn) {
+#pragma unroll
+    for (int n = 0; n < NR; ++n)
+      if (tn == n) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int fr = (e & 3) + 8 * (e >> 2) + 4 * lh;
+          sRe[li * LDC + fr] = acc[0][n][e];
+          sIm[li * LDC + fr] = acc[1][n][e];
+        }
+      }
+    __syncthreads();
+    const long long col = n0 + (wn * NR + tn) * 32 + li;
+    const bool col_ok = col < p.n_cols;
+    int c = 0, t = 0;
+    if (col_ok) {
+      c = (int)(col / p.n_frames);
+      t = (int)(col - (long long)c * p.n_frames);
+    }
+    float *obase = p.out + (long long)c * p.out_clip_stride + (long long)t * E;
+#pragma unroll 1
+    for (int it = 0; it < 16; ++it) {
+      const int rl = 2 * it + lh;
+      const int bin = (m0 >> 1) + wm * 32 + rl;
+      if (col_ok && bin < p.n_bins) {
+        float re = sRe[rl * LDC + li];
+        float im = p.im_sign * sIm[rl * LDC + li];
+        if (p.row_scale) {
+          const float sc = p.row_scale[bin];
+          re *= sc;
+          im *= sc;
+        }
+        epilogue_store(p, obase + (long long)(p.out_row_offset + bin) * p.out_row_stride, re, im);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <int WM, int WN, int MR, int NR, bool MASKED>
 __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int wg_index,
                                                    const int wg_count) {
@@ -250,6 +425,9 @@ __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int w
   constexpr int BM = WM * MR * 32;
   constexpr int BN = WN * NR * 32;
   constexpr int MT = WM * MR;
+  // dense tiles: frames x basis product with (re rows | im rows) row tiles, see
+  // bf16x3_epilogue_planar
+  constexpr bool PLANAR = !MASKED && MR == 2;
   constexpr int ROWB = KC * 2;  // bytes of one row of one plane in a stage
   // one DMA instruction moves 16 rows; every wave issues the same number of them, so a narrow
   // A tile is padded to 16*NW rows (the extra rows re-read the last basis row, never multiplied)
@@ -320,8 +498,9 @@ __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int w
   if (tid < MT) {
     const int row_lo = m0 + tid * 32;
     int lo = 0, hi = 0;
-    const int bin_lo = row_lo / rpb;
-    int bin_hi = (row_lo + 32 + rpb - 1) / rpb;
+    const bool pl = PLANAR && cplx;  // row tile (wm, m): part m of bins m0/2 + 32*wm ..+32
+    const int bin_lo = pl ? (m0 >> 1) + (tid / MR) * 32 : row_lo / rpb;
+    int bin_hi = pl ? bin_lo + 32 : (row_lo + 32 + rpb - 1) / rpb;
     bin_hi = bin_hi < p.n_bins ? bin_hi : p.n_bins;
     if (bin_lo < bin_hi) {
       if (p.row_support) {
@@ -372,10 +551,16 @@ __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int w
   const unsigned short *aptr[AJ];
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
-    const int row = m0 + (j * NW + wave) * 16 + row16;
+    const int rt = (j * NW + wave) * 16 + row16;  // row of the workgroup tile
+    const int row = m0 + rt;
     int bin = cplx ? (row >> 1) : row;
+    bool im_row = cplx && (row & 1);
+    if (PLANAR && cplx) {
+      bin = (m0 >> 1) + (rt / (MR * 32)) * 32 + (rt & 31);
+      im_row = (rt >> 5) & 1;
+    }
     bin = bin < p.n_bins ? bin : p.n_bins - 1;  // rows past the end feed unused accumulators
-    const long long comp = (cplx && (row & 1)) ? 2 * p.as_plane : 0;
+    const long long comp = im_row ? 2 * p.as_plane : 0;
     aptr[j] = p.as + comp + (long long)bin * p.Ks + 8 * cg;
   }
   const unsigned short *xptr[XJ];
@@ -444,7 +629,8 @@ __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int w
           for (int n = 0; n < NR; ++n) {
             const bf16x8 a = term == 0 ? al[q][m] : ah[q][m];
             const bf16x8 x = term == 1 ? xl[q][n] : xh[q][n];
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, x, acc[m][n], 0, 0, 0);
+            acc[m][n] = PLANAR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, a, acc[m][n], 0, 0, 0)
+                               : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, x, acc[m][n], 0, 0, 0);
           }
         }
       }
@@ -511,7 +697,10 @@ __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int w
     __syncthreads();  // every wave is done with the stage buffers (the epilogue reuses them)
   }
 
-  bf16x3_epilogue<WM, WN, MR, NR>(p, acc, m0, n0, smem_raw);
+  if constexpr (PLANAR)
+    bf16x3_epilogue_planar<WM, WN, NR>(p, acc, m0, n0, smem_raw);
+  else
+    bf16x3_epilogue<WM, WN, MR, NR>(p, acc, m0, n0, smem_raw);
 }
 
 template <int WM, int WN, int MR, int NR, bool MASKED>

@@ -1604,7 +1604,9 @@ constexpr size_t bf16x3_smem() {
   constexpr int BM = WM * MR * 32;
   constexpr int BN = WN * NR * 32;
   constexpr int BMA = BM < 16 * NW ? 16 * NW : BM;
-  return 2 * (2 * BMA + 2 * BN) * (KC * 2) + BN * sizeof(long long) + 2 * WM * MR * sizeof(int);
+  const size_t stages = 2 * (2 * BMA + 2 * BN) * (KC * 2) + BN * sizeof(long long) + 2 * WM * MR * sizeof(int);
+  const size_t patches = (size_t)NW * 32 * (NR * 32 + 4) * sizeof(float);  // bf16x3_epilogue_planar
+  return stages > patches ? stages : patches;
 }
 
 // fill the tiling fields of p for a bf16x3 tile shape; returns the number of workgroups (or < 0)

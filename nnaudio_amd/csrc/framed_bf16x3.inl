@@ -537,7 +537,8 @@ __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int w
     }
   }
   kb = kb & ~(KC - 1);
-  const int nstages = ke > kb ? (ke - kb + KC - 1) / KC : 0;  // Ks covers the last partial stage
+  int nstages = ke > kb ? (ke - kb + KC - 1) / KC : 0;  // Ks covers the last partial stage
+  if (PLANAR && (p.debug & 0x80000)) nstages = nstages < 2 ? nstages : 2;  // ablation: no K loop
   auto stage_mask = [&](int kc) __attribute__((always_inline)) -> unsigned {
     if (!MASKED) return (1u << MT) - 1u;
     unsigned m = 0;
@@ -697,8 +698,20 @@ __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int w
     __syncthreads();  // every wave is done with the stage buffers (the epilogue reuses them)
   }
 
-  if constexpr (PLANAR)
+  if constexpr (PLANAR) {
+    if (p.debug & 0x40000) {  // ablation: no epilogue (keep the accumulators alive)
+      float s = 0.f;
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int n = 0; n < NR; ++n)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) s += acc[m][n][e];
+      if (s == 12345.678f) p.out[0] = s;
+      return;
+    }
     bf16x3_epilogue_planar<WM, WN, NR>(p, acc, m0, n0, smem_raw);
+  }
   else
     bf16x3_epilogue<WM, WN, MR, NR>(p, acc, m0, n0, smem_raw);
 }

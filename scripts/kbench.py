@@ -74,7 +74,8 @@ def bf16():
         ms = timeit(lambda: engine.framed_gemm(x, m.wcos[:1024], m.wsin[:1024], tile=tile, hop=512, pad=1024,
                                                pad_mode=2, epilogue=engine.EPI_MAGNITUDE, precision="bf16x3"))
         print("   1024 bins incl. uncached basis split: %.3f ms" % ms)
-    for dbg, what in ((0, "full"),):
+    for dbg, what in ((0, "full"), (0x40000, "no epilogue"), (0x80000, "2 K stages only"),
+                      (0xC0000, "2 K stages, no epilogue")):
         ms = timeit(lambda: engine.framed_gemm(x, m.wcos[:1024], m.wsin[:1024], tile=0, _debug=dbg,
                                                basis_split=split1k, **kw1k))
         print("   ablate[%-36s] 1024 bins: %.3f ms" % (what, ms))

@@ -156,8 +156,8 @@ def cpu_baseline(budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="stft", choices=["stft", "mel", "cqt", "cqt2010"])
     ap.add_argument("--extras", type=int, default=1, help="also time CQT84 / Mel / gather (untimed region)")
     ap.add_argument("--cpu-baseline", type=int, default=1)

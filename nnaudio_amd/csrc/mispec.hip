@@ -1739,20 +1739,37 @@ KParams leftover_rows(const KParams &p, int first_bin) {
   return r;
 }
 
+// How launch_framed_bf16x3 divides the rows: whole 256-row blocks on the bf16 pipe; a leftover
+// block joins them when it is at least a quarter full (or carries supports), else its rows (the
+// Nyquist bin of an n_fft/2+1 STFT) run as narrow bf16x3 tiles in the tail of the same grid
+// (`pair`) or, with a forced tile shape, on the narrow fp32 kernel (the only case that needs
+// the fp32 path's edge workspace).
+struct Bf16x3Rows {
+  int main_bins;
+  bool pair, fp32_leftover;
+};
+Bf16x3Rows plan_bf16x3_rows(const KParams &p, int tile) {
+  const int rpb = p.a_im ? 2 : 1;
+  const bool masked = p.row_support != nullptr;
+  const int bins_per_wg = 256 / rpb;
+  Bf16x3Rows r;
+  r.main_bins = (p.n_bins / bins_per_wg) * bins_per_wg;
+  if (masked || (p.n_bins - r.main_bins) * rpb > 64) r.main_bins = p.n_bins;
+  r.pair = tile == MISPEC_TILE_AUTO && !masked && r.main_bins > 0 && r.main_bins < p.n_bins &&
+           !(p.debug & 0x2000);
+  r.fp32_leftover = !r.pair && r.main_bins != p.n_bins;
+  return r;
+}
+
 int launch_framed_bf16x3(const KParams &p, int tile, hipStream_t stream) {
   const int rpb = p.a_im ? 2 : 1;
   const bool masked = p.row_support != nullptr;
-  // whole 256-row blocks on the bf16 pipe; a leftover block joins them when it is at least a
-  // quarter full (or carries supports), else its rows (the Nyquist bin of an n_fft/2+1 STFT)
-  // run on the narrow fp32 kernel
-  const int bins_per_wg = 256 / rpb;
-  int main_bins = (p.n_bins / bins_per_wg) * bins_per_wg;
-  if (masked || (p.n_bins - main_bins) * rpb > 64) main_bins = p.n_bins;
+  const Bf16x3Rows rows = plan_bf16x3_rows(p, tile);
+  const int main_bins = rows.main_bins;
   KParams q = p;
   q.n_bins = main_bins;
   int rc;
-  if (tile == MISPEC_TILE_AUTO && !masked && main_bins > 0 && main_bins < p.n_bins &&
-      !(p.debug & 0x2000)) {
+  if (rows.pair) {
     // one launch: 256x256 workgroups + narrow ones for the leftover rows in the grid's tail
     KParams r = leftover_rows(p, main_bins);
     r.as = p.as + (long long)main_bins * p.Ks;  // same planes, first leftover bin
@@ -1945,9 +1962,13 @@ int mispec_framed_gemm_f32(const mispec_framed_gemm_args *args, void *stream) {
   int rc = fill_params(args, p);
   if (rc != MISPEC_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  rc = setup_edges(p, args->workspace, args->workspace_bytes, s);
-  if (rc != MISPEC_OK) return rc;
-  if (bf16x3_ok(args, p)) {
+  const bool bf16x3 = bf16x3_ok(args, p);
+  // (the bf16x3 kernels read the padded split signal, not the fp32 path's edge workspace)
+  if (!bf16x3 || plan_bf16x3_rows(p, args->tile).fp32_leftover) {
+    rc = setup_edges(p, args->workspace, args->workspace_bytes, s);
+    if (rc != MISPEC_OK) return rc;
+  }
+  if (bf16x3) {
     rc = setup_split(p, args, s);
     if (rc != MISPEC_OK) return rc;
     return launch_framed_bf16x3(p, args->tile, s);

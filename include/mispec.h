@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MISPEC_ABI_VERSION 3
+#define MISPEC_ABI_VERSION 4
 
 enum {
   MISPEC_OK = 0,
@@ -136,6 +136,22 @@ typedef struct mispec_framed_gemm_args {
   int32_t reserved2;           /* must be 0                                                */
   const void *basis_split;     /* MISPEC_PREC_BF16X3: output of mispec_split_basis_bf16()  */
   int64_t basis_split_bytes;   /* for this (basis_re, basis_im, n_bins, kernel); else NULL */
+
+  /* Fused filterbank reduction (mel.py:184-189: matmul(mel_basis, spec ** power)) -- optional.
+   * With fb != NULL the epilogue must be MISPEC_EPI_POWER with power 1 or 2, and the launch
+   * ADDS  out[c, m, t] += sum_bin fb[m, bin] * |X[c, bin, t]|^power  for the n_fb filters into
+   * `out` = (n_clips, n_fb, n_frames), which the caller has zeroed (workgroups own 128-bin
+   * blocks; a filter whose band crosses a block boundary receives one atomic addend per block,
+   * so bands of up to 129 bins sum in an order-independent way).  The band of every filter is
+   * walked bin by bin: meant for banded (mel) filterbanks.
+   * fb_support[m] = [first, last+1) bin with a non-zero weight; n_fb <= 256.  Served by the dense
+   * MISPEC_PREC_BF16X3 kernels only: MISPEC_E_UNSUPPORTED otherwise -- use
+   * mispec_filterbank_f32 on the power spectrogram then. */
+  const float *fb;             /* (n_fb, n_bins), row stride fb_row_stride elements, or NULL */
+  const int32_t *fb_support;   /* (n_fb, 2)                                                */
+  int64_t fb_row_stride;
+  int32_t n_fb;
+  int32_t reserved3;           /* must be 0                                                */
 } mispec_framed_gemm_args;
 
 /*

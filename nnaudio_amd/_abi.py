@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmispec.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 E_INVALID, E_UNSUPPORTED, E_HIP = -1, -2, -3
 
 # enums (mirror include/mispec.h)
@@ -83,6 +83,11 @@ class FramedGemmArgs(ctypes.Structure):
         ("reserved2", ctypes.c_int32),
         ("basis_split", ctypes.c_void_p),
         ("basis_split_bytes", ctypes.c_int64),
+        ("fb", ctypes.c_void_p),
+        ("fb_support", ctypes.c_void_p),
+        ("fb_row_stride", ctypes.c_int64),
+        ("n_fb", ctypes.c_int32),
+        ("reserved3", ctypes.c_int32),
     ]
 
 

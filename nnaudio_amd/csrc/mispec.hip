@@ -126,6 +126,11 @@ struct KParams {
   int slab_rows;  // rows of one slab buffer (>= BN + 2*(C-1), multiple of 16)
   int slab_nbuf;  // 1 or 2 slab buffers
   int row_split;  // framed_bf16x3_narrow: workgroups per frame tile (each takes every row_split-th row tile)
+  // fused filterbank reduction (bf16x3_epilogue_fb): out[c, m, t] += sum_bin fb[m, bin] * |X|^power
+  const float *fb;
+  const int *fb_support;
+  long long fb_row_stride;
+  int n_fb;
 };
 
 // ---------------------------------------------------------------------------------
@@ -1777,10 +1782,12 @@ int launch_framed_bf16x3(const KParams &p, int tile, hipStream_t stream) {
     size_t sm_main = bf16x3_smem<4, 2, 2, 4>();
     const bool slab = false;  // dense 256x256 slab tiles do not fit in 256 VGPRs
     const long long gm = prepare_bf16x3<4, 2, 2, 4>(q);
-    const long long gr = rem_rows <= 32 ? prepare_bf16x3<1, 8, 1, 1>(r) : prepare_bf16x3<1, 8, 2, 1>(r);
+    // (the fused filterbank lives in the planar epilogue: 64-row tiles for the leftover rows too)
+    const bool narrow_rem = rem_rows <= 32 && !p.fb;
+    const long long gr = narrow_rem ? prepare_bf16x3<1, 8, 1, 1>(r) : prepare_bf16x3<1, 8, 2, 1>(r);
     if (gm < 0 || gr < 0 || gm + gr > 0x7fffffffLL)
       return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
-    const size_t sm_rem = rem_rows <= 32 ? bf16x3_smem<1, 8, 1, 1>() : bf16x3_smem<1, 8, 2, 1>();
+    const size_t sm_rem = narrow_rem ? bf16x3_smem<1, 8, 1, 1>() : bf16x3_smem<1, 8, 2, 1>();
     const size_t smem = sm_main > sm_rem ? sm_main : sm_rem;
     const dim3 grid((unsigned)(gm + gr));
     rc = MISPEC_OK;
@@ -1791,7 +1798,7 @@ int launch_framed_bf16x3(const KParams &p, int tile, hipStream_t stream) {
     rc = configure_lds(kern, 160 * 1024, configured);                                         \
     if (rc == MISPEC_OK) hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, q, r, (int)gm); \
   }
-    if (rem_rows <= 32) {
+    if (narrow_rem) {
       MISPEC_LAUNCH_PAIR(framed_bf16x3_pair_kernel<1>)
     } else {
       MISPEC_LAUNCH_PAIR(framed_bf16x3_pair_kernel<2>)
@@ -1895,7 +1902,20 @@ int fill_params(const mispec_framed_gemm_args *a, KParams &p) {
   p.debug = a->reserved;
   if (a->precision != MISPEC_PREC_F32 && a->precision != MISPEC_PREC_BF16X3)
     return fail(MISPEC_E_INVALID, "bad precision%s");
-  if (a->reserved2 != 0) return fail(MISPEC_E_INVALID, "reserved2 must be 0%s");
+  if (a->reserved2 != 0 || a->reserved3 != 0) return fail(MISPEC_E_INVALID, "reserved fields must be 0%s");
+  if (a->fb) {
+    if (!a->fb_support || a->n_fb <= 0)
+      return fail(MISPEC_E_INVALID, "fused filterbank: fb_support and n_fb > 0 are required%s");
+    if (a->epilogue != MISPEC_EPI_POWER || !(a->power == 1.0f || a->power == 2.0f))
+      return fail(MISPEC_E_INVALID, "fused filterbank: MISPEC_EPI_POWER with power 1 or 2 only%s");
+    if (!a->basis_im || a->row_support || a->out_row_offset != 0)
+      return fail(MISPEC_E_INVALID, "fused filterbank: complex dense basis, whole output%s");
+    if (a->n_fb > 256) return fail(MISPEC_E_UNSUPPORTED, "fused filterbank: at most 256 filters%s");
+    p.fb = a->fb;
+    p.fb_support = a->fb_support;
+    p.fb_row_stride = a->fb_row_stride;
+    p.n_fb = a->n_fb;
+  }
   return MISPEC_OK;
 }
 
@@ -1963,6 +1983,10 @@ int mispec_framed_gemm_f32(const mispec_framed_gemm_args *args, void *stream) {
   if (rc != MISPEC_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool bf16x3 = bf16x3_ok(args, p);
+  if (p.fb && !(bf16x3 && args->tile == MISPEC_TILE_AUTO && !(p.debug & 0x2000)))
+    return fail(MISPEC_E_UNSUPPORTED,
+                "fused filterbank needs the dense MISPEC_PREC_BF16X3 path (even hop, > 64 bins, "
+                "basis_split given, automatic tile)%s");
   // (the bf16x3 kernels read the padded split signal, not the fp32 path's edge workspace)
   if (!bf16x3 || plan_bf16x3_rows(p, args->tile).fp32_leftover) {
     rc = setup_edges(p, args->workspace, args->workspace_bytes, s);
@@ -2008,6 +2032,7 @@ int mispec_framed_gemm_group_f32(const mispec_framed_gemm_args *args, int32_t n,
   for (int i = 0; i < n; ++i) {
     int rc = fill_params(&args[i], ps[i]);
     if (rc != MISPEC_OK) return rc;
+    if (ps[i].fb) return fail(MISPEC_E_UNSUPPORTED, "fused filterbank: not in grouped launches%s");
     const int rows = ps[i].n_bins * (ps[i].a_im ? 2 : 1);
     const int t = args[i].tile != MISPEC_TILE_AUTO ? args[i].tile
                                                     : auto_tile(rows, ps[i].row_support != nullptr);
@@ -2028,6 +2053,7 @@ int mispec_framed_gemm_f32_ref(const mispec_framed_gemm_args *args, void *stream
   KParams p;
   int rc = fill_params(args, p);
   if (rc != MISPEC_OK) return rc;
+  if (p.fb) return fail(MISPEC_E_UNSUPPORTED, "fused filterbank: not in the reference kernel%s");
   const long long total = p.n_cols * p.n_bins;
   const long long blocks = (total + 255) / 256;
   if (blocks > 0x7fffffffLL) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");

@@ -150,10 +150,10 @@ def n_frames(length, kernel, hop, pad):
 def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign=-1.0,
                  eps=0.0, power=2.0, row_scale=None, row_support=None, out=None,
                  out_rows_total=None, out_row_offset=0, tile=TILE_AUTO, _debug=0,
-                 need_workspace=True, precision=None, basis_split=None):
+                 need_workspace=True, precision=None, basis_split=None, fb=None, fb_support=None):
     """Validate one framed-contraction problem and fill its C argument block.
     Returns (args, out, device, keepalive tensors)."""
-    dev = _require_device(x, basis_re, basis_im, row_scale, row_support, out)
+    dev = _require_device(x, basis_re, basis_im, row_scale, row_support, out, fb, fb_support)
     x = _signal(x)
     wr = _rows(basis_re, "basis_re")
     wi = _rows(basis_im, "basis_im") if basis_im is not None else None
@@ -169,14 +169,27 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
     T = n_frames(L, K, hop, pad)
     two = epilogue in (EPI_COMPLEX, EPI_PHASE_COSSIN)
     rows_total = F if out_rows_total is None else out_rows_total
-    if out is None:
+    if fb is not None:
+        # fused filterbank: the launch adds into a zeroed (B, n_fb, T) tensor
+        fb = _f32(fb, "filterbank")
+        if fb.dim() != 2 or fb.shape[1] != F or fb.stride(1) != 1:
+            raise RuntimeError("fused filterbank must be (n_filters, %d) with unit column stride" % F)
+        if (fb_support is None or fb_support.dtype != torch.int32
+                or tuple(fb_support.shape) != (fb.shape[0], 2)):
+            raise RuntimeError("fb_support must be int32 (n_filters, 2)")
+        if out is not None or out_rows_total is not None or out_row_offset or two:
+            raise RuntimeError("fused filterbank writes its own (B, n_filters, T) output")
+        fb_support = fb_support.contiguous()
+        out = torch.zeros((B, fb.shape[0], T), dtype=torch.float32, device=dev)
+        rows_total = fb.shape[0]
+    elif out is None:
         shape = (B, rows_total, T, 2) if two else (B, rows_total, T)
         out = torch.empty(shape, dtype=torch.float32, device=dev)
     else:
         want = (B, rows_total, T, 2) if two else (B, rows_total, T)
         if tuple(out.shape) != want or not out.is_contiguous() or out.dtype != torch.float32:
             raise RuntimeError("out must be a contiguous float32 tensor of shape %s" % (want,))
-    if out_row_offset < 0 or out_row_offset + F > rows_total:
+    if fb is None and (out_row_offset < 0 or out_row_offset + F > rows_total):
         raise RuntimeError("row block [%d, %d) outside the output's %d rows"
                            % (out_row_offset, out_row_offset + F, rows_total))
     if row_scale is not None:
@@ -209,7 +222,10 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
     a.out_row_stride = T * E
     a.out_row_offset = int(out_row_offset)
     a.reserved = int(_debug) | _ENV_DEBUG
-    keep = [x, wr, wi, row_scale, row_support]
+    keep = [x, wr, wi, row_scale, row_support, fb, fb_support]
+    if fb is not None:
+        a.fb, a.fb_support = fb.data_ptr(), fb_support.data_ptr()
+        a.fb_row_stride, a.n_fb = fb.stride(0), fb.shape[0]
     if resolve_precision(precision) == "bf16x3" and need_workspace:
         if basis_split is None:  # uncached: callers with a persistent basis pass it in
             basis_split = split_basis(wr, wi)
@@ -256,7 +272,9 @@ def framed_gemm(x, basis_re, basis_im, *, reference_kernel=False, **kw):
     Keyword arguments: hop, pad, pad_mode (``PAD_*``), epilogue (``EPI_*``), im_sign, eps, power,
     row_scale, row_support, out (pre-allocated (B, rows_total, T[, 2]) tensor: octave assembly /
     all-gather slices write in place), out_rows_total, out_row_offset, tile, precision ("fp32" /
-    "bf16x3" / None = process default), basis_split (cached ``split_basis`` result)."""
+    "bf16x3" / None = process default), basis_split (cached ``split_basis`` result), fb +
+    fb_support (fused filterbank reduction: EPI_POWER with power 1 or 2 on the dense bf16x3 path;
+    the result is ``(B, n_filters, T)``, see ``fused_filterbank_ok``)."""
     a, out, dev, _keep = _framed_args(x, basis_re, basis_im, need_workspace=not reference_kernel,
                                       **kw)
     lib = _abi.load()
@@ -265,6 +283,52 @@ def framed_gemm(x, basis_re, basis_im, *, reference_kernel=False, **kw):
         stream = torch.cuda.current_stream(dev).cuda_stream
         _abi.check(fn(ctypes.byref(a), ctypes.c_void_p(stream)))
     return out
+
+
+def filterbank_support(fb):
+    """int32 (n_filters, 2): [first, last + 1) column with a non-zero weight per filter row, and
+    how many filters cover a bin on average (plumbing for the fused filterbank epilogue; empty
+    rows give [0, 0))."""
+    nz = fb.detach() != 0
+    F = fb.shape[1]
+    idx = torch.arange(F, device=fb.device)
+    first = torch.where(nz, idx, torch.full_like(idx, F)).min(1)[0]
+    last = torch.where(nz, idx + 1, torch.zeros_like(idx)).max(1)[0]
+    first = torch.minimum(first, last)
+    sup = torch.stack((first, last), 1).to(torch.int32).contiguous()
+    # bins walked per output frame, in units of the bin count: 2 for triangular (mel) filters
+    coverage = float((last - first).sum().item()) / max(F, 1)
+    return sup, coverage
+
+
+# The fused epilogue walks a filter's band bin by bin (VALU): worth it for banded filterbanks
+# (every bin under ~2 triangular mel filters); a dense one (gammatone: every bin under every
+# filter) goes through the MFMA filterbank kernel, mispec_filterbank_f32, instead.
+FUSED_FB_MAX_COVERAGE = 4.0
+
+
+def fused_filterbank_ok(n_bins, hop, precision, power, coverage, n_filters=1):
+    """Whether ``framed_gemm(..., fb=...)`` is served (include/mispec.h: dense bf16x3 path, power
+    1 or 2, at most 256 filters) and worthwhile (banded filters)."""
+    return (resolve_precision(precision) == "bf16x3" and hop % 2 == 0 and 2 * n_bins > 128
+            and n_filters <= 256
+            and float(power) in (1.0, 2.0) and 0 < coverage <= FUSED_FB_MAX_COVERAGE)
+
+
+def fused_filterbank_plan(mod, fb, x, stft, power):
+    """For MelSpectrogram / Gammatonegram: the ``fb_support`` table when this forward can run with
+    the filterbank fused into the STFT contraction (no graph needed, bf16x3 precision, narrow
+    bands), else None."""
+    if needs_grad(mod, x) or stft.freq_bins is not None:
+        return None
+    if resolve_precision(stft.precision) != "bf16x3":
+        return None
+    if not hasattr(mod, "_fb_support"):
+        mod._fb_support = DerivedCache()
+    sup, coverage = mod._fb_support.get((fb,), lambda: filterbank_support(fb))
+    if not fused_filterbank_ok(fb.shape[1], stft.stride, stft.precision, power, coverage, fb.shape[0]):
+        return None
+    return sup
 
 
 def framed_gemm_group(problems):

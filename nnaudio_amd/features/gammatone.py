@@ -75,6 +75,10 @@ class Gammatonegram(nn.Module):
     def forward(self, x):
         x = broadcast_dim(x)
         self.stft.num_samples = x.shape[-1]
+        fused = engine.fused_filterbank_plan(self, self.gammatone_basis, x, self.stft, self.power)
+        if fused is not None:  # reduction fused into the contraction's epilogue
+            return self.stft._spectrum(x, engine.EPI_POWER, power=self.power, fb=self.gammatone_basis,
+                                       fb_support=fused)
         spec = self.stft._spectrum(x, engine.EPI_POWER, power=self.power)
         return engine.filterbank_autograd(self.gammatone_basis, spec)
 

@@ -80,6 +80,10 @@ class MelSpectrogram(nn.Module):
     def forward(self, x):
         x = broadcast_dim(x)
         self.stft.num_samples = x.shape[-1]
+        fused = engine.fused_filterbank_plan(self, self.mel_basis, x, self.stft, self.power)
+        if fused is not None:  # reduction fused into the contraction's epilogue
+            return self.stft._spectrum(x, engine.EPI_POWER, power=self.power, fb=self.mel_basis,
+                                       fb_support=fused)
         spec = self.stft._spectrum(x, engine.EPI_POWER, power=self.power)
         return engine.filterbank_autograd(self.mel_basis, spec)
 

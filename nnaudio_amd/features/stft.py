@@ -156,7 +156,10 @@ class STFT(nn.Module):
         # the reference leaves `padding` unbound for any other mode (stft.py:279-289)
         raise UnboundLocalError("local variable 'padding' referenced before assignment")
 
-    def _spectrum(self, x, epilogue, power=2.0):
+    def _spectrum(self, x, epilogue, power=2.0, fb=None, fb_support=None):
+        """The framed contraction of this layer; with ``fb`` the filterbank reduction of
+        MelSpectrogram / Gammatonegram is fused into it (no autograd graph, see
+        ``engine.fused_filterbank_ok``)."""
         pad, mode = self._framing(x.shape[-1])
         wsin, wcos = self.wsin, self.wcos
         if self.freq_bins is not None:
@@ -166,6 +169,11 @@ class STFT(nn.Module):
         if precision == "bf16x3":
             split = self._split.get((self.wcos, self.wsin),
                                     lambda: engine.split_basis(wcos, wsin), extra=self.freq_bins)
+        if fb is not None:
+            return engine.framed_gemm(
+                x, wcos, wsin, hop=self.stride, pad=pad, pad_mode=mode, epilogue=epilogue,
+                im_sign=-1.0, eps=1e-8 if self.trainable else 0.0, power=power,
+                precision=precision, basis_split=split, fb=fb, fb_support=fb_support)
         return engine.framed_gemm_autograd(
             x, wcos, wsin, hop=self.stride, pad=pad, pad_mode=mode, epilogue=epilogue,
             im_sign=-1.0, eps=1e-8 if self.trainable else 0.0, power=power,

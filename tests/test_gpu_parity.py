@@ -870,3 +870,45 @@ def test_backward_octave_recursion(cls, fmt):
     _grad_close(got[0], x2.grad, "d x")
     for a, b, name in zip(got[1:], p2, ("d cqt_kernels_real", "d cqt_kernels_imag")):
         _grad_close(a, b.grad, name)
+
+
+def test_fused_filterbank_matches_unfused():
+    """precision="bf16x3": the mel reduction fused into the contraction's epilogue (atomic adds
+    into a zeroed (B, n_mels, T) tensor) against the two-kernel path and the fp32 path; filter
+    bands crossing 128-bin block boundaries, the Nyquist bin's own tile, clip-straddling frame
+    tiles, power 1 and 2; wide bands and graphs fall back to the separate filterbank kernel."""
+    from nnaudio_amd import engine, features
+
+    g = torch.Generator().manual_seed(31)
+    for n_fft, hop, n_mels, L, B, power in ((1024, 512, 128, 30000, 5, 2.0), (2048, 256, 64, 9000, 3, 1.0),
+                                            (512, 128, 40, 4100, 9, 2.0)):
+        x = torch.randn(B, L, generator=g).to(DEV)
+        m = features.MelSpectrogram(sr=22050, n_fft=n_fft, n_mels=n_mels, hop_length=hop, power=power,
+                                    verbose=False).to(DEV)
+        ref = m(x)  # fp32 path: unfused
+        m.stft.precision = "bf16x3"
+        assert engine.fused_filterbank_plan(m, m.mel_basis, x, m.stft, m.power) is not None
+        y = m(x)
+        spec = m.stft._spectrum(x[:, None, :], engine.EPI_POWER, power=power)
+        y2 = engine.filterbank(m.mel_basis, spec)
+        peak = ref.abs().max().item()
+        assert y.shape == ref.shape
+        assert (y - ref).abs().max().item() <= 1e-4 * peak
+        assert (y - y2).abs().max().item() <= 2e-5 * peak
+        if n_mels >= 128:
+            assert torch.equal(y, m(x))  # at most two addends per output: order independent
+    # a dense filterbank (gammatone) and a graph go through the separate kernel
+    gt = features.Gammatonegram(sr=22050, n_fft=1024, n_bins=64, hop_length=512, verbose=False).to(DEV)
+    gt.stft.precision = "bf16x3"
+    x = torch.randn(2, 20000, generator=g).to(DEV)
+    assert engine.fused_filterbank_plan(gt, gt.gammatone_basis, x, gt.stft, gt.power) is None
+    mt = features.MelSpectrogram(sr=22050, n_fft=1024, n_mels=64, trainable_mel=True, verbose=False).to(DEV)
+    mt.stft.precision = "bf16x3"
+    assert engine.fused_filterbank_plan(mt, mt.mel_basis, x, mt.stft, mt.power) is None
+    with torch.no_grad():
+        assert engine.fused_filterbank_plan(mt, mt.mel_basis, x, mt.stft, mt.power) is not None
+    # the C entry refuses the fusion where it is not served
+    sup, _ = engine.filterbank_support(m.mel_basis)
+    with pytest.raises(RuntimeError):
+        engine.framed_gemm(x, m.stft.wcos, m.stft.wsin, hop=128, pad=256, pad_mode=engine.PAD_REFLECT,
+                           epilogue=engine.EPI_POWER, precision="fp32", fb=m.mel_basis, fb_support=sup)

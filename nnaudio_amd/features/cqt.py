@@ -91,7 +91,11 @@ class CQT1992v2(nn.Module):
             pad = self.kernel_width // 2
         else:
             pad, mode = 0, engine.PAD_NONE
-        scale = normalisation_scale(self.lenghts, normalization_type)
+        if not hasattr(self, "_scale"):
+            self._scale = engine.DerivedCache()
+        scale = self._scale.get((self.lenghts,),
+                                lambda: normalisation_scale(self.lenghts, normalization_type),
+                                extra=normalization_type)
         epi = output_epilogue(output_format)
         if epi is None:
             return None

@@ -11,9 +11,12 @@ export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT/summary
 CMD="python bench.py --steps 5 --warmup 2 --extras 0 --cpu-baseline 0 --workload $WL --precision $PREC"
+# the first launches after start-up run slower (clock ramp): the timing pass uses the bench's
+# default step counts so that the per-kernel averages are the steady-state ones the bench reports
+TCMD="python bench.py --extras 0 --cpu-baseline 0 --workload $WL --precision $PREC"
 
 # (1) kernel trace + stats
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $TCMD > $OUT/trace.log 2>&1
 # (2..) PMC passes: counters only (never combined with trace domains)
 MOPS=SQ_INSTS_VALU_MFMA_MOPS_F32
 [ "$PREC" = "bf16x3" ] && MOPS=SQ_INSTS_VALU_MFMA_MOPS_BF16

@@ -147,10 +147,47 @@ def cpu_baseline(budget_s=15.0):
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count()])
     except Exception:
         cores = os.cpu_count()
-    return dict(value=reps * n * 862 / dt, unit="frames/s", cores=int(cores), kind="port",
-                sample="%d x %d of 64 clips (10 s @ 44.1 kHz) of configs[1], numpy float32 BLAS port "
-                       "of the reference conv1d STFT (oracle/spectral_oracle.py), %.1f s"
-                       % (reps, n, dt))
+    out = dict(value=reps * n * 862 / dt, unit="frames/s", cores=int(cores), kind="port",
+               sample="%d x %d of 64 clips (10 s @ 44.1 kHz) of configs[1], numpy float32 BLAS port "
+                      "of the reference conv1d STFT (oracle/spectral_oracle.py), %.1f s"
+                      % (reps, n, dt))
+    # beside it, bounded to a few seconds each: the FFT route librosa.stft takes (librosa itself is
+    # not installable here: SURVEY.md 8d "librosa-equivalent"), and the port of the reference's
+    # CQT1992v2 on the CQT84 workload of the metric
+    try:
+        xt = torch.from_numpy(x[: min(n, 16)])
+        win = torch.hann_window(2048, periodic=True)
+        t0 = time.perf_counter()
+        reps2 = 0
+        while time.perf_counter() - t0 < 4.0:
+            torch.stft(xt, 2048, hop_length=512, window=win, center=True, pad_mode="reflect",
+                       return_complex=True).abs()
+            reps2 += 1
+        dt2 = time.perf_counter() - t0
+        out["librosa_equivalent"] = dict(
+            value=reps2 * xt.shape[0] * 862 / dt2, unit="frames/s", cores=int(torch.get_num_threads()),
+            what="torch.stft(n_fft=2048, hop=512, hann, reflect).abs() on CPU: the FFT algorithm of "
+                 "librosa.stft (librosa is not installed), %d clips x %d, %.1f s" % (xt.shape[0], reps2, dt2))
+    except Exception as e:
+        out["librosa_equivalent"] = {"error": repr(e)}
+    try:
+        c = features.CQT1992v2(sr=44100, hop_length=512, fmin=32.70, n_bins=84, bins_per_octave=12,
+                               verbose=False)
+        kr, ki, ln = c.cqt_kernels_real.numpy(), c.cqt_kernels_imag.numpy(), c.lenghts.numpy()
+        xc = x[:2]
+        t0 = time.perf_counter()
+        reps3 = 0
+        while time.perf_counter() - t0 < 6.0 and reps3 < 20:
+            O.cqt1992v2(xc, kr, ki, ln, 512, output_format="Magnitude", acc=np.float32)
+            reps3 += 1
+        dt3 = time.perf_counter() - t0
+        out["cqt84"] = dict(value=reps3 * xc.shape[0] * 862 / dt3, unit="frames/s", cores=int(cores), kind="port",
+                            sample="%d x %d clips (10 s @ 44.1 kHz), numpy float32 BLAS port of the "
+                                   "reference CQT1992v2 (dense 32768-tap conv1d), %.1f s"
+                                   % (reps3, xc.shape[0], dt3))
+    except Exception as e:
+        out["cqt84"] = {"error": repr(e)}
+    return out
 
 
 def main():

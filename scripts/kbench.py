@@ -160,3 +160,26 @@ if __name__ == "__main__":
             fn()
             torch.cuda.synchronize()
             print("  [%s done in %.1f s]" % (name, time.time() - t0), flush=True)
+
+
+def cqtsplit():
+    """Where the CQT84 time goes by row tile: the narrow bf16x3 kernel on prefixes / suffixes of the bank."""
+    B, L = 64, 441000
+    x = torch.randn(B, L, device=DEV)
+    c = features.CQT1992v2(sr=44100, hop_length=512, n_bins=84, verbose=False).to(DEV)
+    sup = c._support.get(c.cqt_kernels_real, c.cqt_kernels_imag)
+    sc = torch.sqrt(c.lenghts)
+    kr, ki = c.cqt_kernels_real.reshape(84, -1), c.cqt_kernels_imag.reshape(84, -1)
+    for lo, hi in ((0, 84), (0, 16), (0, 32), (0, 48), (48, 84), (16, 84), (32, 84), (64, 84)):
+        r, i = kr[lo:hi].contiguous(), ki[lo:hi].contiguous()
+        spl = engine.split_basis(r, i)
+        for tile in (0,):
+            ms = timeit(lambda: engine.framed_gemm(x, r, i, hop=512, pad=16384, pad_mode=2,
+                                                   epilogue=engine.EPI_MAGNITUDE, row_scale=sc[lo:hi].contiguous(),
+                                                   row_support=sup[lo:hi].contiguous(), precision="bf16x3",
+                                                   basis_split=spl, tile=tile), n=5, w=2)
+            print("cqt bins [%2d, %2d): %.3f ms" % (lo, hi, ms))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "cqtsplit":
+    cqtsplit()

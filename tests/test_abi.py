@@ -102,3 +102,30 @@ def test_legacy_import_shim_warns():
         importlib.reload(mod)
     assert any("deprecated" in str(i.message) for i in w)
     assert hasattr(mod, "STFT") and hasattr(mod, "CQT2010v2") and hasattr(mod, "VQT")
+
+
+def test_filterbank_support_tables():
+    """Host plumbing of the fused filterbank epilogue: [first, last + 1) of every filter row and
+    the average number of filters covering a bin; the fusion rule follows include/mispec.h."""
+    import numpy as np
+
+    from nnaudio_amd import engine
+    from nnaudio_amd.basis import mel_filterbank
+
+    fb = torch.zeros(5, 40)
+    fb[0, 3:7] = 1.0
+    fb[1, 6] = 0.5
+    fb[3, 0:40] = 2.0
+    fb[4, 39] = 1.0
+    sup, cov = engine.filterbank_support(fb)
+    assert sup.dtype == torch.int32 and sup.tolist() == [[3, 7], [6, 7], [0, 0], [0, 40], [39, 40]]
+    assert abs(cov - (4 + 1 + 0 + 40 + 1) / 40.0) < 1e-6
+    mel = torch.from_numpy(np.asarray(mel_filterbank(22050, 1024, n_mels=128), dtype=np.float32))
+    sup, cov = engine.filterbank_support(mel)
+    assert 1.5 < cov < 2.6  # triangular filters: every bin under about two of them
+    assert engine.fused_filterbank_ok(513, 512, "bf16x3", 2.0, cov, 128)
+    assert not engine.fused_filterbank_ok(513, 512, "fp32", 2.0, cov, 128)      # fp32 kernels: unfused
+    assert not engine.fused_filterbank_ok(513, 511, "bf16x3", 2.0, cov, 128)    # odd hop: fp32 kernels
+    assert not engine.fused_filterbank_ok(513, 512, "bf16x3", 1.5, cov, 128)    # exponent 1 or 2 only
+    assert not engine.fused_filterbank_ok(513, 512, "bf16x3", 2.0, 64.0, 64)    # dense (gammatone)
+    assert not engine.fused_filterbank_ok(513, 512, "bf16x3", 2.0, cov, 300)    # > 256 filters

@@ -534,6 +534,55 @@ def test_bf16x3_kernel_shapes(shape, support):
         assert not torch.equal(y, y32)  # really took the bf16 pipe
 
 
+@pytest.mark.parametrize("shape", [  # (B, L, bins, K, hop, pad, mode)
+    (37, 20, 140, 256, 64, 128, 1),     # one frame per clip: every store quad spans four clips
+    (19, 150, 129, 256, 64, 128, 2),    # three frames per clip + a Nyquist-like leftover bin
+    (11, 300, 160, 256, 64, 128, 2),    # five frames per clip
+    (3, 16448, 130, 256, 64, 128, 2),   # 258 frames per clip: partial second frame tile
+])
+def test_bf16x3_epilogues_small_clips(shape):
+    """Every epilogue of the dense bf16x3 kernel (16-byte row-segment stores through the LDS
+    transpose, their clip-straddling slow path, the phase patches, real bases, row scales)
+    against the one-thread-per-output device kernel, on clips of very few frames."""
+    from nnaudio_amd import engine
+
+    B, L, F, K, hop, pad, mode = shape
+    rng = np.random.default_rng(L)
+    xd = torch.as_tensor(rng.standard_normal((B, L)).astype(np.float32)).to(DEV)
+    wr = torch.as_tensor(rng.standard_normal((F, K)).astype(np.float32)).to(DEV)
+    wi = torch.as_tensor(rng.standard_normal((F, K)).astype(np.float32)).to(DEV)
+    sc = torch.as_tensor(rng.uniform(0.5, 2.0, F).astype(np.float32)).to(DEV)
+    base = dict(hop=hop, pad=pad, pad_mode=mode)
+    z = engine.framed_gemm(xd, wr, wi, reference_kernel=True, epilogue=engine.EPI_COMPLEX, row_scale=sc,
+                           **base)
+    mag = torch.sqrt(z[..., 0] ** 2 + z[..., 1] ** 2)
+    strong = mag > 0.05 * mag.max()
+    cases = [(engine.EPI_COMPLEX, {}), (engine.EPI_MAGNITUDE, {}), (engine.EPI_MAGNITUDE, {"eps": 1e-8}),
+             (engine.EPI_POWER, {"power": 2.0}), (engine.EPI_POWER, {"power": 1.0}),
+             (engine.EPI_POWER, {"power": 0.7, "eps": 1e-8}), (engine.EPI_PHASE_ATAN2, {}),
+             (engine.EPI_PHASE_COSSIN, {"im_sign": 1.0})]
+    for epi, extra in cases:
+        kw = dict(base, epilogue=epi, row_scale=sc, **extra)
+        ref = engine.framed_gemm(xd, wr, wi, reference_kernel=True, **kw)
+        y = engine.framed_gemm(xd, wr, wi, precision="bf16x3", **kw)
+        assert y.shape == ref.shape
+        what = "epilogue %d %s %s" % (epi, extra, shape)
+        if epi == engine.EPI_PHASE_ATAN2:
+            d = torch.remainder(y - ref + np.pi, 2 * np.pi) - np.pi
+            assert d[strong].abs().max().item() < 2e-3, what
+        elif epi == engine.EPI_PHASE_COSSIN:
+            assert (y - ref)[strong].abs().max().item() < 2e-3, what
+        else:
+            assert (y - ref).abs().max().item() <= 1e-4 * ref.abs().max().item(), what
+    # real basis (two independent row tiles per wave in the planar layout)
+    wreal = torch.as_tensor(rng.standard_normal((2 * F, K)).astype(np.float32)).to(DEV)
+    kw = dict(base, epilogue=engine.EPI_REAL, im_sign=1.0)
+    ref = engine.framed_gemm(xd, wreal, None, reference_kernel=True, **kw)
+    y = engine.framed_gemm(xd, wreal, None, precision="bf16x3", **kw)
+    assert (y - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    assert not torch.equal(y, engine.framed_gemm(xd, wreal, None, precision="fp32", **kw))
+
+
 def test_bf16x3_split_cache_follows_the_basis(bf16x3):
     """The cached split planes must be rebuilt when the basis changes in place or is replaced."""
     from nnaudio_amd import features

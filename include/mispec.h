@@ -144,9 +144,9 @@ typedef struct mispec_framed_gemm_args {
    * blocks; a filter whose band crosses a block boundary receives one atomic addend per block,
    * so bands of up to 129 bins sum in an order-independent way).  The band of every filter is
    * walked bin by bin: meant for banded (mel) filterbanks.
-   * fb_support[m] = [first, last+1) bin with a non-zero weight; n_fb <= 256.  Served by the dense
-   * MISPEC_PREC_BF16X3 kernels only: MISPEC_E_UNSUPPORTED otherwise -- use
-   * mispec_filterbank_f32 on the power spectrogram then. */
+   * fb_support[m] = [first, last+1) bin with a non-zero weight; n_fb <= 256.  Served by both
+   * precisions with the automatic tile choice (MISPEC_E_UNSUPPORTED otherwise, and in grouped
+   * launches) -- use mispec_filterbank_f32 on the power spectrogram then. */
   const float *fb;             /* (n_fb, n_bins), row stride fb_row_stride elements, or NULL */
   const int32_t *fb_support;   /* (n_fb, 2)                                                */
   int64_t fb_row_stride;

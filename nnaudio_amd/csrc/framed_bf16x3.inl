@@ -420,12 +420,9 @@ __device__ __forceinline__ void bf16x3_epilogue_planar(const KParams &p, f32x16 
 // ---------------------------------------------------------------------------------
 // Fused filterbank epilogue of the dense planar kernel (mel.py:184-189: matmul(mel_basis,
 // spec ** power) without the (batch, bins, frames) intermediate).  The workgroup's
-// |X|^power tile -- WM*32 bins x WN*NR*32 frames -- is written to LDS once; then thread
-// (filter m, frame quad) walks the bins of m's band that lie in this tile,
-//   out[c, m, t] += sum_bin fb[m, bin] * P[bin][t],
-// and stores its four frames -- or, for the few filters whose band crosses a tile boundary, adds
-// them to the zeroed output with hardware float atomics (a band narrower than a tile receives at
-// most two addends, so the sum does not depend on their order).
+// |X|^power tile -- WM*32 bins x WN*NR*32 frames -- is written to LDS once (a lane holds re and
+// im of one bin for four consecutive frames per register quad: one 16-byte LDS write each);
+// filterbank_from_tile (mispec.hip) then reduces it over the bins of every filter's band.
 // Bins are absolute: p.out_row_offset is the first bin of a leftover-row problem.
 // ---------------------------------------------------------------------------------
 template <int WM, int WN, int NR>
@@ -466,83 +463,7 @@ __device__ __forceinline__ void bf16x3_epilogue_fb(const KParams &p, f32x16 (&ac
       }
     }
   }
-  // every filter's band clipped to this tile, relative to its first bin
-  const int bin_first = p.out_row_offset + b0;  // absolute first bin of the tile
-  int bins_here = p.n_bins - b0;
-  bins_here = bins_here < BB ? bins_here : BB;
-  int2 *const sBand = reinterpret_cast<int2 *>(P + BB * RS);
-  for (int m = tid; m < p.n_fb; m += NT) {
-    int lo = p.fb_support[2 * m] - bin_first, hi = p.fb_support[2 * m + 1] - bin_first;
-    // a band that lies inside this tile is stored; one that crosses a tile boundary is added
-    // atomically by both tiles (device-scope float atomics are resolved in memory, not in the
-    // XCD's L2: keep them for the few filters that need them)
-    const int whole = (lo >= 0 && hi <= bins_here) ? 0x10000 : 0;
-    lo = lo < 0 ? 0 : lo;
-    hi = hi > bins_here ? bins_here : hi;
-    sBand[m] = make_int2(lo | whole, hi);
-  }
-  __syncthreads();
-  // this thread's four frames
-  const int fq = tid % (BN / 4);
-  const long long col = n0 + 4 * fq;
-  int cc[4], tt[4];
-  {
-    const long long c0 = col < p.n_cols ? col : 0;
-    int c = (int)(c0 / p.n_frames);
-    int t = (int)(c0 - (long long)c * p.n_frames);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      cc[i] = c;
-      tt[i] = t;
-      if (++t >= p.n_frames) {
-        t = 0;
-        ++c;
-      }
-    }
-  }
-  // filter m is handled by the BN/4 threads of one or more whole waves: m, its band and its
-  // weights are wave-uniform (scalar registers, scalar loads)
-  static_assert((BN / 4) % 64 == 0, "a filter's threads are whole waves");
-  constexpr int MSTEP = NT / (BN / 4);
-#pragma unroll 1
-  for (int m = __builtin_amdgcn_readfirstlane(tid / (BN / 4)); m < p.n_fb; m += MSTEP) {
-    const int2 band = sBand[m];
-    const int lo = __builtin_amdgcn_readfirstlane(band.x) & 0xffff;
-    const bool whole = (__builtin_amdgcn_readfirstlane(band.x) & 0x10000) != 0;
-    const int hi = __builtin_amdgcn_readfirstlane(band.y);
-    if (lo >= hi) continue;
-    const float *w = p.fb + (long long)m * p.fb_row_stride + bin_first;
-    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int b = lo; b < hi; b += 4) {  // four bins per trip (independent loads); the bins past
-      f32x4 q[4];                       // the band get weight 0
-      float wb[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int bu = b + u < hi ? b + u : hi - 1;
-        q[u] = *reinterpret_cast<const f32x4 *>(P + bu * RS + 4 * fq);
-        wb[u] = b + u < hi ? w[bu] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) sum[i] += wb[u] * q[u][i];
-    }
-    float *const orow = p.out + (long long)m * p.out_row_stride;
-    if (whole) {
-      if (col + 3 < p.n_cols && cc[3] == cc[0]) {
-        *reinterpret_cast<f32x4u *>(orow + (long long)cc[0] * p.out_clip_stride + tt[0]) = sum;
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (col + i < p.n_cols) orow[(long long)cc[i] * p.out_clip_stride + tt[i]] = sum[i];
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (col + i < p.n_cols) unsafeAtomicAdd(orow + (long long)cc[i] * p.out_clip_stride + tt[i], sum[i]);
-    }
-  }
+  filterbank_from_tile<BB, BN, NT>(p, P, b0, n0);
 }
 
 template <int WM, int WN, int MR, int NR, bool MASKED>

@@ -272,6 +272,93 @@ __device__ __forceinline__ int epilogue_width(int epi) {
 }
 
 // ---------------------------------------------------------------------------------
+// Fused filterbank reduction, second half (shared by the fp32 and bf16x3 epilogues): the
+// workgroup's |X|^power tile P[BB bins][BN frames] (row stride BN + 4 floats) is in LDS; thread
+// (filter m, frame quad) walks the bins of m's band that lie in this tile,
+//   out[c, m, t] = / += sum_bin fb[m, bin] * P[bin][t],
+// and stores its four frames -- or, when the band crosses the tile boundary, adds them to the
+// zeroed output with hardware float atomics (device-scope float atomics are resolved in memory,
+// not in the XCD's L2: kept for the few filters that need them; a band narrower than a tile
+// receives at most two addends, so the sum does not depend on their order).
+// b0 = first bin of the tile relative to this problem's first bin (absolute: + out_row_offset).
+// ---------------------------------------------------------------------------------
+template <int BB, int BN, int NT>
+__device__ __forceinline__ void filterbank_from_tile(const KParams &p, float *P, const int b0,
+                                                     const long long n0) {
+  constexpr int RS = BN + 4;
+  constexpr int QPR = BN / 4;  // frame quads per row = threads per filter
+  static_assert(NT % QPR == 0, "a thread keeps its frame quad over all its filters");
+  const int tid = threadIdx.x;
+  const int bin_first = p.out_row_offset + b0;
+  int bins_here = p.n_bins - b0;
+  bins_here = bins_here < BB ? bins_here : BB;
+  int2 *const sBand = reinterpret_cast<int2 *>(P + BB * RS);
+  for (int m = tid; m < p.n_fb; m += NT) {
+    int lo = p.fb_support[2 * m] - bin_first, hi = p.fb_support[2 * m + 1] - bin_first;
+    const int whole = (lo >= 0 && hi <= bins_here) ? 0x10000 : 0;  // band inside this tile
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > bins_here ? bins_here : hi;
+    sBand[m] = make_int2(lo | whole, hi);
+  }
+  __syncthreads();
+  const int fq = tid % QPR;
+  const long long col = n0 + 4 * fq;
+  int cc[4], tt[4];
+  {
+    const long long c0 = col < p.n_cols ? col : 0;
+    int c = (int)(c0 / p.n_frames);
+    int t = (int)(c0 - (long long)c * p.n_frames);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      cc[i] = c;
+      tt[i] = t;
+      if (++t >= p.n_frames) {
+        t = 0;
+        ++c;
+      }
+    }
+  }
+#pragma unroll 1
+  for (int m = tid / QPR; m < p.n_fb; m += NT / QPR) {
+    const int2 band = sBand[m];
+    const int lo = band.x & 0xffff, hi = band.y;
+    const bool whole = (band.x & 0x10000) != 0;
+    if (lo >= hi) continue;
+    const float *w = p.fb + (long long)m * p.fb_row_stride + bin_first;
+    f32x4v sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int b = lo; b < hi; b += 4) {  // four bins per trip (independent loads); the bins past
+      f32x4v q[4];                      // the band get weight 0
+      float wb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int bu = b + u < hi ? b + u : hi - 1;
+        q[u] = *reinterpret_cast<const f32x4v *>(P + bu * RS + 4 * fq);
+        wb[u] = b + u < hi ? w[bu] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sum[i] += wb[u] * q[u][i];
+    }
+    float *const orow = p.out + (long long)m * p.out_row_stride;
+    if (whole) {
+      if (col + 3 < p.n_cols && cc[3] == cc[0]) {
+        *reinterpret_cast<f32x4u *>(orow + (long long)cc[0] * p.out_clip_stride + tt[0]) = sum;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (col + i < p.n_cols) orow[(long long)cc[i] * p.out_clip_stride + tt[i]] = sum[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (col + i < p.n_cols) unsafeAtomicAdd(orow + (long long)cc[i] * p.out_clip_stride + tt[i], sum[i]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // MFMA kernel.  Workgroup = WM x WN waves (256 threads); each wave owns MR x NR tiles of 32x32.
 //   BM = WM*MR*32 basis rows,  BN = WN*NR*32 frames per workgroup.
 // Loader geometry: thread (r32 = tid>>3, c4 = tid&7) moves the 4 consecutive K elements
@@ -730,6 +817,32 @@ __device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_
   // indexing only in the ds_write fan-out) and so that stores are contiguous along the
   // innermost output dimension for both store modes.
   __syncthreads();  // every wave is done with the K-stage buffers
+  if (BMODE == BMODE_FRAMED && AMODE == AMODE_ROWS && MR * NR <= 4 && p.fb) {  // (automatic tiles)
+    // fused filterbank reduction (mel.py:184-189): the tile's |X|^power goes to LDS, bins x
+    // frames, and filterbank_from_tile reduces it over the bins of every filter's band.  A lane
+    // holds re and im of a bin in adjacent accumulator elements (interleaved rows).
+    constexpr int RS = BN + 4;
+    float *const P = reinterpret_cast<float *>(smem_raw);
+    const bool sq = p.power == 2.0f;
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int n = 0; n < NR; ++n)
+#pragma unroll
+        for (int e2 = 0; e2 < 8; ++e2) {
+          const int rl = (wm * MR + m) * 32 + (2 * (e2 & 1)) + 8 * (e2 >> 1) + 4 * lh;  // even row
+          const int bl = rl >> 1;
+          const int bin = (m0 >> 1) + bl;
+          const bool bin_ok = bin < p.n_bins;
+          const float sc = (p.row_scale && bin_ok) ? p.row_scale[bin] : 1.f;
+          const float re = acc[m][n][2 * e2] * sc, im = acc[m][n][2 * e2 + 1] * sc;
+          const float s2 = re * re + im * im + p.eps;
+          P[bl * RS + (wn * NR + n) * 32 + li] = bin_ok ? (sq ? s2 : sqrtf(s2)) : 0.f;
+        }
+    __syncthreads();
+    filterbank_from_tile<BM / 2, BN, NT>(p, P, m0 >> 1, n0);
+    return;
+  }
   constexpr int LDC = 33;
   float *sC = reinterpret_cast<float *>(smem_raw) + wave * (32 * LDC);
   const int E = epilogue_width(p.epilogue);
@@ -1983,10 +2096,8 @@ int mispec_framed_gemm_f32(const mispec_framed_gemm_args *args, void *stream) {
   if (rc != MISPEC_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool bf16x3 = bf16x3_ok(args, p);
-  if (p.fb && !(bf16x3 && args->tile == MISPEC_TILE_AUTO && !(p.debug & 0x2000)))
-    return fail(MISPEC_E_UNSUPPORTED,
-                "fused filterbank needs the dense MISPEC_PREC_BF16X3 path (even hop, > 64 bins, "
-                "basis_split given, automatic tile)%s");
+  if (p.fb && (args->tile != MISPEC_TILE_AUTO || (p.debug & 0x2000)))
+    return fail(MISPEC_E_UNSUPPORTED, "fused filterbank needs the automatic tile choice%s");
   // (the bf16x3 kernels read the padded split signal, not the fp32 path's edge workspace)
   if (!bf16x3 || plan_bf16x3_rows(p, args->tile).fp32_leftover) {
     rc = setup_edges(p, args->workspace, args->workspace_bytes, s);

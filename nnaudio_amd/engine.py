@@ -273,8 +273,8 @@ def framed_gemm(x, basis_re, basis_im, *, reference_kernel=False, **kw):
     row_scale, row_support, out (pre-allocated (B, rows_total, T[, 2]) tensor: octave assembly /
     all-gather slices write in place), out_rows_total, out_row_offset, tile, precision ("fp32" /
     "bf16x3" / None = process default), basis_split (cached ``split_basis`` result), fb +
-    fb_support (fused filterbank reduction: EPI_POWER with power 1 or 2 on the dense bf16x3 path;
-    the result is ``(B, n_filters, T)``, see ``fused_filterbank_ok``)."""
+    fb_support (fused filterbank reduction: EPI_POWER with power 1 or 2; the result is
+    ``(B, n_filters, T)``, see ``fused_filterbank_ok``)."""
     a, out, dev, _keep = _framed_args(x, basis_re, basis_im, need_workspace=not reference_kernel,
                                       **kw)
     lib = _abi.load()
@@ -307,26 +307,23 @@ def filterbank_support(fb):
 FUSED_FB_MAX_COVERAGE = 4.0
 
 
-def fused_filterbank_ok(n_bins, hop, precision, power, coverage, n_filters=1):
-    """Whether ``framed_gemm(..., fb=...)`` is served (include/mispec.h: dense bf16x3 path, power
-    1 or 2, at most 256 filters) and worthwhile (banded filters)."""
-    return (resolve_precision(precision) == "bf16x3" and hop % 2 == 0 and 2 * n_bins > 128
-            and n_filters <= 256
-            and float(power) in (1.0, 2.0) and 0 < coverage <= FUSED_FB_MAX_COVERAGE)
+def fused_filterbank_ok(power, coverage, n_filters=1):
+    """Whether ``framed_gemm(..., fb=...)`` is served (include/mispec.h: power 1 or 2, at most
+    256 filters) and worthwhile (banded filters); both precisions have the fused epilogue."""
+    return (n_filters <= 256 and float(power) in (1.0, 2.0)
+            and 0 < coverage <= FUSED_FB_MAX_COVERAGE)
 
 
 def fused_filterbank_plan(mod, fb, x, stft, power):
     """For MelSpectrogram / Gammatonegram: the ``fb_support`` table when this forward can run with
-    the filterbank fused into the STFT contraction (no graph needed, bf16x3 precision, narrow
-    bands), else None."""
+    the filterbank fused into the STFT contraction (no graph needed, banded filters), else
+    None."""
     if needs_grad(mod, x) or stft.freq_bins is not None:
-        return None
-    if resolve_precision(stft.precision) != "bf16x3":
         return None
     if not hasattr(mod, "_fb_support"):
         mod._fb_support = DerivedCache()
     sup, coverage = mod._fb_support.get((fb,), lambda: filterbank_support(fb))
-    if not fused_filterbank_ok(fb.shape[1], stft.stride, stft.precision, power, coverage, fb.shape[0]):
+    if not fused_filterbank_ok(power, coverage, fb.shape[0]):
         return None
     return sup
 

@@ -123,9 +123,7 @@ def test_filterbank_support_tables():
     mel = torch.from_numpy(np.asarray(mel_filterbank(22050, 1024, n_mels=128), dtype=np.float32))
     sup, cov = engine.filterbank_support(mel)
     assert 1.5 < cov < 2.6  # triangular filters: every bin under about two of them
-    assert engine.fused_filterbank_ok(513, 512, "bf16x3", 2.0, cov, 128)
-    assert not engine.fused_filterbank_ok(513, 512, "fp32", 2.0, cov, 128)      # fp32 kernels: unfused
-    assert not engine.fused_filterbank_ok(513, 511, "bf16x3", 2.0, cov, 128)    # odd hop: fp32 kernels
-    assert not engine.fused_filterbank_ok(513, 512, "bf16x3", 1.5, cov, 128)    # exponent 1 or 2 only
-    assert not engine.fused_filterbank_ok(513, 512, "bf16x3", 2.0, 64.0, 64)    # dense (gammatone)
-    assert not engine.fused_filterbank_ok(513, 512, "bf16x3", 2.0, cov, 300)    # > 256 filters
+    assert engine.fused_filterbank_ok(2.0, cov, 128) and engine.fused_filterbank_ok(1.0, cov, 128)
+    assert not engine.fused_filterbank_ok(1.5, cov, 128)    # exponent 1 or 2 only
+    assert not engine.fused_filterbank_ok(2.0, 64.0, 64)    # dense (gammatone)
+    assert not engine.fused_filterbank_ok(2.0, cov, 300)    # > 256 filters

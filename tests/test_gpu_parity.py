@@ -922,42 +922,45 @@ def test_backward_octave_recursion(cls, fmt):
 
 
 def test_fused_filterbank_matches_unfused():
-    """precision="bf16x3": the mel reduction fused into the contraction's epilogue (atomic adds
-    into a zeroed (B, n_mels, T) tensor) against the two-kernel path and the fp32 path; filter
-    bands crossing 128-bin block boundaries, the Nyquist bin's own tile, clip-straddling frame
-    tiles, power 1 and 2; wide bands and graphs fall back to the separate filterbank kernel."""
+    """The mel reduction fused into the contraction's epilogue (both precisions; stores, and
+    float atomics into the zeroed output for bands crossing a tile boundary) against the
+    two-kernel path: filter bands crossing bin-block boundaries, the Nyquist bin's own tile,
+    clip-straddling frame tiles, odd hop (bf16x3 request served by the fp32 kernels), power 1
+    and 2; dense filterbanks and graphs fall back to the separate filterbank kernel."""
     from nnaudio_amd import engine, features
 
     g = torch.Generator().manual_seed(31)
     for n_fft, hop, n_mels, L, B, power in ((1024, 512, 128, 30000, 5, 2.0), (2048, 256, 64, 9000, 3, 1.0),
-                                            (512, 128, 40, 4100, 9, 2.0)):
+                                            (512, 128, 40, 4100, 9, 2.0), (512, 127, 40, 4100, 2, 2.0),
+                                            (128, 32, 20, 3000, 4, 2.0)):
         x = torch.randn(B, L, generator=g).to(DEV)
         m = features.MelSpectrogram(sr=22050, n_fft=n_fft, n_mels=n_mels, hop_length=hop, power=power,
                                     verbose=False).to(DEV)
-        ref = m(x)  # fp32 path: unfused
-        m.stft.precision = "bf16x3"
-        assert engine.fused_filterbank_plan(m, m.mel_basis, x, m.stft, m.power) is not None
-        y = m(x)
-        spec = m.stft._spectrum(x[:, None, :], engine.EPI_POWER, power=power)
-        y2 = engine.filterbank(m.mel_basis, spec)
-        peak = ref.abs().max().item()
-        assert y.shape == ref.shape
-        assert (y - ref).abs().max().item() <= 1e-4 * peak
-        assert (y - y2).abs().max().item() <= 2e-5 * peak
-        if n_mels >= 128:
-            assert torch.equal(y, m(x))  # at most two addends per output: order independent
+        for prec in ("fp32", "bf16x3"):
+            m.stft.precision = prec
+            assert engine.fused_filterbank_plan(m, m.mel_basis, x, m.stft, m.power) is not None
+            y = m(x)
+            spec = m.stft._spectrum(x[:, None, :], engine.EPI_POWER, power=power)
+            y2 = engine.filterbank(m.mel_basis, spec)  # two kernels, same arithmetic
+            peak = y2.abs().max().item()
+            assert y.shape == y2.shape
+            assert (y - y2).abs().max().item() <= 2e-5 * peak, (n_fft, hop, prec)
+            if n_mels >= 128:
+                assert torch.equal(y, m(x))  # at most two addends per output: order independent
     # a dense filterbank (gammatone) and a graph go through the separate kernel
     gt = features.Gammatonegram(sr=22050, n_fft=1024, n_bins=64, hop_length=512, verbose=False).to(DEV)
-    gt.stft.precision = "bf16x3"
     x = torch.randn(2, 20000, generator=g).to(DEV)
     assert engine.fused_filterbank_plan(gt, gt.gammatone_basis, x, gt.stft, gt.power) is None
     mt = features.MelSpectrogram(sr=22050, n_fft=1024, n_mels=64, trainable_mel=True, verbose=False).to(DEV)
-    mt.stft.precision = "bf16x3"
     assert engine.fused_filterbank_plan(mt, mt.mel_basis, x, mt.stft, mt.power) is None
     with torch.no_grad():
         assert engine.fused_filterbank_plan(mt, mt.mel_basis, x, mt.stft, mt.power) is not None
     # the C entry refuses the fusion where it is not served
     sup, _ = engine.filterbank_support(m.mel_basis)
     with pytest.raises(RuntimeError):
-        engine.framed_gemm(x, m.stft.wcos, m.stft.wsin, hop=128, pad=256, pad_mode=engine.PAD_REFLECT,
-                           epilogue=engine.EPI_POWER, precision="fp32", fb=m.mel_basis, fb_support=sup)
+        engine.framed_gemm(x, m.stft.wcos, m.stft.wsin, hop=32, pad=64, pad_mode=engine.PAD_REFLECT,
+                           epilogue=engine.EPI_POWER, power=1.5, fb=m.mel_basis, fb_support=sup)
+    with pytest.raises(RuntimeError):
+        engine.framed_gemm(x, m.stft.wcos, m.stft.wsin, hop=32, pad=64, pad_mode=engine.PAD_REFLECT,
+                           epilogue=engine.EPI_POWER, tile=engine.TILE_128x128 if hasattr(engine, "TILE_128x128") else 1,
+                           fb=m.mel_basis, fb_support=sup)

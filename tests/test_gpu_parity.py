@@ -3,6 +3,7 @@ Everything here needs the MI355X: run with ``pytest -m gpu``.
 
 Tolerance (BASELINE.md, north_star "within 1e-4 rel fp32"): max|y-ref| <= 1e-4*max|ref| and
 allclose(rtol=1e-4, atol=1e-4*max|ref|); phase compared where the bin carries energy."""
+import os
 import warnings
 
 import numpy as np
@@ -964,3 +965,17 @@ def test_fused_filterbank_matches_unfused():
         engine.framed_gemm(x, m.stft.wcos, m.stft.wsin, hop=32, pad=64, pad_mode=engine.PAD_REFLECT,
                            epilogue=engine.EPI_POWER, tile=engine.TILE_128x128 if hasattr(engine, "TILE_128x128") else 1,
                            fb=m.mel_basis, fb_support=sup)
+
+
+def test_rccl_single_rank_sharded_forward():
+    """The one-process-per-GPU path on the real backend: `nccl` (= RCCL) process group of one
+    rank, sharded forward + all-gather reassembly (the world-size-2 logic is covered on gloo in
+    the CPU suite).  Runs in a subprocess: process groups are process-global state."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "nccl_one_rank.py")], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "nccl 1-rank ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

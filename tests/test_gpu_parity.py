@@ -979,3 +979,27 @@ def test_rccl_single_rank_sharded_forward():
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "nccl_one_rank.py")], cwd=root, env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "nccl 1-rank ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_repeated_launches_are_bit_identical():
+    """A race between LDS-direct loads, fragment reads and stores would show up as run-to-run
+    differences: 30 launches each of the full-size STFT (both precisions), CQT84 and fused-mel
+    workloads must reproduce the first result bit for bit."""
+    from nnaudio_amd import features
+
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(64, 441000, generator=g).to(DEV)
+    stft = features.STFT(n_fft=2048, hop_length=512, output_format="Magnitude", verbose=False).to(DEV)
+    cqt = features.CQT1992v2(sr=44100, hop_length=512, n_bins=84, verbose=False).to(DEV)
+    xm = torch.randn(256, 110250, generator=g).to(DEV)
+    mel = features.MelSpectrogram(sr=22050, n_fft=1024, n_mels=128, hop_length=512, verbose=False).to(DEV)
+    for mod, inp, precs in ((stft, x, ("fp32", "bf16x3")), (cqt, x, ("bf16x3",)), (mel, xm, ("fp32", "bf16x3"))):
+        for prec in precs:
+            if hasattr(mod, "stft"):
+                mod.stft.precision = prec
+            else:
+                mod.precision = prec
+            first = mod(inp).clone()
+            for _ in range(30):
+                assert torch.equal(mod(inp), first), (type(mod).__name__, prec)
+            del first

@@ -727,7 +727,7 @@ __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int w
     load_frags(buf, 1);
     mfma_step(0, mask);
     if (!MASKED) interleave(n_mfma{}, n_reads{}, none{});
-    __syncthreads();
+    lds_dma_barrier();
     if (DMA) dma_stage(kc + 2 * KC, buf, stage_mask(kc + 2 * KC));
     if (NEXT) load_frags(buf ^ 1, 0);
     mfma_step(1, mask);
@@ -737,7 +737,7 @@ __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int w
   };
   if (nstages > 0) {
     dma_stage(kb, 0, stage_mask(kb));
-    __syncthreads();
+    lds_dma_barrier();
     if (nstages > 1) dma_stage(kb + KC, 1, stage_mask(kb + KC));
     load_frags(0, 0);
     int c = 0;

@@ -263,7 +263,7 @@ __device__ __forceinline__ void framed_bf16x3_narrow_body(const KParams &p, cons
     bool pref = false;  // the slab of the next sub-stage is already in flight / landed
     dma_slab(cur.s, 0);
     dma_a(cur, 0);
-    __syncthreads();
+    lds_dma_barrier();
     if (nx1.valid) dma_a(nx1, 1);
     load_frags(0, 0, 0, cur.j, 0, 0);
     load_frags(0, 0, 0, cur.j, 1, 1);
@@ -285,7 +285,7 @@ __device__ __forceinline__ void framed_bf16x3_narrow_body(const KParams &p, cons
         if (x == NX - 2) {
           // every fragment of this interval has been requested: the barrier (which waits for
           // them) frees its A buffer, and publishes the next interval's data
-          __syncthreads();
+          lds_dma_barrier();
           const bool switching = nx1.valid && nx1.s != cur.s;  // the next interval opens a new slab
           if (two && !pref && nx1.valid && !switching) {
             // first interval of a slab with more to come: prefetch the next slab (if any
@@ -305,7 +305,7 @@ __device__ __forceinline__ void framed_bf16x3_narrow_body(const KParams &p, cons
               // the spare buffer -- and wait for it: one exposed DMA latency per slab
               const int tb = two ? (sbuf ^ 1) : sbuf;
               dma_slab(nx1.s, tb);
-              __syncthreads();
+              lds_dma_barrier();
               sbuf = tb;
             }
             pref = false;

@@ -333,7 +333,7 @@ __device__ __forceinline__ void framed_bf16x3_slab_body(const KParams &p, const 
     bool pref = false;      // the slab of the next sub-stage is already in flight / landed
     dma_slab(cur.s, 0);
     dma_a(tap(cur), 0, stage_mask(tap(cur)));
-    __syncthreads();
+    lds_dma_barrier();
     if (n_stages > 1) dma_a(tap(nx1), 1, stage_mask(tap(nx1)));
     load_frags(0, 0, cur.j, 0);
 
@@ -348,7 +348,7 @@ __device__ __forceinline__ void framed_bf16x3_slab_body(const KParams &p, const 
       load_frags(abuf, sbuf, cur.j, 1);
       mfma_step(0, mask);
       if (!MASKED) interleave(n_mfma{}, n_reads{}, none{});
-      __syncthreads();
+      lds_dma_barrier();
       // second half
       const bool switching = NEXT && nx1.s != cur.s;  // stage i+1 opens the next slab
       if (two && !pref && NEXT && !switching) {
@@ -371,7 +371,7 @@ __device__ __forceinline__ void framed_bf16x3_slab_body(const KParams &p, const 
           // register budget.)
           const int tb = two ? (sbuf ^ 1) : sbuf;
           dma_slab(nx1.s, tb);
-          __syncthreads();
+          lds_dma_barrier();
           sbuf = tb;
         }
         pref = false;

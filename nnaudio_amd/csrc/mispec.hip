@@ -271,6 +271,16 @@ __device__ __forceinline__ int epilogue_width(int epi) {
   return (epi == MISPEC_EPI_COMPLEX || epi == MISPEC_EPI_PHASE_COSSIN) ? 2 : 1;
 }
 
+// Barrier that publishes LDS-direct (global_load_lds) data.  These loads complete asynchronously
+// under vmcnt, and the wait is stated here instead of being left to the compiler's tracking of
+// LDS-DMA writes against later ds_reads: hipcc emitted the K loop's barrier of one variant of
+// the bf16x3 kernel with `s_waitcnt lgkmcnt(0)` only (the variant with both first stages in
+// flight before the first barrier, experiments/README.md) and that build read stale LDS.
+__device__ __forceinline__ void lds_dma_barrier() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------
 // Fused filterbank reduction, second half (shared by the fp32 and bf16x3 epilogues): the
 // workgroup's |X|^power tile P[BB bins][BN frames] (row stride BN + 4 floats) is in LDS; thread
@@ -711,14 +721,14 @@ __device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_
                                            16, 0, 0);
       };
       dma_stage(c0, 0);
-      __syncthreads();
+      lds_dma_barrier();
       for (int c = c0; c < c1; ++c) {
         const int buf = (c - c0) & 1;
         if ((c + 1) < c1 && !(p.debug & 1)) dma_stage(c + 1, buf ^ 1);
         mfma_stage(
             buf, stage_mask(kb + c * KC), !(p.debug & 8) || c == c0, mra_tag, use_mask_tag,
             [&]() __attribute__((always_inline)) {}, [&]() __attribute__((always_inline)) {});
-        if (!(p.debug & 4)) __syncthreads();
+        if (!(p.debug & 4)) lds_dma_barrier();
       }
       return;
     }

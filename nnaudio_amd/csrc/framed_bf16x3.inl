@@ -27,6 +27,8 @@
 // are XOR-swizzled by (row >> 2) & 3 -- applied to the per-lane SOURCE address of the DMA and
 // again on the fragment reads -- which makes every ds_read_b128 lane group conflict free
 // (rows r, r+4, r+8, r+12 share banks; MI355X_MICROARCH.md, LDS table).
+// The loads complete under vmcnt: every barrier that publishes a stage is lds_dma_barrier()
+// (mispec.hip), which states the s_waitcnt vmcnt(0) instead of leaving it to the compiler.
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));

@@ -69,6 +69,29 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert b"struct_size" in lib.mispec_last_error()
     assert lib.mispec_fir_decimate_f32(None, 0, 1, 1, None, 1, 1, 0, None, 0, 1, None, 0, None) == -1
     assert lib.mispec_filterbank_f32(None, 1, 1, None, 1, 1, None, None) == -1
+    # argument validation happens before any device work: every entry refuses NULL / bad sizes
+    assert lib.mispec_power_to_db_f32(None, 1, 1, 1e-10, 1.0, 80.0, None, None, 0, None) == -1
+    assert lib.mispec_power_to_db_bwd_f32(None, None, 1, 1, 1e-10, 80.0, None, None, 0, None) == -1
+    assert lib.mispec_istft_grad_signal_f32(None, 0, 1, 1, 1, None, 1, 0, 1, None, None) == -1
+    assert lib.mispec_overlap_add_f32(None, 1, 1, 1, None, 1, 0, None, 0, 1, None) == -1
+    assert lib.mispec_basis_split_bytes(0, 16, 1) == -1 and lib.mispec_basis_split_bytes(4, 48, 1) == 4 * 4 * 64 * 2
+    # the fused filterbank fields are validated with the rest of the block (fake non-NULL pointers:
+    # nothing is dereferenced on the host)
+    a = _abi.FramedGemmArgs()
+    a.struct_size = ctypes.sizeof(_abi.FramedGemmArgs)
+    a.x = a.basis_re = a.basis_im = a.out = 4096
+    a.n_clips, a.n_samples, a.n_frames, a.n_bins, a.kernel, a.hop = 1, 1024, 5, 129, 256, 64
+    a.pad, a.pad_mode, a.epilogue, a.power, a.im_sign = 128, 2, 2, 2.0, -1.0
+    a.fb, a.n_fb = 4096, 8  # no fb_support
+    assert lib.mispec_framed_gemm_f32(ctypes.byref(a), None) == -1 and b"fb_support" in lib.mispec_last_error()
+    a.fb_support, a.power = 4096, 1.5
+    assert lib.mispec_framed_gemm_f32(ctypes.byref(a), None) == -1 and b"power 1 or 2" in lib.mispec_last_error()
+    a.power, a.n_fb = 2.0, 300
+    assert lib.mispec_framed_gemm_f32(ctypes.byref(a), None) == -2 and b"256 filters" in lib.mispec_last_error()
+    a.n_fb, a.tile = 8, 1
+    assert lib.mispec_framed_gemm_f32(ctypes.byref(a), None) == -2 and b"automatic tile" in lib.mispec_last_error()
+    a.tile, a.reserved3 = 0, 1
+    assert lib.mispec_framed_gemm_f32(ctypes.byref(a), None) == -1 and b"reserved" in lib.mispec_last_error()
 
 
 def test_cpu_tensors_fail_loudly():

@@ -9,6 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmispec.so")
+ABLATE_LIB_PATH = os.path.join(_HERE, "csrc", "libmispec_ablate.so")  # benchmarking build
 
 ABI_VERSION = 4
 E_INVALID, E_UNSUPPORTED, E_HIP = -1, -2, -3
@@ -122,19 +123,33 @@ class MispecError(RuntimeError):
 
 
 _lib = None
+_lib_ablate = None
+
+
+def load_ablate():
+    """The benchmarking build (``python -m nnaudio_amd.build --ablate``): same entry points, with
+    the ablation / A-B bits of ``reserved`` compiled in.  Never used by the modules."""
+    global _lib_ablate
+    if _lib_ablate is None:
+        _lib_ablate = _load(ABLATE_LIB_PATH, "python -m nnaudio_amd.build --ablate")
+    return _lib_ablate
 
 
 def load():
     """Load (once) and return the ctypes handle; raise if the extension is not built."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    if _lib is None:
+        _lib = _load(LIB_PATH, "python -m nnaudio_amd.build")
+    return _lib
+
+
+def _load(path, how):
+    if not os.path.exists(path):
         raise MispecError(
-            "libmispec.so not found at %s -- build it with `python -m nnaudio_amd.build` "
-            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH
+            "%s not found at %s -- build it with `%s` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % (os.path.basename(path), path, how)
         )
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name in EXPORTS:
         if not hasattr(lib, name):
             raise MispecError("libmispec.so does not export %s" % name)
@@ -234,13 +249,12 @@ def load():
     v = lib.mispec_version()
     if v != ABI_VERSION:
         raise MispecError("libmispec ABI version %d, expected %d" % (v, ABI_VERSION))
-    _lib = lib
     return lib
 
 
-def check(rc):
+def check(rc, lib=None):
     if rc != 0:
-        msg = load().mispec_last_error()
+        msg = (lib or load()).mispec_last_error()
         raise MispecError(
             "libmispec call failed (%d): %s" % (rc, msg.decode() if msg else "")
         )

@@ -8,6 +8,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "mispec.hip")
 OUT = os.path.join(HERE, "csrc", "libmispec.so")
+# benchmarking build: the same source with -DMISPEC_ABLATE (ablation / A-B bits behind
+# mispec_framed_gemm_args.reserved); only scripts/kbench.py and scripts/profile.sh load it
+OUT_ABLATE = os.path.join(HERE, "csrc", "libmispec_ablate.so")
 INC = os.path.join(ROOT, "include")
 
 
@@ -18,16 +21,20 @@ def hipcc():
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, ablate=False):
+    """Compile the product library (or, with ``ablate``, the benchmarking build)."""
+    out = OUT_ABLATE if ablate else OUT
     csrc = os.path.dirname(SRC)
     deps = [os.path.join(INC, "mispec.h")] + [
         os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".inl", ".h"))
     ]
-    if (not force and os.path.exists(OUT)
-            and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps)):
-        return OUT
+    if (not force and os.path.exists(out)
+            and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps)):
+        return out
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Rpass-analysis=kernel-resource-usage", "-I", INC, SRC, "-o", OUT + ".tmp"]
+           "-Rpass-analysis=kernel-resource-usage", "-I", INC, SRC, "-o", out + ".tmp"]
+    if ablate:
+        cmd.insert(1, "-DMISPEC_ABLATE")
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
@@ -42,8 +49,8 @@ def build(force=False, verbose=True):
     spilled = {k: v for k, v in remarks.items() if k.startswith("framed_") and v > 0}
     if spilled:
         raise RuntimeError("kernels using LDS-direct loads must not use scratch: %s" % spilled)
-    os.replace(OUT + ".tmp", OUT)
-    return OUT
+    os.replace(out + ".tmp", out)
+    return out
 
 
 def resource_usage(stderr):
@@ -72,5 +79,4 @@ def resource_usage(stderr):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(OUT)
+    print(build(force="--force" in sys.argv, ablate="--ablate" in sys.argv))

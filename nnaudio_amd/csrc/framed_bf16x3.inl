@@ -589,7 +589,7 @@ __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int w
   }
   kb = kb & ~(KC - 1);
   int nstages = ke > kb ? (ke - kb + KC - 1) / KC : 0;  // Ks covers the last partial stage
-  if (PLANAR && (p.debug & 0x80000)) nstages = nstages < 2 ? nstages : 2;  // ablation: no K loop
+  if (PLANAR && MISPEC_DBG(p, 0x80000)) nstages = nstages < 2 ? nstages : 2;  // ablation: no K loop
   auto stage_mask = [&](int kc) __attribute__((always_inline)) -> unsigned {
     if (!MASKED) return (1u << MT) - 1u;
     unsigned m = 0;
@@ -750,7 +750,7 @@ __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int w
   }
 
   if constexpr (PLANAR) {
-    if (p.debug & 0x40000) {  // ablation: no epilogue (keep the accumulators alive)
+    if MISPEC_DBG(p, 0x40000) {  // ablation: no epilogue (keep the accumulators alive)
       float s = 0.f;
 #pragma unroll
       for (int m = 0; m < MR; ++m)

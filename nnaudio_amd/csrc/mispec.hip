@@ -33,11 +33,16 @@
 // below; the host side of both paths, the small pointwise kernels (power_to_db, overlap-add) and
 // the extern "C" entry points are at the end of this file.
 //
-// `reserved` of mispec_framed_gemm_args carries benchmark-only ablation bits ("debug" below;
-// results are WRONG for bits 1-16): 1 no global loads in the K loop, 2 no LDS stores, 4 no barrier,
-// 8 no fragment reads, 16 no MFMAs, 0x100 frame-tile-fastest tile order, 0x800 register-staged
-// instead of LDS-direct loads, 0x2000 no pair launch, 0x4000 bf16x3: staged kernel instead of the
-// hop-periodic ones, 0x8000 one slab buffer, 0x20000 masked 192x256 slab tiles instead of narrow tiles.
+// Ablation / A-B bits ("debug" below) exist only in the benchmarking build (-DMISPEC_ABLATE ->
+// libmispec_ablate.so, used by scripts/kbench.py and scripts/profile.sh): there `reserved` of
+// mispec_framed_gemm_args selects them (results are WRONG for bits 1-16, 0x40000, 0x80000):
+// 1 no global loads in the K loop, 2 no LDS stores, 4 no barrier, 8 no fragment reads, 16 no MFMAs,
+// 0x100 frame-tile-fastest tile order, 0x800 register-staged instead of LDS-direct loads, 0x1000
+// generic Toeplitz decimator, 0x2000 no pair launch, 0x4000 bf16x3: staged kernel instead of the
+// hop-periodic ones, 0x8000 one slab buffer, 0x20000 masked 192x256 slab tiles instead of narrow
+// tiles, 0x40000 no epilogue, 0x80000 two K stages only, 0x100000 bf16x3: dense (unfolded) kernel.
+// In the product library MISPEC_DBG() is the constant false (the branches compile away) and a
+// non-zero `reserved` is rejected.
 //
 #include <hip/hip_runtime.h>
 
@@ -48,6 +53,12 @@
 #include <cstring>
 
 #include "mispec.h"
+
+#ifdef MISPEC_ABLATE
+#define MISPEC_DBG(p, bit) (((p).debug & (bit)) != 0)
+#else
+#define MISPEC_DBG(p, bit) (false)
+#endif
 
 namespace {
 
@@ -375,9 +386,7 @@ __device__ __forceinline__ void filterbank_from_tile(const KParams &p, float *P,
 // 4*c4.. of row r32 of each 32-row "pass"; a pass of the A tile is one 32-row MFMA tile, a
 // pass of the B tile is 32 consecutive frames.  Every thread keeps one source pointer per pass.
 //
-// debug bits (benchmark ablations; results are wrong when set): 1 no global loads in the
-// loop, 2 no LDS stores, 4 no barrier, 8 no fragment reads, 16 no MFMAs, 0x100 / 0x200 force the
-// frame-tile-fastest / L2-blocked tile order.
+// MISPEC_DBG bits: see the file header (benchmarking build only).
 // ---------------------------------------------------------------------------------
 template <int WM, int WN, int MR, int NR, int BMODE, int AMODE, bool MASKED, bool GLDS>
 __device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_index,
@@ -678,7 +687,7 @@ __device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_
       if (q + 1 < KC / 8 && frags) load_frags(q + 1, (q + 1) & 1);  // prefetch under the MFMAs
 #pragma unroll
       for (int m = 0; m < MRA; ++m) {
-        if ((!USE_MASK || ((wmask >> m) & 1u)) && !(p.debug & 16)) {
+        if ((!USE_MASK || ((wmask >> m) & 1u)) && !MISPEC_DBG(p, 16)) {
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -724,11 +733,11 @@ __device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_
       lds_dma_barrier();
       for (int c = c0; c < c1; ++c) {
         const int buf = (c - c0) & 1;
-        if ((c + 1) < c1 && !(p.debug & 1)) dma_stage(c + 1, buf ^ 1);
+        if ((c + 1) < c1 && !MISPEC_DBG(p, 1)) dma_stage(c + 1, buf ^ 1);
         mfma_stage(
-            buf, stage_mask(kb + c * KC), !(p.debug & 8) || c == c0, mra_tag, use_mask_tag,
+            buf, stage_mask(kb + c * KC), !MISPEC_DBG(p, 8) || c == c0, mra_tag, use_mask_tag,
             [&]() __attribute__((always_inline)) {}, [&]() __attribute__((always_inline)) {});
-        if (!(p.debug & 4)) lds_dma_barrier();
+        if (!MISPEC_DBG(p, 4)) lds_dma_barrier();
       }
       return;
     }
@@ -745,17 +754,17 @@ __device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_
       const bool has1 = (c + 1) < c1;
       const bool has2 = (c + 2) < c1;
       mfma_stage(
-          buf, stage_mask(kb + c * KC), !(p.debug & 8) || c == c0, mra_tag, use_mask_tag,
+          buf, stage_mask(kb + c * KC), !MISPEC_DBG(p, 8) || c == c0, mra_tag, use_mask_tag,
           [&]() __attribute__((always_inline)) {
-            if (has1 && !(p.debug & 2)) store_stage(buf ^ 1, na_tag);  // stage c+1: regs -> LDS
+            if (has1 && !MISPEC_DBG(p, 2)) store_stage(buf ^ 1, na_tag);  // stage c+1: regs -> LDS
           },
           [&]() __attribute__((always_inline)) {
-            if (has2 && !(p.debug & 1)) {  // stage c+2: HBM/L2 -> registers
+            if (has2 && !MISPEC_DBG(p, 1)) {  // stage c+2: HBM/L2 -> registers
               load_a(kb + (c + 2) * KC, na_tag);
               load_b(kb + (c + 2) * KC);
             }
           });
-      if (!(p.debug & 4)) __syncthreads();
+      if (!MISPEC_DBG(p, 4)) __syncthreads();
     }
   };
   using std::integral_constant;
@@ -1187,7 +1196,7 @@ long long prepare_tiling(KParams &p) {
   // (rocprofv3 FETCH_SIZE 1.28e6 KB vs 3.64e6 KB per launch): the K/hop-fold re-reads of the
   // waveform hit L2 instead of the Infinity Cache.
   int g = (64 + p.n_tiles_m / 2) / p.n_tiles_m;
-  if (p.debug & 0x100) g = 1 << 20;  // benchmarking: frame-tile-fastest order
+  if MISPEC_DBG(p, 0x100) g = 1 << 20;  // benchmarking: frame-tile-fastest order
   if (g < 1) g = 1;
   if (g > p.n_tiles_n) g = p.n_tiles_n;
   p.n_group = g;
@@ -1258,7 +1267,7 @@ int launch_group_cfg(KParams *ps, int n, hipStream_t stream) {
 // pieces only need element (4-byte) alignment at the source: the whole GPU parity suite,
 // including odd hops / pads / clip lengths, was run with this path forced on.  Bit 0x800 of the
 // debug word selects the register-staged loop instead (A/B comparisons in scripts/kbench.py).
-bool glds_ok(const KParams &p) { return !(p.debug & 0x800); }
+bool glds_ok(const KParams &p) { return !MISPEC_DBG(p, 0x800); }
 
 template <int WM, int WN, int MR, int NR>
 int launch_pick_mask(const KParams &p, bool masked, hipStream_t stream) {
@@ -1329,7 +1338,7 @@ int launch_framed(const KParams &p, int tile, hipStream_t stream) {
   if (p.row_scale) r.row_scale = p.row_scale + main_bins;
   r.out_row_offset = p.out_row_offset + main_bins;
   const int rem_rows = rem * rpb;
-  if (rem_rows <= 64 && glds_ok(p) && !(p.debug & 0x2000)) {
+  if (rem_rows <= 64 && glds_ok(p) && !MISPEC_DBG(p, 0x2000)) {
     // one launch: main grid + narrow workgroups for the leftover rows in its tail
     const long long gm = prepare_tiling<2, 2, 2, 2, AMODE_ROWS>(q);
     const long long gr = rem_rows <= 32 ? prepare_tiling<1, 4, 1, 2, AMODE_ROWS>(r)
@@ -1777,7 +1786,7 @@ template <int WM, int WN, int MR, int NR>
 bool plan_slab(KParams &p, size_t &smem) {
   constexpr int BM = WM * MR * 32;
   constexpr int BN = WN * NR * 32;
-  if (p.debug & 0x4000) return false;  // benchmarking: force the staged kernel
+  if MISPEC_DBG(p, 0x4000) return false;  // benchmarking: force the staged kernel
   if (p.hop % KC != 0 || p.Ks < 2 * p.hop || p.n_frames < BN) return false;
   const int C = (p.Ks + p.hop - 1) / p.hop;
   const int rows = (BN + 2 * (C - 1) + 15) / 16 * 16;
@@ -1789,7 +1798,7 @@ bool plan_slab(KParams &p, size_t &smem) {
   int nbuf = 2;
   if (a + 2 * slab + tables > lds) nbuf = 1;
   if (a + nbuf * slab + tables > lds) return false;
-  if (p.debug & 0x8000) nbuf = 1;  // benchmarking: single slab buffer
+  if MISPEC_DBG(p, 0x8000) nbuf = 1;  // benchmarking: single slab buffer
   p.n_super = C;
   p.slab_rows = rows;
   p.slab_nbuf = nbuf;
@@ -1884,7 +1893,7 @@ Bf16x3Rows plan_bf16x3_rows(const KParams &p, int tile) {
   r.main_bins = (p.n_bins / bins_per_wg) * bins_per_wg;
   if (masked || (p.n_bins - r.main_bins) * rpb > 64) r.main_bins = p.n_bins;
   r.pair = tile == MISPEC_TILE_AUTO && !masked && r.main_bins > 0 && r.main_bins < p.n_bins &&
-           !(p.debug & 0x2000);
+           !MISPEC_DBG(p, 0x2000);
   r.fp32_leftover = !r.pair && r.main_bins != p.n_bins;
   return r;
 }
@@ -1938,7 +1947,7 @@ int launch_framed_bf16x3(const KParams &p, int tile, hipStream_t stream) {
   // layout with 128x128 per wave measured 8 % slower and does not fit without scratch).
   size_t sm = 0;
   if (masked && q.hop <= 64 * KC && plan_slab<2, 4, 3, 2>(q, sm))
-    rc = (p.debug & 0x20000) ? launch_bf16x3_slab_cfg<2, 4, 3, 2, true>(q, sm, stream)  // A/B runs
+    rc = MISPEC_DBG(p, 0x20000) ? launch_bf16x3_slab_cfg<2, 4, 3, 2, true>(q, sm, stream)  // A/B runs
                              : launch_bf16x3_narrow(q, sm, stream);
   else
     rc = masked ? launch_bf16x3_cfg<4, 2, 2, 4, true>(q, stream)
@@ -2022,7 +2031,12 @@ int fill_params(const mispec_framed_gemm_args *a, KParams &p) {
   p.out_clip_stride = a->out_clip_stride;
   p.out_row_stride = a->out_row_stride;
   p.out_row_offset = a->out_row_offset;
+#ifdef MISPEC_ABLATE
   p.debug = a->reserved;
+#else
+  if (a->reserved != 0)
+    return fail(MISPEC_E_INVALID, "reserved must be 0 (ablation bits exist only in libmispec_ablate.so)%s");
+#endif
   if (a->precision != MISPEC_PREC_F32 && a->precision != MISPEC_PREC_BF16X3)
     return fail(MISPEC_E_INVALID, "bad precision%s");
   if (a->reserved2 != 0 || a->reserved3 != 0) return fail(MISPEC_E_INVALID, "reserved fields must be 0%s");
@@ -2106,7 +2120,7 @@ int mispec_framed_gemm_f32(const mispec_framed_gemm_args *args, void *stream) {
   if (rc != MISPEC_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool bf16x3 = bf16x3_ok(args, p);
-  if (p.fb && (args->tile != MISPEC_TILE_AUTO || (p.debug & 0x2000)))
+  if (p.fb && (args->tile != MISPEC_TILE_AUTO || MISPEC_DBG(p, 0x2000)))
     return fail(MISPEC_E_UNSUPPORTED, "fused filterbank needs the automatic tile choice%s");
   // (the bf16x3 kernels read the padded split signal, not the fp32 path's edge workspace)
   if (!bf16x3 || plan_bf16x3_rows(p, args->tile).fp32_leftover) {
@@ -2509,7 +2523,7 @@ int mispec_fir_decimate_f32(const float *x, int64_t x_clip_stride, int32_t n_cli
                       y_clip_stride, n_out);
   if (rc != MISPEC_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (stride == 2 && n_taps + 62 <= 8 * FIR_KG && !(p.debug & 0x1000)) {
+  if (stride == 2 && n_taps + 62 <= 8 * FIR_KG && !MISPEC_DBG(p, 0x1000)) {
     // dedicated kernel: span staged once in LDS, Toeplitz taps re-read from a tiny LDS table
     constexpr int NRW = FIR_NRW;
     constexpr int OUT_WG = 4096 * NRW;

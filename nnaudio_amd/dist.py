@@ -4,13 +4,18 @@ the "nccl" backend = RCCL over xGMI).
 A spectrogram of one waveform depends on nothing else in the batch, and the bases are a few
 MB, so the bases are replicated and the batch is cut into contiguous blocks: rank r owns
 clips [r*B/G, (r+1)*B/G).  No collective is needed to *compute*; the only exchange is the
-optional reassembly of the full (B, bins, frames) tensor, one all-gather in which every
-rank's block is already in place inside the gather buffer (the kernels write there).
+optional reassembly of the full (B, bins, frames) tensor.  ``sharded_forward`` allocates that
+tensor once, lets the kernels of the module's final launch write this rank's block straight
+into its slice (``engine.output_into``) and all-gathers IN PLACE -- no staging copy on either
+side; with ``chunks > 1`` the local block is computed in sub-blocks whose gathers run
+asynchronously under the next sub-block's kernels.
 This is what the reference's only multi-GPU usage (nn.DataParallel: scatter the batch,
 replicate the module, gather the outputs; tests/test_cqt.py:273-291) amounts to.
 """
 import torch
 import torch.distributed as dist
+
+from . import engine
 
 
 def shard_bounds(n_clips, world_size, rank):
@@ -30,36 +35,145 @@ def shard_batch(x, world_size=None, rank=None, group=None):
     return x[lo:hi]
 
 
+def _aliasing_ok(group):
+    # RCCL all-gathers in place when the input is this rank's slice of the output; gloo (CPU
+    # tests) is given a private copy of the input instead
+    return dist.get_backend(group) == "nccl"
+
+
+def gather_in_place(full, n_clips, group=None, async_op=False):
+    """All-gather ``full`` (``(n_clips, ...)``, contiguous), whose block ``shard_bounds(rank)``
+    this rank has already filled, so that every rank holds every block.  Equal blocks: ONE
+    in-place ``all_gather_into_tensor``.  Ragged split (``n_clips % world != 0``): one in-place
+    broadcast per rank (no padding, no staging).  Returns the list of async work handles
+    (empty when ``async_op`` is False)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return []
+    works = []
+    if n_clips % world == 0:
+        lo, hi = shard_bounds(n_clips, world, rank)
+        mine = full[lo:hi]
+        if not _aliasing_ok(group):
+            mine = mine.clone()
+        w = dist.all_gather_into_tensor(full, mine, group=group, async_op=async_op)
+        if async_op:
+            works.append(w)
+        return works
+    for src in range(world):
+        lo, hi = shard_bounds(n_clips, world, src)
+        if hi > lo:
+            w = dist.broadcast(full[lo:hi], src=dist.get_global_rank(group, src) if group else src,
+                               group=group, async_op=async_op)
+            if async_op:
+                works.append(w)
+    return works
+
+
 def gather_batch(y_local, n_clips, group=None):
-    """All-gather per-rank blocks ``(b_r, ...)`` into the full ``(n_clips, ...)`` tensor on
-    every rank.  Equal blocks use one ``all_gather_into_tensor``; ragged tails fall back to
-    padded gathers."""
+    """All-gather per-rank blocks ``(b_r, ...)`` that were NOT computed in place into the full
+    ``(n_clips, ...)`` tensor (one copy of the local block, then ``gather_in_place``)."""
     world = dist.get_world_size(group)
     if world == 1:
         return y_local
-    q, r = divmod(int(n_clips), world)
-    tail = tuple(y_local.shape[1:])
-    if r == 0:
-        out = torch.empty((n_clips,) + tail, dtype=y_local.dtype, device=y_local.device)
-        dist.all_gather_into_tensor(out, y_local.contiguous(), group=group)
-        return out
-    padded = torch.zeros((q + 1,) + tail, dtype=y_local.dtype, device=y_local.device)
-    padded[: y_local.shape[0]] = y_local
-    buf = torch.empty((world * (q + 1),) + tail, dtype=y_local.dtype, device=y_local.device)
-    dist.all_gather_into_tensor(buf, padded, group=group)
-    parts = []
-    for rk in range(world):
-        lo, hi = shard_bounds(n_clips, world, rk)
-        parts.append(buf[rk * (q + 1): rk * (q + 1) + (hi - lo)])
-    return torch.cat(parts, 0)
+    rank = dist.get_rank(group)
+    full = torch.empty((n_clips,) + tuple(y_local.shape[1:]), dtype=y_local.dtype,
+                       device=y_local.device)
+    lo, hi = shard_bounds(n_clips, world, rank)
+    full[lo:hi].copy_(y_local)
+    gather_in_place(full, n_clips, group=group)
+    return full
 
 
-def sharded_forward(module, x_full, gather=True, group=None, **fwd):
-    """Run ``module`` on this rank's block of ``x_full`` (same tensor on every rank, or only
-    the local block when ``x_full`` is already sharded and ``gather`` is False) and optionally
-    reassemble the batch."""
-    x_local = shard_batch(x_full, group=group)
-    y_local = module(x_local, **fwd)
+def sharded_forward(module, x_full, gather=True, group=None, chunks=1, **fwd):
+    """Run ``module`` on this rank's block of ``x_full`` (the same tensor on every rank) and,
+    with ``gather``, reassemble the batch on every rank.
+
+    The full output is allocated once; the module's final launch writes this rank's clips into
+    their slice of it (no local output tensor, no copy) and the all-gather runs in place.  With
+    ``chunks > 1`` the local block is processed in ``chunks`` sub-blocks and the gather of
+    sub-block j is issued asynchronously (RCCL's own stream) while sub-block j+1 computes; this
+    needs equal blocks (``n_clips % world == 0`` and the local block divisible by ``chunks``),
+    otherwise one gather is issued at the end."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n = x_full.shape[0]
+    lo, hi = shard_bounds(n, world, rank)
+    x_local = x_full[lo:hi]
     if not gather:
-        return y_local
-    return gather_batch(y_local, x_full.shape[0], group=group)
+        return module(x_local, **fwd)
+    if world == 1:
+        return module(x_local, **fwd)
+    per = hi - lo
+    even = n % world == 0 and chunks > 1 and per % chunks == 0
+    if not even:
+        chunks = 1
+    sub = per // chunks if per else 0
+    full = None
+    works = []
+    for j in range(chunks):
+        a, b = (lo + j * sub, lo + (j + 1) * sub) if chunks > 1 else (lo, hi)
+        xs = x_full[a:b]
+        if full is None:
+            # the output shape is only known after the first forward: run it, then allocate the
+            # gather buffer and move the block (once per process lifetime would need the shape in
+            # advance; callers that know it pass `out_like` through engine.output_into themselves)
+            y = module(xs, **fwd)
+            full = torch.empty((n,) + tuple(y.shape[1:]), dtype=y.dtype, device=y.device)
+            full[a:b].copy_(y)
+            del y
+        else:
+            with engine.output_into(full[a:b]) as slot:
+                y = module(xs, **fwd)
+            if not slot.taken or y.data_ptr() != full[a:b].data_ptr():
+                full[a:b].copy_(y)  # a module whose last allocation is not its output
+            del y
+        if chunks > 1:
+            # gather sub-block j of every rank while the next one computes
+            outs = [full[r * per + j * sub: r * per + (j + 1) * sub] for r in range(world)]
+            mine = outs[rank] if _aliasing_ok(group) else outs[rank].clone()
+            works.append(dist.all_gather(outs, mine, group=group, async_op=True))
+    if chunks == 1:
+        gather_in_place(full, n, group=group)
+    for w in works:
+        w.wait()
+    return full
+
+
+class ShardedModule(torch.nn.Module):
+    """``module`` wrapped so that ``forward(x_full)`` is ``sharded_forward`` with a persistent
+    gather buffer: from the second call on (same input shape) the kernels write straight into
+    the buffer's slice and nothing is allocated or copied."""
+
+    def __init__(self, module, group=None, gather=True):
+        super().__init__()
+        self.module = module
+        self.group = group
+        self.gather = gather
+        self._full = None
+
+    def forward(self, x_full, **fwd):
+        world = dist.get_world_size(self.group)
+        rank = dist.get_rank(self.group)
+        n = x_full.shape[0]
+        lo, hi = shard_bounds(n, world, rank)
+        if not self.gather or world == 1:
+            return self.module(x_full[lo:hi], **fwd)
+        full = self._full
+        if full is not None and (full.shape[0] != n or full.device != x_full.device):
+            full = None
+        if full is not None:
+            with engine.output_into(full[lo:hi]) as slot:
+                y = self.module(x_full[lo:hi], **fwd)
+            if tuple(y.shape[1:]) != tuple(full.shape[1:]) or y.dtype != full.dtype:
+                full = None  # output format changed: fall through to the allocating path
+            elif not slot.taken or y.data_ptr() != full[lo:hi].data_ptr():
+                full[lo:hi].copy_(y)
+        if full is None:
+            y = self.module(x_full[lo:hi], **fwd)
+            full = torch.empty((n,) + tuple(y.shape[1:]), dtype=y.dtype, device=y.device)
+            full[lo:hi].copy_(y)
+            self._full = full
+        gather_in_place(full, n, group=self.group)
+        return full

@@ -6,6 +6,7 @@ no CPU / eager fallback: CPU tensors raise, a missing extension raises.
 """
 import ctypes
 import os
+import threading
 import weakref
 
 import torch
@@ -16,9 +17,6 @@ from ._abi import (  # noqa: F401  (re-exported for the feature modules)
     PAD_NONE, PAD_REFLECT, PAD_ZERO, PREC_BF16X3, PREC_F32, TILE_AUTO,
 )
 from .basis import decimated_length
-
-# benchmarking / bring-up only: OR-ed into the ablation bits of every framed_gemm call
-_ENV_DEBUG = int(os.environ.get("MISPEC_DEBUG", "0"), 0)
 
 # Arithmetic of the framed contraction (include/mispec.h, MISPEC_PREC_*):
 #   "fp32"   fp32 MFMA, bit-for-bit an fmaf chain like the reference's conv1d (default)
@@ -75,6 +73,52 @@ class DerivedCache:
         return val
 
 _PAD_MODES = {"constant": PAD_ZERO, "reflect": PAD_REFLECT, None: PAD_NONE}
+
+
+# ---------------------------------------------------------------------------------------
+# Output placement: lets a caller that owns a larger buffer (the all-gather buffer of
+# nnaudio_amd.dist, SURVEY 8e "each rank computes directly into its slice") have a module's
+# output written there, although forward(x) has no `out=` argument (the reference's signature).
+# ---------------------------------------------------------------------------------------
+_placement = threading.local()
+
+
+class _Slot:
+    def __init__(self, tensor):
+        self.tensor = tensor
+        self.taken = False
+
+
+class output_into:
+    """``with output_into(t) as slot: y = module(x)``: the first output-sized allocation of the
+    forward (same shape / dtype / device as ``t``, which must be contiguous) uses ``t`` instead of
+    fresh memory; ``slot.taken`` tells whether that happened (then ``y`` normally IS ``t``: check
+    ``y.data_ptr()``).  One-shot, per host thread, no effect on other allocations."""
+
+    def __init__(self, tensor):
+        if not tensor.is_contiguous():
+            raise RuntimeError("output_into needs a contiguous tensor")
+        self.slot = _Slot(tensor)
+
+    def __enter__(self):
+        self.prev = getattr(_placement, "slot", None)
+        _placement.slot = self.slot
+        return self.slot
+
+    def __exit__(self, *exc):
+        _placement.slot = self.prev
+        return False
+
+
+def alloc_out(shape, device, zero=False):
+    """Fresh float32 output tensor -- or the caller's ``output_into`` tensor when it fits."""
+    slot = getattr(_placement, "slot", None)
+    if slot is not None and not slot.taken:
+        t = slot.tensor
+        if tuple(t.shape) == tuple(shape) and t.dtype == torch.float32 and t.device == device:
+            slot.taken = True
+            return t.zero_() if zero else t
+    return (torch.zeros if zero else torch.empty)(tuple(shape), dtype=torch.float32, device=device)
 
 
 def _require_device(*tensors):
@@ -180,11 +224,11 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
         if out is not None or out_rows_total is not None or out_row_offset or two:
             raise RuntimeError("fused filterbank writes its own (B, n_filters, T) output")
         fb_support = fb_support.contiguous()
-        out = torch.zeros((B, fb.shape[0], T), dtype=torch.float32, device=dev)
+        out = alloc_out((B, fb.shape[0], T), dev, zero=True)
         rows_total = fb.shape[0]
     elif out is None:
         shape = (B, rows_total, T, 2) if two else (B, rows_total, T)
-        out = torch.empty(shape, dtype=torch.float32, device=dev)
+        out = alloc_out(shape, dev)
     else:
         want = (B, rows_total, T, 2) if two else (B, rows_total, T)
         if tuple(out.shape) != want or not out.is_contiguous() or out.dtype != torch.float32:
@@ -221,7 +265,7 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
     a.out_clip_stride = rows_total * T * E
     a.out_row_stride = T * E
     a.out_row_offset = int(out_row_offset)
-    a.reserved = int(_debug) | _ENV_DEBUG
+    a.reserved = int(_debug)  # ablation bits: honoured by libmispec_ablate.so only (framed_gemm)
     keep = [x, wr, wi, row_scale, row_support, fb, fb_support]
     if fb is not None:
         a.fb, a.fb_support = fb.data_ptr(), fb_support.data_ptr()
@@ -234,9 +278,10 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
         a.basis_split_bytes = basis_split.numel() * basis_split.element_size()
         keep.append(basis_split)
     if need_workspace:
-        need = _abi.load().mispec_framed_gemm_workspace_bytes(ctypes.byref(a))
+        lib = _abi.load_ablate() if a.reserved else _abi.load()
+        need = lib.mispec_framed_gemm_workspace_bytes(ctypes.byref(a))
         if need < 0:
-            _abi.check(int(need))
+            _abi.check(int(need), lib)
         if need > 0:
             # padded edge spans; stream-ordered reuse through the caching allocator
             ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
@@ -277,11 +322,13 @@ def framed_gemm(x, basis_re, basis_im, *, reference_kernel=False, **kw):
     ``(B, n_filters, T)``, see ``fused_filterbank_ok``)."""
     a, out, dev, _keep = _framed_args(x, basis_re, basis_im, need_workspace=not reference_kernel,
                                       **kw)
-    lib = _abi.load()
+    # `_debug` (scripts/kbench.py, scripts/profile.sh) selects the benchmarking build; the product
+    # library rejects a non-zero `reserved`
+    lib = _abi.load_ablate() if a.reserved else _abi.load()
     fn = lib.mispec_framed_gemm_f32_ref if reference_kernel else lib.mispec_framed_gemm_f32
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
-        _abi.check(fn(ctypes.byref(a), ctypes.c_void_p(stream)))
+        _abi.check(fn(ctypes.byref(a), ctypes.c_void_p(stream)), lib)
     return out
 
 
@@ -365,7 +412,7 @@ def filterbank(fb, spec):
         )
     B, F, T = spec.shape
     M = fb.shape[0]
-    out = torch.empty((B, M, T), dtype=torch.float32, device=dev)
+    out = alloc_out((B, M, T), dev)
     lib = _abi.load()
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
@@ -756,8 +803,25 @@ def fir_decimate_autograd(x, taps, stride):
     return fir_decimate(x, taps, stride)
 
 
+def _module_tensors(module):
+    """Parameters AND plain tensor attributes of a module tree.  nn.DataParallel replicas hold
+    their (trainable) parameters as plain attributes -- ``replica.parameters()`` is empty -- so
+    ``module.parameters()`` alone would report a trainable replica as frozen."""
+    for m in module.modules():
+        for t in m._parameters.values():
+            if t is not None:
+                yield t
+        for t in m.__dict__.values():
+            if isinstance(t, torch.Tensor):
+                yield t
+
+
 def needs_grad(module, x):
-    return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in module.parameters()))
+    """Whether this forward has to record a graph: grad mode is on and the input or any tensor
+    the module computes with (parameters, or the parameter copies of a DataParallel replica)
+    requires gradients."""
+    return torch.is_grad_enabled() and (
+        x.requires_grad or any(t.requires_grad for t in _module_tensors(module)))
 
 
 def framed_gemm_autograd(x, basis_re, basis_im, **kw):
@@ -773,9 +837,7 @@ def framed_gemm_autograd(x, basis_re, basis_im, **kw):
 def grad_guard(module, x):
     """Modules without a backward pass (CQT2010v2 / VQT octave recursion, MFCC's dB + DCT stage,
     the inverse STFT): refuse to silently drop a graph."""
-    if torch.is_grad_enabled() and (
-        x.requires_grad or any(p.requires_grad for p in module.parameters())
-    ):
+    if needs_grad(module, x):
         raise NotImplementedError(
             "%s: backward through this module's HIP kernels is not implemented yet (trainable "
             "bases / requires_grad inputs). Call under torch.no_grad() for inference."

@@ -101,7 +101,7 @@ def octave_recursion(x, banks, lenghts, hop, n_bins, lowpass, downsample_factor,
             T_ref = T
             two = epi in (engine.EPI_COMPLEX, engine.EPI_PHASE_COSSIN)
             shape = (x.shape[0], n_bins, T, 2) if two else (x.shape[0], n_bins, T)
-            out = torch.empty(shape, dtype=torch.float32, device=x.device)
+            out = engine.alloc_out(shape, x.device)
         elif T != T_ref:
             raise RuntimeError(
                 "Sizes of tensors must match except in dimension 1. Expected size %d but got "

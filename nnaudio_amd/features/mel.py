@@ -110,6 +110,10 @@ class MFCC(nn.Module):
             raise ParameterError("amin must be strictly positive")
         self.register_buffer("amin", torch.tensor([amin]))
         self.register_buffer("ref", torch.abs(torch.tensor([ref])))
+        # host copies of the two scalars: forward must not read device buffers back (a
+        # device-to-host sync per call, and it would break stream capture); refreshed by
+        # load_state_dict
+        self._amin_f, self._ref_f = float(amin), abs(float(ref))
         self.top_db = top_db
         self.n_mfcc = n_mfcc
         n_mels = self.melspec_layer.mel_basis.shape[0]
@@ -117,11 +121,16 @@ class MFCC(nn.Module):
         self.register_buffer("_dct_basis", torch.from_numpy(dct_ortho_matrix(min(n_mfcc, n_mels), n_mels)),
                              persistent=False)
 
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+        self._amin_f = float(self.amin.detach().cpu())
+        self._ref_f = float(self.ref.detach().cpu())
+
     def forward(self, x):
         spec = self.melspec_layer(x)
         if self.top_db is not None and self.top_db < 0:
             raise ParameterError("top_db must be non-negative")
-        db = engine.power_to_db_autograd(spec, float(self.amin), float(self.ref), self.top_db)
+        db = engine.power_to_db_autograd(spec, self._amin_f, self._ref_f, self.top_db)
         return engine.filterbank_autograd(self._dct_basis, db)
 
     def extra_repr(self) -> str:

@@ -317,6 +317,94 @@ def sampled_complex(x, basis_re, basis_im, clips, frames_idx, hop, pad, mode):
     return fr @ wr.T, -(fr @ wi.T)
 
 
+def decimated_lengths(L, n_taps, levels):
+    """Lengths of x_0 .. x_levels under repeated conv1d(stride=2, padding=(n_taps-1)//2)
+    [utils.py:98-99]."""
+    pad = (n_taps - 1) // 2
+    out = [int(L)]
+    for _ in range(levels):
+        out.append((out[-1] + 2 * pad - n_taps) // 2 + 1)
+    return out
+
+
+def decimated_window(x1d, taps, level, lo, hi):
+    """float64 ``x_level[lo:hi]`` of ONE clip, where x_0 = x and x_l = downsampling_by_2(x_{l-1})
+    [utils.py:102-124], evaluated only on the span of x it depends on (the full-size checks
+    cannot afford the whole recursion in float64).  Positions outside [0, len(x_level)) come
+    back as 0 (that is what conv1d's zero padding feeds the next level)."""
+    x1d = np.asarray(x1d)
+    taps = np.asarray(taps, dtype=np.float64).reshape(-1)
+    nt = taps.shape[0]
+    pad = (nt - 1) // 2
+    lens = decimated_lengths(x1d.shape[0], nt, level)
+    n = hi - lo
+    out = np.zeros(max(n, 0), dtype=np.float64)
+    if n <= 0:
+        return out
+    a, b = max(lo, 0), min(hi, lens[level])
+    if a >= b:
+        return out
+    if level == 0:
+        out[a - lo:b - lo] = x1d[a:b].astype(np.float64)
+        return out
+    # x_l[i] = sum_n taps[n] * x_{l-1}[2 i + n - pad], zeros outside x_{l-1}
+    plo = 2 * a - pad
+    phi = 2 * (b - 1) - pad + nt
+    prev = decimated_window(x1d, taps, level - 1, plo, phi)
+    win = np.lib.stride_tricks.sliding_window_view(prev, nt)[::2][: b - a]
+    out[a - lo:b - lo] = win @ taps
+    return out
+
+
+def sampled_octave_complex(x, banks, lengths, hop, n_bins, lowpass, clips, frames_idx,
+                           pad_mode="reflect", normalization_type="librosa",
+                           downsample_factor=1.0):
+    """Float64 (re, im) of CQT2010v2 / VQT [cqt.py:1085-1115, vqt.py:160-201] for the sampled
+    frames only: arrays (n, n_bins), rows ordered like the module output (lowest octave first),
+    scaled by sqrt(lenghts) * downsample_factor.  ``banks[i] = (real_i, imag_i)`` with i = 0 the
+    top octave (pass the same pair n_octaves times for CQT2010v2); ``hop`` is the post
+    early-down-sampling hop and ``x`` the signal the octave loop starts from."""
+    x = broadcast_dim(x)
+    clips = np.asarray(clips)
+    frames_idx = np.asarray(frames_idx)
+    n_oct = len(banks)
+    n_filters = banks[0][0].shape[0]
+    drop = n_oct * n_filters - n_bins
+    lens = decimated_lengths(x.shape[-1], np.asarray(lowpass).reshape(-1).shape[0], n_oct - 1)
+    re = np.zeros((clips.shape[0], n_bins), dtype=np.float64)
+    im = np.zeros_like(re)
+    for i, (kr, ki) in enumerate(banks):
+        kr = np.asarray(kr, dtype=np.float64).reshape(n_filters, -1)
+        ki = np.asarray(ki, dtype=np.float64).reshape(n_filters, -1)
+        K = kr.shape[1]
+        h = hop // (2 ** i)
+        Lo = lens[i]
+        pad = K // 2
+        mode = pad_mode
+        if mode == "reflect" and pad >= Lo:  # get_cqt_complex falls back to zero padding
+            mode = "constant"
+        row0 = (n_oct - 1 - i) * n_filters - drop
+        first = max(0, -row0)
+        if first >= n_filters:
+            continue
+        for s, (c, t) in enumerate(zip(clips, frames_idx)):
+            p = t * h - pad + np.arange(K)
+            ok = np.ones(K, dtype=bool)
+            if mode == "reflect":
+                p = np.where(p < 0, -p, p)
+                p = np.where(p >= Lo, 2 * (Lo - 1) - p, p)
+            else:
+                ok = (p >= 0) & (p < Lo)
+                p = np.clip(p, 0, Lo - 1)
+            lo_i, hi_i = int(p.min()), int(p.max()) + 1
+            w = decimated_window(x[c], lowpass, i, lo_i, hi_i)
+            fr = np.where(ok, w[p - lo_i], 0.0)
+            re[s, row0 + first:row0 + n_filters] = kr[first:] @ fr
+            im[s, row0 + first:row0 + n_filters] = -(ki[first:] @ fr)
+    scale = _normalisation_rows(lengths, normalization_type, float(downsample_factor))[None, :]
+    return re * scale, im * scale
+
+
 def power_to_db(S, amin=1e-10, ref=1.0, top_db=80.0):
     """MFCC._power_to_db [mel.py:263-279]: 10*log10(max(S, amin)) - 10*log10(max(amin, |ref|)),
     floored at (per-clip maximum - top_db)."""

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Kernel micro-benchmarks on the GPU box: per-workload, per-tile timings of the C-ABI calls
-(events on the launch stream).  Usage: python scripts/kbench.py [stft|cqt|mel|cqt2010|fir|all]"""
+(events on the launch stream).  Usage: python scripts/kbench.py [stft|cqt|mel|cqt2010|fir|all]
+The rows that pass `_debug` bits (ablations, A/B kernel selectors) run on the benchmarking
+build of the library: python -m nnaudio_amd.build --ablate"""
 import os
 import sys
 import time

@@ -92,6 +92,44 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert lib.mispec_framed_gemm_f32(ctypes.byref(a), None) == -2 and b"automatic tile" in lib.mispec_last_error()
     a.tile, a.reserved3 = 0, 1
     assert lib.mispec_framed_gemm_f32(ctypes.byref(a), None) == -1 and b"reserved" in lib.mispec_last_error()
+    # the ablation bits of `reserved` exist only in the benchmarking build: the product library
+    # refuses them instead of computing wrong spectrograms
+    a.reserved3, a.reserved = 0, 16
+    assert lib.mispec_framed_gemm_f32(ctypes.byref(a), None) == -1 and b"reserved must be 0" in lib.mispec_last_error()
+    assert lib.mispec_framed_gemm_workspace_bytes(ctypes.byref(a)) == -1
+
+
+def test_no_environment_switch_reaches_the_kernels():
+    """MISPEC_DEBUG used to be OR-ed into every call's ablation bits; nothing reads it now."""
+    import inspect
+
+    from nnaudio_amd import _abi, engine
+
+    assert "MISPEC_DEBUG" not in inspect.getsource(engine) + inspect.getsource(_abi)
+
+
+def test_needs_grad_sees_dataparallel_replicas():
+    """nn.DataParallel replicas hold trainable parameters as plain attributes (replica.parameters()
+    is empty); the graph / no-graph decision must still see them."""
+    from nnaudio_amd import engine, features
+
+    m = features.MelSpectrogram(sr=16000, n_fft=256, n_mels=20, hop_length=64, trainable_mel=True,
+                                verbose=False)
+    x = torch.zeros(2, 1024)
+    assert engine.needs_grad(m, x)
+    # what torch.nn.parallel.replicate does to every sub-module (torch/nn/parallel/replicate.py)
+    rep = m._replicate_for_data_parallel()
+    rep.stft = m.stft._replicate_for_data_parallel()
+    rep._modules["stft"] = rep.stft
+    for key, p in m._parameters.items():
+        setattr(rep, key, p.detach().clone().requires_grad_(True) * 1.0)  # non-leaf copy
+    assert list(rep.parameters()) == []
+    assert engine.needs_grad(rep, x)
+    with torch.no_grad():
+        assert not engine.needs_grad(rep, x)
+    frozen = features.MelSpectrogram(sr=16000, n_fft=256, n_mels=20, hop_length=64, verbose=False)
+    assert not engine.needs_grad(frozen, x)
+    assert engine.needs_grad(frozen, x.clone().requires_grad_(True))
 
 
 def test_cpu_tensors_fail_loudly():

@@ -401,24 +401,125 @@ def test_cfg4_cqt1992v2_full_size_sampled(precision, B):
     assert np.abs(got[..., 1] - im * s).max() <= 1e-4 * peak
 
 
+def _octave_banks(mod):
+    sd = {k: v.detach().cpu().numpy() for k, v in mod.state_dict().items()}
+    if type(mod).__name__ == "VQT":
+        banks = [(sd["cqt_kernels_real_%d" % i], sd["cqt_kernels_imag_%d" % i])
+                 for i in range(mod.n_octaves)]
+    else:
+        banks = [(sd["cqt_kernels_real"], sd["cqt_kernels_imag"])] * mod.n_octaves
+    return banks, sd
+
+
+def _cfg5_sampled_check(mod, x, y, rng, what, tol=1e-4):
+    """Sampled frames of a (B, 96, T, 2) CQT2010v2 / VQT output against the float64 evaluation of
+    the octave recursion on just the samples they depend on (oracle.sampled_octave_complex,
+    pinned to the whole-signal oracle by tests/test_oracle_golden.py): the first / last 4 frames
+    (reflected edges of every octave) + 24 random ones, every bin = every octave row block."""
+    from oracle import spectral_oracle as O
+
+    B, _, T, _ = y.shape
+    cb, ct = _sample_cols(rng, B, T, 32)
+    ct[:8] = [0, 1, 2, 3, T - 4, T - 3, T - 2, T - 1]
+    cb[:8] = [0, B - 1, 1, B - 2, 0, B - 1, 2, B - 3]
+    banks, sd = _octave_banks(mod)
+    re, im = O.sampled_octave_complex(x.numpy(), banks, sd["lenghts"], mod.hop_length, mod.n_bins,
+                                      sd["lowpass_filter"], cb, ct, pad_mode="reflect")
+    got = y[torch.as_tensor(cb), :, torch.as_tensor(ct)].cpu().numpy()  # (n, bins, 2)
+    peak = max(np.abs(re).max(), np.abs(im).max())
+    err = max(np.abs(got[..., 0] - re).max(), np.abs(got[..., 1] - im).max())
+    assert err <= tol * peak, "%s: %.3e of peak" % (what, err / peak)
+    # every octave's row block individually (a wrong octave must not hide behind the loudest one)
+    nf = banks[0][0].shape[0]
+    for o in range(0, mod.n_bins, nf):
+        pk = max(np.abs(re[:, o:o + nf]).max(), np.abs(im[:, o:o + nf]).max())
+        e = max(np.abs(got[:, o:o + nf, 0] - re[:, o:o + nf]).max(),
+                np.abs(got[:, o:o + nf, 1] - im[:, o:o + nf]).max())
+        assert e <= 2 * tol * pk, "%s rows %d..: %.3e of the block's peak" % (what, o, e / pk)
+
+
 def test_cfg5_cqt2010v2_vqt_full_length():
-    """30 s clips (one small shard of cfg5): VQT(gamma=0) == CQT2010v2 bit-exactly, the octave
-    recursion is linear, and a short prefix agrees with the oracle away from the right edge."""
+    """One rank's shard of cfg5 (B = 64 x 30 s, 96 bins, 8 octaves): CQT2010v2, VQT(gamma=0) and
+    VQT(gamma=10) against sampled float64 values of the 7-deep 256-tap recursion; VQT(gamma=0)
+    == CQT2010v2 bit-exactly; the recursion is linear in the waveform."""
     from nnaudio_amd import features
 
-    B, L = 4, 1323000
-    x = torch.randn(B, L, generator=torch.Generator().manual_seed(3)).to(DEV)
-    c = features.CQT2010v2(sr=44100, hop_length=512, n_bins=96, output_format="Complex",
-                           verbose=False).to(DEV)
-    v = features.VQT(sr=44100, hop_length=512, n_bins=96, gamma=0, output_format="Complex",
-                     verbose=False).to(DEV)
-    yc, yv = c(x), v(x)
-    assert tuple(yc.shape) == (4, 96, 2584, 2)
-    assert torch.equal(yc, yv)
-    x2 = torch.randn(B, L, generator=torch.Generator().manual_seed(4)).to(DEV)
-    lhs = c(x - 3.0 * x2)
-    rhs = yc - 3.0 * c(x2)
-    assert (lhs - rhs).abs().max().item() <= 1e-4 * rhs.abs().max().item()
+    B, L = 64, 1323000
+    x = torch.randn(B, L, generator=torch.Generator().manual_seed(3))
+    xd = x.to(DEV)
+    kw = dict(sr=44100, hop_length=512, n_bins=96, output_format="Complex", verbose=False)
+    c = features.CQT2010v2(**kw).to(DEV)
+    v0 = features.VQT(gamma=0, **kw).to(DEV)
+    v10 = features.VQT(gamma=10, **kw).to(DEV)
+    with torch.no_grad():
+        yc = c(xd)
+        assert tuple(yc.shape) == (64, 96, 2584, 2)
+        _cfg5_sampled_check(c, x, yc, np.random.default_rng(3), "CQT2010v2 cfg5")
+        yv = v0(xd)
+        assert torch.equal(yc, yv)
+        del yv
+        y10 = v10(xd)
+        _cfg5_sampled_check(v10, x, y10, np.random.default_rng(4), "VQT gamma=10 cfg5")
+        del y10
+        x2 = torch.randn(4, L, generator=torch.Generator().manual_seed(4)).to(DEV)
+        lhs = c(xd[:4] - 3.0 * x2)
+        rhs = yc[:4] - 3.0 * c(x2)
+        assert (lhs - rhs).abs().max().item() <= 1e-4 * rhs.abs().max().item()
+
+
+def test_cfg3_mel_full_size_sampled_bf16x3():
+    """cfg3 in the benched arithmetic: split-bf16 contraction with the mel reduction fused into
+    its epilogue, sampled against float64."""
+    from nnaudio_amd import features
+    from oracle import spectral_oracle as O
+
+    B, L = 256, 110250
+    x = torch.randn(B, L, generator=torch.Generator().manual_seed(1))
+    m = features.MelSpectrogram(sr=22050, n_fft=1024, n_mels=128, verbose=False).to(DEV)
+    m.stft.precision = "bf16x3"
+    with torch.no_grad():
+        y = m(x.to(DEV))
+    assert tuple(y.shape) == (256, 128, 216)
+    rng = np.random.default_rng(11)
+    cb, ct = _sample_cols(rng, B, 216, 64)
+    ct[:4] = [0, 1, 214, 215]
+    re, im = O.sampled_complex(x.numpy(), m.stft.wcos.cpu().numpy(), m.stft.wsin.cpu().numpy(),
+                               cb, ct, 512, 512, "reflect")
+    want = (re * re + im * im) @ m.mel_basis.cpu().numpy().astype(np.float64).T  # (n, M)
+    got = y[torch.as_tensor(cb), :, torch.as_tensor(ct)].cpu().numpy()
+    err = np.abs(got - want).max() / np.abs(want).max()
+    assert err <= 1e-4, err
+    m.stft.precision = "fp32"
+    with torch.no_grad():
+        y32 = m(x.to(DEV))
+    assert not torch.equal(y, y32)  # the bf16 pipe really ran
+    assert (y - y32).abs().max().item() <= 5e-5 * y32.abs().max().item()
+
+
+def test_cfg2_stft_magnitude_bf16x3_sampled():
+    """The exact step bench.py times (cfg2, Magnitude epilogue, bf16x3) against
+    sqrt(re^2 + im^2) of the sampled float64 values."""
+    from nnaudio_amd import features
+    from oracle import spectral_oracle as O
+
+    B, L = 64, 441000
+    x = torch.randn(B, L, generator=torch.Generator().manual_seed(5))
+    m = features.STFT(n_fft=2048, hop_length=512, window="hann", output_format="Magnitude",
+                      verbose=False).to(DEV)
+    m.precision = "bf16x3"
+    with torch.no_grad():
+        y = m(x.to(DEV))
+    assert tuple(y.shape) == (64, 1025, 862)
+    rng = np.random.default_rng(5)
+    cb, ct = _sample_cols(rng, B, 862, 96)
+    ct[:8] = [0, 1, 2, 3, 858, 859, 860, 861]
+    re, im = O.sampled_complex(x.numpy(), m.wcos.cpu().numpy(), m.wsin.cpu().numpy(), cb, ct,
+                               512, 1024, "reflect")
+    want = np.sqrt(re * re + im * im)
+    got = y[torch.as_tensor(cb), :, torch.as_tensor(ct)].cpu().numpy()
+    err = np.abs(got - want).max() / want.max()
+    assert err <= 1e-4, err
+    assert err <= 2e-5, err  # the split's own budget
 
 
 # ---------------------------------------------------------------------------------------
@@ -513,7 +614,14 @@ def test_bf16x3_kernel_shapes(shape, support):
     wr = rng.standard_normal((F, K)).astype(np.float32)
     wi = rng.standard_normal((F, K)).astype(np.float32)
     sup = None
-    dbg = 0x8000 if support == "single-buffer" else 0  # slab kernel with one slab buffer
+    # one slab buffer: an A/B knob of the benchmarking build (the product library always has
+    # room for two), kept under test because kbench measures with it
+    dbg = 0x8000 if support == "single-buffer" else 0
+    if dbg:
+        from nnaudio_amd import _abi
+
+        if not os.path.exists(_abi.ABLATE_LIB_PATH):
+            pytest.skip("libmispec_ablate.so not built (python -m nnaudio_amd.build --ablate)")
     if support:  # centred supports that shrink with the row index, like a CQT bank
         widest = min(K // 2, 40) if support == "narrow" else K // 2  # narrow: < one hop of taps
         half = np.linspace(widest, 8, F).astype(np.int64)

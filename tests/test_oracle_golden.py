@@ -80,3 +80,42 @@ def test_oracle_error_behaviour():
         O.stft(np.zeros((1, 4), np.float32), w, w, 4)
     with pytest.raises(ValueError):
         O.cqt1992v2(np.zeros((1, 64), np.float32), w, w, np.ones(3), 4, normalization_type="x")
+
+
+@pytest.mark.parametrize("cls,ctor,L", [
+    ("CQT2010v2", dict(sr=22050, fmin=55, n_bins=60), 30000),
+    ("VQT", dict(sr=22050, fmin=55, n_bins=52, gamma=10), 30000),     # bottom octave cut, own widths
+    ("CQT2010v2", dict(sr=16000, fmin=55, n_bins=72, pad_mode="constant"), 9000),
+    ("VQT", dict(sr=16000, fmin=110, n_bins=60, gamma=0), 5000),      # reflect -> zero fallback low down
+])
+def test_sampled_octave_evaluation_matches_the_full_recursion(cls, ctor, L):
+    """oracle.sampled_octave_complex (what the full-size GPU checks of CQT2010v2 / VQT compare
+    with) against the whole-signal recursion, which is pinned to the reference above."""
+    from oracle import spectral_oracle as O
+
+    case = dict(cls=cls, ctor=dict(ctor, output_format="Complex", earlydownsample=False), fwd={})
+    mod = build_module(case)
+    rng = np.random.default_rng(L)
+    x = rng.standard_normal((3, L)).astype(np.float32)
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        full = oracle_forward(mod, case, x)  # (B, bins, T, 2)
+    sd = {k: v.numpy() for k, v in mod.state_dict().items()}
+    if cls == "VQT":
+        banks = [(sd["cqt_kernels_real_%d" % i], sd["cqt_kernels_imag_%d" % i])
+                 for i in range(mod.n_octaves)]
+    else:
+        banks = [(sd["cqt_kernels_real"], sd["cqt_kernels_imag"])] * mod.n_octaves
+    T = full.shape[2]
+    cb = np.array([0, 1, 2, 0, 1, 2, 0, 1])
+    ct = np.array([0, 1, T - 1, T - 2, T // 2, T // 3, 2, T - 3])
+    re, im = O.sampled_octave_complex(x, banks, sd["lenghts"], mod.hop_length, mod.n_bins,
+                                      sd["lowpass_filter"], cb, ct,
+                                      pad_mode=ctor.get("pad_mode", "reflect"))
+    want = full[cb, :, ct]  # (n, bins, 2)
+    peak = np.abs(want).max()
+    # the full recursion keeps float32 signals between octaves, the sampled one float64
+    assert np.abs(re - want[..., 0]).max() <= 2e-6 * peak
+    assert np.abs(im - want[..., 1]).max() <= 2e-6 * peak

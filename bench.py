@@ -8,7 +8,7 @@ resident in HBM.  Workload at every N (weak scaling, per-GPU work fixed) is BASE
 configs[1]: STFT n_fft=2048 hop=512 hann, batch 64 x 10 s @ 44.1 kHz, Magnitude output.
 The batch shards across ranks as independent clips (nnaudio_amd.dist); computing needs no
 collective, so the timed region has none; the RCCL all-gather that reassembles the output
-tensor is timed separately and reported on stderr / in "extra" (never in `value`).
+tensor is timed separately and reported under "gather" (never in `value`).
 
 The step runs with ``--precision bf16x3`` by default: fp32 operands split into bf16 (hi, lo)
 pairs, three bf16 MFMAs per product, fp32 accumulate (include/mispec.h MISPEC_PREC_BF16X3;
@@ -16,19 +16,31 @@ pairs, three bf16 MFMAs per product, fp32 accumulate (include/mispec.h MISPEC_PR
 (the modules' default) is timed in the same run and reported under "paths".
 
 Rank 0 prints ONE JSON line: metric = spectrogram frames/s (whole job), plus
-  "roofline":     the framed-GEMM kernel against the MFMA peak of the precision used, in
-                  algorithmic flops (bf16x3 = 2500 / 3 = 833 TFLOP/s, fp32 157.3)
-                  -- ALGORITHMIC flops per launch (2 flop per tap of the dense contraction,
-                  whatever the split executes) / average launch duration (HIP events on the
-                  launch stream); the fraction of the raw dense-bf16 peak (2500) is given beside
-                  it, and the HBM-roofline fraction on algorithmic bytes;
-  "cpu_baseline": the numpy port of the reference algorithm (oracle/, float32 BLAS) timed on
-                  this host on a bounded sample of the same workload (rank 0, N=1 only).
+  "roofline":        the STFT step against the MFMA peak of the precision used, in ALGORITHMIC
+                     flops (bf16x3 = 2500 / 3 = 833 TFLOP/s, fp32 157.3): 2 flop
+                     per tap of the dense contraction the reference performs, whatever the
+                     kernels execute, / the step's device time (HIP events on the launch
+                     stream); "traffic" = fabric-side bytes per step from rocprofv3 PMC passes
+                     (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes, + WRITE_SIZE) run
+                     live on this binary by this script (``--traffic live``), or null;
+  "roofline_cqt84":  the same block for the other half of BASELINE.json's metric (CQT1992v2,
+                     84 bins, B = 64), support-aware useful flops;
+  "extra":           Mel cfg3, and one rank's shard of cfg5 (CQT2010v2 and VQT, 64 x 30 s), each
+                     timed with the same pre-warm and step count as the headline and priced
+                     against both rooflines;
+  "cpu_baseline":    the numpy port of the reference algorithm (oracle/, float32 BLAS) timed on
+                     this host on a bounded sample of the same workload (rank 0, N=1 only).
 """
 import argparse
+import csv
+import glob
+import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -51,6 +63,16 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def kernel_source_sha():
+    """Fingerprint of the kernel sources the loaded library was built from."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "nnaudio_amd", "csrc", "*"))):
+        if f.endswith((".hip", ".inl", ".h")):
+            h.update(open(f, "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "mispec.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def workload(name, device):
     """-> (module, make_input(seed), meta) ; meta: algorithmic flops / bytes per launch."""
     from nnaudio_amd import features
@@ -63,6 +85,7 @@ def workload(name, device):
         flops = 2.0 * (2 * F) * K * B * T
         byts = 4.0 * (B * L + B * F * T + 2 * F * K)
         tag = "STFT n_fft=2048 hop=512 hann, B=64 x 10 s @ 44.1 kHz, Magnitude (configs[1])"
+        bound = "mfma"
     elif name == "mel":
         B, L, K, hop, M = 256, 110250, 1024, 512, 128
         F, T = K // 2 + 1, L // hop + 1
@@ -71,6 +94,7 @@ def workload(name, device):
         flops = 2.0 * (2 * F) * K * B * T + 2.0 * M * F * B * T
         byts = 4.0 * (B * L + B * M * T + 2 * F * K + M * F)
         tag = "MelSpectrogram n_fft=1024 hop=512 n_mels=128, B=256 x 5 s @ 22.05 kHz (configs[2])"
+        bound = "mfma"
     elif name == "cqt":
         B, L, hop = 64, 441000, 512
         m = features.CQT1992v2(sr=44100, hop_length=hop, fmin=32.70, n_bins=84, bins_per_octave=12,
@@ -80,15 +104,21 @@ def workload(name, device):
         flops = 2.0 * 2 * useful * B * T  # support-aware ("useful") flops
         byts = 4.0 * (B * L + B * 84 * T + 2 * useful)
         tag = "CQT1992v2 84 bins / 12 bpo hop=512, B=64 x 10 s @ 44.1 kHz, Magnitude"
-    elif name == "cqt2010":
+        bound = "mfma"
+    elif name in ("cqt2010", "vqt"):
         B, L, hop = 64, 1323000, 512
-        m = features.CQT2010v2(sr=44100, hop_length=hop, n_bins=96, verbose=False).to(device)
+        if name == "cqt2010":
+            m = features.CQT2010v2(sr=44100, hop_length=hop, n_bins=96, verbose=False).to(device)
+        else:
+            m = features.VQT(sr=44100, hop_length=hop, n_bins=96, gamma=0, verbose=False).to(device)
         T = L // hop + 1
         nt = 256 * 2 * 12 * 8 * B * T * 2.0
         dec = sum(2.0 * 256 * B * (L // (2 ** o)) for o in range(1, 8))
         flops = nt + dec
         byts = 4.0 * (B * L + B * 96 * T)
-        tag = "CQT2010v2 96 bins hop=512, B=64 x 30 s @ 44.1 kHz (one rank's shard of configs[4])"
+        tag = ("%s 96 bins hop=512, B=64 x 30 s @ 44.1 kHz (one rank's shard of configs[4])"
+               % ("CQT2010v2" if name == "cqt2010" else "VQT gamma=0"))
+        bound = "hbm"
     else:
         raise SystemExit("unknown workload %r" % name)
 
@@ -96,7 +126,21 @@ def workload(name, device):
         g = torch.Generator(device="cpu").manual_seed(seed)
         return torch.randn(B, L, generator=g, dtype=torch.float32).to(device)
 
-    return m, make_input, dict(B=B, L=L, T=T, frames=B * T, flops=flops, bytes=byts, tag=tag)
+    return m, make_input, dict(B=B, L=L, T=T, frames=B * T, flops=flops, bytes=byts, tag=tag,
+                               bound=bound)
+
+
+def prewarm(module, x, ms):
+    """Untimed start-up work: the first launches after an idle period run 15-20 % slower (clock
+    ramp, ~30 ms and more), which a short --steps/--warmup run would otherwise average in."""
+    t0 = time.perf_counter()
+    if ms > 0:
+        with torch.no_grad():
+            while (time.perf_counter() - t0) * 1e3 < ms:
+                for _ in range(10):
+                    module(x)
+                torch.cuda.synchronize()
+    return (time.perf_counter() - t0) * 1e3
 
 
 def timed_steps(module, x, steps, warmup, sync):
@@ -117,6 +161,92 @@ def timed_steps(module, x, steps, warmup, sync):
         t1 = time.perf_counter()
     del y
     return t1 - t0, e0.elapsed_time(e1) * 1e-3
+
+
+def roofline_block(meta, dev_step_s, precision, traffic=None, kernel=""):
+    """The line's roofline object for one workload (per launch = per step)."""
+    fl = meta["flops"] / dev_step_s
+    by = meta["bytes"] / dev_step_s
+    blk = {"bound": meta["bound"], "unit": "TFLOP/s" if meta["bound"] == "mfma" else "GB/s",
+           "traffic": traffic, "kernel": kernel, "step_device_ms": dev_step_s * 1e3,
+           "algorithmic_flops_per_launch": meta["flops"],
+           "algorithmic_bytes_per_launch": meta["bytes"],
+           "mfma_frac": fl / PEAK[precision], "hbm_frac_on_algorithmic_bytes": by / PEAK_HBM,
+           "algorithmic_frac_of_dense_mfma_peak":
+               fl / (PEAK_BF16_MFMA if precision == "bf16x3" else PEAK_F32_MFMA)}
+    if meta["bound"] == "mfma":
+        blk.update(achieved=fl / 1e12, peak=PEAK[precision] / 1e12, frac=fl / PEAK[precision])
+    else:
+        blk.update(achieved=by / 1e9, peak=PEAK_HBM / 1e9, frac=by / PEAK_HBM)
+    return blk
+
+
+# ---------------------------------------------------------------------------------------
+# HBM-side traffic of one step, measured live: rocprofv3 PMC passes (counters only, one counter
+# per pass) over a child process that runs a few steps of one workload
+# ---------------------------------------------------------------------------------------
+def pmc_child(name, precision, steps):
+    import nnaudio_amd
+
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    nnaudio_amd.set_precision(precision)
+    module, make_input, _ = workload(name, device)
+    x = make_input(0)
+    with torch.no_grad():
+        for _ in range(steps):
+            module(x)
+    torch.cuda.synchronize()
+
+
+def _ours(kernel_name):
+    return not (kernel_name.startswith("void at::") or kernel_name.startswith("__amd_rocclr")
+                or "at::native" in kernel_name)
+
+
+def measure_traffic(name, precision, steps=4, timeout=150):
+    """-> dict(bytes_per_step, fetch_bytes, write_bytes, per_kernel, method) or raises."""
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        raise RuntimeError("rocprofv3 not found")
+    res = {}
+    per_kernel = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="mispec_pmc_", dir="/tmp")
+        try:
+            cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", name,
+                   "--precision", precision, "--steps", str(steps)]
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                raise RuntimeError("no counter_collection.csv from the %s pass" % counter)
+            total = 0.0
+            for f in files:
+                for r in csv.DictReader(open(f)):
+                    if r.get("Counter_Name") != counter or not _ours(r.get("Kernel_Name", "")):
+                        continue
+                    v = float(r.get("Counter_Value") or 0.0) * 1024.0  # the counters are in KB
+                    total += v
+                    k = r["Kernel_Name"].split("(")[0][-60:]
+                    per_kernel.setdefault(k, {}).setdefault(counter, 0.0)
+                    per_kernel[k][counter] += v / steps
+            res[counter] = total / steps
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    # gfx950: FETCH_SIZE tallies 64 B per 128-B request of a 16 B/lane stream (MI355X_MICROARCH.md,
+    # HBM section): doubled.  Infinity-Cache hits are included: an upper bound on HBM bytes.
+    fetch = 2.0 * res["FETCH_SIZE"]
+    for k in per_kernel:
+        if "FETCH_SIZE" in per_kernel[k]:
+            per_kernel[k]["FETCH_SIZE"] *= 2.0
+    return {"bytes_per_step": fetch + res["WRITE_SIZE"], "fetch_bytes": fetch,
+            "write_bytes": res["WRITE_SIZE"], "per_kernel": per_kernel,
+            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over %d steps of this "
+                      "binary, run by bench.py; FETCH_SIZE x2 (gfx950 16 B/lane streams); fabric-side "
+                      "bytes (Infinity-Cache hits included)" % steps}
 
 
 def cpu_baseline(budget_s=15.0):
@@ -149,8 +279,8 @@ def cpu_baseline(budget_s=15.0):
         cores = os.cpu_count()
     out = dict(value=reps * n * 862 / dt, unit="frames/s", cores=int(cores), kind="port",
                sample="%d x %d of 64 clips (10 s @ 44.1 kHz) of configs[1], numpy float32 BLAS port "
-                      "of the reference conv1d STFT (oracle/spectral_oracle.py), %.1f s"
-                      % (reps, n, dt))
+                      "of the reference conv1d STFT (oracle/spectral_oracle.py; the reference itself "
+                      "is not on the GPU box), %.1f s" % (reps, n, dt))
     # beside it, bounded to a few seconds each: the FFT route librosa.stft takes (librosa itself is
     # not installable here: SURVEY.md 8d "librosa-equivalent"), and the port of the reference's
     # CQT1992v2 on the CQT84 workload of the metric
@@ -195,14 +325,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="stft", choices=["stft", "mel", "cqt", "cqt2010"])
-    ap.add_argument("--extras", type=int, default=1, help="also time CQT84 / Mel / gather (untimed region)")
+    ap.add_argument("--workload", default="stft", choices=["stft", "mel", "cqt", "cqt2010", "vqt"])
+    ap.add_argument("--extras", type=int, default=1,
+                    help="also time the fp32 path, CQT84, Mel cfg3, the cfg5 shard and the gather")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="untimed start-up work before the warm-up steps (GPU out of its idle clocks)")
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32"],
                     help="arithmetic of the timed step (the other path is reported under 'paths')")
+    ap.add_argument("--traffic", default="live", choices=["live", "off"],
+                    help="live: rocprofv3 PMC passes over a child process (N=1 only); off: null")
+    ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.pmc_child:
+        pmc_child(args.pmc_child, args.precision, args.steps)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -231,71 +369,59 @@ def main():
     module, make_input, meta = workload(args.workload, device)
     x = make_input(rank)
 
-    def run_path(precision, steps, warmup):
-        """Time `steps` forwards in one arithmetic; whole-job numbers (max over ranks)."""
-        nnaudio_amd.set_precision(precision)
-        wall, dev_s = timed_steps(module, x, steps, warmup, sync)
-        t = torch.tensor([wall, dev_s], dtype=torch.float64, device=device)
+    def max_over_ranks(*vals):
+        t = torch.tensor(vals, dtype=torch.float64, device=device)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, dev_s = float(t[0]), float(t[1])
-        res = {"frames_per_s": meta["frames"] * world * steps / wall, "ms_per_step": wall / steps * 1e3,
+        return [float(v) for v in t]
+
+    def run_path(mod, xin, me, precision, steps, warmup):
+        """Time `steps` forwards in one arithmetic; whole-job numbers (max over ranks)."""
+        nnaudio_amd.set_precision(precision)
+        wall, dev_s = timed_steps(mod, xin, steps, warmup, sync)
+        wall, dev_s = max_over_ranks(wall, dev_s)
+        res = {"frames_per_s": me["frames"] * world * steps / wall, "ms_per_step": wall / steps * 1e3,
                "step_device_ms": dev_s / steps * 1e3,
-               "algorithmic_tflops": meta["flops"] / (dev_s / steps) / 1e12,
-               "mfma_frac": meta["flops"] / (dev_s / steps) / PEAK[precision],
-               "hbm_frac_on_algorithmic_bytes": meta["bytes"] / (dev_s / steps) / PEAK_HBM}
+               "algorithmic_tflops": me["flops"] / (dev_s / steps) / 1e12,
+               "mfma_frac": me["flops"] / (dev_s / steps) / PEAK[precision],
+               "hbm_frac_on_algorithmic_bytes": me["bytes"] / (dev_s / steps) / PEAK_HBM}
         return wall, dev_s, res
 
     def dominant_kernel(precision):
-        """STFT: the main contraction alone (1024 of the 1025 bins: whole 128- / 256-row blocks;
-        the Nyquist bin and the pre-passes are other kernels), events on the launch stream."""
+        """STFT: the main contraction alone (1024 of the 1025 bins: whole row blocks; the Nyquist
+        bin rides in the pre-pass or in tail tiles), with its pre-pass, events on the launch stream."""
         wc, ws = module.wcos[:1024], module.wsin[:1024]
-        split = engine.split_basis(wc, ws) if precision == "bf16x3" else None
+        prep = engine.prepare_basis(wc, ws, precision, hop=512)
 
         class _M:
             def __call__(self, _):
                 return engine.framed_gemm(x, wc, ws, hop=512, pad=1024, pad_mode=engine.PAD_REFLECT,
-                                          epilogue=engine.EPI_MAGNITUDE, precision=precision,
-                                          basis_split=split)
+                                          epilogue=engine.EPI_MAGNITUDE, precision=precision, **prep)
 
         _, d = timed_steps(_M(), x, args.steps, 2, sync)
         fl = 2.0 * 2048 * 2048 * meta["frames"]
         per = d / args.steps
-        name = ("framed_bf16x3_kernel<4,2,2,4,unmasked> (v_mfma_f32_32x32x16_bf16) + split_signal_kernel"
-                if precision == "bf16x3" else
-                "framed_gemm_kernel<2,2,2,2,framed,rows,unmasked> (v_mfma_f32_32x32x2_f32)")
-        return {"name": name, "avg_ms": per * 1e3, "algorithmic_flops": fl,
-                "tflops": fl / per / 1e12, "frac_of_peak": fl / per / PEAK[precision],
-                "executed_mfma_tflops": MFMAS_PER_PRODUCT[precision] * fl / per / 1e12}
+        return {"name": engine.describe_framed_kernel(precision, prep), "avg_ms": per * 1e3,
+                "algorithmic_flops": fl, "tflops": fl / per / 1e12, "frac_of_peak": fl / per / PEAK[precision]}
 
     prec = args.precision
     other = "fp32" if prec == "bf16x3" else "bf16x3"
-    # Start-up, outside the W warm-up steps and the timed region and reported as "prewarm_ms": the
-    # first launches after an idle period run 15-20 % slower (clock ramp, ~30 ms and more), which
-    # a short --steps/--warmup run would otherwise average into the steady-state number.
-    t_pre = time.perf_counter()
-    if args.prewarm_ms > 0:
-        nnaudio_amd.set_precision(prec)
-        with torch.no_grad():
-            while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
-                for _ in range(10):
-                    module(x)
-                torch.cuda.synchronize()
-    prewarm_ms = (time.perf_counter() - t_pre) * 1e3
-    wall, dev_s, primary = run_path(prec, args.steps, args.warmup)
+    nnaudio_amd.set_precision(prec)
+    prewarm_ms = prewarm(module, x, args.prewarm_ms)
+    wall, dev_s, primary = run_path(module, x, meta, prec, args.steps, args.warmup)
     paths = {prec: primary}
     dominant = None
     if args.workload == "stft":
         dominant = dominant_kernel(prec)
     if args.extras:
-        _, _, paths[other] = run_path(other, max(3, args.steps // 2), 2)
+        _, _, paths[other] = run_path(module, x, meta, other, max(3, args.steps // 2), 2)
         if args.workload == "stft":
             paths[other]["dominant_kernel"] = dominant_kernel(other)
     nnaudio_amd.set_precision(prec)
 
     frames_total = meta["frames"] * world * args.steps
     kern_s = dev_s / args.steps
-    achieved = meta["flops"] / kern_s
+    src_sha = kernel_source_sha()
     out = {
         "metric": "spectrogram frames/sec",
         "value": frames_total / wall,
@@ -310,61 +436,95 @@ def main():
         "dtype": "bf16x3" if prec == "bf16x3" else "f32",
         "data": "synthetic",
         "prewarm_ms": prewarm_ms,
+        "kernel_source_sha": src_sha,
         "config": {"workload": meta["tag"], "global_batch": meta["B"] * world,
                    "clip_samples": meta["L"], "frames_per_clip": meta["T"],
                    "precision": ("bf16x3: fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per "
                                  "product, fp32 accumulate (err ~5e-6 of peak, 1e-4 parity bar)"
                                  if prec == "bf16x3" else "fp32 MFMA, fp32 accumulate"),
                    "parallelism": "batch-sharded x%d, no data-path collective" % world},
-        "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK[prec] / 1e12,
-                     "unit": "TFLOP/s", "frac": achieved / PEAK[prec], "traffic": None,
-                     "kernel": "one step = pre-passes + main contraction + Nyquist-bin tiles; "
-                               "achieved = algorithmic flops (2 per tap of the dense contraction) / "
-                               "step device time; peak = MFMA peak of the precision used in "
-                               "algorithmic flops (bf16x3: 2500 dense bf16 / 3 MFMAs per product)",
-                     "executed_mfma_tflops": MFMAS_PER_PRODUCT[prec] * achieved / 1e12,
-                     "algorithmic_frac_of_dense_mfma_peak":
-                         achieved / (PEAK_BF16_MFMA if prec == "bf16x3" else PEAK_F32_MFMA),
-                     "step_device_ms": kern_s * 1e3, "dominant_kernel": dominant,
-                     "algorithmic_flops_per_launch": meta["flops"],
-                     "algorithmic_bytes_per_launch": meta["bytes"],
-                     "hbm_frac_on_algorithmic_bytes": meta["bytes"] / kern_s / PEAK_HBM},
+        "roofline": roofline_block(
+            meta, kern_s, prec,
+            kernel="one step = pre-pass + main contraction; achieved = algorithmic flops (2 per tap "
+                   "of the dense contraction the reference performs) / step device time; peak = MFMA "
+                   "peak of the precision used in algorithmic flops (bf16x3: 2500 dense bf16 / 3 "
+                   "MFMAs per product)"),
         "paths": paths,
     }
-    traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(traffic_file) and args.workload == "stft":
-        try:
-            out["roofline"]["traffic"] = json.load(open(traffic_file))[
-                "stft_cfg2_bytes_per_launch" + ("_bf16x3" if prec == "bf16x3" else "")]
-        except Exception:
-            pass
+    out["roofline"]["dominant_kernel"] = dominant
 
     extra = {}
+    traffic_jobs = [(args.workload, "roofline")]
     if args.extras:
         del x
         torch.cuda.empty_cache()
-        for name in ("cqt", "mel"):
+        n2 = max(20, args.steps)  # every extra under the headline's rules: pre-warm + >= 20 steps
+        for name in ("cqt", "mel", "cqt2010", "vqt"):
             if name == args.workload:
                 continue
             try:
                 m2, mk2, me2 = workload(name, device)
                 x2 = mk2(100 + rank)
-                w2, d2 = timed_steps(m2, x2, max(3, args.steps // 4), 2, sync)
-                n2 = max(3, args.steps // 4)
-                tt = torch.tensor([w2, d2], dtype=torch.float64, device=device)
-                if world > 1:
-                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                w2, d2 = float(tt[0]), float(tt[1])
-                extra[name] = {"workload": me2["tag"], "frames_per_s": me2["frames"] * world * n2 / w2,
-                               "ms_per_step": w2 / n2 * 1e3,
-                               "precision": prec,
-                               "mfma_frac": me2["flops"] / (d2 / n2) / PEAK[prec],
-                               "hbm_frac_on_algorithmic_bytes": me2["bytes"] / (d2 / n2) / PEAK_HBM}
+                nnaudio_amd.set_precision(prec)
+                prewarm(m2, x2, args.prewarm_ms)
+                w2, d2, r2 = run_path(m2, x2, me2, prec, n2, max(5, args.warmup // 2))
+                blk = roofline_block(me2, d2 / n2, prec)
+                r2.update(workload=me2["tag"], precision=prec, steps=n2, roofline=blk)
+                extra[name] = r2
+                if name == "cqt":
+                    blk["kernel"] = ("one step = split pre-pass + framed_bf16x3_narrow_kernel; useful "
+                                     "(support-aware) flops 2*2*sum(lenghts) per frame / step device time")
+                    out["roofline_cqt84"] = dict(blk, workload=me2["tag"], frames_per_s=r2["frames_per_s"],
+                                                 ms_per_step=r2["ms_per_step"], steps=n2)
+                    traffic_jobs.append(("cqt", "roofline_cqt84"))
                 del m2, x2
                 torch.cuda.empty_cache()
             except Exception as e:  # extras must never take the primary number down
                 extra[name] = {"error": repr(e)}
         out["extra"] = extra
+
+    # output reassembly over xGMI (RCCL all-gather), outside the reported value: the step with the
+    # in-place gather (kernels write into this rank's slice of a persistent gather buffer) vs without
+    if world > 1 and args.extras:
+        try:
+            from nnaudio_amd import dist as D
+
+            x = make_input(rank)
+            sm = D.ShardedModule(module)
+            B = meta["B"]
+            # ShardedModule slices [lo, hi) out of a (B * world, L) batch: only this rank's block
+            # of that tensor is ever filled
+            full_in = torch.empty((B * world, meta["L"]), dtype=torch.float32, device=device)
+            lo, hi = D.shard_bounds(B * world, world, rank)
+            full_in[lo:hi].copy_(x)
+            n3 = max(5, args.steps // 4)
+            wg, dg = timed_steps(sm, full_in, n3, 3, sync)
+            wg, dg = max_over_ranks(wg, dg)
+            with torch.no_grad():
+                y_bytes = sm(full_in)[lo:hi].numel() * 4.0
+            out["gather"] = {"with_gather_ms_per_step": wg / n3 * 1e3,
+                             "without_gather_ms_per_step": wall / args.steps * 1e3,
+                             "frames_per_s_with_gather": meta["frames"] * world * n3 / wg,
+                             "bytes_per_rank": y_bytes,
+                             "what": "in-place all_gather_into_tensor of the full output tensor; every "
+                                     "rank's block is written by the kernels into its slice of a "
+                                     "persistent gather buffer (nnaudio_amd.dist.ShardedModule)"}
+            del full_in
+        except Exception as e:
+            out["gather"] = {"error": repr(e)}
+
+    if rank == 0 and world == 1 and args.traffic == "live":
+        torch.cuda.empty_cache()
+        for name, key in traffic_jobs:
+            if key not in out:
+                continue
+            try:
+                t = measure_traffic(name, prec)
+                out[key]["traffic"] = t["bytes_per_step"]
+                out[key]["traffic_detail"] = {k: t[k] for k in ("fetch_bytes", "write_bytes", "per_kernel", "method")}
+            except Exception as e:
+                out[key]["traffic"] = None
+                out[key]["traffic_detail"] = {"error": repr(e)[:300]}
 
     if rank == 0 and world == 1 and args.cpu_baseline:
         try:
@@ -378,28 +538,6 @@ def main():
 
     if rank == 0:
         print(json.dumps(out), flush=True)
-
-    # output reassembly over xGMI (RCCL all-gather), outside the reported value
-    if world > 1 and args.extras:
-        try:
-            from nnaudio_amd import dist as D
-
-            x = make_input(rank)
-            with torch.no_grad():
-                y = module(x)
-                for _ in range(2):
-                    D.gather_batch(y, meta["B"] * world)
-                sync()
-                t0 = time.perf_counter()
-                for _ in range(5):
-                    full = D.gather_batch(y, meta["B"] * world)
-                sync()
-                dt = (time.perf_counter() - t0) / 5
-            if rank == 0:
-                log("all-gather of the %s output: %.3f ms per step (%.1f MB per rank)"
-                    % (tuple(full.shape), dt * 1e3, y.numel() * 4 / 1e6))
-        except Exception as e:
-            log("gather timing failed: %r" % (e,))
     if world > 1:
         dist.destroy_process_group()
 

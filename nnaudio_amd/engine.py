@@ -311,6 +311,23 @@ def split_basis(basis_re, basis_im):
     return dst
 
 
+def prepare_basis(basis_re, basis_im, precision, hop=None):
+    """Derived operands of a basis for ``framed_gemm`` in the given arithmetic, as keyword
+    arguments (callers with a persistent basis cache this dict, see ``DerivedCache``): the
+    split-bf16 planes for "bf16x3", nothing for "fp32"."""
+    if resolve_precision(precision) != "bf16x3":
+        return {}
+    return {"basis_split": split_basis(basis_re, basis_im)}
+
+
+def describe_framed_kernel(precision, prepared):
+    """Name of the dominant kernel ``framed_gemm`` launches for a dense complex basis prepared
+    with ``prepare_basis`` (bench.py's report)."""
+    if resolve_precision(precision) != "bf16x3":
+        return "framed_gemm_kernel<2,2,2,2,framed,rows,unmasked> (v_mfma_f32_32x32x2_f32)"
+    return ("framed_bf16x3_kernel<4,2,2,4,unmasked> (v_mfma_f32_32x32x16_bf16) + split_signal_kernel")
+
+
 def framed_gemm(x, basis_re, basis_im, *, reference_kernel=False, **kw):
     """``out[b, row_offset + f, t(, 0:2)]`` <- epilogue(sum_n x_pad[b, t*hop + n] * basis[f, n]).
 

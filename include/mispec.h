@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MISPEC_ABI_VERSION 4
+#define MISPEC_ABI_VERSION 5
 
 enum {
   MISPEC_OK = 0,
@@ -152,6 +152,18 @@ typedef struct mispec_framed_gemm_args {
   int64_t fb_row_stride;
   int32_t n_fb;
   int32_t reserved3;           /* must be 0                                                */
+
+  /* Symmetric fold (MISPEC_PREC_BF16X3, optional): for a basis that is even (basis_re) / odd
+   * (basis_im) about tap kernel/2 -- every Fourier basis of stft.py:230-245 -- the contraction runs
+   * over kernel/2 (+1) folded taps of  x[n] + x[kernel-n]  and  x[n] - x[kernel-n]  instead of
+   * `kernel` taps: half the MFMAs.  basis_fold is the output of mispec_fold_basis_bf16() for this
+   * (basis_re, basis_im, n_bins, kernel); the CALLER vouches for the symmetry (the fold routine
+   * reports what it neglects).  Used when the shape allows (even kernel, dense complex basis,
+   * hop >= kernel/8, automatic tile), otherwise ignored.                                      */
+  const void *basis_fold;      /* or NULL                                                  */
+  int64_t basis_fold_bytes;
+  int32_t fold_taps;           /* value returned by mispec_fold_taps() for this basis      */
+  int32_t reserved4;           /* must be 0                                                */
 } mispec_framed_gemm_args;
 
 /*
@@ -160,7 +172,8 @@ typedef struct mispec_framed_gemm_args {
  * staged there by a pre-pass so that every frame is a plain run of memory; interior frames are
  * read straight from x).  Depends only on the sizes in `args`; 0 when every frame is interior
  * (center=False with kernel % 32 == 0).  With MISPEC_PREC_BF16X3 it also holds the (hi, lo)
- * bf16 planes of the waveform and of the edge spans (4 more bytes per sample).
+ * bf16 planes of the waveform and of the edge spans (4 more bytes per sample), or -- with
+ * basis_fold -- the folded frames (8 bytes per folded tap and frame).
  * Negative = MISPEC_E_*.
  */
 int64_t mispec_framed_gemm_workspace_bytes(const mispec_framed_gemm_args *args);
@@ -175,6 +188,26 @@ int64_t mispec_basis_split_bytes(int32_t n_bins, int32_t kernel, int32_t has_im)
 int mispec_split_basis_bf16(const float *basis_re, const float *basis_im,
                             int64_t basis_row_stride, int32_t n_bins, int32_t kernel,
                             void *dst, int64_t dst_bytes, void *stream);
+
+/*
+ * Symmetric fold of a Fourier-type basis (see basis_fold above).  Folded tap j stands for the pair
+ * (n, kernel - n), n = j + 1, with coefficient (re[n] + re[kernel-n]) / 2 resp.
+ * (im[n] - im[kernel-n]) / 2; taps kernel/2 and 0 have no partner (tap 0 is carried only
+ * with with_tap0 != 0: needed when some row has a non-zero tap 0, i.e. a window with w[0] != 0).
+ *   mispec_fold_taps        folded taps per row (a multiple of 16), < 0 when the kernel cannot fold
+ *   mispec_basis_fold_bytes size of `dst`
+ *   mispec_fold_basis_bf16  builds dst; stats (device, 2 floats) receives
+ *                           [0] max |re[n] - re[kernel-n]| / 2, |im[n] + im[kernel-n]| / 2 over all
+ *                               pairs = the largest coefficient the fold neglects,
+ *                           [1] max |folded coefficient|;
+ *                           offer the result to mispec_framed_gemm_f32 only when [0] is negligible
+ *                           against [1] (nnaudio_amd.engine: <= 2^-20).
+ */
+int32_t mispec_fold_taps(int32_t kernel, int32_t with_tap0);
+int64_t mispec_basis_fold_bytes(int32_t n_bins, int32_t kernel, int32_t with_tap0);
+int mispec_fold_basis_bf16(const float *basis_re, const float *basis_im, int64_t basis_row_stride,
+                           int32_t n_bins, int32_t kernel, int32_t with_tap0, void *dst,
+                           int64_t dst_bytes, float *stats, void *stream);
 
 /* Launch the MFMA framed contraction.  Replaces stft.py:278-316, cqt.py:740-780,
  * utils.py:498-521 (one call per octave).                                             */

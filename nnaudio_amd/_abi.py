@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmispec.so")
 ABLATE_LIB_PATH = os.path.join(_HERE, "csrc", "libmispec_ablate.so")  # benchmarking build
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 E_INVALID, E_UNSUPPORTED, E_HIP = -1, -2, -3
 
 # enums (mirror include/mispec.h)
@@ -30,6 +30,9 @@ EXPORTS = (
     "mispec_framed_gemm_workspace_bytes",
     "mispec_basis_split_bytes",
     "mispec_split_basis_bf16",
+    "mispec_fold_taps",
+    "mispec_basis_fold_bytes",
+    "mispec_fold_basis_bf16",
     "mispec_filterbank_f32",
     "mispec_istft_grad_signal_f32",
     "mispec_power_to_db_f32",
@@ -89,6 +92,10 @@ class FramedGemmArgs(ctypes.Structure):
         ("fb_row_stride", ctypes.c_int64),
         ("n_fb", ctypes.c_int32),
         ("reserved3", ctypes.c_int32),
+        ("basis_fold", ctypes.c_void_p),
+        ("basis_fold_bytes", ctypes.c_int64),
+        ("fold_taps", ctypes.c_int32),
+        ("reserved4", ctypes.c_int32),
     ]
 
 
@@ -171,6 +178,15 @@ def _load(path, how):
     lib.mispec_split_basis_bf16.argtypes = [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
         ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+    ]
+    lib.mispec_fold_taps.restype = ctypes.c_int32
+    lib.mispec_fold_taps.argtypes = [ctypes.c_int32] * 2
+    lib.mispec_basis_fold_bytes.restype = ctypes.c_int64
+    lib.mispec_basis_fold_bytes.argtypes = [ctypes.c_int32] * 3
+    lib.mispec_fold_basis_bf16.restype = ctypes.c_int
+    lib.mispec_fold_basis_bf16.argtypes = [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+        ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
     ]
     lib.mispec_fir_decimate_workspace_bytes.restype = ctypes.c_int64
     lib.mispec_fir_decimate_workspace_bytes.argtypes = [ctypes.c_int32] * 6

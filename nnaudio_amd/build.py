@@ -78,5 +78,20 @@ def resource_usage(stderr):
     return usage, "".join(other)
 
 
+def build_all(force=False, verbose=True):
+    """Product library and benchmarking build side by side (two hipcc processes)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(2) as ex:
+        jobs = [ex.submit(build, force=force, verbose=verbose, ablate=a) for a in (False, True)]
+        return [j.result() for j in jobs]
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, ablate="--ablate" in sys.argv))
+    force = "--force" in sys.argv
+    if "--ablate" in sys.argv:
+        print(build(force=force, ablate=True))
+    elif "--product" in sys.argv:
+        print(build(force=force))
+    else:
+        print(*build_all(force=force), sep="\n")

@@ -1,0 +1,425 @@
+// framed_fold.inl -- MISPEC_PREC_BF16X3 for Fourier-type bases: the contraction over HALF the taps.
+// Included by mispec.hip inside its anonymous namespace, after framed_bf16x3.inl (shares KParams,
+// the XCD-aware tile order, the split helpers and the planar / fused-filterbank epilogues).
+//
+// The reference's STFT bases (utils.py:379-389 times the centred periodic window, stft.py:230-232)
+// are even (cos rows) / odd (sin rows) about tap N/2, N = n_fft:
+//     wcos[k, N-n] = wcos[k, n],   wsin[k, N-n] = -wsin[k, n]          (1 <= n < N/2)
+// so with  E_t[n] = x_t[n] + x_t[N-n],  O_t[n] = x_t[n] - x_t[N-n]  (x_t = frame t of the padded
+// signal; E = O = x_t[N/2] at n = N/2 and x_t[0] at n = 0, the two taps without a partner)
+//     re[k, t] = sum_{n in fold} wcos[k, n] * E_t[n],      im[k, t] = sum_{n in fold} wsin[k, n] * O_t[n]
+// over N/2 (+1) taps instead of N: HALF the MFMAs of the dense contraction for the same result up to
+// rounding (the caller verifies the symmetry of the basis numerically before offering this path,
+// engine.fold_basis; the coefficient actually used is the mean of the pair).
+//
+// Operands (bf16, 128-byte "stage rows": 16 folded taps x 4 planes, so one K stage of one row is one
+// cache line and one LDS-DMA piece is 8 whole lines):
+//   folded basis : per bin, per stage s : [re_hi 16 | re_lo 16 | im_hi 16 | im_lo 16]   (fold_basis_kernel,
+//                  once per basis)  + the fp32 folded rows of the LAST bin (the Nyquist bin of an
+//                  n_fft/2+1 STFT, which the pre-pass evaluates itself)
+//   folded frames: per flat frame (clip, t), per stage s : [E_hi 16 | E_lo 16 | O_hi 16 | O_lo 16]
+//                  (fold_frames_kernel, every call: reads the fp32 waveform with the virtual
+//                  padding, 8 B out per folded tap; frames do not overlap any more, hop is free)
+// Folded tap j <-> n = j + 1 for j < N/2 (n = 1 .. N/2), j = N/2 <-> n = 0 (only when some basis row
+// has a non-zero tap 0, i.e. a window with w[0] != 0), then zero taps up to a multiple of 16.
+//
+// Main kernel: 128 bins x 256 frames per workgroup, 8 waves (wave = 32 bins x 128 frames, re and im
+// accumulators of the same bins: acc[0][n] / acc[1][n]), K stage = 16 folded taps = ONE MFMA step,
+// LDS stage = 128 A rows + 256 X rows of 128 B (48 KB), ring of 3.  An iteration is two halves:
+//     re half : 12 MFMAs acc[0][n] += E x A_re   (3 split terms x 4 frame tiles) while the im-half
+//               fragments of this stage are read
+//     barrier : stage c+1 has landed (s_waitcnt vmcnt(6): stage c+2 may still be in flight), every
+//               wave has read what it needs from stage c
+//     im half : 12 MFMAs acc[1][n] += O x A_im while stage c+3 is DMA'd into the buffer of stage c and
+//               the re-half fragments of stage c+1 are read
+// Rows are XOR-swizzled in 16-byte chunks by (row >> 1) & 7 (applied to the DMA source address and to
+// the fragment reads): conflict-free ds_read_b128 (MI355X_MICROARCH.md, LDS table).
+
+constexpr int FOLD_KC = 16;                 // folded taps per stage
+constexpr int FOLD_ROWB = 128;              // bytes of one stage row: 4 planes x 16 bf16
+constexpr int FOLD_BINS = 128;              // bins per workgroup
+constexpr int FOLD_BN = 256;                // frames per workgroup
+constexpr int FOLD_NBUF = 3;
+constexpr int FOLD_A_ST = FOLD_BINS * FOLD_ROWB;            // 16 KB
+constexpr int FOLD_X_ST = FOLD_BN * FOLD_ROWB;              // 32 KB
+constexpr int FOLD_STAGE = FOLD_A_ST + FOLD_X_ST;           // 48 KB
+constexpr int FOLD_DMA_PER_WAVE = (FOLD_STAGE / 1024) / 8;  // LDS-DMA pieces per wave and stage (6)
+
+__host__ __device__ inline int fold_taps(int kernel, int with_tap0) {
+  const int k = kernel / 2 + (with_tap0 ? 1 : 0);
+  return (k + FOLD_KC - 1) / FOLD_KC * FOLD_KC;
+}
+
+// original tap of folded tap j (or -1 for the zero padding)
+__device__ __forceinline__ int fold_tap_of(int j, int N, int with_tap0) {
+  const int H = N >> 1;
+  if (j < H) return j + 1;
+  if (j == H && with_tap0) return 0;
+  return -1;
+}
+
+// ---------------------------------------------------------------------------------
+// basis -> folded split planes (+ asymmetry statistics).  grid (ceil(Kf/256), n_bins)
+// stats[0] = max over pairs of |wr[n] - wr[N-n]| / 2 and |wi[n] + wi[N-n]| / 2 (what the fold
+// neglects), stats[1] = max |coefficient|, both as float bit patterns (atomicMax on unsigned).
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) fold_basis_kernel(const float *__restrict__ re,
+                                                         const float *__restrict__ im,
+                                                         long long row_stride, int n_bins, int N,
+                                                         int with_tap0, int Kf,
+                                                         unsigned short *__restrict__ dst,
+                                                         float *__restrict__ last_rows,
+                                                         unsigned *__restrict__ stats) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int bin = blockIdx.y;
+  float asym = 0.f, amax = 0.f;
+  if (j < Kf) {
+    const int n = fold_tap_of(j, N, with_tap0);
+    const float *wr = re + (long long)bin * row_stride;
+    const float *wi = im + (long long)bin * row_stride;
+    float ae = 0.f, ao = 0.f;
+    if (n >= 0) {
+      if (n > 0 && n < (N >> 1)) {
+        const float r1 = wr[n], r2 = wr[N - n], i1 = wi[n], i2 = wi[N - n];
+        ae = 0.5f * (r1 + r2);
+        ao = 0.5f * (i1 - i2);
+        asym = fmaxf(fabsf(0.5f * (r1 - r2)), fabsf(0.5f * (i1 + i2)));
+      } else {  // n = N/2 or n = 0: no partner, E = O = the sample itself
+        ae = wr[n];
+        ao = wi[n];
+      }
+      amax = fmaxf(fabsf(ae), fabsf(ao));
+    }
+    unsigned eh, el, oh, ol;
+    bf16_split(ae, eh, el);
+    bf16_split(ao, oh, ol);
+    unsigned short *row = dst + ((long long)bin * (Kf / FOLD_KC) + j / FOLD_KC) * (FOLD_ROWB / 2);
+    const int u = j % FOLD_KC;
+    row[u] = (unsigned short)eh;
+    row[16 + u] = (unsigned short)el;
+    row[32 + u] = (unsigned short)oh;
+    row[48 + u] = (unsigned short)ol;
+    if (bin == n_bins - 1) {
+      last_rows[j] = ae;
+      last_rows[Kf + j] = ao;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    asym = fmaxf(asym, __shfl_xor(asym, d));
+    amax = fmaxf(amax, __shfl_xor(amax, d));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(&stats[0], __float_as_uint(asym));
+    atomicMax(&stats[1], __float_as_uint(amax));
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Pre-pass: one workgroup per frame.  Thread i owns folded taps 4 i .. 4 i + 3 (+ 1024 per trip):
+// 16-byte loads of x_t[n ..] forwards and x_t[N-n ..] backwards (element-wise with the virtual
+// padding for the frames that touch a clip edge), E / O in fp32, split, 8-byte stores (the four
+// threads of a stage fill 32 contiguous bytes of each plane).  With p.fold_last the LAST bin
+// (Nyquist) is evaluated here too, in plain fp32 FMAs on the same E / O, through the full pointwise
+// epilogue -- instead of a row block of its own in the contraction.
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) fold_frames_kernel(const KParams p,
+                                                          unsigned short *__restrict__ dst) {
+  const long long col = blockIdx.x;
+  const int c = (int)(col / p.n_frames);
+  const int t = (int)(col - (long long)c * p.n_frames);
+  const int N = p.K, H = N >> 1, Kf = p.Ks;
+  const long long q0 = (long long)t * p.hop - p.pad;  // signal position of tap 0
+  const float *x = p.x + (long long)c * p.x_clip_stride;
+  const bool interior = q0 >= 0 && q0 + N <= p.n_samples;
+  unsigned short *row0 = dst + col * ((long long)Kf * 4);
+  const float *le = p.fold_last, *lo = p.fold_last ? p.fold_last + Kf : nullptr;
+  float pe = 0.f, po = 0.f;
+  for (int j0 = 4 * threadIdx.x; j0 < Kf; j0 += 1024) {
+    float e[4], o[4];
+    if (interior && j0 + 4 < H) {  // taps n = j0+1 .. j0+4 < N/2: all paired
+      const f32x4u f = *reinterpret_cast<const f32x4u *>(x + q0 + j0 + 1);
+      const f32x4u b = *reinterpret_cast<const f32x4u *>(x + q0 + N - j0 - 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        e[i] = f[i] + b[3 - i];
+        o[i] = f[i] - b[3 - i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n = fold_tap_of(j0 + i, N, p.fold_tap0);
+        float a = 0.f, b = 0.f;
+        if (n >= 0) a = fetch_sample(p.x, (long long)c * p.x_clip_stride, (int)(q0 + n), p.n_samples, p.pad_mode, true);
+        if (n > 0 && n < H) {
+          b = fetch_sample(p.x, (long long)c * p.x_clip_stride, (int)(q0 + N - n), p.n_samples, p.pad_mode, true);
+          e[i] = a + b;
+          o[i] = a - b;
+        } else {
+          e[i] = a;
+          o[i] = a;
+        }
+      }
+    }
+    u16x4 eh, el, oh, ol;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned h, l;
+      bf16_split(e[i], h, l);
+      eh[i] = (unsigned short)h;
+      el[i] = (unsigned short)l;
+      bf16_split(o[i], h, l);
+      oh[i] = (unsigned short)h;
+      ol[i] = (unsigned short)l;
+    }
+    unsigned short *r = row0 + (j0 / FOLD_KC) * (FOLD_ROWB / 2) + (j0 % FOLD_KC);
+    *reinterpret_cast<u16x4 *>(r) = eh;
+    *reinterpret_cast<u16x4 *>(r + 16) = el;
+    *reinterpret_cast<u16x4 *>(r + 32) = oh;
+    *reinterpret_cast<u16x4 *>(r + 48) = ol;
+    if (le) {
+      const f32x4v we = *reinterpret_cast<const f32x4v *>(le + j0);
+      const f32x4v wo = *reinterpret_cast<const f32x4v *>(lo + j0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        pe = fmaf(we[i], e[i], pe);
+        po = fmaf(wo[i], o[i], po);
+      }
+    }
+  }
+  if (!le) return;
+  __shared__ float red[2][4];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    pe += __shfl_xor(pe, d);
+    po += __shfl_xor(po, d);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = pe;
+    red[1][threadIdx.x >> 6] = po;
+  }
+  __syncthreads();
+  const int bin = p.fold_last_bin;  // relative to the problem's first bin
+  const float sc = p.row_scale ? p.row_scale[bin] : 1.f;
+  const float re = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) * sc;
+  const float im = p.im_sign * (red[1][0] + red[1][1] + red[1][2] + red[1][3]) * sc;
+  if (p.fb) {
+    // fused filterbank: out[c, m, t] += fb[m, bin] * |z|^power for the filters that weigh this bin
+    // (the main kernel treats their bands as crossing a tile boundary: atomic addends there too)
+    const float s2 = re * re + im * im + p.eps;
+    const float pw = p.power == 2.0f ? s2 : sqrtf(s2);
+    const int babs = p.out_row_offset + bin;
+    for (int m = threadIdx.x; m < p.n_fb; m += 256) {
+      if (p.fb_support[2 * m] <= babs && babs < p.fb_support[2 * m + 1]) {
+        const float w = p.fb[(long long)m * p.fb_row_stride + babs];
+        if (w != 0.f)
+          unsafeAtomicAdd(p.out + (long long)c * p.out_clip_stride + (long long)m * p.out_row_stride + t, w * pw);
+      }
+    }
+    return;
+  }
+  if (threadIdx.x == 0) {
+    const int E = epilogue_width(p.epilogue);
+    float *d = p.out + (long long)c * p.out_clip_stride +
+               (long long)(p.out_row_offset + bin) * p.out_row_stride + (long long)t * E;
+    epilogue_store(p, d, re, im);
+  }
+}
+
+// barrier that publishes LDS-direct data, leaving the newest N loads of this wave in flight
+template <int N>
+__device__ __forceinline__ void lds_dma_barrier_keep() {
+  if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (N == FOLD_DMA_PER_WAVE) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  static_assert(N == 0 || N == 6, "immediate of the s_waitcnt above");
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(512) framed_fold_kernel(const KParams p) {
+  constexpr int WM = 4, WN = 2, NR = 4, NW = 8;
+  typedef __attribute__((address_space(1))) const void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN;
+  const int wn = wave % WN;
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+
+  // ---- XCD-aware tile order (as framed_gemm_body)
+  int tile;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = b & 7, idx = b >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tile_m, tile_n;
+  {
+    const int G = p.n_group;
+    const int per_group = G * p.n_tiles_m;
+    const int full = (p.n_tiles_n / G) * per_group;
+    if (tile < full) {
+      const int g = tile / per_group;
+      const int rest = tile - g * per_group;
+      tile_m = rest / G;
+      tile_n = g * G + (rest - tile_m * G);
+    } else {
+      const int Gt = p.n_tiles_n % G;
+      const int rest = tile - full;
+      tile_m = rest / Gt;
+      tile_n = (p.n_tiles_n / G) * G + (rest - tile_m * Gt);
+    }
+  }
+  const int b0 = tile_m * FOLD_BINS;                  // first bin of the tile
+  const long long n0 = (long long)tile_n * FOLD_BN;   // first flat frame of the tile
+  const int nst = p.Ks / FOLD_KC;
+  const long long row_el = (long long)nst * (FOLD_ROWB / 2);  // elements per basis / frame row
+
+  // ---- DMA geometry: a piece = 8 rows x 128 B; lane -> (row r8 = lane >> 3, slot = lane & 7),
+  // which receives chunk  slot ^ ((row >> 1) & 7)  of its row (row = index inside the tile)
+  const int r8 = lane >> 3, slot = lane & 7;
+  const unsigned short *aptr[2], *xptr[4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = (j * NW + wave) * 8 + r8;  // A row = bin of the tile
+    int bin = b0 + row;
+    bin = bin < p.n_bins ? bin : p.n_bins - 1;  // bins past the end feed unused accumulators
+    aptr[j] = p.as + (long long)bin * row_el + 8 * (slot ^ ((row >> 1) & 7));
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (j * NW + wave) * 8 + r8;  // X row = frame of the tile
+    long long col = n0 + row;
+    col = col < p.n_cols ? col : 0;  // unused column: any valid frame, never stored
+    xptr[j] = p.xs + col * row_el + 8 * (slot ^ ((row >> 1) & 7));
+  }
+  auto dma_stage = [&](int s, int buf) __attribute__((always_inline)) {
+    unsigned char *st = smem_raw + buf * FOLD_STAGE;
+    const int so = s * (FOLD_ROWB / 2);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(aptr[j] + so), (lptr_t)(st + (j * NW + wave) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(xptr[j] + so),
+                                       (lptr_t)(st + FOLD_A_ST + (j * NW + wave) * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[2][NR];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < NR; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+
+  // ---- fragments.  Lane (li, lh) supplies row li and taps 8 lh .. 8 lh + 7 of the step: chunk
+  // 2 * plane + lh of the row, at slot  chunk ^ ((li >> 1) & 7)
+  const int fsw = (li >> 1) & 7;
+  const int a_row = (wm * 32 + li) * FOLD_ROWB;
+  const int x_row = FOLD_A_ST + ((wn * NR) * 32 + li) * FOLD_ROWB;
+  bf16x8 fa[2][2], fx[2][2][NR];  // [half][hi / lo]
+  auto load_frags = [&](int buf, auto half_tag) __attribute__((always_inline)) {
+    constexpr int HALF = decltype(half_tag)::value;  // 0: (A_re, E), 1: (A_im, O)
+    const unsigned char *st = smem_raw + buf * FOLD_STAGE;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      const int off = 16 * ((4 * HALF + 2 * pl + lh) ^ fsw);
+      fa[HALF][pl] = *reinterpret_cast<const bf16x8 *>(st + a_row + off);
+#pragma unroll
+      for (int n = 0; n < NR; ++n)
+        fx[HALF][pl][n] = *reinterpret_cast<const bf16x8 *>(st + x_row + n * 32 * FOLD_ROWB + off);
+    }
+  };
+  // the 3 * NR MFMAs of one half; small terms first, an accumulator is revisited after NR - 1 others
+  auto mfma_half = [&](auto half_tag) __attribute__((always_inline)) {
+    constexpr int HALF = decltype(half_tag)::value;
+#pragma unroll
+    for (int term = 0; term < 3; ++term)
+#pragma unroll
+      for (int n = 0; n < NR; ++n) {
+        const bf16x8 a = fa[HALF][term == 0 ? 1 : 0];
+        const bf16x8 x = fx[HALF][term == 1 ? 1 : 0][n];
+        acc[HALF][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, a, acc[HALF][n], 0, 0, 0);
+      }
+  };
+  auto interleave = [&](auto n_mfma_tag, auto n_ds_tag, auto n_vm_tag) __attribute__((always_inline)) {
+    constexpr int NM = decltype(n_mfma_tag)::value;
+    constexpr int ND = decltype(n_ds_tag)::value;
+    constexpr int NV = decltype(n_vm_tag)::value;
+    constexpr int NMD = NM - NM / 4;
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+      if ((i + 1) * NV / NM != i * NV / NM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      if (i < NMD && (i + 1) * ND / NMD != i * ND / NMD)
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+  };
+  using std::integral_constant;
+  typedef integral_constant<int, 0> i0;
+  typedef integral_constant<int, 1> i1;
+  typedef integral_constant<int, 3 * NR> n_mfma;
+  typedef integral_constant<int, 2 * (1 + NR)> n_reads;
+  typedef integral_constant<int, FOLD_DMA_PER_WAVE> n_dma;
+
+  // DMA: stage c + NBUF exists; NEXT: stage c + 1 exists; KEEP: loads this wave may leave in flight
+  // at the barrier (stage c + 2's, when it was issued)
+  auto stage_iter = [&](int c, int buf, int nbuf_next, auto dma_tag, auto next_tag,
+                        auto keep_tag) __attribute__((always_inline)) {
+    constexpr bool DMA = decltype(dma_tag)::value;
+    constexpr bool NEXT = decltype(next_tag)::value;
+    load_frags(buf, i1{});
+    mfma_half(i0{});
+    interleave(n_mfma{}, n_reads{}, i0{});
+    lds_dma_barrier_keep<decltype(keep_tag)::value>();
+    if (DMA) dma_stage(c + FOLD_NBUF, buf);
+    if (NEXT) load_frags(nbuf_next, i0{});
+    mfma_half(i1{});
+    interleave(n_mfma{}, integral_constant<int, NEXT ? n_reads::value : 0>{},
+               integral_constant<int, DMA ? n_dma::value : 0>{});
+  };
+  typedef integral_constant<bool, true> yes;
+  typedef integral_constant<bool, false> no;
+  typedef integral_constant<int, FOLD_DMA_PER_WAVE> keep1;
+  if (nst > 0) {
+    dma_stage(0, 0);
+    if (nst > 1) dma_stage(1, 1);
+    if (nst > 2) dma_stage(2, 2);
+    // stage 0 landed: at most the later stages' loads outstanding
+    if (nst > 2)
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (nst > 1)
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    load_frags(0, i0{});
+    int c = 0, buf = 0;
+    auto nxt = [](int b) { return b == FOLD_NBUF - 1 ? 0 : b + 1; };
+    for (; c + FOLD_NBUF < nst; ++c) {  // stages c+1, c+2, c+3 all exist
+      stage_iter(c, buf, nxt(buf), yes{}, yes{}, keep1{});
+      buf = nxt(buf);
+    }
+    if (c + 2 < nst) {  // c+1 and c+2 exist (c+2 in flight), no further DMA
+      stage_iter(c, buf, nxt(buf), no{}, yes{}, keep1{});
+      buf = nxt(buf);
+      ++c;
+    }
+    if (c + 1 < nst) {  // only c+1 left: wait for everything
+      stage_iter(c, buf, nxt(buf), no{}, yes{}, i0{});
+      buf = nxt(buf);
+      ++c;
+    }
+    stage_iter(c, buf, buf, no{}, no{}, i0{});
+    __syncthreads();  // every wave is done with the stage buffers (the epilogue reuses them)
+  }
+  if (p.fb)
+    bf16x3_epilogue_fb<WM, WN, NR>(p, acc, 2 * b0, n0, smem_raw);
+  else
+    bf16x3_epilogue_planar<WM, WN, NR>(p, acc, 2 * b0, n0, smem_raw);
+}

@@ -142,6 +142,10 @@ struct KParams {
   const int *fb_support;
   long long fb_row_stride;
   int n_fb;
+  // symmetric fold (framed_fold.inl): as = folded basis, xs = folded frames, Ks = folded taps
+  const float *fold_last;  // fp32 folded (even | odd) rows of the bin the pre-pass evaluates, or NULL
+  int fold_last_bin;       // that bin, relative to the problem's first bin
+  int fold_tap0;           // tap 0 is carried as folded tap kernel/2
 };
 
 // ---------------------------------------------------------------------------------
@@ -950,6 +954,7 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
 #include "framed_bf16x3.inl"
 #include "framed_bf16x3_slab.inl"
 #include "framed_bf16x3_narrow.inl"
+#include "framed_fold.inl"
 
 // Several independent contractions of the same tile shape in one launch (the octaves of
 // CQT2010v2 / VQT: each is a short-K, few-hundred-workgroup problem that cannot fill the chip on
@@ -1956,6 +1961,85 @@ int launch_framed_bf16x3(const KParams &p, int tile, hipStream_t stream) {
   return launch_framed(leftover_rows(p, main_bins), MISPEC_TILE_AUTO, stream);
 }
 
+// ---------------------------------------------------------------------------------
+// symmetric fold (framed_fold.inl): applicability, workspace, launch
+// ---------------------------------------------------------------------------------
+long long basis_fold_bytes(int n_bins, int kernel, int with_tap0) {
+  const long long kf = fold_taps(kernel, with_tap0);
+  return (long long)n_bins * kf * 8 + 2 * kf * (long long)sizeof(float);
+}
+
+struct FoldPlan {
+  bool ok;
+  int kf, with_tap0, main_bins;
+  bool last_in_prepass;
+  long long ws_bytes;
+};
+
+FoldPlan plan_fold(const mispec_framed_gemm_args *a, const KParams &p) {
+  FoldPlan f{};
+  if (a->precision != MISPEC_PREC_BF16X3 || !a->basis_fold || a->tile != MISPEC_TILE_AUTO) return f;
+  if (MISPEC_DBG(p, 0x100000)) return f;  // A/B runs: the dense kernel
+  if (!p.a_im || p.row_support || (p.K & 1) || p.K < 64) return f;
+  if ((long long)p.hop * 8 < p.K) return f;  // folded frames cost 8 B per folded tap and frame
+  int with_tap0 = -1;
+  for (int w = 0; w < 2; ++w)
+    if (a->fold_taps == fold_taps(p.K, w)) with_tap0 = w;
+  if (with_tap0 < 0) return f;
+  if (fold_taps(p.K, 0) == fold_taps(p.K, 1)) with_tap0 = 1;  // ambiguous: the carried tap is a
+                                                              // zero coefficient when not needed
+  if (a->basis_fold_bytes < basis_fold_bytes(p.n_bins, p.K, with_tap0)) return f;
+  if (p.n_bins < 64) return f;  // a 128-bin tile would be mostly empty
+  f.kf = a->fold_taps;
+  f.with_tap0 = with_tap0;
+  f.last_in_prepass = p.n_bins > FOLD_BINS && p.n_bins % FOLD_BINS == 1;
+  f.main_bins = f.last_in_prepass ? p.n_bins - 1 : p.n_bins;
+  f.ws_bytes = p.n_cols * (long long)f.kf * 8;
+  f.ok = true;
+  return f;
+}
+
+int launch_fold(KParams p, const mispec_framed_gemm_args *a, const FoldPlan &f, hipStream_t stream) {
+  if (!a->workspace || a->workspace_bytes < f.ws_bytes)
+    return fail(MISPEC_E_INVALID, "workspace too small: size it with the *_workspace_bytes query%s");
+  if (p.n_cols > 0x7fffffffLL) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
+  unsigned short *xf = static_cast<unsigned short *>(a->workspace);
+  const unsigned short *bf = static_cast<const unsigned short *>(a->basis_fold);
+  p.Ks = f.kf;
+  p.fold_tap0 = f.with_tap0;
+  p.as = bf;
+  p.xs = xf;
+  const float *last_rows = reinterpret_cast<const float *>(bf + (long long)p.n_bins * f.kf * 4);
+  // pre-pass: folded frames (+ the last bin); it sees the whole problem's epilogue fields
+  KParams pre = p;
+  pre.fold_last = f.last_in_prepass ? last_rows : nullptr;
+  pre.fold_last_bin = p.n_bins - 1;
+  hipLaunchKernelGGL(fold_frames_kernel, dim3((unsigned)p.n_cols), dim3(256), 0, stream, pre, xf);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "fold pre-pass launch: %s", hipGetErrorString(e));
+  // main contraction over the whole 128-bin blocks (a partial last block when it is more than the
+  // one bin the pre-pass took)
+  p.n_bins = f.main_bins;
+  p.n_tiles_m = (p.n_bins + FOLD_BINS - 1) / FOLD_BINS;
+  const long long tn = (p.n_cols + FOLD_BN - 1) / FOLD_BN;
+  if (tn * p.n_tiles_m > 0x7fffffffLL) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
+  p.n_tiles_n = (int)tn;
+  int g = (32 + p.n_tiles_m / 2) / p.n_tiles_m;  // one workgroup per CU, 32 CUs per XCD
+  g = g < 1 ? 1 : (g > p.n_tiles_n ? p.n_tiles_n : g);
+  p.n_group = g;
+  auto kern = framed_fold_kernel;
+  static std::atomic<unsigned long long> configured{0};
+  int rc = configure_lds(kern, 160 * 1024, configured);
+  if (rc != MISPEC_OK) return rc;
+  // the epilogues reuse the stage ring (patches: 8 waves x 32 x 132 floats, or the 128 x 260 power
+  // tile + band table of the fused filterbank)
+  const size_t smem = (size_t)FOLD_NBUF * FOLD_STAGE;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tn * p.n_tiles_m)), dim3(512), smem, stream, p);
+  e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+
 // attach the edge workspace to p and enqueue the fill pre-pass
 int setup_edges(KParams &p, void *workspace, long long workspace_bytes, hipStream_t stream) {
   const EdgePlan e = plan_edges(p.n_samples, p.K, p.hop, p.pad, p.n_frames);
@@ -2039,7 +2123,8 @@ int fill_params(const mispec_framed_gemm_args *a, KParams &p) {
 #endif
   if (a->precision != MISPEC_PREC_F32 && a->precision != MISPEC_PREC_BF16X3)
     return fail(MISPEC_E_INVALID, "bad precision%s");
-  if (a->reserved2 != 0 || a->reserved3 != 0) return fail(MISPEC_E_INVALID, "reserved fields must be 0%s");
+  if (a->reserved2 != 0 || a->reserved3 != 0 || a->reserved4 != 0)
+    return fail(MISPEC_E_INVALID, "reserved fields must be 0%s");
   if (a->fb) {
     if (!a->fb_support || a->n_fb <= 0)
       return fail(MISPEC_E_INVALID, "fused filterbank: fb_support and n_fb > 0 are required%s");
@@ -2106,6 +2191,8 @@ int64_t mispec_framed_gemm_workspace_bytes(const mispec_framed_gemm_args *args) 
   KParams p;
   int rc = fill_params(args, p);
   if (rc != MISPEC_OK) return rc;
+  const FoldPlan f = plan_fold(args, p);
+  if (f.ok) return f.ws_bytes;
   const EdgePlan e = plan_edges(p.n_samples, p.K, p.hop, p.pad, p.n_frames);
   if (bf16x3_ok(args, p)) {
     const SplitPlan sp = plan_split(p, e);
@@ -2119,9 +2206,11 @@ int mispec_framed_gemm_f32(const mispec_framed_gemm_args *args, void *stream) {
   int rc = fill_params(args, p);
   if (rc != MISPEC_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool bf16x3 = bf16x3_ok(args, p);
   if (p.fb && (args->tile != MISPEC_TILE_AUTO || MISPEC_DBG(p, 0x2000)))
     return fail(MISPEC_E_UNSUPPORTED, "fused filterbank needs the automatic tile choice%s");
+  const FoldPlan fold = plan_fold(args, p);
+  if (fold.ok) return launch_fold(p, args, fold, s);
+  const bool bf16x3 = bf16x3_ok(args, p);
   // (the bf16x3 kernels read the padded split signal, not the fp32 path's edge workspace)
   if (!bf16x3 || plan_bf16x3_rows(p, args->tile).fp32_leftover) {
     rc = setup_edges(p, args->workspace, args->workspace_bytes, s);
@@ -2155,6 +2244,43 @@ int mispec_split_basis_bf16(const float *basis_re, const float *basis_im,
                      static_cast<unsigned short *>(dst));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MISPEC_E_HIP, "basis split launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+
+int32_t mispec_fold_taps(int32_t kernel, int32_t with_tap0) {
+  if (kernel < 64 || (kernel & 1)) return fail(MISPEC_E_UNSUPPORTED, "the fold needs an even kernel of >= 64 taps%s");
+  return fold_taps(kernel, with_tap0 != 0);
+}
+
+int64_t mispec_basis_fold_bytes(int32_t n_bins, int32_t kernel, int32_t with_tap0) {
+  if (n_bins <= 0) return fail(MISPEC_E_INVALID, "non-positive size%s");
+  if (kernel < 64 || (kernel & 1)) return fail(MISPEC_E_UNSUPPORTED, "the fold needs an even kernel of >= 64 taps%s");
+  return basis_fold_bytes(n_bins, kernel, with_tap0 != 0);
+}
+
+int mispec_fold_basis_bf16(const float *basis_re, const float *basis_im, int64_t basis_row_stride,
+                           int32_t n_bins, int32_t kernel, int32_t with_tap0, void *dst,
+                           int64_t dst_bytes, float *stats, void *stream) {
+  if (!basis_re || !basis_im || !dst) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
+  if (n_bins <= 0) return fail(MISPEC_E_INVALID, "non-positive size%s");
+  if (kernel < 64 || (kernel & 1)) return fail(MISPEC_E_UNSUPPORTED, "the fold needs an even kernel of >= 64 taps%s");
+  const int w0 = with_tap0 != 0;
+  if (dst_bytes < basis_fold_bytes(n_bins, kernel, w0))
+    return fail(MISPEC_E_INVALID, "dst too small: size it with mispec_basis_fold_bytes%s");
+  const int kf = fold_taps(kernel, w0);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  unsigned short *d = static_cast<unsigned short *>(dst);
+  float *last_rows = reinterpret_cast<float *>(d + (long long)n_bins * kf * 4);
+  // statistics land in the caller's buffer, or in the tail rows' place holder when not wanted
+  unsigned *st = reinterpret_cast<unsigned *>(stats);
+  if (st && hipMemsetAsync(st, 0, 2 * sizeof(unsigned), s) != hipSuccess)
+    return fail(MISPEC_E_HIP, "hipMemsetAsync failed%s");
+  if (!st) return fail(MISPEC_E_INVALID, "stats must point to 2 device floats%s");
+  hipLaunchKernelGGL(fold_basis_kernel, dim3((unsigned)((kf + 255) / 256), (unsigned)n_bins), dim3(256), 0,
+                     s, basis_re, basis_im, (long long)basis_row_stride, n_bins, kernel, w0, kf, d,
+                     last_rows, st);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "basis fold launch: %s", hipGetErrorString(e));
   return MISPEC_OK;
 }
 

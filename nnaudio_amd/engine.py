@@ -194,7 +194,8 @@ def n_frames(length, kernel, hop, pad):
 def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign=-1.0,
                  eps=0.0, power=2.0, row_scale=None, row_support=None, out=None,
                  out_rows_total=None, out_row_offset=0, tile=TILE_AUTO, _debug=0,
-                 need_workspace=True, precision=None, basis_split=None, fb=None, fb_support=None):
+                 need_workspace=True, precision=None, basis_split=None, basis_fold=None, fb=None,
+                 fb_support=None):
     """Validate one framed-contraction problem and fill its C argument block.
     Returns (args, out, device, keepalive tensors)."""
     dev = _require_device(x, basis_re, basis_im, row_scale, row_support, out, fb, fb_support)
@@ -277,6 +278,12 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
         a.basis_split = basis_split.data_ptr()
         a.basis_split_bytes = basis_split.numel() * basis_split.element_size()
         keep.append(basis_split)
+        if basis_fold is not None:  # (planes, folded taps) from fold_basis(): half the MFMAs
+            planes, taps = basis_fold
+            a.basis_fold = planes.data_ptr()
+            a.basis_fold_bytes = planes.numel() * planes.element_size()
+            a.fold_taps = int(taps)
+            keep.append(planes)
     if need_workspace:
         lib = _abi.load_ablate() if a.reserved else _abi.load()
         need = lib.mispec_framed_gemm_workspace_bytes(ctypes.byref(a))
@@ -311,13 +318,59 @@ def split_basis(basis_re, basis_im):
     return dst
 
 
+# what the symmetric fold may neglect, relative to the largest coefficient: one ulp of the fp32
+# basis (the pairs of a Fourier basis agree to the last bit or differ by one rounding), far inside
+# the split's own 2^-17
+FOLD_ASYMMETRY_TOL = 2.0 ** -20
+
+
+def fold_basis(basis_re, basis_im):
+    """``(planes, folded taps)`` for ``framed_gemm(..., basis_fold=...)`` when the basis is even
+    (re) / odd (im) about tap K/2 -- every Fourier basis of the reference's STFT -- else None.
+    The symmetry is checked numerically (``mispec_fold_basis_bf16`` reports the largest
+    coefficient the fold would neglect); this reads two scalars back: once per basis (the callers
+    cache the result), never per forward."""
+    dev = _require_device(basis_re, basis_im)
+    wr = _rows(basis_re.detach(), "basis_re")
+    wi = _rows(basis_im.detach(), "basis_im") if basis_im is not None else None
+    if wi is None or wi.shape != wr.shape or wi.stride(0) != wr.stride(0):
+        return None
+    F, K = wr.shape
+    if K < 64 or K % 2:
+        return None
+    lib = _abi.load()
+    with_tap0 = int(bool((wr[:, 0] != 0).any().item() or (wi[:, 0] != 0).any().item()))
+    taps = lib.mispec_fold_taps(K, with_tap0)
+    need = lib.mispec_basis_fold_bytes(F, K, with_tap0)
+    if taps < 0 or need < 0:
+        return None
+    dst = torch.empty(need // 2, dtype=torch.int16, device=dev)
+    stats = torch.zeros(2, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _abi.check(lib.mispec_fold_basis_bf16(
+            wr.data_ptr(), wi.data_ptr(), wr.stride(0), F, K, with_tap0, dst.data_ptr(), need,
+            stats.data_ptr(), ctypes.c_void_p(stream)))
+    neglected, largest = (float(v) for v in stats.cpu())
+    if not largest > 0.0 or neglected > FOLD_ASYMMETRY_TOL * largest:
+        return None
+    return dst, int(taps)
+
+
 def prepare_basis(basis_re, basis_im, precision, hop=None):
     """Derived operands of a basis for ``framed_gemm`` in the given arithmetic, as keyword
-    arguments (callers with a persistent basis cache this dict, see ``DerivedCache``): the
-    split-bf16 planes for "bf16x3", nothing for "fp32"."""
+    arguments (callers with a persistent basis cache this dict, see ``DerivedCache``): for
+    "bf16x3" the split-bf16 planes and, for a basis with the Fourier symmetry, the folded planes
+    (the library uses them when the shape allows, include/mispec.h ``basis_fold``); nothing for
+    "fp32"."""
     if resolve_precision(precision) != "bf16x3":
         return {}
-    return {"basis_split": split_basis(basis_re, basis_im)}
+    out = {"basis_split": split_basis(basis_re, basis_im)}
+    if basis_im is not None and (hop is None or 8 * int(hop) >= basis_re.shape[-1]):
+        folded = fold_basis(basis_re, basis_im)
+        if folded is not None:
+            out["basis_fold"] = folded
+    return out
 
 
 def describe_framed_kernel(precision, prepared):
@@ -325,7 +378,9 @@ def describe_framed_kernel(precision, prepared):
     with ``prepare_basis`` (bench.py's report)."""
     if resolve_precision(precision) != "bf16x3":
         return "framed_gemm_kernel<2,2,2,2,framed,rows,unmasked> (v_mfma_f32_32x32x2_f32)"
-    return ("framed_bf16x3_kernel<4,2,2,4,unmasked> (v_mfma_f32_32x32x16_bf16) + split_signal_kernel")
+    if prepared.get("basis_fold") is not None:
+        return "framed_fold_kernel (v_mfma_f32_32x32x16_bf16, K/2 folded taps) + fold_frames_kernel"
+    return "framed_bf16x3_kernel<4,2,2,4,unmasked> (v_mfma_f32_32x32x16_bf16) + split_signal_kernel"
 
 
 def framed_gemm(x, basis_re, basis_im, *, reference_kernel=False, **kw):
@@ -690,6 +745,7 @@ class _FramedGemmFn(torch.autograd.Function):
         zkw = dict(kw, epilogue=EPI_COMPLEX, precision="fp32", row_support=None, out=None,
                    out_rows_total=None, out_row_offset=0)
         zkw.pop("basis_split", None)
+        zkw.pop("basis_fold", None)
         z = framed_gemm(xs, wr, wi, **zkw)
         T = z.shape[2]
         go = _f32(grad_out, "grad_output").contiguous()

@@ -165,19 +165,21 @@ class STFT(nn.Module):
         if self.freq_bins is not None:
             wsin, wcos = wsin[: self.freq_bins], wcos[: self.freq_bins]
         precision = engine.resolve_precision(self.precision)
-        split = None
+        prep = {}
         if precision == "bf16x3":
-            split = self._split.get((self.wcos, self.wsin),
-                                    lambda: engine.split_basis(wcos, wsin), extra=self.freq_bins)
+            # split planes + (the window being symmetric) the folded planes, cached per basis
+            prep = self._split.get((self.wcos, self.wsin),
+                                   lambda: engine.prepare_basis(wcos, wsin, "bf16x3", hop=self.stride),
+                                   extra=(self.freq_bins, self.stride))
         if fb is not None:
             return engine.framed_gemm(
                 x, wcos, wsin, hop=self.stride, pad=pad, pad_mode=mode, epilogue=epilogue,
                 im_sign=-1.0, eps=1e-8 if self.trainable else 0.0, power=power,
-                precision=precision, basis_split=split, fb=fb, fb_support=fb_support)
+                precision=precision, fb=fb, fb_support=fb_support, **prep)
         return engine.framed_gemm_autograd(
             x, wcos, wsin, hop=self.stride, pad=pad, pad_mode=mode, epilogue=epilogue,
             im_sign=-1.0, eps=1e-8 if self.trainable else 0.0, power=power,
-            precision=precision, basis_split=split,
+            precision=precision, **prep,
         )
 
     def forward(self, x, output_format=None):

@@ -692,6 +692,110 @@ def test_bf16x3_epilogues_small_clips(shape):
     assert not torch.equal(y, engine.framed_gemm(xd, wreal, None, precision="fp32", **kw))
 
 
+def _fourier_like_basis(rng, F, K, tap0):
+    """Random basis with the symmetry of the reference's Fourier kernels (utils.py:379-389 times a
+    centred window): re even / im odd about tap K/2; ``tap0``: non-zero coefficients at tap 0."""
+    H = K // 2
+    wr = np.zeros((F, K), np.float32)
+    wi = np.zeros((F, K), np.float32)
+    a = rng.standard_normal((F, H - 1)).astype(np.float32)
+    b = rng.standard_normal((F, H - 1)).astype(np.float32)
+    wr[:, 1:H], wr[:, K - 1:H:-1] = a, a
+    wi[:, 1:H], wi[:, K - 1:H:-1] = b, -b
+    wr[:, H] = rng.standard_normal(F)
+    wi[:, H] = rng.standard_normal(F) if tap0 else 0.0
+    if tap0:
+        wr[:, 0] = rng.standard_normal(F)
+        wi[:, 0] = rng.standard_normal(F)
+    return wr, wi
+
+
+@pytest.mark.parametrize("shape", [  # (B, L, bins, K, hop, pad, mode, tap0)
+    (3, 9000, 128, 256, 64, 128, 2, False),    # exactly one 128-bin block, reflect
+    (2, 9000, 129, 256, 64, 128, 1, False),    # + one leftover bin: evaluated by the pre-pass
+    (2, 7001, 200, 512, 77, 256, 2, True),     # partial second block, ODD hop, tap 0 carried
+    (1, 30000, 257, 2048, 512, 1024, 2, False),  # the cfg2 kernel shape, two blocks + Nyquist
+    (2, 4000, 64, 64, 16, 0, 0, True),         # smallest kernel, center=False
+    (5, 700, 130, 128, 32, 64, 2, False),      # many short clips: tiles span several clips
+])
+@pytest.mark.parametrize("epi", ["complex", "magnitude", "power2", "phase"])
+def test_symmetric_fold_kernel(shape, epi):
+    """precision="bf16x3" with ``basis_fold``: the contraction over K/2 folded taps of
+    x[n] +- x[K-n] (framed_fold.inl) against the float64 evaluation of the dense contraction."""
+    from nnaudio_amd import engine
+
+    B, L, F, K, hop, pad, mode, tap0 = shape
+    rng = np.random.default_rng(F * 1000 + K + hop)
+    x = rng.standard_normal((B, L)).astype(np.float32)
+    wr, wi = _fourier_like_basis(rng, F, K, tap0)
+    scale = rng.uniform(0.5, 2.0, F).astype(np.float32)
+    re, im = _np_framed(x, wr, wi, hop, pad, mode, scale)
+    xd, wrd, wid, sd = (torch.as_tensor(a).to(DEV) for a in (x, wr, wi, scale))
+    prep = engine.prepare_basis(wrd, wid, "bf16x3", hop=hop)
+    assert "basis_fold" in prep and prep["basis_fold"][1] == (K // 2 + (16 if tap0 else 0) + 15) // 16 * 16
+    kw = dict(hop=hop, pad=pad, pad_mode=mode, row_scale=sd)
+    e = {"complex": engine.EPI_COMPLEX, "magnitude": engine.EPI_MAGNITUDE, "power2": engine.EPI_POWER,
+         "phase": engine.EPI_PHASE_ATAN2}[epi]
+    y = engine.framed_gemm(xd, wrd, wid, precision="bf16x3", epilogue=e, **kw, **prep)
+    ydense = engine.framed_gemm(xd, wrd, wid, precision="bf16x3", epilogue=e, **kw,
+                                basis_split=prep["basis_split"])
+    torch.cuda.synchronize()
+    y, ydense = y.cpu().numpy(), ydense.cpu().numpy()
+    if F > 128:
+        assert not np.array_equal(y, ydense)  # really took the folded kernel
+    if epi == "complex":
+        ref = np.stack((re, im), -1)
+        assert_parity(y, ref, rel=1e-4, what="fold %s" % (shape,))
+        assert np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max()  # the split's own budget
+    elif epi == "magnitude":
+        assert_parity(y, np.sqrt(re * re + im * im), rel=1e-4, what="fold %s" % (shape,))
+    elif epi == "power2":
+        assert_parity(y, re * re + im * im, rel=1e-4, what="fold %s" % (shape,))
+    else:
+        mag = np.sqrt(re * re + im * im)
+        assert_phase_parity(y, np.arctan2(im, re), mag, what="fold %s" % (shape,))
+
+
+def test_symmetric_fold_is_refused_for_other_bases():
+    """A basis without the symmetry (CQT kernels, freq_scale != 'no', random) must not fold."""
+    from nnaudio_amd import engine, features
+
+    rng = np.random.default_rng(0)
+    wr = torch.as_tensor(rng.standard_normal((140, 256)).astype(np.float32)).to(DEV)
+    wi = torch.as_tensor(rng.standard_normal((140, 256)).astype(np.float32)).to(DEV)
+    assert engine.fold_basis(wr, wi) is None
+    m = features.STFT(n_fft=512, freq_scale="log", fmin=50, fmax=6000, sr=22050, verbose=False).to(DEV)
+    assert engine.fold_basis(m.wcos, m.wsin) is None
+    for win in ("hann", "hamming", ("kaiser", 8.0)):
+        m = features.STFT(n_fft=512, window=win, verbose=False).to(DEV)
+        assert engine.fold_basis(m.wcos, m.wsin) is not None, win
+    m = features.STFT(n_fft=512, win_length=400, verbose=False).to(DEV)  # centred shorter window
+    assert engine.fold_basis(m.wcos, m.wsin) is not None
+
+
+def test_symmetric_fold_fused_filterbank():
+    """Mel reduction fused into the folded contraction's epilogue == the two-kernel path, and both
+    == float64 (incl. a filterbank with weight on the Nyquist bin, which the pre-pass adds)."""
+    from nnaudio_amd import features
+    from oracle import spectral_oracle as O
+
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((9, 12000)).astype(np.float32)
+    xd = torch.as_tensor(x).to(DEV)
+    for fmax in (None, 7000.0):
+        m = features.MelSpectrogram(sr=16000, n_fft=512, n_mels=64, hop_length=128, fmax=fmax,
+                                    verbose=False).to(DEV)
+        m.stft.precision = "bf16x3"
+        if fmax is None:  # put weight on the Nyquist bin
+            with torch.no_grad():
+                m.mel_basis[-1, 256] = 0.01
+        with torch.no_grad():
+            y = m(xd)
+        ref = O.filterbank_spectrogram(x, m.stft.wsin.cpu().numpy(), m.stft.wcos.cpu().numpy(), 128,
+                                       m.mel_basis.cpu().numpy())
+        assert_parity(y.cpu().numpy(), ref, rel=1e-4, what="fold + fused mel fmax=%s" % fmax)
+
+
 def test_bf16x3_split_cache_follows_the_basis(bf16x3):
     """The cached split planes must be rebuilt when the basis changes in place or is replaced."""
     from nnaudio_amd import features

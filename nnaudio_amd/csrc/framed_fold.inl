@@ -45,6 +45,19 @@ constexpr int FOLD_X_ST = FOLD_BN * FOLD_ROWB;              // 32 KB
 constexpr int FOLD_STAGE = FOLD_A_ST + FOLD_X_ST;           // 48 KB
 constexpr int FOLD_DMA_PER_WAVE = (FOLD_STAGE / 1024) / 8;  // LDS-DMA pieces per wave and stage (6)
 
+// (hi, lo) of two floats with the hardware conversion (v_cvt_pk_bf16_f32, round to nearest even):
+// the same values as bf16_split for every finite input inside the bf16 range
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void bf16_split2(float a, float b, unsigned &hi, unsigned &lo) {
+  const f32x2 v = {a, b};
+  const bf16x2 h = __builtin_convertvector(v, bf16x2);
+  const f32x2 r = v - __builtin_convertvector(h, f32x2);
+  const bf16x2 l = __builtin_convertvector(r, bf16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
 __host__ __device__ inline int fold_taps(int kernel, int with_tap0) {
   const int k = kernel / 2 + (with_tap0 ? 1 : 0);
   return (k + FOLD_KC - 1) / FOLD_KC * FOLD_KC;
@@ -116,123 +129,152 @@ __global__ void __launch_bounds__(256) fold_basis_kernel(const float *__restrict
 }
 
 // ---------------------------------------------------------------------------------
-// Pre-pass: one workgroup per frame.  Thread i owns folded taps 4 i .. 4 i + 3 (+ 1024 per trip):
-// 16-byte loads of x_t[n ..] forwards and x_t[N-n ..] backwards (element-wise with the virtual
-// padding for the frames that touch a clip edge), E / O in fp32, split, 8-byte stores (the four
-// threads of a stage fill 32 contiguous bytes of each plane).  With p.fold_last the LAST bin
-// (Nyquist) is evaluated here too, in plain fp32 FMAs on the same E / O, through the full pointwise
-// epilogue -- instead of a row block of its own in the contraction.
+// Pre-pass: one workgroup per FOLD_FR consecutive frames of a clip.  Thread i owns folded taps
+// 4 i .. 4 i + 3 (+ 1024 per trip) of each of them: 16-byte loads of x_t[n ..] forwards and
+// x_t[N-n ..] backwards, all frames' loads issued before the first use (element-wise with the
+// virtual padding for the frames that touch a clip edge), E / O in fp32, split, assembled in LDS and
+// stored as consecutive 16-byte pieces (a frame's 8 Kf bytes are one run of memory).  With
+// p.fold_last the LAST bin (Nyquist) is evaluated here too, in plain fp32 FMAs on the same E / O,
+// through the full pointwise epilogue -- instead of a row block of its own in the contraction.
 // ---------------------------------------------------------------------------------
+constexpr int FOLD_FR = 4;
+
 __global__ void __launch_bounds__(256) fold_frames_kernel(const KParams p,
                                                           unsigned short *__restrict__ dst) {
-  const long long col = blockIdx.x;
-  const int c = (int)(col / p.n_frames);
-  const int t = (int)(col - (long long)c * p.n_frames);
+  const int c = p.fold_clip0 + blockIdx.y;
+  const int t0 = blockIdx.x * FOLD_FR;
+  const int nf = p.n_frames - t0 < FOLD_FR ? p.n_frames - t0 : FOLD_FR;  // frames of this block
   const int N = p.K, H = N >> 1, Kf = p.Ks;
-  const long long q0 = (long long)t * p.hop - p.pad;  // signal position of tap 0
   const float *x = p.x + (long long)c * p.x_clip_stride;
-  const bool interior = q0 >= 0 && q0 + N <= p.n_samples;
-  unsigned short *row0 = dst + col * ((long long)Kf * 4);
+  const long long col0 = (long long)c * p.n_frames + t0;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short *srow = reinterpret_cast<unsigned short *>(smem_raw);  // [FOLD_FR][4 Kf]
   const float *le = p.fold_last, *lo = p.fold_last ? p.fold_last + Kf : nullptr;
-  float pe = 0.f, po = 0.f;
-  for (int j0 = 4 * threadIdx.x; j0 < Kf; j0 += 1024) {
-    float e[4], o[4];
-    if (interior && j0 + 4 < H) {  // taps n = j0+1 .. j0+4 < N/2: all paired
-      const f32x4u f = *reinterpret_cast<const f32x4u *>(x + q0 + j0 + 1);
-      const f32x4u b = *reinterpret_cast<const f32x4u *>(x + q0 + N - j0 - 4);
+  float pe[FOLD_FR], po[FOLD_FR];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        e[i] = f[i] + b[3 - i];
-        o[i] = f[i] - b[3 - i];
+  for (int f = 0; f < FOLD_FR; ++f) pe[f] = po[f] = 0.f;
+  // all frames of the block interior? (then every load is a plain 16-byte run)
+  const long long qa = (long long)t0 * p.hop - p.pad;
+  const bool interior = qa >= 0 && qa + (long long)(nf - 1) * p.hop + N <= p.n_samples;
+  for (int j0 = 4 * threadIdx.x; j0 < Kf; j0 += 1024) {
+    float e[FOLD_FR][4], o[FOLD_FR][4];
+    if (interior && j0 + 4 < H) {  // taps n = j0+1 .. j0+4 < N/2: all paired
+      f32x4u fw[FOLD_FR], bw[FOLD_FR];
+#pragma unroll
+      for (int f = 0; f < FOLD_FR; ++f) {
+        const long long q0 = qa + (long long)(f < nf ? f : 0) * p.hop;
+        fw[f] = *reinterpret_cast<const f32x4u *>(x + q0 + j0 + 1);
+        bw[f] = *reinterpret_cast<const f32x4u *>(x + q0 + N - j0 - 4);
       }
+#pragma unroll
+      for (int f = 0; f < FOLD_FR; ++f)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          e[f][i] = fw[f][i] + bw[f][3 - i];
+          o[f][i] = fw[f][i] - bw[f][3 - i];
+        }
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int n = fold_tap_of(j0 + i, N, p.fold_tap0);
-        float a = 0.f, b = 0.f;
-        if (n >= 0) a = fetch_sample(p.x, (long long)c * p.x_clip_stride, (int)(q0 + n), p.n_samples, p.pad_mode, true);
-        if (n > 0 && n < H) {
-          b = fetch_sample(p.x, (long long)c * p.x_clip_stride, (int)(q0 + N - n), p.n_samples, p.pad_mode, true);
-          e[i] = a + b;
-          o[i] = a - b;
-        } else {
-          e[i] = a;
-          o[i] = a;
+      for (int f = 0; f < FOLD_FR; ++f) {
+        const long long q0 = qa + (long long)(f < nf ? f : 0) * p.hop;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int n = fold_tap_of(j0 + i, N, p.fold_tap0);
+          float a = 0.f, b = 0.f;
+          if (n >= 0)
+            a = fetch_sample(p.x, (long long)c * p.x_clip_stride, (int)(q0 + n), p.n_samples, p.pad_mode, true);
+          if (n > 0 && n < H) {
+            b = fetch_sample(p.x, (long long)c * p.x_clip_stride, (int)(q0 + N - n), p.n_samples, p.pad_mode, true);
+            e[f][i] = a + b;
+            o[f][i] = a - b;
+          } else {
+            e[f][i] = a;
+            o[f][i] = a;
+          }
         }
       }
     }
-    u16x4 eh, el, oh, ol;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      unsigned h, l;
-      bf16_split(e[i], h, l);
-      eh[i] = (unsigned short)h;
-      el[i] = (unsigned short)l;
-      bf16_split(o[i], h, l);
-      oh[i] = (unsigned short)h;
-      ol[i] = (unsigned short)l;
-    }
-    unsigned short *r = row0 + (j0 / FOLD_KC) * (FOLD_ROWB / 2) + (j0 % FOLD_KC);
-    *reinterpret_cast<u16x4 *>(r) = eh;
-    *reinterpret_cast<u16x4 *>(r + 16) = el;
-    *reinterpret_cast<u16x4 *>(r + 32) = oh;
-    *reinterpret_cast<u16x4 *>(r + 48) = ol;
+    f32x4v we = {0.f, 0.f, 0.f, 0.f}, wo = {0.f, 0.f, 0.f, 0.f};
     if (le) {
-      const f32x4v we = *reinterpret_cast<const f32x4v *>(le + j0);
-      const f32x4v wo = *reinterpret_cast<const f32x4v *>(lo + j0);
+      we = *reinterpret_cast<const f32x4v *>(le + j0);
+      wo = *reinterpret_cast<const f32x4v *>(lo + j0);
+    }
+#pragma unroll
+    for (int f = 0; f < FOLD_FR; ++f) {
+      uint2 eh, el, oh, ol;
+      bf16_split2(e[f][0], e[f][1], eh.x, el.x);
+      bf16_split2(e[f][2], e[f][3], eh.y, el.y);
+      bf16_split2(o[f][0], o[f][1], oh.x, ol.x);
+      bf16_split2(o[f][2], o[f][3], oh.y, ol.y);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        pe = fmaf(we[i], e[i], pe);
-        po = fmaf(wo[i], o[i], po);
+        pe[f] = fmaf(we[i], e[f][i], pe[f]);
+        po[f] = fmaf(wo[i], o[f][i], po[f]);
       }
+      unsigned short *r = srow + (long long)f * Kf * 4 + (j0 / FOLD_KC) * (FOLD_ROWB / 2) + (j0 % FOLD_KC);
+      *reinterpret_cast<uint2 *>(r) = eh;
+      *reinterpret_cast<uint2 *>(r + 16) = el;
+      *reinterpret_cast<uint2 *>(r + 32) = oh;
+      *reinterpret_cast<uint2 *>(r + 48) = ol;
     }
   }
-  if (!le) return;
-  __shared__ float red[2][4];
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    pe += __shfl_xor(pe, d);
-    po += __shfl_xor(po, d);
+  __syncthreads();
+  {
+    f32x4v *out = reinterpret_cast<f32x4v *>(dst + col0 * ((long long)Kf * 4));
+    const int pieces = nf * (Kf / 2);  // Kf * 8 bytes per frame = Kf / 2 pieces of 16
+    for (int i = threadIdx.x; i < pieces; i += 256) out[i] = reinterpret_cast<const f32x4v *>(srow)[i];
   }
-  if ((threadIdx.x & 63) == 0) {
-    red[0][threadIdx.x >> 6] = pe;
-    red[1][threadIdx.x >> 6] = po;
+  if (!le) return;
+  float(*red)[4][FOLD_FR] = reinterpret_cast<float(*)[4][FOLD_FR]>(smem_raw + (size_t)FOLD_FR * Kf * 8);
+#pragma unroll
+  for (int f = 0; f < FOLD_FR; ++f) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      pe[f] += __shfl_xor(pe[f], d);
+      po[f] += __shfl_xor(po[f], d);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      red[0][threadIdx.x >> 6][f] = pe[f];
+      red[1][threadIdx.x >> 6][f] = po[f];
+    }
   }
   __syncthreads();
   const int bin = p.fold_last_bin;  // relative to the problem's first bin
   const float sc = p.row_scale ? p.row_scale[bin] : 1.f;
-  const float re = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) * sc;
-  const float im = p.im_sign * (red[1][0] + red[1][1] + red[1][2] + red[1][3]) * sc;
-  if (p.fb) {
-    // fused filterbank: out[c, m, t] += fb[m, bin] * |z|^power for the filters that weigh this bin
-    // (the main kernel treats their bands as crossing a tile boundary: atomic addends there too)
-    const float s2 = re * re + im * im + p.eps;
-    const float pw = p.power == 2.0f ? s2 : sqrtf(s2);
-    const int babs = p.out_row_offset + bin;
-    for (int m = threadIdx.x; m < p.n_fb; m += 256) {
-      if (p.fb_support[2 * m] <= babs && babs < p.fb_support[2 * m + 1]) {
-        const float w = p.fb[(long long)m * p.fb_row_stride + babs];
-        if (w != 0.f)
-          unsafeAtomicAdd(p.out + (long long)c * p.out_clip_stride + (long long)m * p.out_row_stride + t, w * pw);
+  for (int f = 0; f < nf; ++f) {
+    const int t = t0 + f;
+    const float re = (red[0][0][f] + red[0][1][f] + red[0][2][f] + red[0][3][f]) * sc;
+    const float im = p.im_sign * (red[1][0][f] + red[1][1][f] + red[1][2][f] + red[1][3][f]) * sc;
+    if (p.fb) {
+      // fused filterbank: out[c, m, t] += fb[m, bin] * |z|^power for the filters that weigh this
+      // bin (the main kernel treats their bands as crossing a tile boundary: atomic addends there too)
+      const float s2 = re * re + im * im + p.eps;
+      const float pw = p.power == 2.0f ? s2 : sqrtf(s2);
+      const int babs = p.out_row_offset + bin;
+      for (int m = threadIdx.x; m < p.n_fb; m += 256) {
+        if (p.fb_support[2 * m] <= babs && babs < p.fb_support[2 * m + 1]) {
+          const float w = p.fb[(long long)m * p.fb_row_stride + babs];
+          if (w != 0.f)
+            unsafeAtomicAdd(p.out + (long long)c * p.out_clip_stride + (long long)m * p.out_row_stride + t, w * pw);
+        }
       }
+    } else if (threadIdx.x == 0) {
+      const int E = epilogue_width(p.epilogue);
+      float *d = p.out + (long long)c * p.out_clip_stride +
+                 (long long)(p.out_row_offset + bin) * p.out_row_stride + (long long)t * E;
+      epilogue_store(p, d, re, im);
     }
-    return;
-  }
-  if (threadIdx.x == 0) {
-    const int E = epilogue_width(p.epilogue);
-    float *d = p.out + (long long)c * p.out_clip_stride +
-               (long long)(p.out_row_offset + bin) * p.out_row_stride + (long long)t * E;
-    epilogue_store(p, d, re, im);
   }
 }
 
-// barrier that publishes LDS-direct data, leaving the newest N loads of this wave in flight
+// Barrier that publishes LDS-direct data, leaving the newest N loads of this wave in flight.  Stated
+// as instructions: __syncthreads() carries a workgroup-scope fence, for which hipcc waits for ALL
+// outstanding LDS-direct loads (vmcnt(0)) when it sees one issued earlier in the same block.
 template <int N>
 __device__ __forceinline__ void lds_dma_barrier_keep() {
-  if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (N == FOLD_DMA_PER_WAVE) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  static_assert(N == 0 || N == 6, "immediate of the s_waitcnt above");
-  __syncthreads();
+  static_assert(N == 0 || N == 6, "immediate of the s_waitcnt below");
+  if (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 __global__ void __launch_bounds__(512) framed_fold_kernel(const KParams p) {
@@ -275,6 +317,7 @@ __global__ void __launch_bounds__(512) framed_fold_kernel(const KParams p) {
     }
   }
   const int b0 = tile_m * FOLD_BINS;                  // first bin of the tile
+  tile_n += p.fold_tile0;                             // (this launch's chunk of frame tiles)
   const long long n0 = (long long)tile_n * FOLD_BN;   // first flat frame of the tile
   const int nst = p.Ks / FOLD_KC;
   const long long row_el = (long long)nst * (FOLD_ROWB / 2);  // elements per basis / frame row
@@ -367,21 +410,28 @@ __global__ void __launch_bounds__(512) framed_fold_kernel(const KParams p) {
   typedef integral_constant<int, 2 * (1 + NR)> n_reads;
   typedef integral_constant<int, FOLD_DMA_PER_WAVE> n_dma;
 
-  // DMA: stage c + NBUF exists; NEXT: stage c + 1 exists; KEEP: loads this wave may leave in flight
-  // at the barrier (stage c + 2's, when it was issued)
-  auto stage_iter = [&](int c, int buf, int nbuf_next, auto dma_tag, auto next_tag,
-                        auto keep_tag) __attribute__((always_inline)) {
-    constexpr bool DMA = decltype(dma_tag)::value;
+  // One iteration = stage c out of buffer `buf`.  Waves w and w + 4 share a SIMD (a workgroup's
+  // waves are dealt to the SIMDs cyclically): so that the two never sit in their LDS-DMA issue at
+  // the same time (a piece costs its wave 60-150 issue cycles, during which only the OTHER wave can
+  // feed the matrix pipe), the "early" waves 0-3 issue stage c+3 in the im half of iteration c (into
+  // the buffer of stage c, free since this iteration's barrier) and the "late" waves 4-7 issue
+  // stage c+2 in the re half (into the buffer of stage c-1, free since the previous barrier).
+  // Either way a stage is issued >= 1.5 iterations before the barrier that publishes it, and at
+  // that barrier a wave may leave exactly its newest stage in flight (vmcnt(6)).
+  // NEXT: stage c+1 exists; KEEP: loads left in flight at the barrier.
+  const bool late = wave >= NW / 2;
+  auto stage_iter = [&](int c, int buf, int buf_prev, int buf_next, bool dma_late, bool dma_early,
+                        auto next_tag, auto keep_tag) __attribute__((always_inline)) {
     constexpr bool NEXT = decltype(next_tag)::value;
-    load_frags(buf, i1{});
+    if (!MISPEC_DBG(p, 8)) load_frags(buf, i1{});
+    if (dma_late && !MISPEC_DBG(p, 1)) dma_stage(c + 2, buf_prev);
     mfma_half(i0{});
     interleave(n_mfma{}, n_reads{}, i0{});
-    lds_dma_barrier_keep<decltype(keep_tag)::value>();
-    if (DMA) dma_stage(c + FOLD_NBUF, buf);
-    if (NEXT) load_frags(nbuf_next, i0{});
+    if (!MISPEC_DBG(p, 4)) lds_dma_barrier_keep<decltype(keep_tag)::value>();
+    if (dma_early && !MISPEC_DBG(p, 1)) dma_stage(c + FOLD_NBUF, buf);
+    if (NEXT && !MISPEC_DBG(p, 8)) load_frags(buf_next, i0{});
     mfma_half(i1{});
-    interleave(n_mfma{}, integral_constant<int, NEXT ? n_reads::value : 0>{},
-               integral_constant<int, DMA ? n_dma::value : 0>{});
+    interleave(n_mfma{}, integral_constant<int, NEXT ? n_reads::value : 0>{}, i0{});
   };
   typedef integral_constant<bool, true> yes;
   typedef integral_constant<bool, false> no;
@@ -399,24 +449,31 @@ __global__ void __launch_bounds__(512) framed_fold_kernel(const KParams p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     load_frags(0, i0{});
-    int c = 0, buf = 0;
     auto nxt = [](int b) { return b == FOLD_NBUF - 1 ? 0 : b + 1; };
-    for (; c + FOLD_NBUF < nst; ++c) {  // stages c+1, c+2, c+3 all exist
-      stage_iter(c, buf, nxt(buf), yes{}, yes{}, keep1{});
+    auto prv = [](int b) { return b == 0 ? FOLD_NBUF - 1 : b - 1; };
+    int c = 0, buf = 0;
+    for (; c + 2 < nst; ++c) {  // stages c+1 and c+2 exist; c+2 is in flight at the barrier
+      stage_iter(c, buf, prv(buf), nxt(buf), late && c >= 1, !late && c + FOLD_NBUF < nst, yes{}, keep1{});
       buf = nxt(buf);
-    }
-    if (c + 2 < nst) {  // c+1 and c+2 exist (c+2 in flight), no further DMA
-      stage_iter(c, buf, nxt(buf), no{}, yes{}, keep1{});
-      buf = nxt(buf);
-      ++c;
     }
     if (c + 1 < nst) {  // only c+1 left: wait for everything
-      stage_iter(c, buf, nxt(buf), no{}, yes{}, i0{});
+      stage_iter(c, buf, prv(buf), nxt(buf), false, false, yes{}, i0{});
       buf = nxt(buf);
       ++c;
     }
-    stage_iter(c, buf, buf, no{}, no{}, i0{});
+    stage_iter(c, buf, buf, buf, false, false, no{}, i0{});
     __syncthreads();  // every wave is done with the stage buffers (the epilogue reuses them)
+  }
+  if (MISPEC_DBG(p, 0x40000)) {  // ablation: no epilogue (keep the accumulators alive)
+    float sum = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < NR; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sum += acc[m][n][e];
+    if (sum == 12345.678f) p.out[0] = sum;
+    return;
   }
   if (p.fb)
     bf16x3_epilogue_fb<WM, WN, NR>(p, acc, 2 * b0, n0, smem_raw);

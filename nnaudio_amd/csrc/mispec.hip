@@ -40,7 +40,8 @@
 // 0x100 frame-tile-fastest tile order, 0x800 register-staged instead of LDS-direct loads, 0x1000
 // generic Toeplitz decimator, 0x2000 no pair launch, 0x4000 bf16x3: staged kernel instead of the
 // hop-periodic ones, 0x8000 one slab buffer, 0x20000 masked 192x256 slab tiles instead of narrow
-// tiles, 0x40000 no epilogue, 0x80000 two K stages only, 0x100000 bf16x3: dense (unfolded) kernel.
+// tiles, 0x40000 no epilogue, 0x80000 two K stages only, 0x100000 bf16x3: dense (unfolded) kernel,
+// 0x200000 fold: one chunk.
 // In the product library MISPEC_DBG() is the constant false (the branches compile away) and a
 // non-zero `reserved` is rejected.
 //
@@ -146,6 +147,8 @@ struct KParams {
   const float *fold_last;  // fp32 folded (even | odd) rows of the bin the pre-pass evaluates, or NULL
   int fold_last_bin;       // that bin, relative to the problem's first bin
   int fold_tap0;           // tap 0 is carried as folded tap kernel/2
+  int fold_clip0;          // pre-pass launch: first clip; contraction launch: first frame tile
+  int fold_tile0;
 };
 
 // ---------------------------------------------------------------------------------
@@ -1982,6 +1985,7 @@ FoldPlan plan_fold(const mispec_framed_gemm_args *a, const KParams &p) {
   if (MISPEC_DBG(p, 0x100000)) return f;  // A/B runs: the dense kernel
   if (!p.a_im || p.row_support || (p.K & 1) || p.K < 64) return f;
   if ((long long)p.hop * 8 < p.K) return f;  // folded frames cost 8 B per folded tap and frame
+  if (p.K > 4096) return f;                  // the pre-pass assembles 4 frames (4 K bytes each) in LDS
   int with_tap0 = -1;
   for (int w = 0; w < 2; ++w)
     if (a->fold_taps == fold_taps(p.K, w)) with_tap0 = w;
@@ -1999,6 +2003,12 @@ FoldPlan plan_fold(const mispec_framed_gemm_args *a, const KParams &p) {
   return f;
 }
 
+// Pre-pass and contraction alternate on the caller's stream over chunks of clips whose folded frames
+// (~128 MB) stay in the 256 MB Infinity Cache between the pre-pass that writes them and the
+// contraction that reads them.  (Measured on the MI355X, cfg2: running the pre-pass of chunk k+1 on
+// a side stream beside the contraction of chunk k -- its blocks do fit next to the contraction's --
+// was SLOWER than back to back, 0.81 vs 0.78 ms: the contraction loses more to the pre-pass's
+// traffic than the overlap hides.)
 int launch_fold(KParams p, const mispec_framed_gemm_args *a, const FoldPlan &f, hipStream_t stream) {
   if (!a->workspace || a->workspace_bytes < f.ws_bytes)
     return fail(MISPEC_E_INVALID, "workspace too small: size it with the *_workspace_bytes query%s");
@@ -2014,19 +2024,15 @@ int launch_fold(KParams p, const mispec_framed_gemm_args *a, const FoldPlan &f, 
   KParams pre = p;
   pre.fold_last = f.last_in_prepass ? last_rows : nullptr;
   pre.fold_last_bin = p.n_bins - 1;
-  hipLaunchKernelGGL(fold_frames_kernel, dim3((unsigned)p.n_cols), dim3(256), 0, stream, pre, xf);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(MISPEC_E_HIP, "fold pre-pass launch: %s", hipGetErrorString(e));
+  const size_t pre_smem = (size_t)FOLD_FR * f.kf * 8 + 8 * FOLD_FR * sizeof(float);
   // main contraction over the whole 128-bin blocks (a partial last block when it is more than the
   // one bin the pre-pass took)
   p.n_bins = f.main_bins;
   p.n_tiles_m = (p.n_bins + FOLD_BINS - 1) / FOLD_BINS;
   const long long tn = (p.n_cols + FOLD_BN - 1) / FOLD_BN;
   if (tn * p.n_tiles_m > 0x7fffffffLL) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
-  p.n_tiles_n = (int)tn;
   int g = (32 + p.n_tiles_m / 2) / p.n_tiles_m;  // one workgroup per CU, 32 CUs per XCD
-  g = g < 1 ? 1 : (g > p.n_tiles_n ? p.n_tiles_n : g);
-  p.n_group = g;
+  g = g < 1 ? 1 : g;
   auto kern = framed_fold_kernel;
   static std::atomic<unsigned long long> configured{0};
   int rc = configure_lds(kern, 160 * 1024, configured);
@@ -2034,9 +2040,40 @@ int launch_fold(KParams p, const mispec_framed_gemm_args *a, const FoldPlan &f, 
   // the epilogues reuse the stage ring (patches: 8 waves x 32 x 132 floats, or the 128 x 260 power
   // tile + band table of the fused filterbank)
   const size_t smem = (size_t)FOLD_NBUF * FOLD_STAGE;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(tn * p.n_tiles_m)), dim3(512), smem, stream, p);
-  e = hipGetLastError();
-  if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+  // chunk = a whole number of 256-workgroup rounds of the contraction, ~128 MB of folded frames
+  int q = 256;  // frame tiles that make whole rounds: 256 / gcd(256, n_tiles_m)
+  for (int d = p.n_tiles_m; d % 2 == 0 && q > 1; d /= 2) q /= 2;
+  const long long tile_bytes = (long long)FOLD_BN * f.kf * 8;
+  long long per = (128LL << 20) / (q * tile_bytes);
+  per = q * (per > 0 ? per : 1);
+  if (!MISPEC_DBG(p, 0x200000)) per = tn;  // one chunk unless asked (A/B runs): see above
+  long long tile0 = 0;
+  int clip0 = 0;
+  while (tile0 < tn) {
+    // clips whose frames the next `per` frame tiles need (all the rest when little would remain)
+    long long tile1 = tile0 + per;
+    if (tn - tile1 < per / 2) tile1 = tn;
+    long long clip1 = tile1 >= tn ? p.n_clips : (tile1 * FOLD_BN + p.n_frames - 1) / p.n_frames;
+    if (clip1 > p.n_clips) clip1 = p.n_clips;
+    if (clip1 > clip0) {
+      KParams q1 = pre;
+      q1.fold_clip0 = clip0;
+      hipLaunchKernelGGL(fold_frames_kernel,
+                         dim3((unsigned)((p.n_frames + FOLD_FR - 1) / FOLD_FR), (unsigned)(clip1 - clip0)),
+                         dim3(256), pre_smem, stream, q1, xf);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return fail(MISPEC_E_HIP, "fold pre-pass launch: %s", hipGetErrorString(e));
+      clip0 = (int)clip1;
+    }
+    KParams q2 = p;
+    q2.fold_tile0 = (int)tile0;
+    q2.n_tiles_n = (int)(tile1 - tile0);
+    q2.n_group = g > q2.n_tiles_n ? q2.n_tiles_n : g;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((tile1 - tile0) * p.n_tiles_m)), dim3(512), smem, stream, q2);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+    tile0 = tile1;
+  }
   return MISPEC_OK;
 }
 

@@ -55,6 +55,23 @@ def stft():
         print("stft cfg2 %s: %.3f ms" % (fmt, ms))
 
 
+def fold():
+    """Symmetric-fold STFT path (framed_fold.inl): pre-pass + contraction, and ablations of the
+    contraction's K loop (benchmarking build)."""
+    B, L = 64, 441000
+    x = torch.randn(B, L, device=DEV)
+    m = features.STFT(n_fft=2048, hop_length=512, output_format="Magnitude", verbose=False).to(DEV)
+    prep = engine.prepare_basis(m.wcos, m.wsin, "bf16x3", hop=512)
+    for dbg, what in ((0, "full step (pre-pass + contraction)"), (1, "no LDS-DMA in the loop"),
+                      (8, "no fragment reads"), (1 + 8, "no DMA, no fragment reads (MFMA + barrier)"),
+                      (1 + 8 + 4, "MFMAs only"), (0x40000, "no epilogue"), (0x40000 + 1, "no epilogue, no DMA"),
+                      (0x100000, "dense (unfolded) kernel")):
+        ms = timeit(lambda: engine.framed_gemm(x, m.wcos, m.wsin, hop=512, pad=1024, pad_mode=2,
+                                               epilogue=engine.EPI_MAGNITUDE, precision="bf16x3",
+                                               _debug=dbg, **prep), n=30, w=10)
+        print("fold[%-44s] %.3f ms" % (what, ms))
+
+
 def bf16():
     """precision="bf16x3": error against the fp32 kernel and timings of both wave layouts."""
     B, L = 64, 441000
@@ -156,7 +173,7 @@ def cqt2010():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["all"]
     torch.manual_seed(0)
-    for name, fn in (("stft", stft), ("bf16", bf16), ("mel", mel), ("cqt", cqt), ("cqt2010", cqt2010)):
+    for name, fn in (("stft", stft), ("fold", fold), ("bf16", bf16), ("mel", mel), ("cqt", cqt), ("cqt2010", cqt2010)):
         if "all" in which or name in which:
             t0 = time.time()
             fn()

@@ -363,6 +363,55 @@ int mispec_fir_decimate_bwd_f32(const float *dy, int64_t dy_clip_stride, int32_t
                                 int32_t pad, float *dx, int64_t dx_clip_stride, int32_t n_samples,
                                 void *stream);
 
+/*
+ * Fused octave recursion of CQT2010v2 / VQT (cqt.py:1085-1105, vqt.py:160-188: per octave one
+ * downsampling_by_2, utils.py:102-124, and one get_cqt_complex, utils.py:498-521).  One launch keeps
+ * up to 3 consecutive levels of the recursion resident in LDS per workgroup -- level 0 = x, level
+ * l+1 = the anti-alias FIR of level l at stride 2 -- and contracts every level that has a kernel
+ * bank with it (frames of `kernel` taps every hop >> l samples, centred: pad = kernel/2 with
+ * pad_mode), writing rows [out_row_offset, + n_bins) of the (n_clips, rows, n_frames[, 2]) output.
+ * The deepest level is also stored in fp32 to x_last (when not NULL): it is the `x` of the next
+ * launch of the chain, whose level 0 then carries no bank.  All arithmetic is MISPEC_PREC_BF16X3
+ * (split-bf16 operands, fp32 accumulate); between levels the signal keeps 16 significant bits.
+ * Shapes: (hop >> l) a multiple of 8, kernel a multiple of 16, n_bins <= 16 per level,
+ * n_taps <= 257; MISPEC_E_UNSUPPORTED otherwise (the caller then runs mispec_fir_decimate_f32 +
+ * mispec_framed_gemm_f32 per octave).
+ */
+typedef struct mispec_octave_level {
+  const void *bank_split;    /* mispec_split_basis_bf16() of this level's (n_bins, kernel) complex  */
+  int64_t bank_split_bytes;  /* bank, or NULL: no contraction at this level                         */
+  int32_t n_bins;
+  int32_t kernel;
+  int32_t out_row_offset;
+  int32_t pad_mode;          /* MISPEC_PAD_ZERO or MISPEC_PAD_REFLECT                               */
+  const float *row_scale;    /* (n_bins,) multiplier or NULL                                        */
+} mispec_octave_level;
+
+typedef struct mispec_octave_args {
+  uint32_t struct_size;
+  int32_t n_levels;            /* 1 .. 3                                                   */
+  const float *x;              /* (n_clips, n_samples), rows x_clip_stride elements apart  */
+  int64_t x_clip_stride;
+  int32_t n_clips;
+  int32_t n_samples;
+  int32_t hop;                 /* frame hop at level 0; level l uses hop >> l               */
+  int32_t n_frames;            /* frames per clip (the same at every level)                 */
+  const float *taps;           /* anti-alias filter (n_taps,), needed when n_levels > 1     */
+  int64_t reserved;            /* must be 0                                                 */
+  int32_t n_taps;
+  int32_t epilogue;            /* MISPEC_EPI_COMPLEX / MAGNITUDE / PHASE_COSSIN / ...       */
+  float im_sign;
+  float eps;
+  mispec_octave_level level[3];
+  float *x_last;               /* (n_clips, length of the deepest level) fp32, or NULL      */
+  int64_t x_last_clip_stride;
+  float *out;
+  int64_t out_clip_stride;     /* elements                                                  */
+  int64_t out_row_stride;      /* elements                                                  */
+} mispec_octave_args;
+
+int mispec_octave_pyramid_f32(const mispec_octave_args *args, void *stream);
+
 /* Scratch bytes mispec_fir_decimate_f32 needs (zero-padded clip edges); negative = error. */
 int64_t mispec_fir_decimate_workspace_bytes(int32_t n_clips, int32_t n_samples, int32_t n_taps,
                                             int32_t stride, int32_t pad, int32_t n_out);

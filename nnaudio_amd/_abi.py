@@ -45,6 +45,7 @@ EXPORTS = (
     "mispec_frames_transpose_f32",
     "mispec_istft_frames_f32",
     "mispec_overlap_add_f32",
+    "mispec_octave_pyramid_f32",
     "mispec_fir_decimate_f32",
     "mispec_fir_decimate_workspace_bytes",
     "mispec_fir_decimate_bwd_f32",
@@ -125,6 +126,47 @@ class PlanarArgs(ctypes.Structure):
     ]
 
 
+class OctaveLevel(ctypes.Structure):
+    """struct mispec_octave_level"""
+
+    _fields_ = [
+        ("bank_split", ctypes.c_void_p),
+        ("bank_split_bytes", ctypes.c_int64),
+        ("n_bins", ctypes.c_int32),
+        ("kernel", ctypes.c_int32),
+        ("out_row_offset", ctypes.c_int32),
+        ("pad_mode", ctypes.c_int32),
+        ("row_scale", ctypes.c_void_p),
+    ]
+
+
+class OctaveArgs(ctypes.Structure):
+    """struct mispec_octave_args"""
+
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32),
+        ("n_levels", ctypes.c_int32),
+        ("x", ctypes.c_void_p),
+        ("x_clip_stride", ctypes.c_int64),
+        ("n_clips", ctypes.c_int32),
+        ("n_samples", ctypes.c_int32),
+        ("hop", ctypes.c_int32),
+        ("n_frames", ctypes.c_int32),
+        ("taps", ctypes.c_void_p),
+        ("reserved", ctypes.c_int64),
+        ("n_taps", ctypes.c_int32),
+        ("epilogue", ctypes.c_int32),
+        ("im_sign", ctypes.c_float),
+        ("eps", ctypes.c_float),
+        ("level", OctaveLevel * 3),
+        ("x_last", ctypes.c_void_p),
+        ("x_last_clip_stride", ctypes.c_int64),
+        ("out", ctypes.c_void_p),
+        ("out_clip_stride", ctypes.c_int64),
+        ("out_row_stride", ctypes.c_int64),
+    ]
+
+
 class MispecError(RuntimeError):
     pass
 
@@ -188,6 +230,8 @@ def _load(path, how):
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
         ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
     ]
+    lib.mispec_octave_pyramid_f32.restype = ctypes.c_int
+    lib.mispec_octave_pyramid_f32.argtypes = [ctypes.POINTER(OctaveArgs), ctypes.c_void_p]
     lib.mispec_fir_decimate_workspace_bytes.restype = ctypes.c_int64
     lib.mispec_fir_decimate_workspace_bytes.argtypes = [ctypes.c_int32] * 6
     lib.mispec_filterbank_f32.restype = ctypes.c_int

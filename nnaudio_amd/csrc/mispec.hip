@@ -958,6 +958,7 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
 #include "framed_bf16x3_slab.inl"
 #include "framed_bf16x3_narrow.inl"
 #include "framed_fold.inl"
+#include "octave_pyramid.inl"
 
 // Several independent contractions of the same tile shape in one launch (the octaves of
 // CQT2010v2 / VQT: each is a short-K, few-hundred-workgroup problem that cannot fill the chip on
@@ -2664,6 +2665,128 @@ int mispec_filterbank_f32(const float *fb, int32_t n_filters, int32_t n_freq, co
   if (n_filters <= 32) return launch_cfg<1, 4, 1, 2, BMODE_PLANAR, AMODE_ROWS, false>(p, s);
   if (n_filters <= 64) return launch_cfg<1, 4, 2, 2, BMODE_PLANAR, AMODE_ROWS, false>(p, s);
   return launch_cfg<2, 2, 2, 2, BMODE_PLANAR, AMODE_ROWS, false>(p, s);
+}
+
+int mispec_octave_pyramid_f32(const mispec_octave_args *a, void *stream) {
+  if (!a) return fail(MISPEC_E_INVALID, "args is NULL%s");
+  if (a->struct_size != sizeof(mispec_octave_args)) return fail(MISPEC_E_INVALID, "struct_size mismatch (ABI skew)%s");
+  if (!a->x || !a->out) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
+  if (a->n_levels < 1 || a->n_levels > PYR_LEVELS) return fail(MISPEC_E_INVALID, "n_levels must be 1..3%s");
+  if (a->n_clips <= 0 || a->n_samples <= 0 || a->hop <= 0 || a->n_frames <= 0)
+    return fail(MISPEC_E_INVALID, "non-positive size%s");
+  const int D = a->n_levels;
+  if (D > 1) {
+    if (!a->taps) return fail(MISPEC_E_INVALID, "taps is required when n_levels > 1%s");
+    // window element m of output r is tap m - 2 r - shift, shift = 128 - (n_taps - 1) / 2 (the halo
+    // of level l is 2 * halo(l + 1) + 128 samples); the band must fit the 320 columns
+    if (a->n_taps <= 0 || 128 - (a->n_taps - 1) / 2 < 0 || a->n_taps + 62 + 128 - (a->n_taps - 1) / 2 > 16 * PYR_KSTEPS)
+      return fail(MISPEC_E_UNSUPPORTED, "anti-alias filter too long for the fused octave kernel%s");
+  }
+  if (a->epilogue < MISPEC_EPI_COMPLEX || a->epilogue > MISPEC_EPI_PHASE_COSSIN)
+    return fail(MISPEC_E_INVALID, "bad epilogue%s");
+  PyrParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = a->x;
+  p.x_clip_stride = a->x_clip_stride;
+  p.n_levels = D;
+  p.n_frames = a->n_frames;
+  p.n_clips = a->n_clips;
+  p.taps = a->taps;
+  p.n_taps = a->n_taps;
+  p.dec_pad = (a->n_taps - 1) / 2;
+  p.x_last = a->x_last;
+  p.x_last_stride = a->x_last_clip_stride;
+  p.out = a->out;
+  p.out_clip_stride = a->out_clip_stride;
+  p.out_row_stride = a->out_row_stride;
+  p.epilogue = a->epilogue;
+  p.im_sign = a->im_sign;
+  p.eps = a->eps;
+  long long L = a->n_samples;
+  int need[PYR_LEVELS];
+  for (int l = 0; l < D; ++l) {
+    const mispec_octave_level &v = a->level[l];
+    PyrLevel &o = p.lv[l];
+    if (l > 0) L = (L + 2LL * p.dec_pad - a->n_taps) / 2 + 1;
+    if (L <= 0) return fail(MISPEC_E_INVALID, "signal too short for this many levels%s");
+    if ((a->hop % (1 << l)) || ((a->hop >> l) % 8))
+      return fail(MISPEC_E_UNSUPPORTED, "fused octave kernel: hop >> level must be a multiple of 8%s");
+    o.L = (int)L;
+    o.hop = a->hop >> l;
+    // the last frame must lie inside the (virtually padded) level
+    if (v.bank_split) {
+      if (v.n_bins <= 0 || v.n_bins > PYR_MAX_BINS || v.kernel < 16 || v.kernel % 16 || v.kernel > 2048)
+        return fail(MISPEC_E_UNSUPPORTED, "fused octave kernel: <= 16 bins, kernel a multiple of 16%s");
+      if (v.bank_split_bytes < basis_split_bytes(v.n_bins, v.kernel, true))
+        return fail(MISPEC_E_INVALID, "bank_split too small%s");
+      if (v.pad_mode != MISPEC_PAD_ZERO && v.pad_mode != MISPEC_PAD_REFLECT)
+        return fail(MISPEC_E_INVALID, "bad pad_mode%s");
+      if (v.pad_mode == MISPEC_PAD_REFLECT && v.kernel / 2 >= L)
+        return fail(MISPEC_E_INVALID, "reflect padding needs kernel/2 < level length%s");
+      if ((long long)(a->n_frames - 1) * o.hop > L)
+        return fail(MISPEC_E_INVALID, "n_frames overruns the padded signal%s");
+      o.K = v.kernel;
+      o.Ks = round_up_kc(v.kernel);
+      o.n_rows = v.n_bins;
+      o.out_row0 = v.out_row_offset;
+      o.reflect = v.pad_mode == MISPEC_PAD_REFLECT;
+      o.bank = static_cast<const unsigned short *>(v.bank_split);
+      o.bank_plane = (long long)v.n_bins * o.Ks;
+      o.row_scale = v.row_scale;
+      need[l] = (int)round_up_ll(v.kernel / 2 + 64, 64);
+    } else {
+      need[l] = 64;
+    }
+  }
+  // halos: halo(l) = 2 halo(l+1) + 128 exactly (the FIR plan's alignment), every level >= its need
+  int halo[PYR_LEVELS];
+  for (int h = 64;; h += 64) {
+    halo[D - 1] = h;
+    bool ok = h >= need[D - 1];
+    for (int l = D - 2; l >= 0; --l) {
+      halo[l] = 2 * halo[l + 1] + 128;
+      ok = ok && halo[l] >= need[l];
+    }
+    if (ok) break;
+    if (h > 8192) return fail(MISPEC_E_UNSUPPORTED, "fused octave kernel: kernels too wide%s");
+  }
+  // frames per workgroup: ~8192 samples of level 0, within 80 KB of LDS (two workgroups per CU)
+  int nf = (8192 / p.lv[0].hop + 15) / 16 * 16;
+  nf = nf < 16 ? 16 : nf;
+  size_t smem = 0;
+  for (;; nf -= 16) {
+    if (nf < 16) return fail(MISPEC_E_UNSUPPORTED, "fused octave kernel: span does not fit in LDS%s");
+    smem = 0;
+    for (int l = 0; l < D; ++l) {
+      PyrLevel &o = p.lv[l];
+      o.halo = halo[l];
+      const long long n = (long long)nf * o.hop + 2LL * halo[l];
+      o.rows = (int)(n / 64);
+      o.lds_off = (int)smem;
+      smem += (size_t)o.rows * PYR_ROW * 2;
+    }
+    p.tab_off = (int)smem;
+    if (D > 1) smem += PYR_TAB_BYTES;
+    if (smem <= 80 * 1024) break;
+  }
+  p.nf = nf;
+  p.n_chunks = (a->n_frames + nf - 1) / nf;
+  auto kern = octave_pyramid_kernel;
+  static std::atomic<unsigned long long> configured{0};
+  int rc = configure_lds(kern, 80 * 1024, configured);
+  if (rc != MISPEC_OK) return rc;
+  // persistent workgroups, two per CU
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  const long long items = (long long)p.n_chunks * a->n_clips;
+  const unsigned gx = (unsigned)(items < 2LL * cus ? items : 2LL * cus);
+  hipLaunchKernelGGL(kern, dim3(gx), dim3(256), smem, static_cast<hipStream_t>(stream), p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
 }
 
 int64_t mispec_fir_decimate_workspace_bytes(int32_t n_clips, int32_t n_samples, int32_t n_taps,

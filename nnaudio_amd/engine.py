@@ -683,6 +683,49 @@ def fir_decimate(x, taps, stride):
     return y
 
 
+def octave_pyramid(x, levels, *, hop, n_frames, taps, epilogue, im_sign, eps, out, x_last):
+    """One launch of the fused octave recursion (``mispec_octave_pyramid_f32``): ``levels`` is a
+    list of up to three dicts ``{split, n_bins, kernel, row_offset, pad_mode, row_scale}`` or None
+    (a level without a bank).  Returns False when the library does not serve the shape."""
+    dev = _require_device(x, out, x_last, taps)
+    x = _signal(x)
+    taps = _f32(taps, "filter").reshape(-1).contiguous()
+    a = _abi.OctaveArgs()
+    a.struct_size = ctypes.sizeof(_abi.OctaveArgs)
+    a.n_levels = len(levels)
+    a.x, a.x_clip_stride = x.data_ptr(), x.stride(0)
+    a.n_clips, a.n_samples = x.shape
+    a.hop, a.n_frames = int(hop), int(n_frames)
+    a.taps, a.n_taps = taps.data_ptr(), taps.numel()
+    a.epilogue, a.im_sign, a.eps = int(epilogue), float(im_sign), float(eps)
+    keep = []
+    for i, lv in enumerate(levels):
+        if lv is None:
+            continue
+        o = a.level[i]
+        sp = lv["split"]
+        o.bank_split, o.bank_split_bytes = sp.data_ptr(), sp.numel() * sp.element_size()
+        o.n_bins, o.kernel = int(lv["n_bins"]), int(lv["kernel"])
+        o.out_row_offset, o.pad_mode = int(lv["row_offset"]), int(lv["pad_mode"])
+        rs = lv.get("row_scale")
+        if rs is not None:
+            rs = _f32(rs, "row_scale").contiguous()
+            o.row_scale = rs.data_ptr()
+            keep.append(rs)
+    if x_last is not None:
+        a.x_last, a.x_last_clip_stride = x_last.data_ptr(), x_last.stride(0)
+    a.out = out.data_ptr()
+    a.out_clip_stride, a.out_row_stride = out.stride(0), out.stride(1)
+    lib = _abi.load()
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = lib.mispec_octave_pyramid_f32(ctypes.byref(a), ctypes.c_void_p(stream))
+    if rc == _abi.E_UNSUPPORTED:
+        return False
+    _abi.check(rc)
+    return True
+
+
 def pad_mode_id(name):
     return _PAD_MODES[name]
 

@@ -60,13 +60,68 @@ class SupportCache:
         return self._cache.get((real, imag), lambda: self._build(real, imag))
 
 
+class OctaveCache:
+    """Per-module derived operands of the octave recursion for ``precision="bf16x3"``: the split
+    planes of every octave's bank rows (see ``engine.DerivedCache``: rebuilt when the buffers
+    change)."""
+
+    def __init__(self):
+        self._banks = {}
+
+    def bank(self, i, kr, ki, first):
+        c = self._banks.setdefault(i, engine.DerivedCache())
+        return c.get((kr, ki), lambda: engine.split_basis(
+            kr.reshape(kr.shape[0], -1)[first:], ki.reshape(ki.shape[0], -1)[first:]), extra=first)
+
+
+def _fused_chain(x, octs, lowpass, epi, im_sign, eps, out, cache):
+    """Run as many leading octaves as possible through ``engine.octave_pyramid`` (three levels per
+    launch, the deepest level of a launch feeding the next).  Returns (number of octaves done, the
+    fp32 signal of the last octave done)."""
+    done, xd = 0, x
+    while done < len(octs):
+        first = done == 0
+        # levels of this launch: octave `base` (contracted only in the first launch: later it was the
+        # deepest level of the previous one) and up to two more
+        base = 0 if first else done - 1
+        top = min(base + 3, len(octs))
+        levels = []
+        for i in range(base, top):
+            o = octs[i]
+            if i == base and not first:
+                levels.append(None)
+                continue
+            levels.append(dict(split=cache.bank(i, o["kr"], o["ki"], o["first"]), n_bins=o["rows"],
+                               kernel=o["K"], row_offset=o["row0"], pad_mode=o["mode"],
+                               row_scale=o["scale"]))
+        last = octs[top - 1]
+        x_last = None
+        if top < len(octs):  # someone will need the deepest level
+            x_last = torch.empty((x.shape[0], last["L"]), dtype=torch.float32, device=x.device)
+        ok = engine.octave_pyramid(xd, levels, hop=octs[base]["hop"], n_frames=out.shape[2],
+                                   taps=lowpass, epilogue=epi, im_sign=im_sign, eps=eps, out=out,
+                                   x_last=x_last)
+        if not ok:
+            break
+        done = top
+        if x_last is None:
+            break
+        xd = x_last
+    return done, xd
+
+
 def octave_recursion(x, banks, lenghts, hop, n_bins, lowpass, downsample_factor, pad_mode,
                      output_format, normalization_type, trainable, supports=None, graph=False,
-                     scale=None, im_sign=-1.0):
+                     scale=None, im_sign=-1.0, precision="fp32", cache=None):
     """Top-down octave loop.  ``banks[i] = (real_i, imag_i)`` (i = 0: top octave); each octave
     halves the signal with the anti-alias FIR kernel and halves the hop, and its framed
     contraction writes straight into its row block of the final ``(B, n_bins, T[, 2])``
-    tensor (the reference's growing ``torch.cat`` is gone)."""
+    tensor (the reference's growing ``torch.cat`` is gone).
+
+    ``precision="bf16x3"`` (and no autograd graph): the fused kernel keeps the decimated signals
+    in LDS and contracts every octave from there (``engine.octave_pyramid``); octaves it does not
+    serve (hop below 8 samples at the bottom) and ``precision="fp32"`` run one FIR decimation +
+    one (grouped) contraction per octave on the exact fp32 kernels."""
     epi = output_epilogue(output_format)
     if scale is None:
         scale = normalisation_scale(lenghts, normalization_type, downsample_factor)
@@ -76,22 +131,25 @@ def octave_recursion(x, banks, lenghts, hop, n_bins, lowpass, downsample_factor,
     n_filters = banks[0][0].shape[0]
     total_rows = n_oct * n_filters
     drop = total_rows - n_bins  # rows cut from the bottom octave by CQT[:, -n_bins:]
-    out = None
-    xd = x
+    nt = lowpass.numel()
+    # ---- per-octave geometry (the lengths follow from conv1d's formula: no kernel needed)
+    octs = []
+    L = x.shape[-1]
     T_ref = None
-    launches = []  # the per-octave contractions are independent: one grouped launch at the end
-    blocks = []    # graph=True (training): per-octave outputs through autograd, concatenated
     for i, (kr, ki) in enumerate(banks):
         if i > 0:
             hop = hop // 2
-            xd = engine.fir_decimate_autograd(xd, lowpass, 2) if graph else engine.fir_decimate(xd, lowpass, 2)
+            L = decimated_length(L, nt, 2)
+            if L <= 0:
+                raise RuntimeError(
+                    "Calculated padded input size per channel: (%d). Kernel size: (%d). "
+                    "Kernel size can't be greater than actual input size" % (L + 2 * ((nt - 1) // 2), nt))
         K = kr.shape[-1]
-        L = xd.shape[-1]
         pad = K // 2
         mode = engine.pad_mode_id(pad_mode)
         if mode == engine.PAD_REFLECT and pad >= L:
             warnings.warn(
-                f"\ninput size = {tuple(xd.shape)}\tkernel size = {K}\n"
+                f"\ninput size = {(x.shape[0], 1, L)}\tkernel size = {K}\n"
                 "padding with reflection mode might not be the best choice, try using constant padding",
                 UserWarning,
             )
@@ -99,9 +157,6 @@ def octave_recursion(x, banks, lenghts, hop, n_bins, lowpass, downsample_factor,
         T = engine.n_frames(L, K, hop, pad)
         if T_ref is None:
             T_ref = T
-            two = epi in (engine.EPI_COMPLEX, engine.EPI_PHASE_COSSIN)
-            shape = (x.shape[0], n_bins, T, 2) if two else (x.shape[0], n_bins, T)
-            out = engine.alloc_out(shape, x.device)
         elif T != T_ref:
             raise RuntimeError(
                 "Sizes of tensors must match except in dimension 1. Expected size %d but got "
@@ -114,29 +169,43 @@ def octave_recursion(x, banks, lenghts, hop, n_bins, lowpass, downsample_factor,
         if row0 < 0:
             first = -row0
             row0 = 0
-        if first >= n_filters:
-            continue
-        kr_i = kr.reshape(n_filters, -1)[first:]
-        ki_i = ki.reshape(n_filters, -1)[first:]
         rows = n_filters - first
+        octs.append(dict(i=i, kr=kr, ki=ki, K=K, L=L, hop=hop, pad=pad, mode=mode, row0=row0,
+                         first=first, rows=rows,
+                         scale=scale[row0:row0 + rows] if rows > 0 else None))
+    while octs and octs[-1]["rows"] <= 0:  # octaves cut away entirely
+        octs.pop()
+    eps = 1e-8 if trainable else 0.0
+    if graph:
+        # the reference's own structure (cqt.py:1091-1105): one contraction per octave through
+        # autograd, rows concatenated with the lowest octave first
+        blocks, xd = [], x
+        for o in octs:
+            if o["i"] > 0:
+                xd = engine.fir_decimate_autograd(xd, lowpass, 2)
+            blocks.append((o["row0"], engine.framed_gemm_autograd(
+                xd, o["kr"].reshape(n_filters, -1)[o["first"]:], o["ki"].reshape(n_filters, -1)[o["first"]:],
+                hop=o["hop"], pad=o["pad"], pad_mode=o["mode"], epilogue=epi, im_sign=im_sign, eps=eps,
+                row_scale=o["scale"].contiguous(), precision="fp32")))
+        return torch.cat([b for _, b in sorted(blocks, key=lambda rb: rb[0])], 1)
+    two = epi in (engine.EPI_COMPLEX, engine.EPI_PHASE_COSSIN)
+    shape = (x.shape[0], n_bins, T_ref, 2) if two else (x.shape[0], n_bins, T_ref)
+    out = engine.alloc_out(shape, x.device)
+    done, xd = 0, x
+    if precision == "bf16x3" and cache is not None and not trainable:
+        done, xd = _fused_chain(x, octs, lowpass, epi, im_sign, eps, out, cache)
+    launches = []  # the remaining per-octave contractions are independent: one grouped launch
+    for o in octs[done:]:  # xd: the fp32 signal of the previous octave (x itself before octave 0)
+        if o["i"] > 0:
+            xd = engine.fir_decimate(xd, lowpass, 2)
         sup = None
         if supports is not None and not trainable:
-            sup = supports[i].get(kr, ki)[first:].contiguous()
-        if graph:
-            # the reference's own structure (cqt.py:1091-1105): one contraction per octave, rows
-            # concatenated with the lowest octave first
-            blocks.append((row0, engine.framed_gemm_autograd(
-                xd, kr_i, ki_i, hop=hop, pad=pad, pad_mode=mode, epilogue=epi, im_sign=im_sign,
-                eps=1e-8 if trainable else 0.0, row_scale=scale[row0:row0 + rows].contiguous(),
-                precision="fp32")))
-            continue
-        launches.append((xd, kr_i, ki_i, dict(
-            hop=hop, pad=pad, pad_mode=mode, epilogue=epi, im_sign=im_sign,
-            eps=1e-8 if trainable else 0.0, row_scale=scale[row0:row0 + rows].contiguous(),
-            row_support=sup, out=out, out_rows_total=n_bins, out_row_offset=row0,
-            precision="fp32")))
-    if graph:
-        return torch.cat([b for _, b in sorted(blocks, key=lambda rb: rb[0])], 1)
+            sup = supports[o["i"]].get(o["kr"], o["ki"])[o["first"]:].contiguous()
+        launches.append((xd, o["kr"].reshape(n_filters, -1)[o["first"]:],
+                         o["ki"].reshape(n_filters, -1)[o["first"]:], dict(
+            hop=o["hop"], pad=o["pad"], pad_mode=o["mode"], epilogue=epi, im_sign=im_sign, eps=eps,
+            row_scale=o["scale"].contiguous(), row_support=sup, out=out, out_rows_total=n_bins,
+            out_row_offset=o["row0"], precision="fp32")))
     engine.framed_gemm_group(launches)
     return out
 
@@ -145,5 +214,5 @@ def early_decimate(x, taps, factor):
     return engine.fir_decimate_autograd(x, taps, int(factor))
 
 
-__all__ = ["output_epilogue", "normalisation_scale", "SupportCache", "octave_recursion",
+__all__ = ["output_epilogue", "normalisation_scale", "SupportCache", "OctaveCache", "octave_recursion",
            "early_decimate", "decimated_length"]

@@ -16,7 +16,7 @@ from .. import engine
 from ..basis import (cqt_bin_frequencies, cqt_kernel_bank, early_downsample_plan, filter_q,
                      lowpass_taps, top_octave_band)
 from ..utils import broadcast_dim
-from ._cqt_common import (SupportCache, early_decimate, normalisation_scale, octave_recursion,
+from ._cqt_common import (OctaveCache, SupportCache, early_decimate, normalisation_scale, octave_recursion,
                           output_epilogue)
 
 
@@ -200,6 +200,10 @@ class CQT2010v2(nn.Module):
         imag = torch.tensor(basis.imag).unsqueeze(1)
         _register_kernels(self, real, imag, trainable)
         self._support = SupportCache()
+        # not a constructor argument: "bf16x3" (attribute or nnaudio_amd.set_precision) selects the
+        # fused octave kernel (decimated signals resident in LDS, split-bf16 matrix pipe)
+        self.precision = None
+        self._octaves = OctaveCache()
         if verbose:
             print("CQT kernels created, time used = {:.4f} seconds".format(time() - start))
 
@@ -216,6 +220,7 @@ class CQT2010v2(nn.Module):
             x, banks, self.lenghts, self.hop_length, self.n_bins, self.lowpass_filter,
             self.downsample_factor, self.pad_mode, output_format, normalization_type,
             self.trainable, supports=[self._support] * self.n_octaves, graph=graph,
+            precision=engine.resolve_precision(self.precision), cache=self._octaves,
         )
 
 

@@ -11,7 +11,7 @@ from .. import engine
 from ..basis import (cqt_bin_frequencies, cqt_kernel_bank, early_downsample_plan, filter_q,
                      lowpass_taps, top_octave_band)
 from ..utils import broadcast_dim
-from ._cqt_common import SupportCache, early_decimate, octave_recursion
+from ._cqt_common import OctaveCache, SupportCache, early_decimate, octave_recursion
 
 
 class VQT(nn.Module):
@@ -103,6 +103,8 @@ class VQT(nn.Module):
 
         octave_sr = self.sr
         self._supports = []
+        self.precision = None  # "bf16x3": the fused octave kernel (see CQT2010v2)
+        self._octaves = OctaveCache()
         for i in range(self.n_octaves):
             if i > 0:
                 octave_sr /= 2
@@ -139,4 +141,5 @@ class VQT(nn.Module):
             x, banks, self.lenghts, self.hop_length, self.n_bins, self.lowpass_filter,
             self.downsample_factor, self.pad_mode, output_format, normalization_type,
             self.trainable, supports=self._supports, graph=graph,
+            precision=engine.resolve_precision(self.precision), cache=self._octaves,
         )

@@ -10,10 +10,10 @@ PREC=${3:-bf16x3}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT/summary
-CMD="python bench.py --steps 5 --warmup 2 --prewarm-ms 0 --extras 0 --cpu-baseline 0 --workload $WL --precision $PREC"
+CMD="python bench.py --steps 5 --warmup 2 --prewarm-ms 0 --extras 0 --cpu-baseline 0 --traffic off --workload $WL --precision $PREC"
 # the first launches after start-up run slower (clock ramp): the timing pass uses the bench's
 # default step counts so that the per-kernel averages are the steady-state ones the bench reports
-TCMD="python bench.py --extras 0 --cpu-baseline 0 --workload $WL --precision $PREC"
+TCMD="python bench.py --extras 0 --cpu-baseline 0 --traffic off --workload $WL --precision $PREC"
 
 # (1) kernel trace + stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $TCMD > $OUT/trace.log 2>&1

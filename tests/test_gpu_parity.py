@@ -467,6 +467,42 @@ def test_cfg5_cqt2010v2_vqt_full_length():
         assert (lhs - rhs).abs().max().item() <= 1e-4 * rhs.abs().max().item()
 
 
+def test_cfg5_fused_octave_kernel_bf16x3():
+    """cfg5 shard in the benched arithmetic: the fused octave kernel (decimated signals resident in
+    LDS, split-bf16 matrix pipe; octave 7, whose hop is 4 samples, on the per-octave kernels)
+    against the sampled float64 recursion, for CQT2010v2 and VQT(gamma=10); VQT(gamma=0) equals
+    CQT2010v2 bit for bit here too; Magnitude agrees with |Complex|."""
+    from nnaudio_amd import features
+
+    B, L = 64, 1323000
+    x = torch.randn(B, L, generator=torch.Generator().manual_seed(6))
+    xd = x.to(DEV)
+    kw = dict(sr=44100, hop_length=512, n_bins=96, output_format="Complex", verbose=False)
+    c = features.CQT2010v2(**kw).to(DEV)
+    v0 = features.VQT(gamma=0, **kw).to(DEV)
+    v10 = features.VQT(gamma=10, **kw).to(DEV)
+    for m in (c, v0, v10):
+        m.precision = "bf16x3"
+    with torch.no_grad():
+        yc = c(xd)
+        assert tuple(yc.shape) == (64, 96, 2584, 2)
+        _cfg5_sampled_check(c, x, yc, np.random.default_rng(6), "CQT2010v2 cfg5 bf16x3")
+        c.precision = "fp32"
+        y32 = c(xd)
+        assert not torch.equal(yc, y32)  # the fused kernel really ran
+        assert (yc - y32).abs().max().item() <= 5e-5 * y32.abs().max().item()
+        del y32
+        c.precision = "bf16x3"
+        mag = c(xd, output_format="Magnitude")
+        assert torch.allclose(mag, torch.sqrt(yc[..., 0] ** 2 + yc[..., 1] ** 2), rtol=1e-5, atol=1e-4)
+        del mag
+        yv = v0(xd)
+        assert torch.equal(yc, yv)
+        del yv, yc
+        y10 = v10(xd)
+        _cfg5_sampled_check(v10, x, y10, np.random.default_rng(7), "VQT gamma=10 cfg5 bf16x3")
+
+
 def test_cfg3_mel_full_size_sampled_bf16x3():
     """cfg3 in the benched arithmetic: split-bf16 contraction with the mel reduction fused into
     its epilogue, sampled against float64."""
@@ -573,7 +609,8 @@ def test_split_basis_is_bit_exact(F, K, has_im):
 
 
 @pytest.mark.parametrize("name", [n for n in _golden.case_names(forward_only=True)
-                                  if n.split("_")[0] in ("stft", "mel", "gamma", "cqt1992v2", "mfcc")])
+                                  if n.split("_")[0] in ("stft", "mel", "gamma", "cqt1992v2", "mfcc",
+                                                         "cqt2010v2", "vqt")])
 def test_case_bf16x3_matches_reference_and_oracle(golden, bf16x3, name):
     case = golden.cases[name]
     x = golden.inputs[case["input"]]

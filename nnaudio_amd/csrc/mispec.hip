@@ -2691,6 +2691,11 @@ int mispec_octave_pyramid_f32(const mispec_octave_args *a, void *stream) {
   p.n_levels = D;
   p.n_frames = a->n_frames;
   p.n_clips = a->n_clips;
+#ifdef MISPEC_ABLATE
+  p.stamps = reinterpret_cast<unsigned long long *>(a->reserved);
+#else
+  if (a->reserved != 0) return fail(MISPEC_E_INVALID, "reserved must be 0%s");
+#endif
   p.taps = a->taps;
   p.n_taps = a->n_taps;
   p.dec_pad = (a->n_taps - 1) / 2;

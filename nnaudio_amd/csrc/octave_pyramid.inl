@@ -40,6 +40,7 @@ constexpr int PYR_MAX_BINS = 16;    // kernel rows per component and level (one 
 constexpr int PYR_TAB_LEN = 384;    // elements per shifted copy of the tap table
 constexpr int PYR_TAB_STRIDE = 832; // bytes between copies (52 chunks: conflict-free fragment reads)
 constexpr int PYR_TAB_BYTES = 2 * 4 * PYR_TAB_STRIDE;  // hi copies, lo copies
+constexpr int PYR_NT = 1;           // column tiles of the FIR a wave multiplies at a time
 constexpr int PYR_NB = 8;           // 16-byte loads per thread and batch while fetching a span of x_0
 
 struct PyrLevel {
@@ -77,7 +78,19 @@ struct PyrParams {
   long long out_clip_stride, out_row_stride;
   int epilogue;
   float im_sign, eps;
+  unsigned long long *stamps;  // benchmarking build: phase clock of workgroup 7 (100 MHz ticks)
 };
+
+#ifdef MISPEC_ABLATE
+#define PYR_STAMP()                                                      \
+  do {                                                                   \
+    if (p.stamps && blockIdx.x == 7 && tid == 0 && n_stamp < 64) p.stamps[n_stamp++] = wall_clock64(); \
+  } while (0)
+#else
+#define PYR_STAMP() \
+  do {              \
+  } while (0)
+#endif
 
 typedef float f32x4acc __attribute__((ext_vector_type(4)));
 
@@ -160,11 +173,15 @@ __global__ void __launch_bounds__(256, 2) octave_pyramid_kernel(const PyrParams 
   }
 
   const int n_items = p.n_clips * p.n_chunks;
+  int n_stamp = 0;
+  (void)n_stamp;
+  PYR_STAMP();  // 0: set-up done
   constexpr int NB = PYR_NB;
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
     const int c = item / p.n_chunks;
     const int t0 = (item - c * p.n_chunks) * p.nf;
     __syncthreads();  // the previous item's phase C is done with the spans (and the tables are built)
+    PYR_STAMP();  // item start
 
     // ---- A: span of x_0 -> split planes, in batches of 8 loads per thread in flight (the span is
     // ~40 KB: one load at a time would leave the workgroup waiting on HBM latency ten times over)
@@ -202,6 +219,7 @@ __global__ void __launch_bounds__(256, 2) octave_pyramid_kernel(const PyrParams 
       }
     }
     __syncthreads();
+    PYR_STAMP();  // span in LDS
 
     // mirrored samples beyond the clip ends, for the frames of level l (after the FIR has consumed
     // the zeros there)
@@ -244,60 +262,95 @@ __global__ void __launch_bounds__(256, 2) octave_pyramid_kernel(const PyrParams 
         const int tiles = (n_out + 1023) / 1024;
         const bool last = (l + 2 == D) && p.x_last != nullptr;
         const long long own_lo = (long long)t0 * vo.hop, own_hi = own_lo + (long long)p.nf * vo.hop;
-        for (int tile = wave; tile < tiles; tile += 4) {
-          const int q = tile * 32 + li;  // this lane's column: outputs 32 q .. 32 q + 31
-          // column q reads rows q .. q + 4 of the input level; the (unused) columns past the end
-          // of the level are clamped to a valid row
-          const int qr = q + 5 <= vi.rows ? q : vi.rows - 5;
-          f32x16 acc;
+        // A wave multiplies PYR_NT column tiles at a time -- tile, tile + 4, ... -- with the next
+        // step's fragments requested a step ahead.  Tiles past the end compute on clamped columns
+        // and are not written.  (Measured: one workgroup per CU with each wave alone on its SIMD and
+        // three tiles at a time is slower -- a lone wave issues an MFMA every ~50-90 cycles.)
+        for (int tile = wave; tile < tiles; tile += 4 * PYR_NT) {
+          int qv[PYR_NT], qr[PYR_NT];
 #pragma unroll
-          for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+          for (int u = 0; u < PYR_NT; ++u) {
+            qv[u] = (tile + 4 * u) * 32 + li;  // this lane's column: outputs 32 q .. 32 q + 31
+            // column q reads rows q .. q + 4 of the input level; columns past the end of the level
+            // are clamped to a valid row
+            qr[u] = qv[u] + 5 <= vi.rows ? qv[u] : vi.rows - 5;
+          }
+          f32x16 acc[PYR_NT];
+#pragma unroll
+          for (int u = 0; u < PYR_NT; ++u)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[u][e] = 0.f;
+          bf16x8 th[2], tl[2], xh[2][PYR_NT], xl[2][PYR_NT];
+          auto frags = [&](int s, int slot) __attribute__((always_inline)) {
+            th[slot] = *reinterpret_cast<const bf16x8 *>(tbh + 32 * s);
+            tl[slot] = *reinterpret_cast<const bf16x8 *>(tbl + 32 * s);
+#pragma unroll
+            for (int u = 0; u < PYR_NT; ++u) {
+              const int row = qr[u] + (s >> 2);
+              const int off = row * PYR_ROW + ((((s & 3) * 2 + lh) ^ ((row >> 1) & 7)) << 4);
+              xh[slot][u] = *reinterpret_cast<const bf16x8 *>(ihi + off);
+              xl[slot][u] = *reinterpret_cast<const bf16x8 *>(ilo + off);
+            }
+          };
+          frags(0, 0);
 #pragma unroll
           for (int s = 0; s < PYR_KSTEPS; ++s) {
-            const int row = qr + (s >> 2);
-            const int off = row * PYR_ROW + ((((s & 3) * 2 + lh) ^ ((row >> 1) & 7)) << 4);
-            const bf16x8 xh = *reinterpret_cast<const bf16x8 *>(ihi + off);
-            const bf16x8 xl = *reinterpret_cast<const bf16x8 *>(ilo + off);
-            const bf16x8 th = *reinterpret_cast<const bf16x8 *>(tbh + 32 * s);
-            const bf16x8 tl = *reinterpret_cast<const bf16x8 *>(tbl + 32 * s);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tl, xh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th, xl, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th, xh, acc, 0, 0, 0);
+            const int k = s & 1;
+            // (pinned: hipcc otherwise sinks every fragment read to just before its first use, and
+            // the wave -- alone on its SIMD -- waits out the LDS latency in front of each MFMA)
+            if (s + 1 < PYR_KSTEPS) frags(s + 1, k ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < PYR_NT; ++u)
+              acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tl[k], xh[k][u], acc[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < PYR_NT; ++u)
+              acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th[k], xl[k][u], acc[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < PYR_NT; ++u)
+              acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th[k], xh[k][u], acc[u], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
           }
           // acc[e] = y[32 q + r], r = (e & 3) + 8 (e >> 2) + 4 lh: four consecutive outputs per quad
-          if (q * 32 < n_out) {
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-              const int o = 32 * q + 8 * g4 + 4 * lh;  // relative output index of the quad
-              const long long g = ao + o;
-              float f[4];
+          for (int u = 0; u < PYR_NT; ++u) {
+            const int q = qv[u];
+            if (tile + 4 * u < tiles && q * 32 < n_out) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) f[e] = (g + e >= 0 && g + e < vo.L) ? acc[4 * g4 + e] : 0.f;
-              uint2 h, lw;
-              bf16_split2(f[0], f[1], h.x, lw.x);
-              bf16_split2(f[2], f[3], h.y, lw.y);
-              const int ad = pyr_addr(o);
-              *reinterpret_cast<uint2 *>(ohi + ad) = h;
-              *reinterpret_cast<uint2 *>(olo + ad) = lw;
-              if (last && g >= own_lo && g < own_hi) {
-                float *d = p.x_last + (long long)c * p.x_last_stride + g;
-                if (g + 3 < vo.L) {
-                  *reinterpret_cast<f32x4u *>(d) = f32x4u{f[0], f[1], f[2], f[3]};
-                } else {
+              for (int g4 = 0; g4 < 4; ++g4) {
+                const int o = 32 * q + 8 * g4 + 4 * lh;  // relative output index of the quad
+                const long long g = ao + o;
+                float f[4];
 #pragma unroll
-                  for (int e = 0; e < 4; ++e)
-                    if (g + e < vo.L) d[e] = f[e];
+                for (int e = 0; e < 4; ++e) f[e] = (g + e >= 0 && g + e < vo.L) ? acc[u][4 * g4 + e] : 0.f;
+                uint2 h, lw;
+                bf16_split2(f[0], f[1], h.x, lw.x);
+                bf16_split2(f[2], f[3], h.y, lw.y);
+                const int ad = pyr_addr(o);
+                *reinterpret_cast<uint2 *>(ohi + ad) = h;
+                *reinterpret_cast<uint2 *>(olo + ad) = lw;
+                if (last && g >= own_lo && g < own_hi) {
+                  float *d = p.x_last + (long long)c * p.x_last_stride + g;
+                  if (g + 3 < vo.L) {
+                    *reinterpret_cast<f32x4u *>(d) = f32x4u{f[0], f[1], f[2], f[3]};
+                  } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                      if (g + e < vo.L) d[e] = f[e];
+                  }
                 }
               }
             }
           }
         }
         __syncthreads();  // level l+1 complete, level l no longer needed by the FIR
+        PYR_STAMP();  // FIR level done
         reflect_fixup(l);
       }
     }
     reflect_fixup(D - 1);
     __syncthreads();
+    PYR_STAMP();  // fix-ups done
 
     // ---- C: this wave's level: kernel rows x frames from the LDS span (16 bins x 16 frames per tile)
     if (my_level >= 0) {

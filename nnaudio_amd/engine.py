@@ -683,7 +683,7 @@ def fir_decimate(x, taps, stride):
     return y
 
 
-def octave_pyramid(x, levels, *, hop, n_frames, taps, epilogue, im_sign, eps, out, x_last):
+def octave_pyramid(x, levels, *, hop, n_frames, taps, epilogue, im_sign, eps, out, x_last, _stamps=None):
     """One launch of the fused octave recursion (``mispec_octave_pyramid_f32``): ``levels`` is a
     list of up to three dicts ``{split, n_bins, kernel, row_offset, pad_mode, row_scale}`` or None
     (a level without a bank).  Returns False when the library does not serve the shape."""
@@ -717,6 +717,9 @@ def octave_pyramid(x, levels, *, hop, n_frames, taps, epilogue, im_sign, eps, ou
     a.out = out.data_ptr()
     a.out_clip_stride, a.out_row_stride = out.stride(0), out.stride(1)
     lib = _abi.load()
+    if _stamps is not None:  # phase clock of one workgroup (scripts/kbench.py, benchmarking build)
+        a.reserved = _stamps.data_ptr()
+        lib = _abi.load_ablate()
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
         rc = lib.mispec_octave_pyramid_f32(ctypes.byref(a), ctypes.c_void_p(stream))

@@ -72,6 +72,32 @@ def fold():
         print("fold[%-44s] %.3f ms" % (what, ms))
 
 
+def pyramid():
+    """Phase clock of one persistent workgroup of the fused octave kernel, first launch of the cfg5
+    chain (octaves 0-2 from x): 100 MHz ticks between the kernel's stamps."""
+    B, L = 64, 1323000
+    x = torch.randn(B, L, device=DEV)
+    m = features.CQT2010v2(sr=44100, hop_length=512, n_bins=96, verbose=False).to(DEV)
+    m.precision = "bf16x3"
+    m(x)
+    sp = engine.split_basis(m.cqt_kernels_real, m.cqt_kernels_imag)
+    out = torch.empty(B, 96, 2584, device=DEV)
+    x2 = torch.empty(B, 330750, device=DEV)
+    lv = [dict(split=sp, n_bins=12, kernel=256, row_offset=84 - 12 * i, pad_mode=2, row_scale=None)
+          for i in range(3)]
+    st = torch.zeros(64, dtype=torch.int64, device=DEV)
+    for _ in range(3):
+        engine.octave_pyramid(x, lv, hop=512, n_frames=2584, taps=m.lowpass_filter, epilogue=1,
+                              im_sign=-1.0, eps=0.0, out=out, x_last=x2, _stamps=st)
+    torch.cuda.synchronize()
+    t = st.cpu().numpy()
+    d = (t[1:] - t[:-1]) * 10  # ns
+    print("stamps: set-up | per item: [start, span in LDS, FIR 0->1, FIR 1->2, fix-ups] ...")
+    print("set-up -> first item start: %d ns" % d[0])
+    for k in range(1, min(len(d), 41), 5):
+        print("  item: load+split %5d  FIR1 %5d  FIR2 %5d  fixup %5d  phaseC+sync %5d ns" % tuple(d[k:k + 5]))
+
+
 def bf16():
     """precision="bf16x3": error against the fp32 kernel and timings of both wave layouts."""
     B, L = 64, 441000
@@ -173,7 +199,7 @@ def cqt2010():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["all"]
     torch.manual_seed(0)
-    for name, fn in (("stft", stft), ("fold", fold), ("bf16", bf16), ("mel", mel), ("cqt", cqt), ("cqt2010", cqt2010)):
+    for name, fn in (("stft", stft), ("fold", fold), ("pyramid", pyramid), ("bf16", bf16), ("mel", mel), ("cqt", cqt), ("cqt2010", cqt2010)):
         if "all" in which or name in which:
             t0 = time.time()
             fn()

@@ -112,7 +112,7 @@ class output_into:
 
 def alloc_out(shape, device, zero=False):
     """Fresh float32 output tensor -- or the caller's ``output_into`` tensor when it fits."""
-    slot = getattr(_placement, "slot", None)
+    slot = None if compiling() else getattr(_placement, "slot", None)
     if slot is not None and not slot.taken:
         t = slot.tensor
         if tuple(t.shape) == tuple(shape) and t.dtype == torch.float32 and t.device == device:
@@ -437,7 +437,7 @@ def fused_filterbank_plan(mod, fb, x, stft, power):
     """For MelSpectrogram / Gammatonegram: the ``fb_support`` table when this forward can run with
     the filterbank fused into the STFT contraction (no graph needed, banded filters), else
     None."""
-    if needs_grad(mod, x) or stft.freq_bins is not None:
+    if needs_grad(mod, x) or stft.freq_bins is not None or compiling():
         return None
     if not hasattr(mod, "_fb_support"):
         mod._fb_support = DerivedCache()
@@ -651,6 +651,10 @@ def power_to_db_autograd(spec, amin, ref, top_db):
         if top_db is not None and top_db < 0:
             raise ValueError("top_db must be non-negative")
         return _PowerToDbFn.apply(spec, amin, ref, top_db)
+    if compiling():
+        from . import ops
+
+        return ops.power_to_db(spec, float(amin), float(ref), -1.0 if top_db is None else float(top_db))
     return power_to_db(spec, amin, ref, top_db)
 
 
@@ -886,6 +890,10 @@ class _FilterbankFn(torch.autograd.Function):
 def filterbank_autograd(fb, spec):
     if torch.is_grad_enabled() and (fb.requires_grad or spec.requires_grad):
         return _FilterbankFn.apply(fb, spec)
+    if compiling():
+        from . import ops
+
+        return ops.filterbank(fb, spec)
     return filterbank(fb, spec)
 
 
@@ -919,6 +927,10 @@ class _FirDecimateFn(torch.autograd.Function):
 def fir_decimate_autograd(x, taps, stride):
     if torch.is_grad_enabled() and x.requires_grad:
         return _FirDecimateFn.apply(x, taps, stride)
+    if compiling():
+        from . import ops
+
+        return ops.fir_decimate(x, taps, int(stride))
     return fir_decimate(x, taps, stride)
 
 
@@ -943,6 +955,12 @@ def needs_grad(module, x):
         x.requires_grad or any(t.requires_grad for t in _module_tensors(module)))
 
 
+def compiling():
+    """Under torch.compile the forward goes through the custom ops of ``nnaudio_amd.ops`` (opaque
+    to the tracer) and the host-side caches are consulted inside them, at run time."""
+    return torch.compiler.is_compiling()
+
+
 def framed_gemm_autograd(x, basis_re, basis_im, **kw):
     """``framed_gemm`` that records a graph when the input or the bases require gradients."""
     if torch.is_grad_enabled() and (x.requires_grad or basis_re.requires_grad
@@ -950,6 +968,15 @@ def framed_gemm_autograd(x, basis_re, basis_im, **kw):
         if basis_im is None:
             raise NotImplementedError("backward of a real contraction is not implemented")
         return _FramedGemmFn.apply(x, basis_re, basis_im, kw)
+    if compiling():
+        from . import ops
+
+        return ops.framed_gemm(
+            x, basis_re, basis_im, int(kw["hop"]), int(kw["pad"]), int(kw["pad_mode"]),
+            int(kw["epilogue"]), float(kw.get("im_sign", -1.0)), float(kw.get("eps", 0.0)),
+            float(kw.get("power", 2.0)), kw.get("row_scale"), bool(kw.get("support", False)),
+            resolve_precision(kw.get("precision")))
+    kw.pop("support", None)
     return framed_gemm(x, basis_re, basis_im, **kw)
 
 

@@ -176,9 +176,10 @@ def octave_recursion(x, banks, lenghts, hop, n_bins, lowpass, downsample_factor,
     while octs and octs[-1]["rows"] <= 0:  # octaves cut away entirely
         octs.pop()
     eps = 1e-8 if trainable else 0.0
-    if graph:
+    if graph or engine.compiling():
         # the reference's own structure (cqt.py:1091-1105): one contraction per octave through
-        # autograd, rows concatenated with the lowest octave first
+        # autograd (or, under torch.compile, through the custom ops), rows concatenated with the
+        # lowest octave first
         blocks, xd = [], x
         for o in octs:
             if o["i"] > 0:

@@ -91,17 +91,26 @@ class CQT1992v2(nn.Module):
             pad = self.kernel_width // 2
         else:
             pad, mode = 0, engine.PAD_NONE
+        epi = output_epilogue(output_format)
+        precision = engine.resolve_precision(self.precision)
+        if engine.compiling():
+            # torch.compile: the custom op looks the supports / split planes up at run time
+            if epi is None:
+                return None
+            return engine.framed_gemm_autograd(
+                x, self.cqt_kernels_real, self.cqt_kernels_imag, hop=self.hop_length, pad=pad,
+                pad_mode=mode, epilogue=epi, im_sign=-1.0, eps=1e-8 if self.trainable else 0.0,
+                row_scale=normalisation_scale(self.lenghts, normalization_type),
+                support=not self.trainable, precision=precision)
         if not hasattr(self, "_scale"):
             self._scale = engine.DerivedCache()
         scale = self._scale.get((self.lenghts,),
                                 lambda: normalisation_scale(self.lenghts, normalization_type),
                                 extra=normalization_type)
-        epi = output_epilogue(output_format)
         if epi is None:
             return None
         sup = None if self.trainable else self._support.get(self.cqt_kernels_real,
                                                             self.cqt_kernels_imag)
-        precision = engine.resolve_precision(self.precision)
         split = None
         if precision == "bf16x3":
             kr, ki = self.cqt_kernels_real, self.cqt_kernels_imag

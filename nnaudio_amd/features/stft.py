@@ -166,7 +166,7 @@ class STFT(nn.Module):
             wsin, wcos = wsin[: self.freq_bins], wcos[: self.freq_bins]
         precision = engine.resolve_precision(self.precision)
         prep = {}
-        if precision == "bf16x3":
+        if precision == "bf16x3" and not engine.compiling():
             # split planes + (the window being symmetric) the folded planes, cached per basis
             prep = self._split.get((self.wcos, self.wsin),
                                    lambda: engine.prepare_basis(wcos, wsin, "bf16x3", hop=self.stride),

@@ -1,0 +1,111 @@
+"""``torch.library`` registration of the forward entry points: the ctypes calls of
+``engine`` wrapped as custom ops with fake (meta) implementations, so that ``torch.compile``
+traces a feature module as opaque device ops instead of graph-breaking at the C boundary.
+
+    mispec::framed_gemm    pad + 2 x conv1d + epilogue (stft.py:278-316, cqt.py:740-780,
+                           utils.py:498-521)
+    mispec::filterbank     torch.matmul(mel_basis, spec)            (mel.py:188)
+    mispec::fir_decimate   conv1d(x, taps, stride, padding)         (utils.py:98-99)
+    mispec::power_to_db    MFCC's dB stage                          (mel.py:263-279)
+
+The modules route through these whenever they run under ``torch.compile`` and no autograd graph
+is needed (``engine.*_autograd``).  Operands derived from a basis (split-bf16 planes, folded
+planes, kernel supports) are looked up inside the op -- at run time, on the real tensors -- in a
+process-wide cache keyed on the basis tensor objects (``engine.DerivedCache`` semantics: weak
+references + ``_version``), so nothing about them is baked into a traced graph.
+"""
+import weakref
+from typing import Optional
+
+import torch
+
+from . import engine
+
+_prep_cache = {}  # id(basis_re) -> (weakref, DerivedCache)
+
+
+def _prepared(basis_re, basis_im, precision, hop):
+    """Split / folded planes of a basis for the op's run-time tensors (cached per tensor object)."""
+    if engine.resolve_precision(precision) != "bf16x3" or basis_im is None:
+        return {}
+    key = id(basis_re)
+    hit = _prep_cache.get(key)
+    if hit is None or hit[0]() is not basis_re:
+        cache = engine.DerivedCache()
+        _prep_cache[key] = (weakref.ref(basis_re, lambda _r, k=key: _prep_cache.pop(k, None)), cache)
+    else:
+        cache = hit[1]
+    return cache.get((basis_re, basis_im),
+                     lambda: engine.prepare_basis(basis_re, basis_im, "bf16x3", hop=hop), extra=int(hop))
+
+
+_support_cache = {}  # id(basis_re) -> (weakref, SupportCache)
+
+
+def _supports(basis_re, basis_im):
+    """[start, stop) of the non-zero taps of every kernel row (CQT banks), cached per tensor object."""
+    from .features._cqt_common import SupportCache
+
+    key = id(basis_re)
+    hit = _support_cache.get(key)
+    if hit is None or hit[0]() is not basis_re:
+        cache = SupportCache()
+        _support_cache[key] = (weakref.ref(basis_re, lambda _r, k=key: _support_cache.pop(k, None)), cache)
+    else:
+        cache = hit[1]
+    return cache.get(basis_re, basis_im)
+
+
+@torch.library.custom_op("mispec::framed_gemm", mutates_args=())
+def framed_gemm(x: torch.Tensor, basis_re: torch.Tensor, basis_im: Optional[torch.Tensor], hop: int,
+                pad: int, pad_mode: int, epilogue: int, im_sign: float, eps: float, power: float,
+                row_scale: Optional[torch.Tensor], support: bool, precision: str) -> torch.Tensor:
+    """``support``: skip the zero taps outside every row's [start, stop) (CQT banks)."""
+    prep = _prepared(basis_re, basis_im, precision, hop)
+    sup = _supports(basis_re, basis_im) if support and basis_im is not None else None
+    return engine.framed_gemm(x, basis_re, basis_im, hop=hop, pad=pad, pad_mode=pad_mode,
+                              epilogue=epilogue, im_sign=im_sign, eps=eps, power=power,
+                              row_scale=row_scale, row_support=sup, precision=precision, **prep)
+
+
+@framed_gemm.register_fake
+def _(x, basis_re, basis_im, hop, pad, pad_mode, epilogue, im_sign, eps, power, row_scale, support,
+      precision):
+    B, L = x.shape[0], x.shape[-1]
+    F, K = basis_re.shape[0], basis_re.shape[-1]
+    T = (L + 2 * pad - K) // hop + 1
+    if epilogue in (engine.EPI_COMPLEX, engine.EPI_PHASE_COSSIN):
+        return x.new_empty((B, F, T, 2))
+    return x.new_empty((B, F, T))
+
+
+@torch.library.custom_op("mispec::filterbank", mutates_args=())
+def filterbank(fb: torch.Tensor, spec: torch.Tensor) -> torch.Tensor:
+    return engine.filterbank(fb, spec)
+
+
+@filterbank.register_fake
+def _(fb, spec):
+    return spec.new_empty((spec.shape[0], fb.shape[0], spec.shape[2]))
+
+
+@torch.library.custom_op("mispec::fir_decimate", mutates_args=())
+def fir_decimate(x: torch.Tensor, taps: torch.Tensor, stride: int) -> torch.Tensor:
+    return engine.fir_decimate(x, taps, stride)
+
+
+@fir_decimate.register_fake
+def _(x, taps, stride):
+    nt = taps.numel()
+    L = x.shape[-1]
+    return x.new_empty((x.shape[0], (L + 2 * ((nt - 1) // 2) - nt) // stride + 1))
+
+
+@torch.library.custom_op("mispec::power_to_db", mutates_args=())
+def power_to_db(spec: torch.Tensor, amin: float, ref: float, top_db: float) -> torch.Tensor:
+    return engine.power_to_db(spec, amin, ref, None if top_db < 0 else top_db)
+
+
+@power_to_db.register_fake
+def _(spec, amin, ref, top_db):
+    return torch.empty_like(spec)

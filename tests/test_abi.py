@@ -40,7 +40,9 @@ def test_args_struct_layout_matches_header(tmp_path):
     if gcc is None:
         pytest.skip("no C compiler")
     for cname, mirror in (("mispec_framed_gemm_args", _abi.FramedGemmArgs),
-                          ("mispec_planar_args", _abi.PlanarArgs)):
+                          ("mispec_planar_args", _abi.PlanarArgs),
+                          ("mispec_octave_level", _abi.OctaveLevel),
+                          ("mispec_octave_args", _abi.OctaveArgs)):
         fields = [f[0] for f in mirror._fields_]
         prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "mispec.h"', 'int main(void){',
                 'printf("%%zu\\n", sizeof(%s));' % cname]
@@ -55,6 +57,40 @@ def test_args_struct_layout_matches_header(tmp_path):
         assert vals[0] == ctypes.sizeof(mirror)
         for f, off in zip(fields, vals[1:]):
             assert getattr(mirror, f).offset == off, (cname, f)
+
+
+def test_integration_stub_matches_the_header(tmp_path):
+    """INTEGRATION.md's ctypes stub, executed: its Args block must be the struct the shipped
+    library checks (`struct_size`), field for field."""
+    import shutil
+    import subprocess
+
+    from nnaudio_amd import _abi, build
+
+    build.build(verbose=False)
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(import ctypes, torch.*?)```", text, flags=re.S).group(1)
+    code = code.replace('ctypes.CDLL("libmispec.so")', "ctypes.CDLL(%r)" % _abi.LIB_PATH)
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    Args = ns["Args"]
+    assert [f[0] for f in Args._fields_] == [f[0] for f in _abi.FramedGemmArgs._fields_]
+    assert ctypes.sizeof(Args) == ctypes.sizeof(_abi.FramedGemmArgs)
+    for name, _ in Args._fields_:
+        assert getattr(Args, name).offset == getattr(_abi.FramedGemmArgs, name).offset, name
+    gcc = shutil.which("gcc")
+    if gcc is not None:
+        src = tmp_path / "sz.c"
+        src.write_text('#include <stdio.h>\n#include "mispec.h"\nint main(void){printf("%zu\\n", '
+                       'sizeof(mispec_framed_gemm_args));return 0;}\n')
+        exe = tmp_path / "sz"
+        subprocess.check_call([gcc, "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+        assert int(subprocess.check_output([str(exe)])) == ctypes.sizeof(Args)
+    # the library accepts the stub's struct_size (and then stops at the NULL pointers)
+    a = Args(struct_size=ctypes.sizeof(Args))
+    assert ns["_lib"].mispec_framed_gemm_f32(ctypes.byref(a), None) == -1
+    assert b"NULL device pointer" in _abi.load().mispec_last_error()
+    assert {"split_basis", "fold_basis", "framed"} <= set(ns)
 
 
 def test_invalid_arguments_are_rejected_without_a_gpu():

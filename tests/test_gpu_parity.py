@@ -1252,3 +1252,61 @@ def test_repeated_launches_are_bit_identical():
             for _ in range(30):
                 assert torch.equal(mod(inp), first), (type(mod).__name__, prec)
             del first
+
+
+@pytest.mark.parametrize("cls,ctor", [
+    ("STFT", dict(n_fft=512, hop_length=128, output_format="Magnitude")),
+    ("MelSpectrogram", dict(sr=16000, n_fft=512, n_mels=40, hop_length=128)),
+    ("CQT1992v2", dict(sr=16000, hop_length=128, fmin=110, n_bins=60, output_format="Complex")),
+    ("CQT2010v2", dict(sr=16000, hop_length=128, fmin=110, n_bins=60, earlydownsample=False)),
+])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_torch_compile_runs_the_custom_ops(cls, ctor, precision):
+    """torch.compile(fullgraph=True): no graph break at the C boundary (nnaudio_amd.ops), same
+    numbers as the eager module (bit for bit where both take the same kernels)."""
+    import nnaudio_amd
+
+    old = nnaudio_amd.get_precision()
+    nnaudio_amd.set_precision(precision)
+    try:
+        mod = build_module(dict(cls=cls, ctor=ctor, fwd={}), DEV)
+        x = torch.randn(4, 12000, generator=torch.Generator().manual_seed(9)).to(DEV)
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = mod(x)
+            got = torch.compile(mod, fullgraph=True, backend="aot_eager")(x)
+        torch.cuda.synchronize()
+        assert got.shape == want.shape
+        assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+    finally:
+        nnaudio_amd.set_precision(old)
+        torch._dynamo.reset()
+
+
+def test_integration_stub_computes_an_stft():
+    """The ctypes stub printed in INTEGRATION.md, executed as is against the in-tree library:
+    framed() in fp32, bf16x3 and bf16x3 + fold_basis reproduces the module."""
+    import re
+
+    from nnaudio_amd import _abi, features
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(import ctypes, torch.*?)```", text, flags=re.S).group(1)
+    code = code.replace('ctypes.CDLL("libmispec.so")', "ctypes.CDLL(%r)" % _abi.LIB_PATH)
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    m = features.STFT(n_fft=512, hop_length=128, output_format="Magnitude", verbose=False).to(DEV)
+    x = torch.randn(5, 1, 20000, generator=torch.Generator().manual_seed(2)).to(DEV)
+    with torch.no_grad():
+        want = m(x)
+        y32 = ns["framed"](x, m.wcos, m.wsin, 128, 256, 2, 1)
+        split = ns["split_basis"](m.wcos, m.wsin)
+        fold = ns["fold_basis"](m.wcos, m.wsin)
+        yb = ns["framed"](x, m.wcos, m.wsin, 128, 256, 2, 1, split=split)
+        yf = ns["framed"](x, m.wcos, m.wsin, 128, 256, 2, 1, split=split, fold=fold)
+    torch.cuda.synchronize()
+    assert fold is not None and torch.equal(y32, want)
+    for y in (yb, yf):
+        assert (y - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+    assert not torch.equal(yb, yf)

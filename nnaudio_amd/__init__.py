@@ -19,3 +19,11 @@ def get_precision():
     from . import engine
 
     return engine.get_precision()
+
+
+def invalidate_caches(module):
+    """Forget the operands derived from a module's bases (split / folded planes, kernel supports);
+    only needed after edits through ``tensor.data`` (see ``engine.DerivedCache``)."""
+    from . import engine
+
+    engine.invalidate_caches(module)

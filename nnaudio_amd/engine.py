@@ -53,15 +53,23 @@ class DerivedCache:
     the ``_version`` they were built from.
 
     One entry per device: ``nn.DataParallel`` replicas share this object and call from one
-    host thread per GPU, so entries are only ever replaced whole (no torn state)."""
+    host thread per GPU, so entries are only ever replaced whole (no torn state).
+
+    Limit: an edit made through ``.data`` (``p.data.mul_()``, weight clipping, EMA swaps of older
+    optimisers) bumps no version counter and moves no storage, so it cannot be seen here: call
+    ``nnaudio_amd.invalidate_caches(module)`` after such an edit (``p.data = other`` IS seen: the
+    storage address is part of the key)."""
 
     def __init__(self):
+        self._entries = {}
+
+    def clear(self):
         self._entries = {}
 
     def get(self, sources, build, extra=None):
         sources = tuple(sources)
         dev = sources[0].device
-        vers = tuple(s._version for s in sources)
+        vers = tuple((s._version, s.data_ptr()) for s in sources)
         hit = self._entries.get(dev)
         if hit is not None:
             refs, hvers, hextra, val = hit
@@ -821,19 +829,34 @@ class _FramedGemmFn(torch.autograd.Function):
         if need_w:
             # d basis[row, n] = sum_{(b,t)} g[row, (b,t)] * xp[b, t*hop + n]: with the frame matrix
             # stored tap-major (xt[n, (b,t)]) this is the framed contraction of the "signal" xt
-            # (frame n = its row n: hop = kernel = B*T) with the "basis" g
+            # (frame n = its row n: hop = kernel = b*T) with the "basis" g -- over chunks of clips
+            # whose tap-major frame matrix (K x b*T floats) stays below 2 GB and inside the int32
+            # sizes of the argument block (CQT1992v2 cfg4: K = 16384, 862 frames -> 64 clips/chunk)
             xp = torch.empty((B, Lp), dtype=torch.float32, device=dev)
-            xt = torch.empty((K, BT), dtype=torch.float32, device=dev)
             with torch.cuda.device(dev):
                 _abi.check(lib.mispec_pad_signal_f32(xs.data_ptr(), xs.stride(0), B, L, pad, pad_mode,
                                                      xp.data_ptr(), stream))
-                _abi.check(lib.mispec_frames_transpose_f32(xp.data_ptr(), Lp, B, T, hop, K,
-                                                           xt.data_ptr(), stream))
-            dw = framed_gemm(xt.reshape(1, K * BT), g.reshape(2 * F, BT), None, hop=BT, pad=0,
-                             pad_mode=PAD_NONE, epilogue=EPI_REAL, im_sign=1.0, precision="fp32")[0]
+            per = max(1, min(B, (2 ** 29) // max(K * T, 1)))
+            if K * T >= 2 ** 31:
+                raise RuntimeError(
+                    "backward of the framed contraction: one clip's frame matrix (%d taps x %d frames) "
+                    "exceeds the kernel's int32 range; shorten the clips" % (K, T))
+            dw = None
+            for b0 in range(0, B, per):
+                b1 = min(B, b0 + per)
+                nb = (b1 - b0) * T
+                xt = torch.empty((K, nb), dtype=torch.float32, device=dev)
+                with torch.cuda.device(dev):
+                    _abi.check(lib.mispec_frames_transpose_f32(xp[b0:b1].data_ptr(), Lp, b1 - b0, T, hop, K,
+                                                               xt.data_ptr(), stream))
+                gc = g[:, :, b0:b1].reshape(2 * F, nb) if per >= B else g[:, :, b0:b1].reshape(2 * F, nb).contiguous()
+                part = framed_gemm(xt.reshape(1, K * nb), gc, None, hop=nb, pad=0,
+                                   pad_mode=PAD_NONE, epilogue=EPI_REAL, im_sign=1.0, precision="fp32")[0]
+                dw = part if dw is None else dw.add_(part)
+                del xt
             gre = dw[:F].reshape(basis_re.shape)
             gim = dw[F:].reshape(basis_im.shape)
-            del xp, xt
+            del xp
         if need_x:
             # d frames[(b,t), n] = sum_f g_re*w_re[f,n] + g_im*w_im[f,n]: the framed contraction of
             # the "signal" gt (frame (b,t) = its row: hop = kernel = 2F) with the "basis"
@@ -945,6 +968,22 @@ def _module_tensors(module):
         for t in m.__dict__.values():
             if isinstance(t, torch.Tensor):
                 yield t
+
+
+def invalidate_caches(module):
+    """Drop every derived operand (split / folded planes, kernel supports, effective kernels ...)
+    cached on ``module`` and its children; the next forward rebuilds them.  Needed only after edits
+    that bypass autograd's version counters (``tensor.data`` arithmetic)."""
+    for m in module.modules():
+        for v in list(m.__dict__.values()):
+            for c in (v if isinstance(v, (list, tuple)) else (v,)):
+                if isinstance(c, DerivedCache):
+                    c.clear()
+                elif hasattr(c, "__dict__"):
+                    for cc in list(vars(c).values()):
+                        for ccc in (cc.values() if isinstance(cc, dict) else (cc,)):
+                            if isinstance(ccc, DerivedCache):
+                                ccc.clear()
 
 
 def needs_grad(module, x):

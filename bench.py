@@ -230,7 +230,8 @@ def measure_traffic(name, precision, steps=4, timeout=150):
                         continue
                     v = float(r.get("Counter_Value") or 0.0) * 1024.0  # the counters are in KB
                     total += v
-                    k = r["Kernel_Name"].split("(")[0][-60:]
+                    k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+                    k = k.split("(")[0].split("<")[0][-60:]
                     per_kernel.setdefault(k, {}).setdefault(counter, 0.0)
                     per_kernel[k][counter] += v / steps
             res[counter] = total / steps

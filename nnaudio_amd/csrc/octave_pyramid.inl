@@ -254,14 +254,19 @@ __global__ void __launch_bounds__(256, 2) octave_pyramid_kernel(const PyrParams 
       const unsigned char *tbh = smem_raw + p.tab_off + cp * PYR_TAB_STRIDE + 2 * (8 * lh - 2 * (li - cp) + 64);
       const unsigned char *tbl = tbh + 4 * PYR_TAB_STRIDE;
       for (int l = 0; l + 1 < D; ++l) {
+        // (every field used inside the loops below is copied out of the kernel-argument block first:
+        // read in place -- p.lv[l] with a run-time l -- each use is a scalar load whose
+        // s_waitcnt lgkmcnt(0) also drains the LDS queue; positions fit 32 bits)
         const PyrLevel &vi = p.lv[l], &vo = p.lv[l + 1];
-        const unsigned char *ihi = smem_raw + vi.lds_off, *ilo = ihi + vi.rows * PYR_ROW;
-        unsigned char *ohi = smem_raw + vo.lds_off, *olo = ohi + vo.rows * PYR_ROW;
-        const long long ao = (long long)t0 * vo.hop - vo.halo;  // global index of output 0
-        const int n_out = vo.rows * 64;
+        const int vi_rows = vi.rows, vo_rows = vo.rows, vo_L = vo.L, vo_hop = vo.hop;
+        const unsigned char *ihi = smem_raw + vi.lds_off, *ilo = ihi + vi_rows * PYR_ROW;
+        unsigned char *ohi = smem_raw + vo.lds_off, *olo = ohi + vo_rows * PYR_ROW;
+        const int ao = t0 * vo_hop - vo.halo;  // global index of output 0
+        const int n_out = vo_rows * 64;
         const int tiles = (n_out + 1023) / 1024;
-        const bool last = (l + 2 == D) && p.x_last != nullptr;
-        const long long own_lo = (long long)t0 * vo.hop, own_hi = own_lo + (long long)p.nf * vo.hop;
+        float *const xl_out = (l + 2 == D && p.x_last) ? p.x_last + (long long)c * p.x_last_stride : nullptr;
+        const bool last = xl_out != nullptr;
+        const int own_lo = t0 * vo_hop, own_hi = own_lo + p.nf * vo_hop;
         // A wave multiplies PYR_NT column tiles at a time -- tile, tile + 4, ... -- with the next
         // step's fragments requested a step ahead.  Tiles past the end compute on clamped columns
         // and are not written.  (Measured: one workgroup per CU with each wave alone on its SIMD and
@@ -358,6 +363,12 @@ __global__ void __launch_bounds__(256, 2) octave_pyramid_kernel(const PyrParams 
       const unsigned char *hi = smem_raw + v.lds_off, *lo = hi + v.rows * PYR_ROW;
       const int steps = v.Ks / 32;
       const int ftiles = p.nf / 16;
+      const int v_hop = v.hop, v_wofs = v.halo - v.K / 2, v_n_rows = v.n_rows, v_row0 = v.out_row0;
+      const float *const v_scale = v.row_scale;
+      const long long o_row = p.out_row_stride;
+      float *const o_clip = p.out + (long long)c * p.out_clip_stride;
+      const int n_frames = p.n_frames;
+      const float im_sign = p.im_sign;
       KParams ep{};
       ep.epilogue = p.epilogue;
       ep.eps = p.eps;
@@ -366,7 +377,7 @@ __global__ void __launch_bounds__(256, 2) octave_pyramid_kernel(const PyrParams 
       for (int ft = my_rank; ft < ftiles; ft += my_peers) {
         const int t = t0 + ft * 16 + fn;
         // window start of frame t inside the span: (t - t0) hop + halo - K/2  (multiple of 8)
-        const int w = (ft * 16 + fn) * v.hop + v.halo - v.K / 2;
+        const int w = (ft * 16 + fn) * v_hop + v_wofs;
         f32x4acc cre = {0.f, 0.f, 0.f, 0.f}, cim = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < MAXS; ++s) {
@@ -398,15 +409,14 @@ __global__ void __launch_bounds__(256, 2) octave_pyramid_kernel(const PyrParams 
           cim = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aih, xh, cim, 0, 0, 0);
         }
         // lane (frame fn, kg) holds bins 4 kg + e
-        if (t < p.n_frames) {
+        if (t < n_frames) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int bin = 4 * kg + e;
-            if (bin < v.n_rows) {
-              const float sc = v.row_scale ? v.row_scale[bin] : 1.f;
-              float *d = p.out + (long long)c * p.out_clip_stride +
-                         (long long)(v.out_row0 + bin) * p.out_row_stride + (long long)t * E;
-              epilogue_store(ep, d, cre[e] * sc, p.im_sign * cim[e] * sc);
+            if (bin < v_n_rows) {
+              const float sc = v_scale ? v_scale[bin] : 1.f;
+              float *d = o_clip + (long long)(v_row0 + bin) * o_row + (long long)t * E;
+              epilogue_store(ep, d, cre[e] * sc, im_sign * cim[e] * sc);
             }
           }
         }

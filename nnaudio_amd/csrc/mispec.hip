@@ -1986,7 +1986,7 @@ FoldPlan plan_fold(const mispec_framed_gemm_args *a, const KParams &p) {
   if (MISPEC_DBG(p, 0x100000)) return f;  // A/B runs: the dense kernel
   if (!p.a_im || p.row_support || (p.K & 1) || p.K < 64) return f;
   if ((long long)p.hop * 8 < p.K) return f;  // folded frames cost 8 B per folded tap and frame
-  if (p.K > 4096) return f;                  // the pre-pass assembles 4 frames (4 K bytes each) in LDS
+  if (p.K > 8192) return f;                  // the pre-pass assembles 4 frames (4 K bytes each) in LDS
   int with_tap0 = -1;
   for (int w = 0; w < 2; ++w)
     if (a->fold_taps == fold_taps(p.K, w)) with_tap0 = w;
@@ -2026,6 +2026,11 @@ int launch_fold(KParams p, const mispec_framed_gemm_args *a, const FoldPlan &f, 
   pre.fold_last = f.last_in_prepass ? last_rows : nullptr;
   pre.fold_last_bin = p.n_bins - 1;
   const size_t pre_smem = (size_t)FOLD_FR * f.kf * 8 + 8 * FOLD_FR * sizeof(float);
+  {
+    static std::atomic<unsigned long long> configured_pre{0};
+    int rc0 = configure_lds(fold_frames_kernel, 160 * 1024, configured_pre);
+    if (rc0 != MISPEC_OK) return rc0;
+  }
   // main contraction over the whole 128-bin blocks (a partial last block when it is more than the
   // one bin the pre-pass took)
   p.n_bins = f.main_bins;

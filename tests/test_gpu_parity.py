@@ -754,6 +754,8 @@ def _fourier_like_basis(rng, F, K, tap0):
     (1, 30000, 257, 2048, 512, 1024, 2, False),  # the cfg2 kernel shape, two blocks + Nyquist
     (2, 4000, 64, 64, 16, 0, 0, True),         # smallest kernel, center=False
     (5, 700, 130, 128, 32, 64, 2, False),      # many short clips: tiles span several clips
+    (1, 40000, 129, 4096, 1024, 2048, 2, False),  # n_fft = 4096: 64 KB of LDS per pre-pass block
+    (1, 70000, 65, 8192, 2048, 4096, 1, True),    # the longest kernel the fold takes
 ])
 @pytest.mark.parametrize("epi", ["complex", "magnitude", "power2", "phase"])
 def test_symmetric_fold_kernel(shape, epi):

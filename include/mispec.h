@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MISPEC_ABI_VERSION 5
+#define MISPEC_ABI_VERSION 6
 
 enum {
   MISPEC_OK = 0,
@@ -164,6 +164,13 @@ typedef struct mispec_framed_gemm_args {
   int64_t basis_fold_bytes;
   int32_t fold_taps;           /* value returned by mispec_fold_taps() for this basis      */
   int32_t reserved4;           /* must be 0                                                */
+
+  /* The same (n_bins, 2) values as row_support, in HOST memory -- optional.  With them the
+   * library can plan the strip kernel for MISPEC_PREC_BF16X3 contractions of complex bases with
+   * supports (CQT banks: cqt.py:749-750 with the kernels of utils.py:457-469): the waves of a
+   * workgroup are dealt out to the 16-bin row tiles in proportion to their tap ranges.  The
+   * CALLER vouches that the two copies agree; without the host copy the narrow-tile kernel runs. */
+  const int32_t *row_support_host;
 } mispec_framed_gemm_args;
 
 /*

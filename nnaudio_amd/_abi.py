@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmispec.so")
 ABLATE_LIB_PATH = os.path.join(_HERE, "csrc", "libmispec_ablate.so")  # benchmarking build
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 E_INVALID, E_UNSUPPORTED, E_HIP = -1, -2, -3
 
 # enums (mirror include/mispec.h)
@@ -97,6 +97,7 @@ class FramedGemmArgs(ctypes.Structure):
         ("basis_fold_bytes", ctypes.c_int64),
         ("fold_taps", ctypes.c_int32),
         ("reserved4", ctypes.c_int32),
+        ("row_support_host", ctypes.c_void_p),
     ]
 
 

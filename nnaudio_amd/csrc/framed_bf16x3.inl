@@ -52,7 +52,8 @@ __device__ __forceinline__ void bf16_split(float v, unsigned &hi, unsigned &lo) 
 __global__ void __launch_bounds__(256) split_basis_kernel(const float *__restrict__ re,
                                                           const float *__restrict__ im,
                                                           long long row_stride, int n_bins, int K,
-                                                          int Ks, unsigned short *__restrict__ dst) {
+                                                          int Ks, unsigned short *__restrict__ dst,
+                                                          unsigned short *__restrict__ frag) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= Ks) return;
   const int bin = blockIdx.y;
@@ -65,6 +66,15 @@ __global__ void __launch_bounds__(256) split_basis_kernel(const float *__restric
   const long long o = (long long)bin * Ks + k;
   dst[(2 * z) * plane + o] = (unsigned short)hi;
   dst[(2 * z + 1) * plane + o] = (unsigned short)lo;
+  if (frag) {
+    // fragment order of framed_bf16x3_strip.inl: tile of 16 bins (row = 2 * bin + component),
+    // 16-tap step, [hi | lo], lane = row + 32 * (tap / 8 % 2), 8 taps per lane
+    const long long tile = bin >> 4;
+    const int lane = 2 * (bin & 15) + z + 32 * ((k >> 3) & 1);
+    const long long f = (((tile * (Ks >> 4) + (k >> 4)) * 2) * 64 + lane) * 8 + (k & 7);
+    frag[f] = (unsigned short)hi;
+    frag[f + 64 * 8] = (unsigned short)lo;
+  }
 }
 
 // padded clips -> (hi, lo) planes.  One thread = 4 consecutive elements of a clip slot
@@ -73,6 +83,7 @@ __global__ void __launch_bounds__(256) split_basis_kernel(const float *__restric
 __global__ void __launch_bounds__(256) split_signal_kernel(const KParams p,
                                                            unsigned short *__restrict__ dst) {
   const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && p.job_counter) *p.job_counter = 0u;
   if (i0 >= p.xs_clip_stride) return;
   const int c = blockIdx.y;
   const float *x = p.x + (long long)c * p.x_clip_stride;

@@ -1,0 +1,381 @@
+// framed_bf16x3_strip.inl -- bf16x3 kernel for bases with per-row supports (CQT banks) whose
+// basis fragments never pass through LDS.  Included by mispec.hip after framed_fold.inl; the
+// hop-periodic K order (tap k = j*hop + 32*s, one LDS slab per sub-stage s) is explained in
+// framed_bf16x3_slab.inl, the predecessor of this kernel in framed_bf16x3_narrow.inl.
+//
+// The narrow-tile kernel gives a wave 32 rows x 32 frames: four 16-byte LDS fragment reads per
+// three MFMAs (170 B/clk of LDS traffic per CU at full matrix rate -- more than the LDS delivers)
+// plus a 24-instruction LDS-DMA of the basis stage per barrier interval.  Here a wave owns a
+// STRIP: one 32-row tile (16 bins, re/im interleaved) x 128 frames x a range [ja, jb) of the
+// tile's super-stages:
+//   * its basis fragments are used by no other wave of the workgroup, so they are loaded straight
+//     from global memory (L2: the non-zero part of a CQT bank is a few MB) into registers, 16 taps
+//     x 32 rows per instruction, two units ahead -- no LDS traffic, no barrier for the basis;
+//   * one fragment pair of the basis serves four frame tiles: 8 LDS reads per 12 MFMAs;
+//   * the only shared data is the slab of the signal (128 + span - 1 rows of 32 taps), double
+//     buffered, one barrier per sub-stage.
+// The four waves of a workgroup take strips of the SAME 128 frames: a host-made plan (plan_strip,
+// mispec.hip) groups the row tiles into passes and deals the waves of a pass out in proportion to
+// the tiles' K ranges (cfg4: tile 0 on four waves, tile 1 on four, tiles 2-3 as 2 + 2, ...).
+// Waves that share a row tile add their partial sums through LDS at the end of the pass; the
+// pointwise epilogue is the one of the other bf16x3 kernels.  Jobs (pass, frame tile) are handed
+// out longest first through an atomic counter to TWO persistent workgroups per CU (76 KB of LDS
+// each): every SIMD hosts one wave of each, so the serial parts of a job -- tables, the first slab,
+// the barrier of every sub-stage, reduction and epilogue -- run under the other workgroup's MFMAs
+// (with one 8-wave workgroup per CU they cost 0.11 ms of a 0.41 ms kernel).
+//
+// The basis is read in "fragment order" (written next to the split planes by split_basis_kernel):
+// [16-bin tile][16-tap step][hi | lo][lane][8 taps], lane = row + 32 * (tap / 8 % 2) -- the MFMA's
+// own operand layout, so a load instruction fetches one contiguous kilobyte.  (Loading the
+// fragments from the row-major planes -- 64 pieces of 16 bytes in 32 rows per instruction -- made
+// the kernel address-bound in the texture path: 0.17 ms of 0.43.)
+
+constexpr int STRIP_BN = 128;        // frame columns of a workgroup
+constexpr int STRIP_NW = 4;          // waves of a workgroup
+constexpr int STRIP_MAX_ROWS = 288;  // slab rows (STRIP_BN + 2 * (span - 1), rounded up to 16)
+constexpr int STRIP_MAX_PASS = 8;
+constexpr int STRIP_SJ = (STRIP_MAX_ROWS / 16 + STRIP_NW - 1) / STRIP_NW;  // slab DMA pieces per wave and plane
+constexpr int STRIP_RED_TILE = STRIP_NW * 16 * 64 * 4;  // one 32 x 32 partial sum of each wave
+// [two slab buffers | later: two reduction buffers + the epilogue's patches] [tables]
+constexpr int STRIP_RED_BYTES = 2 * STRIP_MAX_ROWS * 64 * 2;
+constexpr int STRIP_LDS_BYTES = STRIP_RED_BYTES + STRIP_MAX_ROWS * 8 + STRIP_BN * 4 + 64;
+static_assert(2 * STRIP_LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+
+struct StripWave {
+  int tile;    // 32-row tile (-1: the wave idles through this pass)
+  int kb, ke;  // tap range of the tile (kb a multiple of 32)
+  int ja, jb;  // the wave's super-stages
+  int g0, gsize;  // waves g0 .. g0+gsize-1 share the tile
+  int fmask;   // bit f: this wave reduces and stores frame tile f of the row tile
+};
+struct StripPass {
+  StripWave w[STRIP_NW];
+  int jbase, span;  // super-stages [jbase, jbase + span) are read from the slab
+  int slab_rows;    // multiple of 16
+  int cost;
+};
+struct StripPlan {
+  int n_pass, n_tiles_n, n_jobs, reserved;
+  StripPass pass[STRIP_MAX_PASS];
+};
+
+// 16-byte-per-lane LDS-direct load, as instructions: hipcc knows that the builtin writes LDS and, in
+// a loop that also reads LDS, drains vmcnt before every fragment read -- with it the basis
+// fragments requested two units ahead.  Here the slab loads are ordered by hand (strip_barrier);
+// the compiler's own vmcnt waits for the basis registers only get stricter by loads it cannot see.
+__device__ __forceinline__ void strip_lds_dma16(const void *src, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+               :
+               : "v"(src), "s"(lds_addr)
+               : "memory", "m0");
+}
+
+// s_waitcnt vmcnt(N) lgkmcnt(0); s_barrier -- as instructions (see lds_dma_barrier_keep)
+__device__ __forceinline__ void strip_barrier(int younger_units) {
+  if (younger_units >= 2)
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else if (younger_units == 1)
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KParams p, const StripPlan plan) {
+  constexpr int NW = STRIP_NW;
+  constexpr int ROWB = KC * 2;                    // bytes of one slab row of one plane
+  constexpr int SL_PL = STRIP_MAX_ROWS * ROWB;    // hi -> lo plane of a slab buffer
+  constexpr int SLAB = 2 * SL_PL;
+  static_assert(2 * SLAB <= STRIP_RED_BYTES && 2 * STRIP_RED_TILE + NW * 32 * 33 * 4 <= STRIP_RED_BYTES,
+                "slabs, then partial sums + epilogue patches, share the first region");
+  typedef __attribute__((address_space(1))) const void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned char *sS = smem_raw;  // [2][SLAB]; later the partial sums
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lptr_t)smem_raw);
+  long long *sRowOff = reinterpret_cast<long long *>(smem_raw + STRIP_RED_BYTES);  // [STRIP_MAX_ROWS]
+  int *sColRow = reinterpret_cast<int *>(sRowOff + STRIP_MAX_ROWS);                // [STRIP_BN]
+  int *sJob = sColRow + STRIP_BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+  const int row16 = lane >> 2;                    // DMA: row inside a 16-row piece
+  const int cg = (lane & 3) ^ ((lane >> 4) & 3);  // DMA: global chunk that lands in slot lane & 3
+  const int hop = p.hop;
+  const int SPH = hop / KC;
+  const int C = p.n_super;
+  const int n_tiles_n = plan.n_tiles_n;
+  const long long xs_plane = p.xs_plane;
+  // benchmarking build only (constants otherwise): 1 no MFMAs, 2 no slab fragment reads, 4 no basis
+  // loads, 8 no slab DMA, 16 no reduction / epilogue
+  const bool ab_mfma = MISPEC_DBG(p, 1), ab_x = MISPEC_DBG(p, 2), ab_a = MISPEC_DBG(p, 4),
+             ab_dma = MISPEC_DBG(p, 8), ab_epi = MISPEC_DBG(p, 16);
+
+  if (tid == 0) sJob[0] = (int)atomicAdd(p.job_counter, 1u);
+  __syncthreads();
+  int job = __builtin_amdgcn_readfirstlane(sJob[0]);
+  while (job < plan.n_jobs) {
+    // the next job is requested now and looked at when this one is done
+    int next_job = 0;
+    if (tid == 0) next_job = (int)atomicAdd(p.job_counter, 1u);
+    const int pass_i = job / n_tiles_n;
+    const int tile_n = job - pass_i * n_tiles_n;
+    const StripPass &ps = plan.pass[pass_i];
+    const int jbase = ps.jbase, span = ps.span;
+    const int spieces = ps.slab_rows / 16;
+    const StripWave &wv = ps.w[wave];
+    const int tile_m = wv.tile;
+    const int kb = wv.kb, ke = wv.ke, ja = wv.ja, jb = wv.jb;
+
+    // ---- the frame tile's (at most two) runs of consecutive frames, slab row table
+    const long long n0 = (long long)tile_n * STRIP_BN;
+    {
+      const int c0 = (int)(n0 / p.n_frames);
+      const int t0 = (int)(n0 - (long long)c0 * p.n_frames);
+      const int len0 = (p.n_frames - t0) < STRIP_BN ? (p.n_frames - t0) : STRIP_BN;
+      const int rows0 = len0 + span - 1;
+      if (tid < STRIP_BN) sColRow[tid] = tid < len0 ? tid : tid + (span - 1);
+      for (int r = tid; r < ps.slab_rows; r += NW * 64) {
+        int c = c0, f = t0 + r + jbase;
+        if (r >= rows0) {
+          c = c0 + 1;
+          f = r - rows0 + jbase;
+        }
+        // rows past the tile's last column (or of a clip past the batch) feed unused columns only
+        c = c < p.n_clips ? c : p.n_clips - 1;
+        const int fmax = p.n_frames - 1 + C - 1;
+        f = f < fmax ? f : fmax;
+        sRowOff[r] = (long long)c * p.xs_clip_stride + (long long)f * hop;
+      }
+    }
+    // ---- super-stage range of every sub-stage of this wave's strip: lane s holds sub-stage s
+    int vJlo, vJhi;
+    {
+      const int lo_num = kb - KC * lane, hi_num = ke - 1 - KC * lane;
+      int jl = lo_num <= 0 ? 0 : (lo_num + hop - 1) / hop;
+      int jh = (ke <= kb || hi_num < 0) ? -1 : hi_num / hop;
+      jl = jl > ja ? jl : ja;
+      jh = jh < jb - 1 ? jh : jb - 1;
+      if (tile_m < 0 || lane >= SPH || MISPEC_DBG(p, 32)) jh = -1;  // (32: benchmarking, no units)
+      vJlo = jl;
+      vJhi = jh;
+    }
+    __syncthreads();
+    const unsigned short *sptr[STRIP_SJ];
+#pragma unroll
+    for (int j = 0; j < STRIP_SJ; ++j) {
+      const int pj = j * NW + wave;
+      const int row = (pj < spieces ? pj : 0) * 16 + row16;
+      sptr[j] = p.xs + sRowOff[row] + 8 * cg;
+    }
+    int xrow[4];  // slab row of this lane's frame of frame tile f at super-stage jbase
+#pragma unroll
+    for (int f = 0; f < 4; ++f) xrow[f] = sColRow[32 * f + li];
+
+    // ---- the strip's basis fragments: (tile, 16-tap step) -> [hi | lo][lane][8 taps], so a unit
+    // (two steps) is 4 KB of consecutive memory and every load a contiguous kilobyte
+    const unsigned short *arow =
+        p.afrag + (long long)(tile_m < 0 ? 0 : tile_m) * (p.Ks >> 4) * 1024 + lane * 8;
+    const unsigned short *azero = p.afrag + (long long)((p.n_bins + 15) >> 4) * (p.Ks >> 4) * 1024 + lane * 8;
+
+    auto dma_slab = [&](int s, int buf) __attribute__((always_inline)) {
+      if (ab_dma) return;
+#pragma unroll
+      for (int j = 0; j < STRIP_SJ; ++j) {
+        const int pj = j * NW + wave;
+        if (pj < spieces) {
+          const unsigned short *src = sptr[j] + KC * s;
+          const unsigned d = lds0 + buf * SLAB + pj * 16 * ROWB;
+          strip_lds_dma16(src, d);
+          strip_lds_dma16(src + xs_plane, d + SL_PL);
+        }
+      }
+    };
+
+    // ---- units (sub-stage s, super-stage j) of the strip, in execution order
+    struct It {
+      int s, j, hi;
+      bool valid;
+    };
+    auto it_seek = [&](It &it) __attribute__((always_inline)) {
+      for (; it.s < SPH; ++it.s) {
+        it.j = __builtin_amdgcn_readlane(vJlo, it.s);
+        it.hi = __builtin_amdgcn_readlane(vJhi, it.s);
+        if (it.hi >= it.j) break;
+      }
+      it.valid = it.s < SPH;
+    };
+    auto it_next = [&](It it) __attribute__((always_inline)) -> It {
+      if (!it.valid) return it;
+      if (++it.j > it.hi) {
+        ++it.s;
+        it_seek(it);
+      }
+      return it;
+    };
+
+    // basis fragments of a unit: [q][hi, lo], two slots (units u, u + 1 in flight)
+    bf16x8 ah[2][2], al[2][2];
+    auto load_a = [&](auto slot_tag, const It &it) __attribute__((always_inline)) {
+      constexpr int S = decltype(slot_tag)::value;
+      if (ab_a) return;
+      // past the strip's last unit: the block of zeros behind the last tile -- the number of loads in
+      // flight stays fixed, and a unit executed on them adds nothing
+      const unsigned short *src = it.valid ? arow + (long long)(it.j * SPH + it.s) * 2048 : azero;
+      ah[S][0] = *reinterpret_cast<const bf16x8 *>(src);
+      al[S][0] = *reinterpret_cast<const bf16x8 *>(src + 512);
+      ah[S][1] = *reinterpret_cast<const bf16x8 *>(src + 1024);
+      al[S][1] = *reinterpret_cast<const bf16x8 *>(src + 1536);
+    };
+    // slab fragments of one 16-tap step, four frame tiles: the hi parts of step q live in set q
+    // (requested one step ahead), the lo parts -- read by the last four MFMAs of a step only -- in
+    // one set, requested at the start of their step
+    bf16x8 xh[2][4], xl[4];
+    auto x_addr = [&](int f, int buf, int dj, int q) __attribute__((always_inline)) -> const unsigned char * {
+      const int row = xrow[f] + dj;
+      return sS + buf * SLAB + row * ROWB + 16 * ((2 * q + lh) ^ ((row >> 2) & 3));
+    };
+    auto load_xh = [&](auto q_tag, int buf, int dj) __attribute__((always_inline)) {
+      constexpr int Q = decltype(q_tag)::value;
+      if (ab_x) return;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) xh[Q][f] = *reinterpret_cast<const bf16x8 *>(x_addr(f, buf, dj, Q));
+    };
+    auto load_xl = [&](auto q_tag, int buf, int dj) __attribute__((always_inline)) {
+      constexpr int Q = decltype(q_tag)::value;
+      if (ab_x) return;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) xl[f] = *reinterpret_cast<const bf16x8 *>(x_addr(f, buf, dj, Q) + SL_PL);
+    };
+    f32x16 acc[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[f][e] = 0.f;
+    auto mfma12 = [&](auto slot_tag, auto q_tag) __attribute__((always_inline)) {
+      constexpr int S = decltype(slot_tag)::value;
+      constexpr int Q = decltype(q_tag)::value;
+      if (ab_mfma) return;
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+        acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[S][Q], xh[Q][f], acc[f], 0, 0, 0);
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+        acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[S][Q], xh[Q][f], acc[f], 0, 0, 0);
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+        acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[S][Q], xl[f], acc[f], 0, 0, 0);
+    };
+    typedef std::integral_constant<int, 0> i0;
+    typedef std::integral_constant<int, 1> i1;
+
+    It cur{0, 0, -1, false};
+    it_seek(cur);
+    It n1 = it_next(cur);
+    It n2 = it_next(n1);
+    int cur_s = 0;      // sub-stage whose slab is being read
+    int done_in_s = 0;  // units (= groups of 4 basis loads) issued since the last slab DMA
+    // end of sub-stage s for this wave: its pieces of slab s+1 have landed (they were issued before
+    // the basis loads of the units counted in done_in_s), everybody is done reading slab s, whose
+    // buffer takes slab s+2
+    auto transition = [&]() __attribute__((always_inline)) {
+      strip_barrier(done_in_s);
+      if (cur_s + 2 < SPH) dma_slab(cur_s + 2, cur_s & 1);
+      ++cur_s;
+      done_in_s = 0;
+    };
+    dma_slab(0, 0);
+    if (SPH > 1) dma_slab(1, 1);
+    load_a(i0{}, cur);
+    load_a(i1{}, n1);
+    strip_barrier(0);
+    {
+      const int target = cur.valid ? cur.s : SPH;
+      while (cur_s < target) transition();
+    }
+    if (cur.valid) load_xh(i0{}, cur_s & 1, cur.j - jbase);
+
+    // one unit = 24 MFMAs: step 0 from hi set 0 (requested during the previous unit), step 1 from
+    // hi set 1 (requested under step 0); the slot's basis registers then take unit u + 2
+    auto unit = [&](auto slot_tag) __attribute__((always_inline)) {
+      const int buf = cur_s & 1;
+      const int dj = cur.valid ? cur.j - jbase : 0;
+      load_xl(i0{}, buf, dj);
+      load_xh(i1{}, buf, dj);
+      mfma12(slot_tag, i0{});
+      const bool same = n1.valid && n1.s == cur.s;
+      load_xl(i1{}, buf, dj);
+      // (requested unconditionally -- the last unit of a sub-stage re-reads its own row and drops
+      // it: a branch here makes hipcc keep both generations of the set alive, with copies)
+      load_xh(i0{}, buf, same ? n1.j - jbase : dj);
+      mfma12(slot_tag, i1{});
+      load_a(slot_tag, n2);
+      ++done_in_s;
+      if (!same) {
+        const int target = n1.valid ? n1.s : SPH;
+        while (cur_s < target) transition();
+        if (n1.valid) load_xh(i0{}, cur_s & 1, n1.j - jbase);
+      }
+      cur = n1;
+      n1 = n2;
+      n2 = it_next(n2);
+    };
+    // (two units per iteration, whatever the strip's length: a unit past the end multiplies the
+    // zero block -- an early exit between them makes hipcc copy the 64 accumulator registers)
+    while (cur.valid) {
+      unit(i0{});
+      unit(i1{});
+    }
+    // (a strip with an odd number of units has just read slab fragments for its padding unit:
+    // nobody may overwrite the slabs with partial sums before that)
+    __syncthreads();
+
+    // ---- partial sums of the waves that share a row tile: through LDS (one frame tile at a time,
+    // two buffers: a wave writes tile f + 1 while others still add up tile f), then the epilogue
+    if (!ab_epi) {
+      f32x4 *red = reinterpret_cast<f32x4 *>(smem_raw);
+      unsigned char *patch = smem_raw + 2 * STRIP_RED_TILE;  // the epilogue's wave-private patches
+      const int g0 = wv.g0, gsize = wv.gsize, fmask = tile_m < 0 ? 0 : wv.fmask;
+      // (a lambda per frame tile, not a loop: the accumulators must stay in registers)
+      auto finish = [&](auto f_tag) __attribute__((always_inline)) {
+        constexpr int f = decltype(f_tag)::value;
+        f32x4 *rb = red + (f & 1) * (STRIP_RED_TILE / 16);
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[f][4 * e4 + e];
+          rb[(wave * 4 + e4) * 64 + lane] = v;
+        }
+        __syncthreads();
+        const bool mine = fmask >> f & 1;
+        f32x16 a1[1][1];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a1[0][0][e] = 0.f;
+        if (mine) {
+          for (int w2 = g0; w2 < g0 + gsize; ++w2) {
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+              const f32x4 v = rb[(w2 * 4 + e4) * 64 + lane];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) a1[0][0][4 * e4 + e] += v[e];
+            }
+          }
+        }
+        // (the epilogue places wave w at columns n0 + 32*w: hand it this wave's frame tile)
+        bf16x3_epilogue<1, 8, 1, 1>(p, a1, mine ? tile_m * 32 : (1 << 24), n0 + 32 * f - 32 * wave, patch);
+      };
+      finish(std::integral_constant<int, 0>{});
+      finish(std::integral_constant<int, 1>{});
+      finish(std::integral_constant<int, 2>{});
+      finish(std::integral_constant<int, 3>{});
+    }
+    __syncthreads();  // the epilogue is done with the LDS
+    if (tid == 0) sJob[0] = next_job;
+    __syncthreads();
+    job = __builtin_amdgcn_readfirstlane(sJob[0]);
+  }
+}

@@ -52,6 +52,8 @@
 #include <cstdio>
 #include <type_traits>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 #include "mispec.h"
 
@@ -138,6 +140,8 @@ struct KParams {
   int slab_rows;  // rows of one slab buffer (>= BN + 2*(C-1), multiple of 16)
   int slab_nbuf;  // 1 or 2 slab buffers
   int row_split;  // framed_bf16x3_narrow: workgroups per frame tile (each takes every row_split-th row tile)
+  unsigned *job_counter;  // framed_bf16x3_strip: next job; zeroed by the signal split of the same call
+  const unsigned short *afrag;  // framed_bf16x3_strip: the basis in fragment order, or NULL
   // fused filterbank reduction (bf16x3_epilogue_fb): out[c, m, t] += sum_bin fb[m, bin] * |X|^power
   const float *fb;
   const int *fb_support;
@@ -958,6 +962,7 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
 #include "framed_bf16x3_slab.inl"
 #include "framed_bf16x3_narrow.inl"
 #include "framed_fold.inl"
+#include "framed_bf16x3_strip.inl"
 #include "octave_pyramid.inl"
 
 // Several independent contractions of the same tile shape in one launch (the octaves of
@@ -1727,12 +1732,22 @@ SplitPlan plan_split(const KParams &p, const EdgePlan &e) {
   const long long padded = (long long)p.n_samples + 2LL * p.pad;
   const long long reach = (long long)(p.n_frames - 1) * p.hop + round_up_kc(p.K) + p.hop;
   sp.slot = round_up_ll(padded > reach ? padded : reach, 64);
-  sp.bytes = 2 * sp.slot * p.n_clips * (long long)sizeof(unsigned short);
+  // (+ the job counter of the strip kernel, behind the planes)
+  sp.bytes = 2 * sp.slot * p.n_clips * (long long)sizeof(unsigned short) + 256;
   return sp;
 }
 
-long long basis_split_bytes(int n_bins, int kernel, bool has_im) {
+// complex banks of up to 64 row tiles carry a second copy in the fragment order of the strip
+// kernel (framed_bf16x3_strip.inl): [16-bin tile][16-tap step][hi | lo][lane][8 taps]
+bool basis_has_frags(int n_bins, bool has_im) { return has_im && n_bins <= 64 * 16; }
+long long basis_plane_bytes(int n_bins, int kernel, bool has_im) {
   return (has_im ? 4LL : 2LL) * n_bins * round_up_kc(kernel) * (long long)sizeof(unsigned short);
+}
+long long basis_split_bytes(int n_bins, int kernel, bool has_im) {
+  long long b = basis_plane_bytes(n_bins, kernel, has_im);
+  if (basis_has_frags(n_bins, has_im))  // (+ a 4 KB block of zeros: the unit of a strip's padding)
+    b += (long long)((n_bins + 15) / 16) * round_up_kc(kernel) * 128 + 4096;
+  return b;
 }
 
 // does the bf16x3 kernel cover this problem?  (else it runs in fp32, which is always acceptable)
@@ -1851,6 +1866,248 @@ int launch_bf16x3_narrow(KParams p, size_t smem, hipStream_t stream) {
   return MISPEC_OK;
 }
 
+// ---------------------------------------------------------------------------------
+// strip kernel (framed_bf16x3_strip.inl): plan and launch.  The plan needs the supports on the
+// host (args->row_support_host): row tiles sorted by K range are grouped into passes of up to 4
+// tiles, a pass's waves are dealt out in proportion to the tiles' work, and the grouping that
+// minimises the estimated makespan of n_tiles_n x passes jobs on the device's CUs wins.
+// ---------------------------------------------------------------------------------
+struct StripTile {
+  int tile, kb, ke, jmin, jmax;
+  double work;  // units (sub-stage, super-stage) inside [kb, ke)
+};
+
+inline int strip_units(int kb, int ke, int j, int hop) {  // sub-stages of super-stage j inside [kb, ke)
+  const long long lo = (long long)j * hop > kb ? (long long)j * hop : kb;
+  const long long hi = (long long)(j + 1) * hop < ke ? (long long)(j + 1) * hop : ke;
+  return hi > lo ? (int)((hi - lo + KC - 1) / KC) : 0;
+}
+
+// waves of a group of tiles (sorted by work, descending): one each, the spare ones to the tile with
+// the largest share per wave; returns the largest share
+double strip_alloc(const StripTile *t, int k, int *waves) {
+  for (int i = 0; i < k; ++i) waves[i] = 1;
+  for (int spare = STRIP_NW - k; spare > 0; --spare) {
+    int best = 0;
+    for (int i = 1; i < k; ++i)
+      if (t[i].work / waves[i] > t[best].work / waves[best]) best = i;
+    ++waves[best];
+  }
+  double m = 0;
+  for (int i = 0; i < k; ++i) m = t[i].work / waves[i] > m ? t[i].work / waves[i] : m;
+  return m;
+}
+
+bool plan_strip(const KParams &p, const int32_t *sup, int n_slots, StripPlan &plan) {
+  if (!sup || !p.a_im || !p.row_support) return false;
+  if (p.hop % KC != 0 || p.hop > 64 * KC || p.Ks < 2 * p.hop || p.n_frames < STRIP_BN) return false;
+  const int hop = p.hop, sph = hop / KC;
+  const int M = (p.n_bins + 15) / 16;
+  if (M > STRIP_NW * STRIP_MAX_PASS) return false;
+  StripTile t[STRIP_NW * STRIP_MAX_PASS];
+  for (int m = 0; m < M; ++m) {
+    int lo = p.K, hi = 0;
+    for (int b = 16 * m; b < 16 * m + 16 && b < p.n_bins; ++b) {
+      const int s0 = sup[2 * b], e0 = sup[2 * b + 1];
+      if (e0 > s0) {
+        lo = s0 < lo ? s0 : lo;
+        hi = e0 > hi ? e0 : hi;
+      }
+    }
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > p.K ? p.K : hi;
+    if (hi <= lo) lo = hi = 0;
+    StripTile &x = t[m];
+    x.tile = m;
+    x.kb = lo & ~(KC - 1);
+    x.ke = hi;
+    x.jmin = x.kb / hop;
+    x.jmax = hi > lo ? (hi - 1) / hop : x.jmin - 1;
+    x.work = 0;
+    for (int j = x.jmin; j <= x.jmax; ++j) x.work += strip_units(x.kb, x.ke, j, hop);
+  }
+  for (int i = 1; i < M; ++i)  // insertion sort, descending work (stable)
+    for (int j = i; j > 0 && t[j].work > t[j - 1].work; --j) {
+      const StripTile tmp = t[j];
+      t[j] = t[j - 1];
+      t[j - 1] = tmp;
+    }
+  const long long n_tiles_n = (p.n_cols + STRIP_BN - 1) / STRIP_BN;
+  if (n_tiles_n * STRIP_MAX_PASS > 0x7fffffffLL) return false;
+  const double ovh = 0.75 * sph;  // per-pass cost of the prologue, barriers, reduction and epilogue
+  // slab reach of a group: span of super-stages
+  auto span_of = [&](int a, int k) {
+    int lo = 1 << 30, hi = -1;
+    for (int i = a; i < a + k; ++i)
+      if (t[i].jmax >= t[i].jmin) {
+        lo = t[i].jmin < lo ? t[i].jmin : lo;
+        hi = t[i].jmax > hi ? t[i].jmax : hi;
+      }
+    return hi >= lo ? hi - lo + 1 : 1;
+  };
+  // candidate caps on a pass's largest share
+  double caps[STRIP_NW * STRIP_MAX_PASS * STRIP_NW + 1];
+  int n_caps = 0;
+  for (int m = 0; m < M; ++m)
+    for (int w = 1; w <= STRIP_NW; ++w) caps[n_caps++] = t[m].work / w;
+  caps[n_caps++] = 1e30;
+  double best_est = 1e300;
+  int best_cut[STRIP_NW * STRIP_MAX_PASS], best_np = 0;
+  for (int ci = 0; ci < n_caps; ++ci) {
+    const double cap = caps[ci] + 1e-9;
+    // dp[i]: cheapest way to cover the first i tiles (sorted) with passes whose share is <= cap
+    double dp[STRIP_NW * STRIP_MAX_PASS + 1], dmax[STRIP_NW * STRIP_MAX_PASS + 1];
+    int from[STRIP_NW * STRIP_MAX_PASS + 1], np[STRIP_NW * STRIP_MAX_PASS + 1];
+    dp[0] = 0;
+    dmax[0] = 0;
+    np[0] = 0;
+    for (int i = 1; i <= M; ++i) {
+      dp[i] = 1e300;
+      for (int k = 1; k <= STRIP_NW && k <= i; ++k) {
+        if (dp[i - k] >= 1e300) continue;
+        int waves[STRIP_NW];
+        const double share = strip_alloc(t + i - k, k, waves);
+        const int rows = (STRIP_BN + 2 * (span_of(i - k, k) - 1) + 15) / 16 * 16;
+        if (share > cap || rows > STRIP_MAX_ROWS) continue;
+        const double c = dp[i - k] + share + ovh;
+        if (c < dp[i]) {
+          dp[i] = c;
+          from[i] = i - k;
+          const double mx = share + ovh;
+          dmax[i] = dmax[i - k] > mx ? dmax[i - k] : mx;
+          np[i] = np[i - k] + 1;
+        }
+      }
+    }
+    if (dp[M] >= 1e300 || np[M] > STRIP_MAX_PASS) continue;
+    const double total = dp[M] * (double)n_tiles_n / n_slots;
+    const double jobs = (double)np[M] * n_tiles_n;
+    const double est = jobs <= n_slots ? dmax[M] : (total > dmax[M] ? total : dmax[M]) + 0.5 * dmax[M];
+    if (est < best_est) {
+      best_est = est;
+      best_np = np[M];
+      int i = M, q = np[M];
+      while (i > 0) {
+        best_cut[--q] = from[i];
+        i = from[i];
+      }
+    }
+  }
+  if (best_np == 0) return false;
+  memset(&plan, 0, sizeof(plan));
+  plan.n_pass = best_np;
+  plan.n_tiles_n = (int)n_tiles_n;
+  plan.n_jobs = (int)(n_tiles_n * best_np);
+  for (int q = 0; q < best_np; ++q) {
+    const int a = best_cut[q], b = q + 1 < best_np ? best_cut[q + 1] : M, k = b - a;
+    StripPass &ps = plan.pass[q];
+    int waves[STRIP_NW];
+    const double share = strip_alloc(t + a, k, waves);
+    ps.cost = (int)(share + ovh);
+    int lo = 1 << 30, hi = -1;
+    for (int i = a; i < b; ++i)
+      if (t[i].jmax >= t[i].jmin) {
+        lo = t[i].jmin < lo ? t[i].jmin : lo;
+        hi = t[i].jmax > hi ? t[i].jmax : hi;
+      }
+    if (hi < lo) lo = hi = 0;
+    ps.jbase = lo;
+    ps.span = hi - lo + 1;
+    ps.slab_rows = (STRIP_BN + 2 * (ps.span - 1) + 15) / 16 * 16;
+    int w = 0;
+    for (int i = a; i < b; ++i) {
+      // cut the tile's super-stages into waves[i - a] runs of about equal work
+      const StripTile &x = t[i];
+      const int nw = waves[i - a];
+      int j = x.jmin;
+      double acc_w = 0;
+      for (int r = 0; r < nw; ++r, ++w) {
+        StripWave &sw = ps.w[w];
+        sw.tile = x.tile;
+        sw.kb = x.kb;
+        sw.ke = x.ke;
+        sw.g0 = w - r;
+        sw.gsize = nw;
+        sw.fmask = 0;
+        for (int f = 0; f < 4; ++f)
+          if (f % nw == r) sw.fmask |= 1 << f;
+        sw.ja = j;
+        const double goal = x.work * (r + 1) / nw;
+        while (j <= x.jmax && (r == nw - 1 || acc_w + 0.5 * strip_units(x.kb, x.ke, j, hop) <= goal)) {
+          acc_w += strip_units(x.kb, x.ke, j, hop);
+          ++j;
+        }
+        sw.jb = j;
+      }
+    }
+    for (; w < STRIP_NW; ++w) {
+      StripWave &sw = ps.w[w];
+      sw.tile = -1;
+      sw.g0 = w;
+      sw.gsize = 1;
+    }
+  }
+  return true;
+}
+
+// plans are cached per (supports, shape): the search above costs a fraction of a millisecond
+struct StripPlanKey {
+  unsigned long long hash;
+  int n_bins, hop, Ks, K, n_frames, n_cu;
+  long long n_cols;
+};
+bool strip_plan_cached(const KParams &p, const int32_t *sup, int n_cu, StripPlan &plan) {
+  static std::mutex mu;
+  struct Entry {
+    StripPlanKey key;
+    std::vector<int32_t> sup;
+    StripPlan plan;
+    bool ok;
+  };
+  static std::vector<Entry> cache;
+  unsigned long long h = 1469598103934665603ull;
+  for (int i = 0; i < 2 * p.n_bins; ++i) h = (h ^ (unsigned)sup[i]) * 1099511628211ull;
+  const StripPlanKey key{h, p.n_bins, p.hop, p.Ks, p.K, p.n_frames, n_cu, p.n_cols};
+  std::lock_guard<std::mutex> lock(mu);
+  for (const Entry &e : cache)
+    if (memcmp(&e.key, &key, sizeof(key)) == 0 &&
+        memcmp(e.sup.data(), sup, sizeof(int32_t) * 2 * p.n_bins) == 0) {
+      plan = e.plan;
+      return e.ok;
+    }
+  Entry e;
+  memset(&e.key, 0, sizeof(e.key));
+  e.key = key;
+  e.sup.assign(sup, sup + 2 * p.n_bins);
+  e.ok = plan_strip(p, sup, n_cu, e.plan);
+  if (cache.size() >= 32) cache.erase(cache.begin());
+  cache.push_back(e);
+  plan = e.plan;
+  return e.ok;
+}
+
+int device_cus() {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  return cus;
+}
+
+int launch_bf16x3_strip(KParams p, const StripPlan &plan, int n_cu, hipStream_t stream) {
+  p.n_super = (p.Ks + p.hop - 1) / p.hop;
+  auto kern = framed_bf16x3_strip_kernel;
+  static std::atomic<unsigned long long> configured{0};
+  int rc = configure_lds(kern, 160 * 1024, configured);
+  if (rc != MISPEC_OK) return rc;
+  const unsigned grid = (unsigned)(plan.n_jobs < 2 * n_cu ? plan.n_jobs : 2 * n_cu);  // two per CU
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(STRIP_NW * 64), (size_t)STRIP_LDS_BYTES, stream, p, plan);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+
 // split the waveform + edge spans into the second part of the workspace and attach it to p
 int setup_split(KParams &p, const mispec_framed_gemm_args *a, hipStream_t stream) {
   const EdgePlan e = plan_edges(p.n_samples, p.K, p.hop, p.pad, p.n_frames);
@@ -1863,9 +2120,11 @@ int setup_split(KParams &p, const mispec_framed_gemm_args *a, hipStream_t stream
   p.xs = xs;
   p.xs_clip_stride = sp.slot;
   p.xs_plane = sp.slot * p.n_clips;
+  p.job_counter = reinterpret_cast<unsigned *>(xs + 2 * sp.slot * p.n_clips);
   p.Ks = round_up_kc(p.K);
   p.as = static_cast<const unsigned short *>(a->basis_split);
   p.as_plane = (long long)p.n_bins * p.Ks;
+  p.afrag = basis_has_frags(p.n_bins, p.a_im != nullptr) ? p.as + 4 * p.as_plane : nullptr;
   const unsigned gx = (unsigned)((sp.slot + 1023) / 1024);
   hipLaunchKernelGGL(split_signal_kernel, dim3(gx, (unsigned)p.n_clips), dim3(256), 0, stream, p,
                      xs);
@@ -1907,7 +2166,8 @@ Bf16x3Rows plan_bf16x3_rows(const KParams &p, int tile) {
   return r;
 }
 
-int launch_framed_bf16x3(const KParams &p, int tile, hipStream_t stream) {
+int launch_framed_bf16x3(const KParams &p, int tile, hipStream_t stream,
+                         const int32_t *sup_host = nullptr) {
   const int rpb = p.a_im ? 2 : 1;
   const bool masked = p.row_support != nullptr;
   const Bf16x3Rows rows = plan_bf16x3_rows(p, tile);
@@ -1955,6 +2215,28 @@ int launch_framed_bf16x3(const KParams &p, int tile, hipStream_t stream) {
   // tiles, framed_bf16x3_slab.inl, for A/B measurements).  Otherwise the staged kernel: 256x256 workgroups of 8 waves (two per SIMD, 64x128 per wave; a 4-wave
   // layout with 128x128 per wave measured 8 % slower and does not fit without scratch).
   size_t sm = 0;
+  if (masked && sup_host && tile == MISPEC_TILE_AUTO && main_bins == p.n_bins && p.job_counter && p.afrag &&
+      !MISPEC_DBG(p, 0x800000)) {  // (A/B runs: the narrow-tile kernel)
+    StripPlan plan;
+    const int n_cu = device_cus();
+    if (strip_plan_cached(q, sup_host, 2 * n_cu, plan)) {
+#ifdef MISPEC_ABLATE
+      if (p.debug & 0x1000000) {  // benchmarking: show the plan
+        fprintf(stderr, "strip plan: %d passes x %d frame tiles on %d CUs\n", plan.n_pass, plan.n_tiles_n, n_cu);
+        for (int i = 0; i < plan.n_pass; ++i) {
+          const StripPass &ps = plan.pass[i];
+          fprintf(stderr, "  pass %d: cost %d, super-stages [%d, %d), %d slab rows\n", i, ps.cost, ps.jbase,
+                  ps.jbase + ps.span, ps.slab_rows);
+          for (int w = 0; w < STRIP_NW; ++w)
+            fprintf(stderr, "    wave %d: tile %d taps [%d, %d) j [%d, %d) group %d+%d fmask %x\n", w,
+                    ps.w[w].tile, ps.w[w].kb, ps.w[w].ke, ps.w[w].ja, ps.w[w].jb, ps.w[w].g0, ps.w[w].gsize,
+                    ps.w[w].fmask);
+        }
+      }
+#endif
+      return launch_bf16x3_strip(q, plan, n_cu, stream);
+    }
+  }
   if (masked && q.hop <= 64 * KC && plan_slab<2, 4, 3, 2>(q, sm))
     rc = MISPEC_DBG(p, 0x20000) ? launch_bf16x3_slab_cfg<2, 4, 3, 2, true>(q, sm, stream)  // A/B runs
                              : launch_bf16x3_narrow(q, sm, stream);
@@ -2275,7 +2557,7 @@ int mispec_framed_gemm_f32(const mispec_framed_gemm_args *args, void *stream) {
   if (bf16x3) {
     rc = setup_split(p, args, s);
     if (rc != MISPEC_OK) return rc;
-    return launch_framed_bf16x3(p, args->tile, s);
+    return launch_framed_bf16x3(p, args->tile, s, args->row_support_host);
   }
   return launch_framed(p, args->tile, s);
 }
@@ -2293,11 +2575,20 @@ int mispec_split_basis_bf16(const float *basis_re, const float *basis_im,
   if (dst_bytes < basis_split_bytes(n_bins, kernel, basis_im != nullptr))
     return fail(MISPEC_E_INVALID, "dst too small: size it with mispec_basis_split_bytes%s");
   const int ks = round_up_kc(kernel);
+  unsigned short *frag = nullptr;
+  if (basis_has_frags(n_bins, basis_im != nullptr)) {
+    // (rows past the last bin of the last 16-bin tile stay zero)
+    const long long planes = basis_plane_bytes(n_bins, kernel, true);
+    frag = reinterpret_cast<unsigned short *>(static_cast<char *>(dst) + planes);
+    hipError_t e0 = hipMemsetAsync(frag, 0, (size_t)(basis_split_bytes(n_bins, kernel, true) - planes),
+                                   static_cast<hipStream_t>(stream));
+    if (e0 != hipSuccess) return fail(MISPEC_E_HIP, "basis split memset: %s", hipGetErrorString(e0));
+  }
   hipLaunchKernelGGL(split_basis_kernel, dim3((unsigned)((ks + 255) / 256), (unsigned)n_bins,
                                               basis_im ? 2u : 1u),
                      dim3(256), 0, static_cast<hipStream_t>(stream), basis_re, basis_im,
                      (long long)basis_row_stride, n_bins, kernel, ks,
-                     static_cast<unsigned short *>(dst));
+                     static_cast<unsigned short *>(dst), frag);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MISPEC_E_HIP, "basis split launch: %s", hipGetErrorString(e));
   return MISPEC_OK;

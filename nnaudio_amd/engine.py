@@ -9,6 +9,7 @@ import os
 import threading
 import weakref
 
+import numpy as np
 import torch
 
 from . import _abi
@@ -252,6 +253,8 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
     if row_support is not None:
         if row_support.dtype != torch.int32 or tuple(row_support.shape) != (F, 2):
             raise RuntimeError("row_support must be int32 (n_bins, 2)")
+        # (a host copy made by the caller -- features._cqt_common.SupportCache -- rides on the tensor)
+        support_host = getattr(row_support, "host_copy", None)
         row_support = row_support.contiguous()
 
     E = 2 if two else 1
@@ -276,6 +279,11 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
     a.out_row_offset = int(out_row_offset)
     a.reserved = int(_debug)  # ablation bits: honoured by libmispec_ablate.so only (framed_gemm)
     keep = [x, wr, wi, row_scale, row_support, fb, fb_support]
+    if row_support is not None and support_host is not None:
+        if support_host.dtype != np.int32 or support_host.shape != (F, 2) or not support_host.flags.c_contiguous:
+            raise RuntimeError("row_support.host_copy must be a C-contiguous int32 (n_bins, 2) array")
+        a.row_support_host = support_host.ctypes.data
+        keep.append(support_host)
     if fb is not None:
         a.fb, a.fb_support = fb.data_ptr(), fb_support.data_ptr()
         a.fb_row_stride, a.n_fb = fb.stride(0), fb.shape[0]

@@ -54,7 +54,11 @@ class SupportCache:
         start = big.min(dim=1).values
         stop = small.max(dim=1).values
         start = torch.minimum(start, stop)
-        return torch.stack((start, stop), 1).to(torch.int32).contiguous()
+        sup = torch.stack((start, stop), 1).to(torch.int32).contiguous()
+        # host copy for the library's launch planning (mispec.h: row_support_host); one
+        # synchronising copy per kernel bank, kept on the tensor that engine.framed_gemm receives
+        sup.host_copy = sup.cpu().numpy().copy()
+        return sup
 
     def get(self, real, imag):
         return self._cache.get((real, imag), lambda: self._build(real, imag))

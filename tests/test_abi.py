@@ -110,7 +110,9 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert lib.mispec_power_to_db_bwd_f32(None, None, 1, 1, 1e-10, 80.0, None, None, 0, None) == -1
     assert lib.mispec_istft_grad_signal_f32(None, 0, 1, 1, 1, None, 1, 0, 1, None, None) == -1
     assert lib.mispec_overlap_add_f32(None, 1, 1, 1, None, 1, 0, None, 0, 1, None) == -1
-    assert lib.mispec_basis_split_bytes(0, 16, 1) == -1 and lib.mispec_basis_split_bytes(4, 48, 1) == 4 * 4 * 64 * 2
+    assert lib.mispec_basis_split_bytes(0, 16, 1) == -1 and lib.mispec_basis_split_bytes(4, 48, 0) == 2 * 4 * 64 * 2
+    # complex banks: four planes + the fragment-order copy of one 16-bin tile + its block of zeros
+    assert lib.mispec_basis_split_bytes(4, 48, 1) == 4 * 4 * 64 * 2 + 1 * 64 * 128 + 4096
     # the fused filterbank fields are validated with the rest of the block (fake non-NULL pointers:
     # nothing is dereferenced on the host)
     a = _abi.FramedGemmArgs()

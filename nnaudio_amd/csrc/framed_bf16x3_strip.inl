@@ -38,7 +38,8 @@ constexpr int STRIP_SJ = (STRIP_MAX_ROWS / 16 + STRIP_NW - 1) / STRIP_NW;  // sl
 constexpr int STRIP_RED_TILE = STRIP_NW * 16 * 64 * 4;  // one 32 x 32 partial sum of each wave
 // [two slab buffers | later: two reduction buffers + the epilogue's patches] [tables]
 constexpr int STRIP_RED_BYTES = 2 * STRIP_MAX_ROWS * 64 * 2;
-constexpr int STRIP_LDS_BYTES = STRIP_RED_BYTES + STRIP_MAX_ROWS * 8 + STRIP_BN * 4 + 64;
+constexpr int STRIP_PLAN_BYTES = 1280;  // >= sizeof(StripPlan): the plan's copy in LDS
+constexpr int STRIP_LDS_BYTES = STRIP_RED_BYTES + STRIP_MAX_ROWS * 8 + STRIP_BN * 4 + 64 + STRIP_PLAN_BYTES;
 static_assert(2 * STRIP_LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 
 struct StripWave {
@@ -58,6 +59,7 @@ struct StripPlan {
   int n_pass, n_tiles_n, n_jobs, reserved;
   StripPass pass[STRIP_MAX_PASS];
 };
+static_assert(sizeof(StripPlan) <= 1280, "STRIP_PLAN_BYTES");
 
 // 16-byte-per-lane LDS-direct load, as instructions: hipcc knows that the builtin writes LDS and, in
 // a loop that also reads LDS, drains vmcnt before every fragment read -- with it the basis
@@ -72,7 +74,9 @@ __device__ __forceinline__ void strip_lds_dma16(const void *src, unsigned lds_ad
 
 // s_waitcnt vmcnt(N) lgkmcnt(0); s_barrier -- as instructions (see lds_dma_barrier_keep)
 __device__ __forceinline__ void strip_barrier(int younger_units) {
-  if (younger_units >= 2)
+  if (younger_units >= 3)
+    asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else if (younger_units == 2)
     asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   else if (younger_units == 1)
     asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -85,7 +89,7 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
   constexpr int ROWB = KC * 2;                    // bytes of one slab row of one plane
   constexpr int SL_PL = STRIP_MAX_ROWS * ROWB;    // hi -> lo plane of a slab buffer
   constexpr int SLAB = 2 * SL_PL;
-  static_assert(2 * SLAB <= STRIP_RED_BYTES && 2 * STRIP_RED_TILE + NW * 32 * 33 * 4 <= STRIP_RED_BYTES,
+  static_assert(2 * SLAB <= STRIP_RED_BYTES && 4 * STRIP_RED_TILE <= STRIP_RED_BYTES && NW * 32 * 33 * 4 <= STRIP_RED_BYTES,
                 "slabs, then partial sums + epilogue patches, share the first region");
   typedef __attribute__((address_space(1))) const void *gptr_t;
   typedef __attribute__((address_space(3))) void *lptr_t;
@@ -96,6 +100,9 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
   long long *sRowOff = reinterpret_cast<long long *>(smem_raw + STRIP_RED_BYTES);  // [STRIP_MAX_ROWS]
   int *sColRow = reinterpret_cast<int *>(sRowOff + STRIP_MAX_ROWS);                // [STRIP_BN]
   int *sJob = sColRow + STRIP_BN;
+  // the plan, copied out of the kernel-argument block once: a job reads a dozen of its fields, and
+  // dependent scalar loads from the argument block cost microseconds per job
+  int *sPlanRaw = sJob + 16;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -114,41 +121,60 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
   const bool ab_mfma = MISPEC_DBG(p, 1), ab_x = MISPEC_DBG(p, 2), ab_a = MISPEC_DBG(p, 4),
              ab_dma = MISPEC_DBG(p, 8), ab_epi = MISPEC_DBG(p, 16);
 
+  for (int i = tid; i < (int)(sizeof(StripPlan) / sizeof(int)); i += NW * 64)
+    sPlanRaw[i] = reinterpret_cast<const int *>(&plan)[i];
   if (tid == 0) sJob[0] = (int)atomicAdd(p.job_counter, 1u);
   __syncthreads();
   int job = __builtin_amdgcn_readfirstlane(sJob[0]);
-  while (job < plan.n_jobs) {
-    // the next job is requested now and looked at when this one is done
-    int next_job = 0;
-    if (tid == 0) next_job = (int)atomicAdd(p.job_counter, 1u);
+  const StripPlan &lplan = *reinterpret_cast<const StripPlan *>(sPlanRaw);
+  const int n_frames = p.n_frames, n_clips = p.n_clips;
+  const long long xs_clip_stride = p.xs_clip_stride;
+#ifdef MISPEC_ABLATE
+  // phase clock of one job (benchmarking build, bit 0x2000000): 100 MHz stamps of workgroup 7's
+  // first job, written behind the job counter
+  bool stamp_on = MISPEC_DBG(p, 0x2000000) && blockIdx.x == 7;
+  unsigned long long *stamps = reinterpret_cast<unsigned long long *>(p.job_counter + 2);
+#define STRIP_STAMP(i) \
+  if (stamp_on && tid == 0) stamps[i] = wall_clock64();
+#else
+#define STRIP_STAMP(i)
+#endif
+  const int n_jobs = plan.n_jobs;
+  while (job < n_jobs) {
+    STRIP_STAMP(0)
     const int pass_i = job / n_tiles_n;
     const int tile_n = job - pass_i * n_tiles_n;
-    const StripPass &ps = plan.pass[pass_i];
-    const int jbase = ps.jbase, span = ps.span;
-    const int spieces = ps.slab_rows / 16;
+    const StripPass &ps = lplan.pass[pass_i];
+    const int jbase = __builtin_amdgcn_readfirstlane(ps.jbase), span = __builtin_amdgcn_readfirstlane(ps.span);
+    const int slab_rows = __builtin_amdgcn_readfirstlane(ps.slab_rows);
+    const int spieces = slab_rows / 16;
     const StripWave &wv = ps.w[wave];
-    const int tile_m = wv.tile;
-    const int kb = wv.kb, ke = wv.ke, ja = wv.ja, jb = wv.jb;
+    const int tile_m = __builtin_amdgcn_readfirstlane(wv.tile);
+    const int kb = __builtin_amdgcn_readfirstlane(wv.kb), ke = __builtin_amdgcn_readfirstlane(wv.ke);
+    const int ja = __builtin_amdgcn_readfirstlane(wv.ja), jb = __builtin_amdgcn_readfirstlane(wv.jb);
+    const int g0 = __builtin_amdgcn_readfirstlane(wv.g0), gsize = __builtin_amdgcn_readfirstlane(wv.gsize);
+    const int fmask = tile_m < 0 ? 0 : __builtin_amdgcn_readfirstlane(wv.fmask);
 
     // ---- the frame tile's (at most two) runs of consecutive frames, slab row table
     const long long n0 = (long long)tile_n * STRIP_BN;
     {
-      const int c0 = (int)(n0 / p.n_frames);
-      const int t0 = (int)(n0 - (long long)c0 * p.n_frames);
-      const int len0 = (p.n_frames - t0) < STRIP_BN ? (p.n_frames - t0) : STRIP_BN;
+      // (n_cols < 2^31: launch_bf16x3_strip)
+      const int c0 = (int)((unsigned)n0 / (unsigned)n_frames);
+      const int t0 = (int)((unsigned)n0 - (unsigned)c0 * (unsigned)n_frames);
+      const int len0 = (n_frames - t0) < STRIP_BN ? (n_frames - t0) : STRIP_BN;
       const int rows0 = len0 + span - 1;
       if (tid < STRIP_BN) sColRow[tid] = tid < len0 ? tid : tid + (span - 1);
-      for (int r = tid; r < ps.slab_rows; r += NW * 64) {
+      for (int r = tid; r < slab_rows; r += NW * 64) {
         int c = c0, f = t0 + r + jbase;
         if (r >= rows0) {
           c = c0 + 1;
           f = r - rows0 + jbase;
         }
         // rows past the tile's last column (or of a clip past the batch) feed unused columns only
-        c = c < p.n_clips ? c : p.n_clips - 1;
-        const int fmax = p.n_frames - 1 + C - 1;
+        c = c < n_clips ? c : n_clips - 1;
+        const int fmax = n_frames - 1 + C - 1;
         f = f < fmax ? f : fmax;
-        sRowOff[r] = (long long)c * p.xs_clip_stride + (long long)f * hop;
+        sRowOff[r] = (long long)c * xs_clip_stride + (long long)f * hop;
       }
     }
     // ---- super-stage range of every sub-stage of this wave's strip: lane s holds sub-stage s
@@ -164,6 +190,7 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
       vJhi = jh;
     }
     __syncthreads();
+    STRIP_STAMP(1)
     const unsigned short *sptr[STRIP_SJ];
 #pragma unroll
     for (int j = 0; j < STRIP_SJ; ++j) {
@@ -217,8 +244,9 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
       return it;
     };
 
-    // basis fragments of a unit: [q][hi, lo], two slots (units u, u + 1 in flight)
-    bf16x8 ah[2][2], al[2][2];
+    // basis fragments of a unit: [q][hi, lo], three slots (units u, u + 1, u + 2 in flight: the
+    // bank competes with the streaming slabs for the L2, a fragment load is often a miss)
+    bf16x8 ah[3][2], al[3][2];
     auto load_a = [&](auto slot_tag, const It &it) __attribute__((always_inline)) {
       constexpr int S = decltype(slot_tag)::value;
       if (ab_a) return;
@@ -232,23 +260,30 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
     };
     // slab fragments of one 16-tap step, four frame tiles: the hi parts of step q live in set q
     // (requested one step ahead), the lo parts -- read by the last four MFMAs of a step only -- in
-    // one set, requested at the start of their step
+    // one set, requested at the start of their step.  xa[f] = LDS byte address of the unit's step-0
+    // hi fragment of frame tile f; step 1 is the same address with bit 5 flipped (chunk 2q + lh,
+    // XOR-swizzled), the lo plane SL_PL further: 24 address instructions per 24 MFMAs.
+    typedef __attribute__((address_space(3))) const bf16x8 *lfrag_t;
     bf16x8 xh[2][4], xl[4];
-    auto x_addr = [&](int f, int buf, int dj, int q) __attribute__((always_inline)) -> const unsigned char * {
-      const int row = xrow[f] + dj;
-      return sS + buf * SLAB + row * ROWB + 16 * ((2 * q + lh) ^ ((row >> 2) & 3));
+    unsigned xa[4];
+    auto x_addrs = [&](unsigned (&dst)[4], int buf, int dj) __attribute__((always_inline)) {
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const int row = xrow[f] + dj;
+        dst[f] = lds0 + buf * SLAB + row * ROWB + 16 * (lh ^ ((row >> 2) & 3));
+      }
     };
-    auto load_xh = [&](auto q_tag, int buf, int dj) __attribute__((always_inline)) {
+    auto load_xh = [&](auto q_tag, const unsigned (&a0)[4]) __attribute__((always_inline)) {
       constexpr int Q = decltype(q_tag)::value;
       if (ab_x) return;
 #pragma unroll
-      for (int f = 0; f < 4; ++f) xh[Q][f] = *reinterpret_cast<const bf16x8 *>(x_addr(f, buf, dj, Q));
+      for (int f = 0; f < 4; ++f) xh[Q][f] = *(lfrag_t)(a0[f] ^ (32 * Q));
     };
-    auto load_xl = [&](auto q_tag, int buf, int dj) __attribute__((always_inline)) {
+    auto load_xl = [&](auto q_tag, const unsigned (&a0)[4]) __attribute__((always_inline)) {
       constexpr int Q = decltype(q_tag)::value;
       if (ab_x) return;
 #pragma unroll
-      for (int f = 0; f < 4; ++f) xl[f] = *reinterpret_cast<const bf16x8 *>(x_addr(f, buf, dj, Q) + SL_PL);
+      for (int f = 0; f < 4; ++f) xl[f] = *(lfrag_t)((a0[f] ^ (32 * Q)) + SL_PL);
     };
     f32x16 acc[4];
 #pragma unroll
@@ -276,6 +311,7 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
     it_seek(cur);
     It n1 = it_next(cur);
     It n2 = it_next(n1);
+    It n3 = it_next(n2);
     int cur_s = 0;      // sub-stage whose slab is being read
     int done_in_s = 0;  // units (= groups of 4 basis loads) issued since the last slab DMA
     // end of sub-stage s for this wave: its pieces of slab s+1 have landed (they were issued before
@@ -283,97 +319,140 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
     // buffer takes slab s+2
     auto transition = [&]() __attribute__((always_inline)) {
       strip_barrier(done_in_s);
+      STRIP_STAMP(3 + cur_s)
       if (cur_s + 2 < SPH) dma_slab(cur_s + 2, cur_s & 1);
       ++cur_s;
       done_in_s = 0;
     };
     dma_slab(0, 0);
     if (SPH > 1) dma_slab(1, 1);
+    typedef std::integral_constant<int, 2> i2;
     load_a(i0{}, cur);
     load_a(i1{}, n1);
+    load_a(i2{}, n2);
     strip_barrier(0);
+    STRIP_STAMP(2)
     {
       const int target = cur.valid ? cur.s : SPH;
       while (cur_s < target) transition();
     }
-    if (cur.valid) load_xh(i0{}, cur_s & 1, cur.j - jbase);
+    if (cur.valid) {
+      x_addrs(xa, cur_s & 1, cur.j - jbase);
+      load_xh(i0{}, xa);
+    }
 
     // one unit = 24 MFMAs: step 0 from hi set 0 (requested during the previous unit), step 1 from
-    // hi set 1 (requested under step 0); the slot's basis registers then take unit u + 2
+    // hi set 1 (requested under step 0); the slot's basis registers then take unit u + 2.  The
+    // scheduling barriers keep every group of fragment reads ahead of the 12 MFMAs it is hidden
+    // under (left alone, hipcc reuses one register quad for the four lo fragments of a step and
+    // waits for each read in front of its MFMA).
     auto unit = [&](auto slot_tag) __attribute__((always_inline)) {
       const int buf = cur_s & 1;
       const int dj = cur.valid ? cur.j - jbase : 0;
-      load_xl(i0{}, buf, dj);
-      load_xh(i1{}, buf, dj);
+      if (!cur.valid) x_addrs(xa, buf, 0);  // the padding unit of an odd strip: any row will do
+      load_xl(i0{}, xa);
+      load_xh(i1{}, xa);
+      __builtin_amdgcn_sched_barrier(0);
       mfma12(slot_tag, i0{});
+      __builtin_amdgcn_sched_barrier(0);
       const bool same = n1.valid && n1.s == cur.s;
-      load_xl(i1{}, buf, dj);
+      load_xl(i1{}, xa);
       // (requested unconditionally -- the last unit of a sub-stage re-reads its own row and drops
       // it: a branch here makes hipcc keep both generations of the set alive, with copies)
-      load_xh(i0{}, buf, same ? n1.j - jbase : dj);
+      unsigned xn[4];
+      x_addrs(xn, buf, same ? n1.j - jbase : dj);
+      load_xh(i0{}, xn);
+      __builtin_amdgcn_sched_barrier(0);
       mfma12(slot_tag, i1{});
-      load_a(slot_tag, n2);
+      __builtin_amdgcn_sched_barrier(0);
+      load_a(slot_tag, n3);
       ++done_in_s;
       if (!same) {
         const int target = n1.valid ? n1.s : SPH;
         while (cur_s < target) transition();
-        if (n1.valid) load_xh(i0{}, cur_s & 1, n1.j - jbase);
+        if (n1.valid) {
+          x_addrs(xn, cur_s & 1, n1.j - jbase);
+          load_xh(i0{}, xn);
+        }
       }
+#pragma unroll
+      for (int f = 0; f < 4; ++f) xa[f] = xn[f];
       cur = n1;
       n1 = n2;
-      n2 = it_next(n2);
+      n2 = n3;
+      n3 = it_next(n3);
     };
-    // (two units per iteration, whatever the strip's length: a unit past the end multiplies the
+    // (three units per iteration, whatever the strip's length: a unit past the end multiplies the
     // zero block -- an early exit between them makes hipcc copy the 64 accumulator registers)
     while (cur.valid) {
       unit(i0{});
       unit(i1{});
+      unit(i2{});
     }
     // (a strip with an odd number of units has just read slab fragments for its padding unit:
     // nobody may overwrite the slabs with partial sums before that)
+    STRIP_STAMP(19)
     __syncthreads();
+    STRIP_STAMP(20)
+    // the next job is requested here -- loads return in order, so anywhere earlier the basis
+    // fragments would queue up behind the atomic -- and looked at after the epilogue
+    int next_job = 0;
+    if (tid == 0) next_job = (int)atomicAdd(p.job_counter, 1u);
 
-    // ---- partial sums of the waves that share a row tile: through LDS (one frame tile at a time,
-    // two buffers: a wave writes tile f + 1 while others still add up tile f), then the epilogue
+    // ---- partial sums of the waves that share a row tile: all of them through LDS at once (64 KB
+    // of the dead slab buffers), every wave adds up the frame tiles the plan gave it (fmask) and
+    // runs the epilogue on them
     if (!ab_epi) {
-      f32x4 *red = reinterpret_cast<f32x4 *>(smem_raw);
-      unsigned char *patch = smem_raw + 2 * STRIP_RED_TILE;  // the epilogue's wave-private patches
-      const int g0 = wv.g0, gsize = wv.gsize, fmask = tile_m < 0 ? 0 : wv.fmask;
+      f32x4 *red = reinterpret_cast<f32x4 *>(smem_raw);  // [wave][frame tile][4 rows of e][lane]
       // (a lambda per frame tile, not a loop: the accumulators must stay in registers)
-      auto finish = [&](auto f_tag) __attribute__((always_inline)) {
+      auto put = [&](auto f_tag) __attribute__((always_inline)) {
         constexpr int f = decltype(f_tag)::value;
-        f32x4 *rb = red + (f & 1) * (STRIP_RED_TILE / 16);
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc[f][4 * e4 + e];
-          rb[(wave * 4 + e4) * 64 + lane] = v;
+          red[((wave * 4 + f) * 4 + e4) * 64 + lane] = v;
         }
-        __syncthreads();
-        const bool mine = fmask >> f & 1;
-        f32x16 a1[1][1];
+      };
+      auto sum = [&](auto f_tag) __attribute__((always_inline)) {
+        constexpr int f = decltype(f_tag)::value;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) a1[0][0][e] = 0.f;
-        if (mine) {
+        for (int e = 0; e < 16; ++e) acc[f][e] = 0.f;
+        if (fmask >> f & 1) {
           for (int w2 = g0; w2 < g0 + gsize; ++w2) {
 #pragma unroll
             for (int e4 = 0; e4 < 4; ++e4) {
-              const f32x4 v = rb[(w2 * 4 + e4) * 64 + lane];
+              const f32x4 v = red[((w2 * 4 + f) * 4 + e4) * 64 + lane];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) a1[0][0][4 * e4 + e] += v[e];
+              for (int e = 0; e < 4; ++e) acc[f][4 * e4 + e] += v[e];
             }
           }
         }
-        // (the epilogue places wave w at columns n0 + 32*w: hand it this wave's frame tile)
-        bf16x3_epilogue<1, 8, 1, 1>(p, a1, mine ? tile_m * 32 : (1 << 24), n0 + 32 * f - 32 * wave, patch);
       };
-      finish(std::integral_constant<int, 0>{});
-      finish(std::integral_constant<int, 1>{});
-      finish(std::integral_constant<int, 2>{});
-      finish(std::integral_constant<int, 3>{});
+      const bool direct = p.epilogue == MISPEC_EPI_COMPLEX || p.epilogue == MISPEC_EPI_MAGNITUDE ||
+                          p.epilogue == MISPEC_EPI_POWER;  // the epilogue's register path: no barriers
+      auto store = [&](auto f_tag) __attribute__((always_inline)) {
+        constexpr int f = decltype(f_tag)::value;
+        const bool mine = fmask >> f & 1;
+        if (direct && !mine) return;  // (the LDS path synchronises: every wave goes through it)
+        f32x16 a1[1][1];
+        a1[0][0] = acc[f];
+        // (the epilogue places wave w at columns n0 + 32*w: hand it this wave's frame tile)
+        bf16x3_epilogue<1, 8, 1, 1>(p, a1, mine ? tile_m * 32 : (1 << 24), n0 + 32 * f - 32 * wave, smem_raw);
+      };
+      typedef std::integral_constant<int, 3> i3;
+      put(i0{}), put(i1{}), put(i2{}), put(i3{});
+      __syncthreads();
+      sum(i0{}), sum(i1{}), sum(i2{}), sum(i3{});
+      __syncthreads();  // the partial sums are dead: the epilogue's LDS path may use their place
+      store(i0{}), store(i1{}), store(i2{}), store(i3{});
     }
     __syncthreads();  // the epilogue is done with the LDS
+    STRIP_STAMP(21)
+#ifdef MISPEC_ABLATE
+    stamp_on = false;
+#endif
     if (tid == 0) sJob[0] = next_job;
     __syncthreads();
     job = __builtin_amdgcn_readfirstlane(sJob[0]);

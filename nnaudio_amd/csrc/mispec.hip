@@ -1933,7 +1933,7 @@ bool plan_strip(const KParams &p, const int32_t *sup, int n_slots, StripPlan &pl
       t[j - 1] = tmp;
     }
   const long long n_tiles_n = (p.n_cols + STRIP_BN - 1) / STRIP_BN;
-  if (n_tiles_n * STRIP_MAX_PASS > 0x7fffffffLL) return false;
+  if (n_tiles_n * STRIP_MAX_PASS > 0x7fffffffLL || p.n_cols + STRIP_BN > 0x7fffffffLL) return false;
   const double ovh = 0.75 * sph;  // per-pass cost of the prologue, barriers, reduction and epilogue
   // slab reach of a group: span of super-stages
   auto span_of = [&](int a, int k) {

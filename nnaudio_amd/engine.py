@@ -310,7 +310,13 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
             ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
             a.workspace, a.workspace_bytes = ws.data_ptr(), need
             keep.append(ws)
+            if a.reserved:  # benchmarking build: scripts read the phase clocks behind the job counter
+                global _last_workspace
+                _last_workspace = (ws, need)
     return a, out, dev, keep
+
+
+_last_workspace = None
 
 
 def split_basis(basis_re, basis_im):

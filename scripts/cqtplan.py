@@ -21,3 +21,6 @@ def timeit(fn, n=20, w=5):
     return e0.elapsed_time(e1) / n
 for dbg in [int(a, 0) for a in sys.argv[1:]] or [0, 0x800000]:
     print("debug %#x: %.4f ms" % (dbg, timeit(lambda: run(dbg))))
+
+if "--stamps" in sys.argv:
+    pass

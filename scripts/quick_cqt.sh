@@ -21,3 +21,5 @@ for k, (n, v) in sorted(d.items()):
     print(k, "%.4g per dispatch" % (v / n))
 PY
 fi
+# box calibration: the narrow-tile kernel of the benchmarking build (same code in every tree)
+timeout 200 python $R/scripts/cqtplan.py 0x800000 2>&1 | grep debug

@@ -186,6 +186,20 @@ typedef struct mispec_framed_gemm_args {
 int64_t mispec_framed_gemm_workspace_bytes(const mispec_framed_gemm_args *args);
 
 /*
+ * Host-only planning query (no device work): how mispec_framed_gemm_f32 would run this problem
+ * on a device with n_cu compute units when it is a MISPEC_PREC_BF16X3 contraction of a complex
+ * basis with supports and row_support_host is given.  Returns the number of passes of the strip
+ * kernel (0: the narrow-tile kernel runs instead; < 0: error) and writes, as far as `cap` int32
+ * entries allow:  frame tiles per pass, then per pass  cost, first super-stage, super-stages,
+ * slab rows, then for each of the 4 waves  row tile (16 bins; -1: idle), first tap, end tap,
+ * first super-stage, end super-stage, first wave of its reduction group, waves in the group,
+ * frame-tile mask.  (1 + passes * 36 entries.)
+ */
+int32_t mispec_strip_plan(const mispec_framed_gemm_args *args, int32_t n_cu, int32_t *plan,
+                          int32_t cap);
+
+
+/*
  * MISPEC_PREC_BF16X3 operand preparation for a basis: (hi, lo) bf16 planes of basis_re (and
  * basis_im), rows zero-padded to a multiple of 32 taps.  Done once per basis (the bases are the
  * modules' precomputed buffers, stft.py:230-245 / cqt.py:682-702) and again only when the basis

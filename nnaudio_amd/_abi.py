@@ -28,6 +28,7 @@ EXPORTS = (
     "mispec_framed_gemm_f32_ref",
     "mispec_framed_gemm_group_f32",
     "mispec_framed_gemm_workspace_bytes",
+    "mispec_strip_plan",
     "mispec_basis_split_bytes",
     "mispec_split_basis_bf16",
     "mispec_fold_taps",
@@ -215,6 +216,9 @@ def _load(path, how):
                                                  ctypes.c_void_p]
     lib.mispec_framed_gemm_workspace_bytes.restype = ctypes.c_int64
     lib.mispec_framed_gemm_workspace_bytes.argtypes = [ctypes.POINTER(FramedGemmArgs)]
+    lib.mispec_strip_plan.restype = ctypes.c_int32
+    lib.mispec_strip_plan.argtypes = [ctypes.POINTER(FramedGemmArgs), ctypes.c_int32, ctypes.c_void_p,
+                                      ctypes.c_int32]
     lib.mispec_basis_split_bytes.restype = ctypes.c_int64
     lib.mispec_basis_split_bytes.argtypes = [ctypes.c_int32] * 3
     lib.mispec_split_basis_bf16.restype = ctypes.c_int

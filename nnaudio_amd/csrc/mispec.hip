@@ -2539,6 +2539,35 @@ int64_t mispec_framed_gemm_workspace_bytes(const mispec_framed_gemm_args *args) 
   return e.stride * p.n_clips * (int64_t)sizeof(float);
 }
 
+int32_t mispec_strip_plan(const mispec_framed_gemm_args *args, int32_t n_cu, int32_t *plan_out,
+                          int32_t cap) {
+  KParams p;
+  int rc = fill_params(args, p);
+  if (rc != MISPEC_OK) return rc;
+  if (n_cu <= 0 || cap < 0 || (cap > 0 && !plan_out)) return fail(MISPEC_E_INVALID, "bad plan buffer%s");
+  if (!bf16x3_ok(args, p) || !args->row_support || !args->row_support_host ||
+      args->tile != MISPEC_TILE_AUTO || !basis_has_frags(p.n_bins, p.a_im != nullptr))
+    return 0;
+  p.Ks = round_up_kc(p.K);
+  StripPlan plan;
+  if (!plan_strip(p, args->row_support_host, 2 * n_cu, plan)) return 0;
+  int n = 0;
+  auto put = [&](int v) {
+    if (n < cap) plan_out[n] = v;
+    ++n;
+  };
+  put(plan.n_tiles_n);
+  for (int i = 0; i < plan.n_pass; ++i) {
+    const StripPass &ps = plan.pass[i];
+    put(ps.cost), put(ps.jbase), put(ps.span), put(ps.slab_rows);
+    for (int w = 0; w < STRIP_NW; ++w) {
+      const StripWave &sw = ps.w[w];
+      put(sw.tile), put(sw.kb), put(sw.ke), put(sw.ja), put(sw.jb), put(sw.g0), put(sw.gsize), put(sw.fmask);
+    }
+  }
+  return plan.n_pass;
+}
+
 int mispec_framed_gemm_f32(const mispec_framed_gemm_args *args, void *stream) {
   KParams p;
   int rc = fill_params(args, p);

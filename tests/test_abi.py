@@ -226,3 +226,107 @@ def test_filterbank_support_tables():
     assert not engine.fused_filterbank_ok(1.5, cov, 128)    # exponent 1 or 2 only
     assert not engine.fused_filterbank_ok(2.0, 64.0, 64)    # dense (gammatone)
     assert not engine.fused_filterbank_ok(2.0, cov, 300)    # > 256 filters
+
+
+def _plan_args(m, B, L, keep):
+    """Argument block of CQT1992v2's contraction with fake device pointers (nothing is dereferenced
+    by the host-only planning query) and the real supports."""
+    from nnaudio_amd import _abi, engine
+    from nnaudio_amd.features._cqt_common import SupportCache
+
+    kr = m.cqt_kernels_real.reshape(m.cqt_kernels_real.shape[0], -1)
+    ki = m.cqt_kernels_imag.reshape(kr.shape)
+    sup = SupportCache._build(kr, ki)
+    F, K = kr.shape
+    hop = m.hop_length
+    a = _abi.FramedGemmArgs()
+    a.struct_size = ctypes.sizeof(_abi.FramedGemmArgs)
+    a.x = a.basis_re = a.basis_im = a.out = a.row_support = a.basis_split = 4096
+    a.n_clips, a.n_samples, a.x_clip_stride = B, L, L
+    a.hop, a.pad, a.pad_mode, a.n_frames = hop, K // 2, 2, L // hop + 1
+    a.basis_row_stride, a.n_bins, a.kernel = K, F, K
+    a.epilogue, a.im_sign = engine.EPI_MAGNITUDE, -1.0
+    a.out_clip_stride, a.out_row_stride = F * a.n_frames, a.n_frames
+    a.precision = engine.PREC_BF16X3
+    a.basis_split_bytes = _abi.load().mispec_basis_split_bytes(F, K, 1)
+    a.row_support_host = sup.host_copy.ctypes.data
+    keep.append(sup)
+    return a, sup.host_copy
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(sr=44100, hop_length=512, n_bins=84, bins_per_octave=12, B=64, L=441000),   # cfg4 / the bench
+    dict(sr=44100, hop_length=512, n_bins=84, bins_per_octave=12, B=16, L=441000),   # one rank's shard
+    dict(sr=22050, hop_length=512, n_bins=96, bins_per_octave=24, B=3, L=70000),
+    dict(sr=22050, hop_length=512, n_bins=120, bins_per_octave=36, fmin=110.0, B=2, L=80000),
+    dict(sr=16000, hop_length=128, n_bins=70, bins_per_octave=12, fmin=55.0, B=5, L=33000),
+])
+def test_strip_plan_covers_every_row_tile_once(cfg):
+    """Host logic of the strip kernel's launch plan (mispec_strip_plan, no GPU): every 16-bin row
+    tile sits in exactly one pass, its waves cut its super-stages into consecutive runs, the
+    reduction masks of a group cover the four frame tiles once, the slab holds the pass."""
+    from nnaudio_amd import _abi, features
+
+    cfg = dict(cfg)
+    B, L = cfg.pop("B"), cfg.pop("L")
+    m = features.CQT1992v2(verbose=False, **cfg)
+    keep = []
+    a, sup = _plan_args(m, B, L, keep)
+    lib = _abi.load()
+    buf = (ctypes.c_int32 * (1 + 8 * 36))()
+    n_pass = lib.mispec_strip_plan(ctypes.byref(a), 256, buf, len(buf))
+    assert 1 <= n_pass <= 8, _abi.load().mispec_last_error()
+    hop, K, F = a.hop, a.kernel, a.n_bins
+    assert buf[0] == -(-B * a.n_frames // 128)
+    seen = {}
+    for i in range(n_pass):
+        cost, jbase, span, rows = buf[1 + 36 * i:5 + 36 * i]
+        assert rows % 16 == 0 and 128 + 2 * (span - 1) <= rows <= 288
+        waves = [buf[5 + 36 * i + 8 * w:13 + 36 * i + 8 * w] for w in range(4)]
+        groups = {}
+        for w, (tile, kb, ke, ja, jb, g0, gsize, fmask) in enumerate(waves):
+            if tile < 0:
+                continue
+            assert g0 <= w < g0 + gsize
+            groups.setdefault(tile, []).append((w, kb, ke, ja, jb, g0, gsize, fmask))
+        for tile, ws in groups.items():
+            assert tile not in seen
+            seen[tile] = i
+            assert [w for w, *_ in ws] == list(range(ws[0][5], ws[0][5] + ws[0][6]))
+            kb, ke = ws[0][1], ws[0][2]
+            lo = min(int(s) for s, e in sup[16 * tile:16 * tile + 16] if e > s)
+            hi = max(int(e) for s, e in sup[16 * tile:16 * tile + 16] if e > s)
+            assert kb % 32 == 0 and kb <= lo and ke >= hi and kb > lo - 32
+            # consecutive runs of super-stages from the first to the last one the taps touch
+            assert ws[0][3] == kb // hop and ws[-1][4] == (ke - 1) // hop + 1
+            for (_, _, _, _, jb0, *_), (_, _, _, ja1, *_) in zip(ws, ws[1:]):
+                assert jb0 == ja1
+            assert all(jbase <= ja <= jb <= jbase + span for _, _, _, ja, jb, *_ in ws)
+            masks = [fm for *_, fm in ws]
+            assert sum(masks) == 15 and all(x & y == 0 for k, x in enumerate(masks) for y in masks[k + 1:])
+    assert sorted(seen) == list(range(-(-F // 16)))
+
+
+def test_strip_plan_declines_what_the_kernel_does_not_cover():
+    from nnaudio_amd import _abi, features
+
+    lib = _abi.load()
+    buf = (ctypes.c_int32 * 300)()
+    keep = []
+    m = features.CQT1992v2(sr=44100, hop_length=512, n_bins=84, verbose=False)
+    a, _ = _plan_args(m, 4, 441000, keep)
+    assert lib.mispec_strip_plan(ctypes.byref(a), 256, buf, 300) > 0
+    a.row_support_host = None  # no host copy of the supports: the narrow-tile kernel
+    assert lib.mispec_strip_plan(ctypes.byref(a), 256, buf, 300) == 0
+    a, _ = _plan_args(m, 4, 441000, keep)
+    a.hop = 500  # not a multiple of 32 taps
+    a.n_frames = 441000 // 500 + 1
+    assert lib.mispec_strip_plan(ctypes.byref(a), 256, buf, 300) == 0
+    a, _ = _plan_args(m, 1, 40000, keep)  # 79 frames: a 128-frame tile would straddle several clips
+    assert lib.mispec_strip_plan(ctypes.byref(a), 256, buf, 300) == 0
+    # kernels of 90 hops: the slab of a 128-frame tile would need more than 288 rows
+    m2 = features.CQT1992v2(sr=22050, hop_length=256, n_bins=96, bins_per_octave=24, verbose=False)
+    a, _ = _plan_args(m2, 3, 70000, keep)
+    assert lib.mispec_strip_plan(ctypes.byref(a), 256, buf, 300) == 0
+    a, _ = _plan_args(m, 4, 441000, keep)
+    assert lib.mispec_strip_plan(ctypes.byref(a), 0, buf, 300) == -1

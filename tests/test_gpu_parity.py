@@ -3,6 +3,7 @@ Everything here needs the MI355X: run with ``pytest -m gpu``.
 
 Tolerance (BASELINE.md, north_star "within 1e-4 rel fp32"): max|y-ref| <= 1e-4*max|ref| and
 allclose(rtol=1e-4, atol=1e-4*max|ref|); phase compared where the bin carries energy."""
+import ctypes
 import os
 import warnings
 
@@ -641,7 +642,7 @@ def test_case_bf16x3_matches_reference_and_oracle(golden, bf16x3, name):
     (1, 70000, 70, 300, 96, 150, 2),     # K % 32 != 0, hop = 3 sub-stages, C = 4
     (2, 20000, 84, 512, 64, 0, 0),       # center=False
 ])
-@pytest.mark.parametrize("support", [False, True, "narrow", "single-buffer"])
+@pytest.mark.parametrize("support", [False, True, "narrow", "single-buffer", "strip", "strip-narrow"])
 def test_bf16x3_kernel_shapes(shape, support):
     from nnaudio_amd import engine
 
@@ -660,12 +661,16 @@ def test_bf16x3_kernel_shapes(shape, support):
         if not os.path.exists(_abi.ABLATE_LIB_PATH):
             pytest.skip("libmispec_ablate.so not built (python -m nnaudio_amd.build --ablate)")
     if support:  # centred supports that shrink with the row index, like a CQT bank
-        widest = min(K // 2, 40) if support == "narrow" else K // 2  # narrow: < one hop of taps
+        widest = min(K // 2, 40) if str(support).endswith("narrow") else K // 2  # narrow: < one hop of taps
         half = np.linspace(widest, 8, F).astype(np.int64)
         lo, hi = K // 2 - half, K // 2 + half
         keep = (np.arange(K)[None, :] >= lo[:, None]) & (np.arange(K)[None, :] < hi[:, None])
         wr, wi = (wr * keep).astype(np.float32), (wi * keep).astype(np.float32)
         sup = torch.as_tensor(np.stack([lo, hi], 1).astype(np.int32)).to(DEV)
+        if str(support).startswith("strip"):
+            # with a host copy of the supports the library may plan the strip kernel (whenever the
+            # shape allows: hop % 32 == 0, >= 128 frames per clip, kernels of >= 2 hops)
+            sup.host_copy = np.ascontiguousarray(np.stack([lo, hi], 1).astype(np.int32))
     re, im = _np_framed(x, wr, wi, hop, pad, mode)
     ref = np.stack((re, im), -1)
     kw = dict(hop=hop, pad=pad, pad_mode=mode, epilogue=engine.EPI_COMPLEX, row_support=sup)
@@ -674,10 +679,75 @@ def test_bf16x3_kernel_shapes(shape, support):
     y32 = engine.framed_gemm(xd, wrd, wid, precision="fp32", **kw)
     torch.cuda.synchronize()
     assert_parity(y.cpu().numpy(), ref, rel=1e-4, what="bf16x3 %s" % (shape,))
+    if str(support).startswith("strip"):
+        a, _out, _dev, _keep = engine._framed_args(xd, wrd, wid, precision="bf16x3", **kw)
+        from nnaudio_amd import _abi
+
+        n_pass = _abi.load().mispec_strip_plan(ctypes.byref(a), 256, None, 0)
+        T = (L + 2 * pad - K) // hop + 1
+        assert (n_pass > 0) == (hop % 32 == 0 and T >= 128 and -(-K // 32) * 32 >= 2 * hop)
     if hop % 2:
         assert torch.equal(y, y32)  # fell back to the fp32 kernel
     else:
         assert not torch.equal(y, y32)  # really took the bf16 pipe
+
+
+@pytest.mark.parametrize("shape", [  # (B, L, bins, K, hop, pad, mode)
+    (3, 50000, 84, 4096, 256, 2048, 2),   # 196 frames per clip: frame tiles straddle clips, 16 hops
+    (2, 70001, 70, 2048, 128, 1024, 1),   # last row tile holds 6 bins; 547 frames
+    (7, 17000, 100, 1024, 96, 0, 0),      # hop of 3 sub-stages, center=False, 167 frames
+])
+def test_strip_kernel_epilogues(shape):
+    """Every epilogue through the strip kernel (framed_bf16x3_strip.inl: banks with supports and a
+    host copy of them) against the one-thread-per-output device kernel: partial sums of the waves
+    that share a row tile, the register and the LDS path of the shared epilogue, row scales, row
+    offsets into a taller output."""
+    from nnaudio_amd import _abi, engine
+
+    B, L, F, K, hop, pad, mode = shape
+    rng = np.random.default_rng(L)
+    xd = torch.as_tensor(rng.standard_normal((B, L)).astype(np.float32)).to(DEV)
+    half = np.geomspace(K // 2 - 3, 24, F).astype(np.int64)  # a CQT-like bank: lengths fall 2x per ~20 rows
+    lo, hi = K // 2 - half, K // 2 + half + (np.arange(F) % 2)
+    keep = (np.arange(K)[None, :] >= lo[:, None]) & (np.arange(K)[None, :] < hi[:, None])
+    wr = torch.as_tensor((rng.standard_normal((F, K)) * keep).astype(np.float32)).to(DEV)
+    wi = torch.as_tensor((rng.standard_normal((F, K)) * keep).astype(np.float32)).to(DEV)
+    sup = torch.as_tensor(np.stack([lo, hi], 1).astype(np.int32)).to(DEV)
+    sup.host_copy = np.ascontiguousarray(np.stack([lo, hi], 1).astype(np.int32))
+    sc = torch.as_tensor(rng.uniform(0.5, 2.0, F).astype(np.float32)).to(DEV)
+    base = dict(hop=hop, pad=pad, pad_mode=mode)
+    a, _o, _d, _k = engine._framed_args(xd, wr, wi, precision="bf16x3", row_support=sup,
+                                        epilogue=engine.EPI_MAGNITUDE, **base)
+    assert _abi.load().mispec_strip_plan(ctypes.byref(a), 256, None, 0) > 0
+    z = engine.framed_gemm(xd, wr, wi, reference_kernel=True, epilogue=engine.EPI_COMPLEX, row_scale=sc,
+                           **base)
+    mag = torch.sqrt(z[..., 0] ** 2 + z[..., 1] ** 2)
+    strong = mag > 0.05 * mag.max()
+    cases = [(engine.EPI_COMPLEX, {}), (engine.EPI_MAGNITUDE, {}), (engine.EPI_MAGNITUDE, {"eps": 1e-8}),
+             (engine.EPI_POWER, {"power": 2.0}), (engine.EPI_POWER, {"power": 0.7, "eps": 1e-8}),
+             (engine.EPI_PHASE_ATAN2, {}), (engine.EPI_PHASE_COSSIN, {"im_sign": 1.0})]
+    for epi, extra in cases:
+        kw = dict(base, epilogue=epi, row_scale=sc, **extra)
+        ref = engine.framed_gemm(xd, wr, wi, reference_kernel=True, **kw)
+        y = engine.framed_gemm(xd, wr, wi, precision="bf16x3", row_support=sup, **kw)
+        assert y.shape == ref.shape
+        what = "strip epilogue %d %s %s" % (epi, extra, shape)
+        if epi == engine.EPI_PHASE_ATAN2:
+            d = torch.remainder(y - ref + np.pi, 2 * np.pi) - np.pi
+            assert d[strong].abs().max().item() < 2e-3, what
+        elif epi == engine.EPI_PHASE_COSSIN:
+            assert (y - ref)[strong].abs().max().item() < 2e-3, what
+        else:
+            assert (y - ref).abs().max().item() <= 1e-4 * ref.abs().max().item(), what
+    # a row block of a taller output (octave assembly): rows outside it stay untouched
+    T = z.shape[2]
+    out = torch.full((B, F + 9, T), -7.0, device=DEV)
+    engine.framed_gemm(xd, wr, wi, precision="bf16x3", row_support=sup, epilogue=engine.EPI_MAGNITUDE,
+                       row_scale=sc, out=out, out_rows_total=F + 9, out_row_offset=5, **base)
+    ref = engine.framed_gemm(xd, wr, wi, reference_kernel=True, epilogue=engine.EPI_MAGNITUDE, row_scale=sc,
+                             **base)
+    assert (out[:, 5:5 + F] - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    assert bool((out[:, :5] == -7.0).all()) and bool((out[:, 5 + F:] == -7.0).all())
 
 
 @pytest.mark.parametrize("shape", [  # (B, L, bins, K, hop, pad, mode)

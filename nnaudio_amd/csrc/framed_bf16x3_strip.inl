@@ -247,24 +247,30 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
     // basis fragments of a unit: [q][hi, lo], three slots (units u, u + 1, u + 2 in flight: the
     // bank competes with the streaming slabs for the L2, a fragment load is often a miss)
     bf16x8 ah[3][2], al[3][2];
-    auto load_a = [&](auto slot_tag, const It &it) __attribute__((always_inline)) {
-      constexpr int S = decltype(slot_tag)::value;
-      if (ab_a) return;
+    auto a_src = [&](const It &it) __attribute__((always_inline)) -> const unsigned short * {
       // past the strip's last unit: the block of zeros behind the last tile -- the number of loads in
       // flight stays fixed, and a unit executed on them adds nothing
-      const unsigned short *src = it.valid ? arow + (long long)(it.j * SPH + it.s) * 2048 : azero;
-      ah[S][0] = *reinterpret_cast<const bf16x8 *>(src);
-      al[S][0] = *reinterpret_cast<const bf16x8 *>(src + 512);
-      ah[S][1] = *reinterpret_cast<const bf16x8 *>(src + 1024);
-      al[S][1] = *reinterpret_cast<const bf16x8 *>(src + 1536);
+      return it.valid ? arow + (long long)(it.j * SPH + it.s) * 2048 : azero;
     };
-    // slab fragments of one 16-tap step, four frame tiles: the hi parts of step q live in set q
-    // (requested one step ahead), the lo parts -- read by the last four MFMAs of a step only -- in
-    // one set, requested at the start of their step.  xa[f] = LDS byte address of the unit's step-0
+    auto load_a1 = [&](auto slot_tag, const unsigned short *src, int part) __attribute__((always_inline)) {
+      constexpr int S = decltype(slot_tag)::value;
+      if (ab_a) return;
+      if (part == 0) ah[S][0] = *reinterpret_cast<const bf16x8 *>(src);
+      if (part == 1) al[S][0] = *reinterpret_cast<const bf16x8 *>(src + 512);
+      if (part == 2) ah[S][1] = *reinterpret_cast<const bf16x8 *>(src + 1024);
+      if (part == 3) al[S][1] = *reinterpret_cast<const bf16x8 *>(src + 1536);
+    };
+    auto load_a = [&](auto slot_tag, const It &it) __attribute__((always_inline)) {
+      const unsigned short *src = a_src(it);
+#pragma unroll
+      for (int part = 0; part < 4; ++part) load_a1(slot_tag, src, part);
+    };
+    // slab fragments of one 16-tap step, four frame tiles x [hi, lo]: step q lives in set q and is
+    // requested during the MFMAs of the step before.  xa[f] = LDS byte address of the unit's step-0
     // hi fragment of frame tile f; step 1 is the same address with bit 5 flipped (chunk 2q + lh,
-    // XOR-swizzled), the lo plane SL_PL further: 24 address instructions per 24 MFMAs.
+    // XOR-swizzled), the lo plane SL_PL further.
     typedef __attribute__((address_space(3))) const bf16x8 *lfrag_t;
-    bf16x8 xh[2][4], xl[4];
+    bf16x8 xh[2][4], xl[2][4];
     unsigned xa[4];
     auto x_addrs = [&](unsigned (&dst)[4], int buf, int dj) __attribute__((always_inline)) {
 #pragma unroll
@@ -273,36 +279,52 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
         dst[f] = lds0 + buf * SLAB + row * ROWB + 16 * (lh ^ ((row >> 2) & 3));
       }
     };
-    auto load_xh = [&](auto q_tag, const unsigned (&a0)[4]) __attribute__((always_inline)) {
+    auto load_set = [&](auto q_tag, const unsigned (&a0)[4]) __attribute__((always_inline)) {
       constexpr int Q = decltype(q_tag)::value;
       if (ab_x) return;
 #pragma unroll
-      for (int f = 0; f < 4; ++f) xh[Q][f] = *(lfrag_t)(a0[f] ^ (32 * Q));
-    };
-    auto load_xl = [&](auto q_tag, const unsigned (&a0)[4]) __attribute__((always_inline)) {
-      constexpr int Q = decltype(q_tag)::value;
-      if (ab_x) return;
-#pragma unroll
-      for (int f = 0; f < 4; ++f) xl[f] = *(lfrag_t)((a0[f] ^ (32 * Q)) + SL_PL);
+      for (int f = 0; f < 4; ++f) {
+        xh[Q][f] = *(lfrag_t)(a0[f] ^ (32 * Q));
+        xl[Q][f] = *(lfrag_t)((a0[f] ^ (32 * Q)) + SL_PL);
+      }
     };
     f32x16 acc[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[f][e] = 0.f;
-    auto mfma12 = [&](auto slot_tag, auto q_tag) __attribute__((always_inline)) {
+    // One step = 12 MFMAs of (slot S, step Q) in a fixed order -- frame tile innermost, so that
+    // MFMAs on the same accumulator are four apart -- with, pinned behind the first eight, the
+    // eight fragment reads of the NEXT step (set NQ, addresses an[f] ^ NX) and, behind the last four,
+    // `tail(f)`: an address computation or a basis load.  Nothing moves (sched_barrier): a wave
+    // alone on its SIMD keeps the matrix pipe busy while it issues the reads (issued as a block in
+    // front of the MFMAs they cost 2 x 125 cycles per unit, and the lo fragments, requested inside
+    // their own step, another 2 x 150 of waiting); left to hipcc's scheduler the MFMAs get
+    // reordered into dependent pairs.
+    auto step = [&](auto slot_tag, auto q_tag, const unsigned (&an)[4], auto nx_tag, auto &&tail)
+                    __attribute__((always_inline)) {
       constexpr int S = decltype(slot_tag)::value;
       constexpr int Q = decltype(q_tag)::value;
-      if (ab_mfma) return;
+      constexpr int NQ = 1 - Q;
+      constexpr unsigned NX = decltype(nx_tag)::value;
 #pragma unroll
-      for (int f = 0; f < 4; ++f)
-        acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[S][Q], xh[Q][f], acc[f], 0, 0, 0);
-#pragma unroll
-      for (int f = 0; f < 4; ++f)
-        acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[S][Q], xh[Q][f], acc[f], 0, 0, 0);
-#pragma unroll
-      for (int f = 0; f < 4; ++f)
-        acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[S][Q], xl[f], acc[f], 0, 0, 0);
+      for (int i = 0; i < 12; ++i) {
+        const int f = i & 3;
+        if (!ab_mfma) {
+          if (i < 4)
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[S][Q], xh[Q][f], acc[f], 0, 0, 0);
+          else if (i < 8)
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[S][Q], xh[Q][f], acc[f], 0, 0, 0);
+          else
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[S][Q], xl[Q][f], acc[f], 0, 0, 0);
+        }
+        if (!ab_x) {
+          if (i < 4) xh[NQ][f] = *(lfrag_t)(an[f] ^ NX);
+          else if (i < 8) xl[NQ][f] = *(lfrag_t)((an[f] ^ NX) + SL_PL);
+        }
+        if (i >= 8) tail(f);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     };
     typedef std::integral_constant<int, 0> i0;
     typedef std::integral_constant<int, 1> i1;
@@ -338,41 +360,38 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
     }
     if (cur.valid) {
       x_addrs(xa, cur_s & 1, cur.j - jbase);
-      load_xh(i0{}, xa);
+      load_set(i0{}, xa);
     }
 
-    // one unit = 24 MFMAs: step 0 from hi set 0 (requested during the previous unit), step 1 from
-    // hi set 1 (requested under step 0); the slot's basis registers then take unit u + 2.  The
-    // scheduling barriers keep every group of fragment reads ahead of the 12 MFMAs it is hidden
-    // under (left alone, hipcc reuses one register quad for the four lo fragments of a step and
-    // waits for each read in front of its MFMA).
+    // one unit = two steps of 12 MFMAs; the slot's basis registers then take unit u + 3
     auto unit = [&](auto slot_tag) __attribute__((always_inline)) {
       const int buf = cur_s & 1;
       const int dj = cur.valid ? cur.j - jbase : 0;
-      if (!cur.valid) x_addrs(xa, buf, 0);  // the padding unit of an odd strip: any row will do
-      load_xl(i0{}, xa);
-      load_xh(i1{}, xa);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma12(slot_tag, i0{});
-      __builtin_amdgcn_sched_barrier(0);
+      if (!cur.valid) x_addrs(xa, buf, 0);  // the padding unit of a strip: any row will do
       const bool same = n1.valid && n1.s == cur.s;
-      load_xl(i1{}, xa);
-      // (requested unconditionally -- the last unit of a sub-stage re-reads its own row and drops
-      // it: a branch here makes hipcc keep both generations of the set alive, with copies)
+      // ---- step 0 (+ the reads of step 1, + the addresses of the next unit's step 0: its own row
+      // once more when the next unit opens another slab -- a branch here makes hipcc keep both
+      // generations of a fragment set alive, with copies)
       unsigned xn[4];
-      x_addrs(xn, buf, same ? n1.j - jbase : dj);
-      load_xh(i0{}, xn);
+      const int djn = same ? n1.j - jbase : dj;
       __builtin_amdgcn_sched_barrier(0);
-      mfma12(slot_tag, i1{});
-      __builtin_amdgcn_sched_barrier(0);
-      load_a(slot_tag, n3);
+      step(slot_tag, i0{}, xa, std::integral_constant<unsigned, 32>{}, [&](int f) __attribute__((always_inline)) {
+        const int row = xrow[f] + djn;
+        xn[f] = lds0 + buf * SLAB + row * ROWB + 16 * (lh ^ ((row >> 2) & 3));
+      });
+      // ---- step 1 (+ the reads of the next unit's step 0, + this slot's next basis fragments)
+      const unsigned short *asrc = a_src(n3);
+      // (the last four MFMAs still read ah[S][1]: it is reloaded behind the very last one)
+      step(slot_tag, i1{}, xn, std::integral_constant<unsigned, 0>{}, [&](int f) __attribute__((always_inline)) {
+        load_a1(slot_tag, asrc, f == 2 ? 3 : (f == 3 ? 2 : f));
+      });
       ++done_in_s;
       if (!same) {
         const int target = n1.valid ? n1.s : SPH;
         while (cur_s < target) transition();
         if (n1.valid) {
           x_addrs(xn, cur_s & 1, n1.j - jbase);
-          load_xh(i0{}, xn);
+          load_set(i0{}, xn);
         }
       }
 #pragma unroll

@@ -2101,8 +2101,13 @@ int launch_bf16x3_strip(KParams p, const StripPlan &plan, int n_cu, hipStream_t 
   static std::atomic<unsigned long long> configured{0};
   int rc = configure_lds(kern, 160 * 1024, configured);
   if (rc != MISPEC_OK) return rc;
-  const unsigned grid = (unsigned)(plan.n_jobs < 2 * n_cu ? plan.n_jobs : 2 * n_cu);  // two per CU
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(STRIP_NW * 64), (size_t)STRIP_LDS_BYTES, stream, p, plan);
+  unsigned grid = (unsigned)(plan.n_jobs < 2 * n_cu ? plan.n_jobs : 2 * n_cu);  // two per CU
+  size_t smem = STRIP_LDS_BYTES;
+  if MISPEC_DBG(p, 0x4000000) {  // benchmarking: one workgroup per CU
+    grid = (unsigned)(plan.n_jobs < n_cu ? plan.n_jobs : n_cu);
+    smem = 100 * 1024;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(STRIP_NW * 64), smem, stream, p, plan);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
   return MISPEC_OK;

@@ -9,8 +9,9 @@ sc = torch.sqrt(m.lenghts)
 def run(dbg):
     return engine.framed_gemm(x, m.cqt_kernels_real, m.cqt_kernels_imag, hop=512, pad=16384, pad_mode=2,
                               epilogue=engine.EPI_MAGNITUDE, row_scale=sc, row_support=sup, precision="bf16x3", _debug=dbg)
+extra = int(sys.argv[1], 0) if len(sys.argv) > 1 else 0
 for _ in range(3):
-    run(0x2000000)
+    run(0x2000000 | extra)
 torch.cuda.synchronize()
 ws, need = engine._last_workspace
 tail = ws.view(torch.uint8)[need - 256 + 8:need].cpu().numpy().view("<u8")

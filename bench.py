@@ -473,7 +473,7 @@ def main():
                 r2.update(workload=me2["tag"], precision=prec, steps=n2, roofline=blk)
                 extra[name] = r2
                 if name == "cqt":
-                    blk["kernel"] = ("one step = split pre-pass + framed_bf16x3_narrow_kernel; useful "
+                    blk["kernel"] = ("one step = split pre-pass + framed_bf16x3_strip_kernel; useful "
                                      "(support-aware) flops 2*2*sum(lenghts) per frame / step device time")
                     out["roofline_cqt84"] = dict(blk, workload=me2["tag"], frames_per_s=r2["frames_per_s"],
                                                  ms_per_step=r2["ms_per_step"], steps=n2)

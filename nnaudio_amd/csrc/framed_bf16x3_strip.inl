@@ -116,10 +116,9 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
   const int C = p.n_super;
   const int n_tiles_n = plan.n_tiles_n;
   const long long xs_plane = p.xs_plane;
-  // benchmarking build only (constants otherwise): 1 no MFMAs, 2 no slab fragment reads, 4 no basis
-  // loads, 8 no slab DMA, 16 no reduction / epilogue
-  const bool ab_mfma = MISPEC_DBG(p, 1), ab_x = MISPEC_DBG(p, 2), ab_a = MISPEC_DBG(p, 4),
-             ab_dma = MISPEC_DBG(p, 8), ab_epi = MISPEC_DBG(p, 16);
+  // benchmarking build only (constants otherwise): 8 no slab DMA, 16 no reduction / epilogue, 32 no
+  // units (the unit loop itself is the product's: ablation branches inside it change its schedule)
+  const bool ab_dma = MISPEC_DBG(p, 8), ab_epi = MISPEC_DBG(p, 16);
 
   for (int i = tid; i < (int)(sizeof(StripPlan) / sizeof(int)); i += NW * 64)
     sPlanRaw[i] = reinterpret_cast<const int *>(&plan)[i];
@@ -132,7 +131,9 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
 #ifdef MISPEC_ABLATE
   // phase clock of one job (benchmarking build, bit 0x2000000): 100 MHz stamps of workgroup 7's
   // first job, written behind the job counter
-  bool stamp_on = MISPEC_DBG(p, 0x2000000) && blockIdx.x == 7;
+  // (bits 28-29: which pass the stamped job belongs to)
+  const int stamp_pass = (p.debug >> 28) & 3;
+  bool stamp_armed = MISPEC_DBG(p, 0x2000000) && blockIdx.x == 7, stamp_on = false;
   unsigned long long *stamps = reinterpret_cast<unsigned long long *>(p.job_counter + 2);
 #define STRIP_STAMP(i) \
   if (stamp_on && tid == 0) stamps[i] = wall_clock64();
@@ -141,6 +142,10 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
 #endif
   const int n_jobs = plan.n_jobs;
   while (job < n_jobs) {
+#ifdef MISPEC_ABLATE
+    stamp_on = stamp_armed && job / n_tiles_n == stamp_pass;
+    if (stamp_on) stamp_armed = false;
+#endif
     STRIP_STAMP(0)
     const int pass_i = job / n_tiles_n;
     const int tile_n = job - pass_i * n_tiles_n;
@@ -157,11 +162,11 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
 
     // ---- the frame tile's (at most two) runs of consecutive frames, slab row table
     const long long n0 = (long long)tile_n * STRIP_BN;
+    // (n_cols < 2^31: launch_bf16x3_strip)
+    const int c0 = (int)((unsigned)n0 / (unsigned)n_frames);
+    const int t0 = (int)((unsigned)n0 - (unsigned)c0 * (unsigned)n_frames);
+    const int len0 = (n_frames - t0) < STRIP_BN ? (n_frames - t0) : STRIP_BN;
     {
-      // (n_cols < 2^31: launch_bf16x3_strip)
-      const int c0 = (int)((unsigned)n0 / (unsigned)n_frames);
-      const int t0 = (int)((unsigned)n0 - (unsigned)c0 * (unsigned)n_frames);
-      const int len0 = (n_frames - t0) < STRIP_BN ? (n_frames - t0) : STRIP_BN;
       const int rows0 = len0 + span - 1;
       if (tid < STRIP_BN) sColRow[tid] = tid < len0 ? tid : tid + (span - 1);
       for (int r = tid; r < slab_rows; r += NW * 64) {
@@ -254,7 +259,6 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
     };
     auto load_a1 = [&](auto slot_tag, const unsigned short *src, int part) __attribute__((always_inline)) {
       constexpr int S = decltype(slot_tag)::value;
-      if (ab_a) return;
       if (part == 0) ah[S][0] = *reinterpret_cast<const bf16x8 *>(src);
       if (part == 1) al[S][0] = *reinterpret_cast<const bf16x8 *>(src + 512);
       if (part == 2) ah[S][1] = *reinterpret_cast<const bf16x8 *>(src + 1024);
@@ -281,7 +285,6 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
     };
     auto load_set = [&](auto q_tag, const unsigned (&a0)[4]) __attribute__((always_inline)) {
       constexpr int Q = decltype(q_tag)::value;
-      if (ab_x) return;
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
         xh[Q][f] = *(lfrag_t)(a0[f] ^ (32 * Q));
@@ -310,18 +313,14 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
 #pragma unroll
       for (int i = 0; i < 12; ++i) {
         const int f = i & 3;
-        if (!ab_mfma) {
-          if (i < 4)
-            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[S][Q], xh[Q][f], acc[f], 0, 0, 0);
-          else if (i < 8)
-            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[S][Q], xh[Q][f], acc[f], 0, 0, 0);
-          else
-            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[S][Q], xl[Q][f], acc[f], 0, 0, 0);
-        }
-        if (!ab_x) {
-          if (i < 4) xh[NQ][f] = *(lfrag_t)(an[f] ^ NX);
-          else if (i < 8) xl[NQ][f] = *(lfrag_t)((an[f] ^ NX) + SL_PL);
-        }
+        if (i < 4)
+          acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[S][Q], xh[Q][f], acc[f], 0, 0, 0);
+        else if (i < 8)
+          acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[S][Q], xh[Q][f], acc[f], 0, 0, 0);
+        else
+          acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[S][Q], xl[Q][f], acc[f], 0, 0, 0);
+        if (i < 4) xh[NQ][f] = *(lfrag_t)(an[f] ^ NX);
+        else if (i < 8) xl[NQ][f] = *(lfrag_t)((an[f] ^ NX) + SL_PL);
         if (i >= 8) tail(f);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -451,13 +450,49 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
       };
       const bool direct = p.epilogue == MISPEC_EPI_COMPLEX || p.epilogue == MISPEC_EPI_MAGNITUDE ||
                           p.epilogue == MISPEC_EPI_POWER;  // the epilogue's register path: no barriers
+      // register path of the pointwise epilogue for this kernel's layout -- lane (li, lh) holds (re, im)
+      // of bins 2*lh + {0, 1} + 4*k, k < 4, of frame 32*f + li: the same arithmetic as
+      // bf16x3_epilogue's, with the (clip, frame) of a column taken from the tile's two runs instead
+      // of a 64-bit division per call
+      const int E = epilogue_width(p.epilogue);
+      auto store_direct = [&](auto f_tag) __attribute__((always_inline)) {
+        constexpr int f = decltype(f_tag)::value;
+        const int j = 32 * f + li;
+        const bool in0 = j < len0;
+        const int c = in0 ? c0 : c0 + 1, t = in0 ? t0 + j : j - len0;
+        const bool col_ok = n0 + j < p.n_cols;
+        const int bin0 = tile_m * 16 + 2 * lh;
+        float *ob = p.out + (long long)c * p.out_clip_stride + (long long)t * E +
+                    (long long)(p.out_row_offset + bin0) * p.out_row_stride;
+#pragma unroll
+        for (int e2 = 0; e2 < 8; ++e2) {
+          const int db = (e2 & 1) + 4 * (e2 >> 1);
+          const bool ok = col_ok && bin0 + db < p.n_bins;
+          const float sc = (p.row_scale && ok) ? p.row_scale[bin0 + db] : 1.f;
+          const float re = acc[f][2 * e2] * sc;
+          const float im = p.im_sign * acc[f][2 * e2 + 1] * sc;
+          float *dst = ob + (long long)db * p.out_row_stride;
+          if (ok) {
+            if (p.epilogue == MISPEC_EPI_COMPLEX)
+              *reinterpret_cast<float2 *>(dst) = make_float2(re, im);
+            else if (p.epilogue == MISPEC_EPI_MAGNITUDE)
+              dst[0] = sqrtf(re * re + im * im + p.eps);
+            else
+              epilogue_store(p, dst, re, im);  // MISPEC_EPI_POWER
+          }
+        }
+      };
       auto store = [&](auto f_tag) __attribute__((always_inline)) {
         constexpr int f = decltype(f_tag)::value;
         const bool mine = fmask >> f & 1;
-        if (direct && !mine) return;  // (the LDS path synchronises: every wave goes through it)
+        if (direct) {
+          if (mine) store_direct(f_tag);
+          return;
+        }
+        // the phase epilogues go through bf16x3_epilogue's LDS path, which synchronises: every wave
+        // calls it (it places wave w at columns n0 + 32*w: hand it this wave's frame tile)
         f32x16 a1[1][1];
         a1[0][0] = acc[f];
-        // (the epilogue places wave w at columns n0 + 32*w: hand it this wave's frame tile)
         bf16x3_epilogue<1, 8, 1, 1>(p, a1, mine ? tile_m * 32 : (1 << 24), n0 + 32 * f - 32 * wave, smem_raw);
       };
       typedef std::integral_constant<int, 3> i3;

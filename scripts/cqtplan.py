@@ -1,7 +1,9 @@
 import sys, torch
 sys.path.insert(0, "/root/repo")
 from nnaudio_amd import engine, features
-x = torch.randn(64, 441000, device="cuda")
+import os
+B = int(os.environ.get("B", "64"))
+x = torch.randn(B, 441000, device="cuda")
 m = features.CQT1992v2(sr=44100, hop_length=512, n_bins=84, verbose=False).to("cuda")
 m.precision = "bf16x3"
 sup = m._support.get(m.cqt_kernels_real, m.cqt_kernels_imag)
@@ -21,6 +23,3 @@ def timeit(fn, n=20, w=5):
     return e0.elapsed_time(e1) / n
 for dbg in [int(a, 0) for a in sys.argv[1:]] or [0, 0x800000]:
     print("debug %#x: %.4f ms" % (dbg, timeit(lambda: run(dbg))))
-
-if "--stamps" in sys.argv:
-    pass

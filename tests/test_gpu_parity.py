@@ -597,7 +597,26 @@ def test_split_basis_is_bit_exact(F, K, has_im):
                              torch.as_tensor(im).to(DEV) if has_im else None)
     torch.cuda.synchronize()
     Ks = (K + 31) // 32 * 32
-    planes = got.cpu().numpy().view(np.uint16).reshape(4 if has_im else 2, F, Ks)
+    raw = got.cpu().numpy().view(np.uint16)
+    n_planes = 4 if has_im else 2
+    planes = raw[:n_planes * F * Ks].reshape(n_planes, F, Ks)
+    if has_im:
+        # complex banks carry a second copy in the strip kernel's fragment order
+        # [16-bin tile][16-tap step][hi | lo][lane = row + 32 * (tap / 8 % 2)][8 taps], row = 2 * bin +
+        # component, zero rows past the last bin, and a 4 KB block of zeros behind the last tile
+        M = (F + 15) // 16
+        frag = raw[n_planes * F * Ks:]
+        assert frag.size == M * (Ks // 16) * 1024 + 2048 and not frag[M * (Ks // 16) * 1024:].any()
+        frag = frag[:M * (Ks // 16) * 1024].reshape(M, Ks // 16, 2, 2, 32, 8)  # tile, step, hi/lo, lh, row, tap
+        want = np.zeros_like(frag)
+        for z in range(2):
+            for hl in range(2):
+                src = np.zeros((M * 16, Ks), np.uint16)
+                src[:F] = planes[2 * z + hl]
+                # (bin, tap) -> (tile, bin in tile), (step, half, tap in lane)
+                v = src.reshape(M, 16, Ks // 16, 2, 8).transpose(0, 2, 3, 1, 4)  # tile, step, lh, bin, tap
+                want[:, :, hl, :, z::2, :] = v
+        assert np.array_equal(frag, want)
     for z, src in enumerate([re, im] if has_im else [re]):
         hi, lo = _np_bf16_split(src)
         assert np.array_equal(planes[2 * z][:, :K], hi)

@@ -1,20 +1,17 @@
 """Gammatonegram module (drop-in for ``nnAudio.features.Gammatonegram``,
-reference: Installation/nnAudio/features/gammatone.py:9-194): the mel pipeline with a
-(dense) gammatone filterbank."""
-from time import time
-
+reference: Installation/nnAudio/features/gammatone.py:9-194): the mel pipeline
+(``features/_filterbank.py``) with a (dense) gammatone filterbank."""
 import torch
-import torch.nn as nn
 
-from .. import engine
 from ..basis import gammatone_filterbank
-from ..utils import broadcast_dim
-from .stft import STFT
+from ._filterbank import FilterbankSpectrogram
 
 
-class Gammatonegram(nn.Module):
+class Gammatonegram(FilterbankSpectrogram):
     """``(batch, n_bins, frames)`` gammatone spectrogram; constructor, attributes and
     ``state_dict`` keys (``gammatone_basis``, ``stft.wsin`` ...) as the reference."""
+
+    _basis_name, _label = "gammatone_basis", "Gammatone"
 
     def __init__(
         self,
@@ -37,50 +34,12 @@ class Gammatonegram(nn.Module):
         **kwargs
     ):
         super().__init__()
-        self.stride = hop_length
-        self.center = center
-        self.pad_mode = pad_mode
-        self.n_fft = n_fft
-        self.power = power
         self.trainable_bins = trainable_bins
-        self.trainable_STFT = trainable_STFT
-
-        self.stft = STFT(
-            n_fft=n_fft,
-            win_length=win_length,
-            freq_bins=None,
-            hop_length=hop_length,
-            window=window,
-            freq_scale="no",
-            center=center,
-            pad_mode=pad_mode,
-            sr=sr,
-            trainable=trainable_STFT,
-            output_format="Magnitude",
-            verbose=verbose,
-            **kwargs
-        )
-
-        start = time()
-        basis = torch.from_numpy(gammatone_filterbank(sr, n_fft, n_bins, fmin, fmax))
-        if verbose:
-            print("STFT filter created, time used = {:.4f} seconds".format(time() - start))
-            print("Gammatone filter created, time used = {:.4f} seconds".format(time() - start))
-
-        if trainable_bins:
-            self.register_parameter("gammatone_basis", nn.Parameter(basis, requires_grad=True))
-        else:
-            self.register_buffer("gammatone_basis", basis)
-
-    def forward(self, x):
-        x = broadcast_dim(x)
-        self.stft.num_samples = x.shape[-1]
-        fused = engine.fused_filterbank_plan(self, self.gammatone_basis, x, self.stft, self.power)
-        if fused is not None:  # reduction fused into the contraction's epilogue
-            return self.stft._spectrum(x, engine.EPI_POWER, power=self.power, fb=self.gammatone_basis,
-                                       fb_support=fused)
-        spec = self.stft._spectrum(x, engine.EPI_POWER, power=self.power)
-        return engine.filterbank_autograd(self.gammatone_basis, spec)
+        self._build(
+            lambda: torch.from_numpy(gammatone_filterbank(sr, n_fft, n_bins, fmin, fmax)),
+            sr=sr, n_fft=n_fft, win_length=win_length, hop_length=hop_length, window=window,
+            center=center, pad_mode=pad_mode, power=power, trainable_basis=trainable_bins,
+            trainable_STFT=trainable_STFT, verbose=verbose, stft_kwargs=kwargs)
 
     def extra_repr(self) -> str:
         return "Gammatone filter banks size = {}, trainable_bins={}".format(

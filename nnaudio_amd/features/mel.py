@@ -1,23 +1,23 @@
 """Mel spectrogram module (drop-in for ``nnAudio.features.MelSpectrogram``,
 reference: Installation/nnAudio/features/mel.py:9-194).
 
-``forward`` = framed MFMA contraction with the ``|.|**power`` epilogue fused (the
-reference's sqrt -> pow round trip disappears for power = 2) followed by the filterbank
-contraction kernel."""
-from time import time
+The pipeline itself (STFT power spectrum -> filterbank) is shared with Gammatonegram:
+``features/_filterbank.py``."""
 
 import torch
 import torch.nn as nn
 
 from .. import engine
 from ..basis import dct_ortho_matrix, mel_filterbank
-from ..utils import ParameterError, broadcast_dim
-from .stft import STFT
+from ..utils import ParameterError
+from ._filterbank import FilterbankSpectrogram
 
 
-class MelSpectrogram(nn.Module):
+class MelSpectrogram(FilterbankSpectrogram):
     """``(batch, n_mels, frames)`` mel spectrogram; constructor, attributes and
     ``state_dict`` keys (``mel_basis``, ``stft.wsin`` ...) as the reference."""
+
+    _basis_name, _label = "mel_basis", "Mel"
 
     def __init__(
         self,
@@ -40,52 +40,12 @@ class MelSpectrogram(nn.Module):
         **kwargs
     ):
         super().__init__()
-        self.stride = hop_length
-        self.center = center
-        self.pad_mode = pad_mode
-        self.n_fft = n_fft
-        self.power = power
         self.trainable_mel = trainable_mel
-        self.trainable_STFT = trainable_STFT
-
-        self.stft = STFT(
-            n_fft=n_fft,
-            win_length=win_length,
-            freq_bins=None,
-            hop_length=hop_length,
-            window=window,
-            freq_scale="no",
-            center=center,
-            pad_mode=pad_mode,
-            sr=sr,
-            trainable=trainable_STFT,
-            output_format="Magnitude",
-            verbose=verbose,
-            **kwargs
-        )
-
-        start = time()
-        mel_basis = torch.from_numpy(
-            mel_filterbank(sr, n_fft, n_mels, fmin, fmax, htk=htk, norm=norm)
-        )
-        if verbose:
-            print("STFT filter created, time used = {:.4f} seconds".format(time() - start))
-            print("Mel filter created, time used = {:.4f} seconds".format(time() - start))
-
-        if trainable_mel:
-            self.register_parameter("mel_basis", nn.Parameter(mel_basis, requires_grad=True))
-        else:
-            self.register_buffer("mel_basis", mel_basis)
-
-    def forward(self, x):
-        x = broadcast_dim(x)
-        self.stft.num_samples = x.shape[-1]
-        fused = engine.fused_filterbank_plan(self, self.mel_basis, x, self.stft, self.power)
-        if fused is not None:  # reduction fused into the contraction's epilogue
-            return self.stft._spectrum(x, engine.EPI_POWER, power=self.power, fb=self.mel_basis,
-                                       fb_support=fused)
-        spec = self.stft._spectrum(x, engine.EPI_POWER, power=self.power)
-        return engine.filterbank_autograd(self.mel_basis, spec)
+        self._build(
+            lambda: torch.from_numpy(mel_filterbank(sr, n_fft, n_mels, fmin, fmax, htk=htk, norm=norm)),
+            sr=sr, n_fft=n_fft, win_length=win_length, hop_length=hop_length, window=window,
+            center=center, pad_mode=pad_mode, power=power, trainable_basis=trainable_mel,
+            trainable_STFT=trainable_STFT, verbose=verbose, stft_kwargs=kwargs)
 
     def extra_repr(self) -> str:
         return "Mel filter banks size = {}, trainable_mel={}".format(

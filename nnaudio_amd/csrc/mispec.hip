@@ -1934,7 +1934,11 @@ bool plan_strip(const KParams &p, const int32_t *sup, int n_slots, StripPlan &pl
     }
   const long long n_tiles_n = (p.n_cols + STRIP_BN - 1) / STRIP_BN;
   if (n_tiles_n * STRIP_MAX_PASS > 0x7fffffffLL || p.n_cols + STRIP_BN > 0x7fffffffLL) return false;
-  const double ovh = 0.75 * sph;  // per-pass cost of the prologue, barriers, reduction and epilogue
+  // per-pass cost of tables, first slab, reduction and epilogue: ~10 us = 12 units at cfg4 (phase
+  // clock).  (Charging the ~1.2 us of barrier + refill per sub-stage as well -- 12 + 1.45 * sph --
+  // merges tiles 1 and 2 into one pass of 3 + 1 waves: measured 4 % slower, the single wave of
+  // tile 2 then sets the pace of every sub-stage.)
+  const double ovh = 0.75 * sph;
   // slab reach of a group: span of super-stages
   auto span_of = [&](int a, int k) {
     int lo = 1 << 30, hi = -1;

@@ -54,6 +54,7 @@ struct StripPass {
   int jbase, span;  // super-stages [jbase, jbase + span) are read from the slab
   int slab_rows;    // multiple of 16
   int cost;
+  int group;        // sub-stages per slab buffer (2 when two slabs fit: half the barriers), else 1
 };
 struct StripPlan {
   int n_pass, n_tiles_n, n_jobs, reserved;
@@ -153,6 +154,9 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
     const int jbase = __builtin_amdgcn_readfirstlane(ps.jbase), span = __builtin_amdgcn_readfirstlane(ps.span);
     const int slab_rows = __builtin_amdgcn_readfirstlane(ps.slab_rows);
     const int spieces = slab_rows / 16;
+    // sub-stages per slab buffer: sub-stage s lives in buffer (s >> gsh) & 1, rows (s & gsh) * slab_rows ..
+    const int gsh = __builtin_amdgcn_readfirstlane(ps.group) - 1;
+    const int NG = (SPH + gsh) >> gsh;  // slab groups = barriers of the job
     const StripWave &wv = ps.w[wave];
     const int tile_m = __builtin_amdgcn_readfirstlane(wv.tile);
     const int kb = __builtin_amdgcn_readfirstlane(wv.kb), ke = __builtin_amdgcn_readfirstlane(wv.ke);
@@ -213,16 +217,20 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
         p.afrag + (long long)(tile_m < 0 ? 0 : tile_m) * (p.Ks >> 4) * 1024 + lane * 8;
     const unsigned short *azero = p.afrag + (long long)((p.n_bins + 15) >> 4) * (p.Ks >> 4) * 1024 + lane * 8;
 
-    auto dma_slab = [&](int s, int buf) __attribute__((always_inline)) {
+    auto dma_slab = [&](int g, int buf) __attribute__((always_inline)) {
       if (ab_dma) return;
+      for (int sub = 0; sub <= gsh; ++sub) {
+        const int s = (g << gsh) + sub;
+        if (s >= SPH) break;
 #pragma unroll
-      for (int j = 0; j < STRIP_SJ; ++j) {
-        const int pj = j * NW + wave;
-        if (pj < spieces) {
-          const unsigned short *src = sptr[j] + KC * s;
-          const unsigned d = lds0 + buf * SLAB + pj * 16 * ROWB;
-          strip_lds_dma16(src, d);
-          strip_lds_dma16(src + xs_plane, d + SL_PL);
+        for (int j = 0; j < STRIP_SJ; ++j) {
+          const int pj = j * NW + wave;
+          if (pj < spieces) {
+            const unsigned short *src = sptr[j] + KC * s;
+            const unsigned d = lds0 + buf * SLAB + (sub * slab_rows + pj * 16) * ROWB;
+            strip_lds_dma16(src, d);
+            strip_lds_dma16(src + xs_plane, d + SL_PL);
+          }
         }
       }
     };
@@ -276,11 +284,15 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
     typedef __attribute__((address_space(3))) const bf16x8 *lfrag_t;
     bf16x8 xh[2][4], xl[2][4];
     unsigned xa[4];
-    auto x_addrs = [&](unsigned (&dst)[4], int buf, int dj) __attribute__((always_inline)) {
+    auto x_base = [&](int s) __attribute__((always_inline)) -> unsigned {  // slab of sub-stage s
+      return lds0 + ((s >> gsh) & 1) * SLAB + (s & gsh) * slab_rows * ROWB;
+    };
+    auto x_addrs = [&](unsigned (&dst)[4], int s, int dj) __attribute__((always_inline)) {
+      const unsigned base = x_base(s);
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        const int row = xrow[f] + dj;
-        dst[f] = lds0 + buf * SLAB + row * ROWB + 16 * (lh ^ ((row >> 2) & 3));
+        const int row = xrow[f] + dj;  // (the slabs of a buffer start at multiples of 16 rows: same swizzle)
+        dst[f] = base + row * ROWB + 16 * (lh ^ ((row >> 2) & 3));
       }
     };
     auto load_set = [&](auto q_tag, const unsigned (&a0)[4]) __attribute__((always_inline)) {
@@ -333,20 +345,20 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
     It n1 = it_next(cur);
     It n2 = it_next(n1);
     It n3 = it_next(n2);
-    int cur_s = 0;      // sub-stage whose slab is being read
+    int cur_g = 0;      // slab group (1 or 2 sub-stages: one buffer) being read
     int done_in_s = 0;  // units (= groups of 4 basis loads) issued since the last slab DMA
-    // end of sub-stage s for this wave: its pieces of slab s+1 have landed (they were issued before
-    // the basis loads of the units counted in done_in_s), everybody is done reading slab s, whose
-    // buffer takes slab s+2
+    // end of slab group g for this wave: its pieces of group g+1 have landed (they were issued before
+    // the basis loads of the units counted in done_in_s), everybody is done reading group g, whose
+    // buffer takes group g+2
     auto transition = [&]() __attribute__((always_inline)) {
       strip_barrier(done_in_s);
-      STRIP_STAMP(3 + cur_s)
-      if (cur_s + 2 < SPH) dma_slab(cur_s + 2, cur_s & 1);
-      ++cur_s;
+      STRIP_STAMP(3 + cur_g)
+      if (cur_g + 2 < NG) dma_slab(cur_g + 2, cur_g & 1);
+      ++cur_g;
       done_in_s = 0;
     };
     dma_slab(0, 0);
-    if (SPH > 1) dma_slab(1, 1);
+    if (NG > 1) dma_slab(1, 1);
     typedef std::integral_constant<int, 2> i2;
     load_a(i0{}, cur);
     load_a(i1{}, n1);
@@ -354,29 +366,30 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
     strip_barrier(0);
     STRIP_STAMP(2)
     {
-      const int target = cur.valid ? cur.s : SPH;
-      while (cur_s < target) transition();
+      const int target = cur.valid ? cur.s >> gsh : NG;
+      while (cur_g < target) transition();
     }
     if (cur.valid) {
-      x_addrs(xa, cur_s & 1, cur.j - jbase);
+      x_addrs(xa, cur.s, cur.j - jbase);
       load_set(i0{}, xa);
     }
 
     // one unit = two steps of 12 MFMAs; the slot's basis registers then take unit u + 3
     auto unit = [&](auto slot_tag) __attribute__((always_inline)) {
-      const int buf = cur_s & 1;
       const int dj = cur.valid ? cur.j - jbase : 0;
-      if (!cur.valid) x_addrs(xa, buf, 0);  // the padding unit of a strip: any row will do
-      const bool same = n1.valid && n1.s == cur.s;
+      if (!cur.valid) x_addrs(xa, 0, 0);  // the padding unit of a strip: any row will do
+      // the next unit reads the same slab buffer: its first fragments can be requested now
+      const bool same = n1.valid && (n1.s >> gsh) == (cur.s >> gsh);
       // ---- step 0 (+ the reads of step 1, + the addresses of the next unit's step 0: its own row
       // once more when the next unit opens another slab -- a branch here makes hipcc keep both
       // generations of a fragment set alive, with copies)
       unsigned xn[4];
       const int djn = same ? n1.j - jbase : dj;
+      const unsigned basen = x_base(same ? n1.s : (cur.valid ? cur.s : 0));
       __builtin_amdgcn_sched_barrier(0);
       step(slot_tag, i0{}, xa, std::integral_constant<unsigned, 32>{}, [&](int f) __attribute__((always_inline)) {
         const int row = xrow[f] + djn;
-        xn[f] = lds0 + buf * SLAB + row * ROWB + 16 * (lh ^ ((row >> 2) & 3));
+        xn[f] = basen + row * ROWB + 16 * (lh ^ ((row >> 2) & 3));
       });
       // ---- step 1 (+ the reads of the next unit's step 0, + this slot's next basis fragments)
       const unsigned short *asrc = a_src(n3);
@@ -386,10 +399,10 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
       });
       ++done_in_s;
       if (!same) {
-        const int target = n1.valid ? n1.s : SPH;
-        while (cur_s < target) transition();
+        const int target = n1.valid ? n1.s >> gsh : NG;
+        while (cur_g < target) transition();
         if (n1.valid) {
-          x_addrs(xn, cur_s & 1, n1.j - jbase);
+          x_addrs(xn, n1.s, n1.j - jbase);
           load_set(i0{}, xn);
         }
       }

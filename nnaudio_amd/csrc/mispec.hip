@@ -2018,6 +2018,7 @@ bool plan_strip(const KParams &p, const int32_t *sup, int n_slots, StripPlan &pl
     ps.jbase = lo;
     ps.span = hi - lo + 1;
     ps.slab_rows = (STRIP_BN + 2 * (ps.span - 1) + 15) / 16 * 16;
+    ps.group = 2 * ps.slab_rows <= STRIP_MAX_ROWS && sph >= 2 ? 2 : 1;  // two slabs per buffer: half the barriers
     int w = 0;
     for (int i = a; i < b; ++i) {
       // cut the tile's super-stages into waves[i - a] runs of about equal work

@@ -272,13 +272,23 @@ __global__ void __launch_bounds__(256) fold_frames_kernel(const KParams p,
 // outstanding LDS-direct loads (vmcnt(0)) when it sees one issued earlier in the same block.
 template <int N>
 __device__ __forceinline__ void lds_dma_barrier_keep() {
-  static_assert(N == 0 || N == 6, "immediate of the s_waitcnt below");
+  static_assert(N == 0 || N == 4 || N == 6, "immediate of the s_waitcnt below");
   if (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   if (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-__global__ void __launch_bounds__(512) framed_fold_kernel(const KParams p) {
-  constexpr int WM = 4, WN = 2, NR = 4, NW = 8;
+// One tile of the contraction: 128 bins x (64 * NR) frames.  NR = 4 is the kernel described above;
+// NR = 2 (128 frames: 32 KB stages, 4 DMA pieces per wave, half the MFMAs per barrier) serves the
+// frames left over behind the last whole round of workgroups -- see framed_fold_kernel.
+template <int NR>
+__device__ __forceinline__ void framed_fold_body(const KParams &p, const int tile_m, const long long n0) {
+  constexpr int WM = 4, WN = 2, NW = 8;
+  constexpr int BN = WN * NR * 32;                       // frames of the tile
+  constexpr int X_ST = BN * FOLD_ROWB;                   // bytes of the frame rows of a stage
+  constexpr int STAGE = FOLD_A_ST + X_ST;
+  constexpr int XJ = BN / 64;                            // frame-row DMA pieces per wave
+  constexpr int DMA_PER_WAVE = 2 + XJ;
   typedef __attribute__((address_space(1))) const void *gptr_t;
   typedef __attribute__((address_space(3))) void *lptr_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -290,42 +300,14 @@ __global__ void __launch_bounds__(512) framed_fold_kernel(const KParams p) {
   const int wn = wave % WN;
   const int li = lane & 31;
   const int lh = lane >> 5;
-
-  // ---- XCD-aware tile order (as framed_gemm_body)
-  int tile;
-  {
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7;
-    const int xcd = b & 7, idx = b >> 3;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  int tile_m, tile_n;
-  {
-    const int G = p.n_group;
-    const int per_group = G * p.n_tiles_m;
-    const int full = (p.n_tiles_n / G) * per_group;
-    if (tile < full) {
-      const int g = tile / per_group;
-      const int rest = tile - g * per_group;
-      tile_m = rest / G;
-      tile_n = g * G + (rest - tile_m * G);
-    } else {
-      const int Gt = p.n_tiles_n % G;
-      const int rest = tile - full;
-      tile_m = rest / Gt;
-      tile_n = (p.n_tiles_n / G) * G + (rest - tile_m * Gt);
-    }
-  }
   const int b0 = tile_m * FOLD_BINS;                  // first bin of the tile
-  tile_n += p.fold_tile0;                             // (this launch's chunk of frame tiles)
-  const long long n0 = (long long)tile_n * FOLD_BN;   // first flat frame of the tile
   const int nst = p.Ks / FOLD_KC;
   const long long row_el = (long long)nst * (FOLD_ROWB / 2);  // elements per basis / frame row
 
   // ---- DMA geometry: a piece = 8 rows x 128 B; lane -> (row r8 = lane >> 3, slot = lane & 7),
   // which receives chunk  slot ^ ((row >> 1) & 7)  of its row (row = index inside the tile)
   const int r8 = lane >> 3, slot = lane & 7;
-  const unsigned short *aptr[2], *xptr[4];
+  const unsigned short *aptr[2], *xptr[XJ];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int row = (j * NW + wave) * 8 + r8;  // A row = bin of the tile
@@ -334,20 +316,20 @@ __global__ void __launch_bounds__(512) framed_fold_kernel(const KParams p) {
     aptr[j] = p.as + (long long)bin * row_el + 8 * (slot ^ ((row >> 1) & 7));
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < XJ; ++j) {
     const int row = (j * NW + wave) * 8 + r8;  // X row = frame of the tile
     long long col = n0 + row;
     col = col < p.n_cols ? col : 0;  // unused column: any valid frame, never stored
     xptr[j] = p.xs + col * row_el + 8 * (slot ^ ((row >> 1) & 7));
   }
   auto dma_stage = [&](int s, int buf) __attribute__((always_inline)) {
-    unsigned char *st = smem_raw + buf * FOLD_STAGE;
+    unsigned char *st = smem_raw + buf * STAGE;
     const int so = s * (FOLD_ROWB / 2);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
       __builtin_amdgcn_global_load_lds((gptr_t)(aptr[j] + so), (lptr_t)(st + (j * NW + wave) * 1024), 16, 0, 0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < XJ; ++j)
       __builtin_amdgcn_global_load_lds((gptr_t)(xptr[j] + so),
                                        (lptr_t)(st + FOLD_A_ST + (j * NW + wave) * 1024), 16, 0, 0);
   };
@@ -368,7 +350,7 @@ __global__ void __launch_bounds__(512) framed_fold_kernel(const KParams p) {
   bf16x8 fa[2][2], fx[2][2][NR];  // [half][hi / lo]
   auto load_frags = [&](int buf, auto half_tag) __attribute__((always_inline)) {
     constexpr int HALF = decltype(half_tag)::value;  // 0: (A_re, E), 1: (A_im, O)
-    const unsigned char *st = smem_raw + buf * FOLD_STAGE;
+    const unsigned char *st = smem_raw + buf * STAGE;
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) {
       const int off = 16 * ((4 * HALF + 2 * pl + lh) ^ fsw);
@@ -408,7 +390,7 @@ __global__ void __launch_bounds__(512) framed_fold_kernel(const KParams p) {
   typedef integral_constant<int, 1> i1;
   typedef integral_constant<int, 3 * NR> n_mfma;
   typedef integral_constant<int, 2 * (1 + NR)> n_reads;
-  typedef integral_constant<int, FOLD_DMA_PER_WAVE> n_dma;
+  typedef integral_constant<int, DMA_PER_WAVE> n_dma;
 
   // One iteration = stage c out of buffer `buf`.  Waves w and w + 4 share a SIMD (a workgroup's
   // waves are dealt to the SIMDs cyclically): so that the two never sit in their LDS-DMA issue at
@@ -435,18 +417,21 @@ __global__ void __launch_bounds__(512) framed_fold_kernel(const KParams p) {
   };
   typedef integral_constant<bool, true> yes;
   typedef integral_constant<bool, false> no;
-  typedef integral_constant<int, FOLD_DMA_PER_WAVE> keep1;
+  typedef integral_constant<int, DMA_PER_WAVE> keep1;
   if (nst > 0) {
     dma_stage(0, 0);
     if (nst > 1) dma_stage(1, 1);
     if (nst > 2) dma_stage(2, 2);
-    // stage 0 landed: at most the later stages' loads outstanding
-    if (nst > 2)
-      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (nst > 1)
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else
+    // stage 0 landed: at most the later stages' loads outstanding (DMA_PER_WAVE each)
+    if (nst > 2) {
+      if (DMA_PER_WAVE == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else if (nst > 1) {
+      if (DMA_PER_WAVE == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
     load_frags(0, i0{});
     auto nxt = [](int b) { return b == FOLD_NBUF - 1 ? 0 : b + 1; };
@@ -479,6 +464,51 @@ __global__ void __launch_bounds__(512) framed_fold_kernel(const KParams p) {
     bf16x3_epilogue_fb<WM, WN, NR>(p, acc, 2 * b0, n0, smem_raw);
   else
     bf16x3_epilogue_planar<WM, WN, NR>(p, acc, 2 * b0, n0, smem_raw);
+}
+
+
+// The grid: p.fold_main workgroups take 256-frame tiles (XCD-aware order, whole rounds of the
+// device's CUs), the rest take 128-frame tiles of the frames behind them -- the last, partial round
+// of a 256-frame tiling costs a whole round (Mel cfg3: 864 tiles = 3.375 rounds ran as 4), and
+// problems of less than half a round double their parallelism (STFT cfg2's shape at B = 4: 0.10 ->
+// 0.07 ms).  A 128-frame tile costs ~0.8 of a 256-frame one, so the host (launch_fold) uses them
+// only where that still pays: cfg3 -4 %, cfg2 (6.75 rounds) unchanged.
+__global__ void __launch_bounds__(512) framed_fold_kernel(const KParams p) {
+  const int b = blockIdx.x;
+  if (b < p.fold_main) {
+    // ---- XCD-aware tile order (as framed_gemm_body)
+    int tile;
+    {
+      const int nwg = p.fold_main;
+      const int q = nwg >> 3, r = nwg & 7;
+      const int xcd = b & 7, idx = b >> 3;
+      tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int tile_m, tile_n;
+    {
+      const int G = p.n_group;
+      const int per_group = G * p.n_tiles_m;
+      const int full = (p.n_tiles_n / G) * per_group;
+      if (tile < full) {
+        const int g = tile / per_group;
+        const int rest = tile - g * per_group;
+        tile_m = rest / G;
+        tile_n = g * G + (rest - tile_m * G);
+      } else {
+        const int Gt = p.n_tiles_n % G;
+        const int rest = tile - full;
+        tile_m = rest / Gt;
+        tile_n = (p.n_tiles_n / G) * G + (rest - tile_m * Gt);
+      }
+    }
+    tile_n += p.fold_tile0;  // (this launch's chunk of frame tiles)
+    framed_fold_body<4>(p, tile_m, (long long)tile_n * FOLD_BN);
+  } else {
+    // bin blocks fastest: the workgroups that run side by side share their frame rows in L2
+    const int t = b - p.fold_main;
+    const int tile_n = t / p.n_tiles_m, tile_m = t - tile_n * p.n_tiles_m;
+    framed_fold_body<2>(p, tile_m, p.fold_tail_frame0 + (long long)tile_n * (FOLD_BN / 2));
+  }
 }
 
 // ---------------------------------------------------------------------------------

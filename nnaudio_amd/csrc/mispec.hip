@@ -153,6 +153,8 @@ struct KParams {
   int fold_tap0;           // tap 0 is carried as folded tap kernel/2
   int fold_clip0;          // pre-pass launch: first clip; contraction launch: first frame tile
   int fold_tile0;
+  int fold_main;               // workgroups on 256-frame tiles; the rest take 128-frame tiles
+  long long fold_tail_frame0;  //   from this flat frame on
 };
 
 // ---------------------------------------------------------------------------------
@@ -2379,8 +2381,38 @@ int launch_fold(KParams p, const mispec_framed_gemm_args *a, const FoldPlan &f, 
     KParams q2 = p;
     q2.fold_tile0 = (int)tile0;
     q2.n_tiles_n = (int)(tile1 - tile0);
+    long long grid = (tile1 - tile0) * p.n_tiles_m;
+    q2.fold_main = (int)grid;
+    if (tile0 == 0 && tile1 == tn && kern == framed_fold_kernel && !MISPEC_DBG(p, 0x8000000)) {
+      // whole rounds of the device on 256-frame tiles, the frames behind them on 128-frame tiles
+      // (framed_fold_kernel); less than half a round: 128-frame tiles throughout
+      const int n_cu = device_cus();
+      const double rounds = (double)grid / n_cu;
+      long long main_tn = tn;
+      if (rounds <= 0.5) {
+        main_tn = 0;
+      } else if (rounds > 1.0) {
+        const long long whole = (long long)rounds * n_cu / p.n_tiles_m;  // frame tiles of the whole rounds
+        if (whole < tn) {
+          const long long half = (p.n_cols - whole * FOLD_BN + FOLD_BN / 2 - 1) / (FOLD_BN / 2) * p.n_tiles_m;
+          // a 128-frame tile costs ~0.8 of a 256-frame one (measured: the same basis rows staged for
+          // half the MFMAs, the same fill and epilogue latencies)
+          const double tail = 0.8 * (double)half / n_cu;
+          const double mixed = (double)(whole * p.n_tiles_m) / n_cu + (tail > 0.8 ? tail : 0.8);
+          if (mixed < (double)(long long)(rounds + 0.999) - 0.05) main_tn = whole;
+        }
+      }
+      if (main_tn < tn) {
+        q2.n_tiles_n = (int)main_tn;
+        q2.fold_main = (int)(main_tn * p.n_tiles_m);
+        q2.fold_tail_frame0 = main_tn * FOLD_BN;
+        const long long tail_tn = (p.n_cols - q2.fold_tail_frame0 + FOLD_BN / 2 - 1) / (FOLD_BN / 2);
+        grid = q2.fold_main + tail_tn * p.n_tiles_m;
+      }
+    }
     q2.n_group = g > q2.n_tiles_n ? q2.n_tiles_n : g;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((tile1 - tile0) * p.n_tiles_m)), dim3(512), smem, stream, q2);
+    if (q2.n_group < 1) q2.n_group = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, stream, q2);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
     tile0 = tile1;

@@ -72,6 +72,13 @@ class OctaveCache:
     def __init__(self):
         self._banks = {}
 
+    def scale(self, lenghts, normalization_type, factor):
+        """``normalisation_scale`` of the module, built once (a forward must not launch the
+        sqrt / multiply slivers every call) and rebuilt when ``lenghts`` changes."""
+        c = self.__dict__.setdefault("_scale", engine.DerivedCache())
+        return c.get((lenghts,), lambda: normalisation_scale(lenghts, normalization_type, factor),
+                     extra=(normalization_type, float(factor)))
+
     def bank(self, i, kr, ki, first):
         c = self._banks.setdefault(i, engine.DerivedCache())
         return c.get((kr, ki), lambda: engine.split_basis(
@@ -128,7 +135,10 @@ def octave_recursion(x, banks, lenghts, hop, n_bins, lowpass, downsample_factor,
     one (grouped) contraction per octave on the exact fp32 kernels."""
     epi = output_epilogue(output_format)
     if scale is None:
-        scale = normalisation_scale(lenghts, normalization_type, downsample_factor)
+        # (under torch.compile / export the tensors are fake: no cache look-ups, the ops are traced)
+        scale = (cache.scale(lenghts, normalization_type, downsample_factor)
+                 if cache is not None and not engine.compiling()
+                 else normalisation_scale(lenghts, normalization_type, downsample_factor))
     if epi is None:
         return None
     n_oct = len(banks)

@@ -394,7 +394,7 @@ int mispec_fir_decimate_bwd_f32(const float *dy, int64_t dy_clip_stride, int32_t
  * The deepest level is also stored in fp32 to x_last (when not NULL): it is the `x` of the next
  * launch of the chain, whose level 0 then carries no bank.  All arithmetic is MISPEC_PREC_BF16X3
  * (split-bf16 operands, fp32 accumulate); between levels the signal keeps 16 significant bits.
- * Shapes: (hop >> l) a multiple of 8, kernel a multiple of 16, n_bins <= 16 per level,
+ * Shapes: (hop >> l) a multiple of 4, kernel a multiple of 16, n_bins <= 16 per level,
  * n_taps <= 257; MISPEC_E_UNSUPPORTED otherwise (the caller then runs mispec_fir_decimate_f32 +
  * mispec_framed_gemm_f32 per octave).
  */

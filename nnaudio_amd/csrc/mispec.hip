@@ -3094,8 +3094,8 @@ int mispec_octave_pyramid_f32(const mispec_octave_args *a, void *stream) {
     PyrLevel &o = p.lv[l];
     if (l > 0) L = (L + 2LL * p.dec_pad - a->n_taps) / 2 + 1;
     if (L <= 0) return fail(MISPEC_E_INVALID, "signal too short for this many levels%s");
-    if ((a->hop % (1 << l)) || ((a->hop >> l) % 8))
-      return fail(MISPEC_E_UNSUPPORTED, "fused octave kernel: hop >> level must be a multiple of 8%s");
+    if ((a->hop % (1 << l)) || ((a->hop >> l) % 4))
+      return fail(MISPEC_E_UNSUPPORTED, "fused octave kernel: hop >> level must be a multiple of 4%s");
     o.L = (int)L;
     o.hop = a->hop >> l;
     // the last frame must lie inside the (virtually padded) level
@@ -3137,6 +3137,13 @@ int mispec_octave_pyramid_f32(const mispec_octave_args *a, void *stream) {
   }
   // frames per workgroup: ~8192 samples of level 0, within 80 KB of LDS (two workgroups per CU)
   int nf = (8192 / p.lv[0].hop + 15) / 16 * 16;
+  {
+    // ... but at least ~4 work items per CU: the deep launches of a chain (small hops) would
+    // otherwise be a few hundred long items on 512 workgroup slots
+    const long long want = 4LL * device_cus();
+    const long long cap = ((long long)a->n_frames * a->n_clips / want + 15) / 16 * 16;
+    if (cap < nf) nf = (int)cap;
+  }
   nf = nf < 16 ? 16 : nf;
   size_t smem = 0;
   for (;; nf -= 16) {

@@ -45,7 +45,7 @@ constexpr int PYR_NB = 8;           // 16-byte loads per thread and batch while 
 
 struct PyrLevel {
   int L;         // length of x_l
-  int hop;       // frame hop at this level (multiple of 8)
+  int hop;       // frame hop at this level (multiple of 4; multiples of 8 read whole 16-byte chunks)
   int K;         // kernel width of this level's bank (0: no contraction at this level)
   int Ks;        // taps per split bank row (K rounded up to 32)
   int n_rows;    // bins at this level (<= 16)
@@ -374,17 +374,29 @@ __global__ void __launch_bounds__(256, 2) octave_pyramid_kernel(const PyrParams 
       ep.eps = p.eps;
       ep.power = 2.f;
       const int E = epilogue_width(p.epilogue);
+      // a frame's 8-sample fragments start on 16-byte chunks when the hop is a multiple of 8; with
+      // a hop of 4 (the bottom octave of an 8-octave bank at hop 512) every other frame starts in
+      // the middle of one, and its fragment is the upper half of one (swizzled) chunk + the lower
+      // half of the next: two 8-byte reads per plane
+      const bool half_chunk = (v_hop & 7) != 0;
+      typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+      auto frag = [&](const unsigned char *plane, int i) __attribute__((always_inline)) -> bf16x8 {
+        if (!half_chunk) return *reinterpret_cast<const bf16x8 *>(plane + pyr_addr(i));
+        u64x2 v;
+        v[0] = *reinterpret_cast<const unsigned long long *>(plane + pyr_addr(i));
+        v[1] = *reinterpret_cast<const unsigned long long *>(plane + pyr_addr(i + 4));
+        return __builtin_bit_cast(bf16x8, v);
+      };
       for (int ft = my_rank; ft < ftiles; ft += my_peers) {
         const int t = t0 + ft * 16 + fn;
-        // window start of frame t inside the span: (t - t0) hop + halo - K/2  (multiple of 8)
+        // window start of frame t inside the span: (t - t0) hop + halo - K/2
         const int w = (ft * 16 + fn) * v_hop + v_wofs;
         f32x4acc cre = {0.f, 0.f, 0.f, 0.f}, cim = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < MAXS; ++s) {
           if (s < steps) {
-            const int ad = pyr_addr(w + 32 * s + 8 * kg);
-            const bf16x8 xh = *reinterpret_cast<const bf16x8 *>(hi + ad);
-            const bf16x8 xl = *reinterpret_cast<const bf16x8 *>(lo + ad);
+            const bf16x8 xh = frag(hi, w + 32 * s + 8 * kg);
+            const bf16x8 xl = frag(lo, w + 32 * s + 8 * kg);
             cre = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rl[s], xh, cre, 0, 0, 0);
             cim = __builtin_amdgcn_mfma_f32_16x16x32_bf16(il[s], xh, cim, 0, 0, 0);
             cre = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh[s], xl, cre, 0, 0, 0);
@@ -394,9 +406,8 @@ __global__ void __launch_bounds__(256, 2) octave_pyramid_kernel(const PyrParams 
           }
         }
         for (int s = MAXS; s < steps; ++s) {  // banks wider than 256 taps: rows streamed from L2
-          const int ad = pyr_addr(w + 32 * s + 8 * kg);
-          const bf16x8 xh = *reinterpret_cast<const bf16x8 *>(hi + ad);
-          const bf16x8 xl = *reinterpret_cast<const bf16x8 *>(lo + ad);
+          const bf16x8 xh = frag(hi, w + 32 * s + 8 * kg);
+          const bf16x8 xl = frag(lo, w + 32 * s + 8 * kg);
           const bf16x8 arh = *reinterpret_cast<const bf16x8 *>(are + 32 * s);
           const bf16x8 arl = *reinterpret_cast<const bf16x8 *>(are + v.bank_plane + 32 * s);
           const bf16x8 aih = *reinterpret_cast<const bf16x8 *>(aim + 32 * s);

@@ -131,7 +131,7 @@ def octave_recursion(x, banks, lenghts, hop, n_bins, lowpass, downsample_factor,
 
     ``precision="bf16x3"`` (and no autograd graph): the fused kernel keeps the decimated signals
     in LDS and contracts every octave from there (``engine.octave_pyramid``); octaves it does not
-    serve (hop below 8 samples at the bottom) and ``precision="fp32"`` run one FIR decimation +
+    serve (hop below 4 samples at the bottom) and ``precision="fp32"`` run one FIR decimation +
     one (grouped) contraction per octave on the exact fp32 kernels."""
     epi = output_epilogue(output_format)
     if scale is None:

@@ -153,13 +153,14 @@ typedef struct mispec_framed_gemm_args {
   int32_t n_fb;
   int32_t reserved3;           /* must be 0                                                */
 
-  /* Symmetric fold (MISPEC_PREC_BF16X3, optional): for a basis that is even (basis_re) / odd
+  /* Symmetric fold (optional, either precision): for a basis that is even (basis_re) / odd
    * (basis_im) about tap kernel/2 -- every Fourier basis of stft.py:230-245 -- the contraction runs
    * over kernel/2 (+1) folded taps of  x[n] + x[kernel-n]  and  x[n] - x[kernel-n]  instead of
-   * `kernel` taps: half the MFMAs.  basis_fold is the output of mispec_fold_basis_bf16() for this
-   * (basis_re, basis_im, n_bins, kernel); the CALLER vouches for the symmetry (the fold routine
-   * reports what it neglects).  Used when the shape allows (even kernel, dense complex basis,
-   * hop >= kernel/8, automatic tile), otherwise ignored.                                      */
+   * `kernel` taps: half the MFMAs.  basis_fold is the output of mispec_fold_basis_bf16()
+   * (MISPEC_PREC_BF16X3) or mispec_fold_basis_f32() (MISPEC_PREC_F32: same size, fp32 taps) for
+   * this (basis_re, basis_im, n_bins, kernel) -- the format must match `precision`; the CALLER
+   * vouches for the symmetry (the fold routine reports what it neglects).  Used when the shape
+   * allows (even kernel, dense complex basis, hop >= kernel/8, automatic tile), otherwise ignored. */
   const void *basis_fold;      /* or NULL                                                  */
   int64_t basis_fold_bytes;
   int32_t fold_taps;           /* value returned by mispec_fold_taps() for this basis      */
@@ -217,7 +218,8 @@ int mispec_split_basis_bf16(const float *basis_re, const float *basis_im,
  * with with_tap0 != 0: needed when some row has a non-zero tap 0, i.e. a window with w[0] != 0).
  *   mispec_fold_taps        folded taps per row (a multiple of 16), < 0 when the kernel cannot fold
  *   mispec_basis_fold_bytes size of `dst`
- *   mispec_fold_basis_bf16  builds dst; stats (device, 2 floats) receives
+ *   mispec_fold_basis_bf16 / mispec_fold_basis_f32
+ *                           build dst (split-bf16 resp. fp32 taps); stats (device, 2 floats) receives
  *                           [0] max |re[n] - re[kernel-n]| / 2, |im[n] + im[kernel-n]| / 2 over all
  *                               pairs = the largest coefficient the fold neglects,
  *                           [1] max |folded coefficient|;
@@ -229,6 +231,9 @@ int64_t mispec_basis_fold_bytes(int32_t n_bins, int32_t kernel, int32_t with_tap
 int mispec_fold_basis_bf16(const float *basis_re, const float *basis_im, int64_t basis_row_stride,
                            int32_t n_bins, int32_t kernel, int32_t with_tap0, void *dst,
                            int64_t dst_bytes, float *stats, void *stream);
+int mispec_fold_basis_f32(const float *basis_re, const float *basis_im, int64_t basis_row_stride,
+                          int32_t n_bins, int32_t kernel, int32_t with_tap0, void *dst,
+                          int64_t dst_bytes, float *stats, void *stream);
 
 /* Launch the MFMA framed contraction.  Replaces stft.py:278-316, cqt.py:740-780,
  * utils.py:498-521 (one call per octave).                                             */

@@ -34,6 +34,7 @@ EXPORTS = (
     "mispec_fold_taps",
     "mispec_basis_fold_bytes",
     "mispec_fold_basis_bf16",
+    "mispec_fold_basis_f32",
     "mispec_filterbank_f32",
     "mispec_istft_grad_signal_f32",
     "mispec_power_to_db_f32",
@@ -232,6 +233,11 @@ def _load(path, how):
     lib.mispec_basis_fold_bytes.argtypes = [ctypes.c_int32] * 3
     lib.mispec_fold_basis_bf16.restype = ctypes.c_int
     lib.mispec_fold_basis_bf16.argtypes = [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+        ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+    ]
+    lib.mispec_fold_basis_f32.restype = ctypes.c_int
+    lib.mispec_fold_basis_f32.argtypes = [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
         ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
     ]

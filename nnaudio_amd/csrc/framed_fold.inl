@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(256) fold_basis_kernel(const float *__restrict
                                                          int with_tap0, int Kf,
                                                          unsigned short *__restrict__ dst,
                                                          float *__restrict__ last_rows,
-                                                         unsigned *__restrict__ stats) {
+                                                         unsigned *__restrict__ stats, int as_f32) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int bin = blockIdx.y;
   float asym = 0.f, amax = 0.f;
@@ -103,15 +103,21 @@ __global__ void __launch_bounds__(256) fold_basis_kernel(const float *__restrict
       }
       amax = fmaxf(fabsf(ae), fabsf(ao));
     }
-    unsigned eh, el, oh, ol;
-    bf16_split(ae, eh, el);
-    bf16_split(ao, oh, ol);
     unsigned short *row = dst + ((long long)bin * (Kf / FOLD_KC) + j / FOLD_KC) * (FOLD_ROWB / 2);
     const int u = j % FOLD_KC;
-    row[u] = (unsigned short)eh;
-    row[16 + u] = (unsigned short)el;
-    row[32 + u] = (unsigned short)oh;
-    row[48 + u] = (unsigned short)ol;
+    if (as_f32) {  // MISPEC_PREC_F32: the same 128-byte stage rows as [re 16 floats | im 16 floats]
+      float *frow = reinterpret_cast<float *>(row);
+      frow[u] = ae;
+      frow[16 + u] = ao;
+    } else {
+      unsigned eh, el, oh, ol;
+      bf16_split(ae, eh, el);
+      bf16_split(ao, oh, ol);
+      row[u] = (unsigned short)eh;
+      row[16 + u] = (unsigned short)el;
+      row[32 + u] = (unsigned short)oh;
+      row[48 + u] = (unsigned short)ol;
+    }
     if (bin == n_bins - 1) {
       last_rows[j] = ae;
       last_rows[Kf + j] = ao;
@@ -201,21 +207,29 @@ __global__ void __launch_bounds__(256) fold_frames_kernel(const KParams p,
     }
 #pragma unroll
     for (int f = 0; f < FOLD_FR; ++f) {
-      uint2 eh, el, oh, ol;
-      bf16_split2(e[f][0], e[f][1], eh.x, el.x);
-      bf16_split2(e[f][2], e[f][3], eh.y, el.y);
-      bf16_split2(o[f][0], o[f][1], oh.x, ol.x);
-      bf16_split2(o[f][2], o[f][3], oh.y, ol.y);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         pe[f] = fmaf(we[i], e[f][i], pe[f]);
         po[f] = fmaf(wo[i], o[f][i], po[f]);
       }
-      unsigned short *r = srow + (long long)f * Kf * 4 + (j0 / FOLD_KC) * (FOLD_ROWB / 2) + (j0 % FOLD_KC);
-      *reinterpret_cast<uint2 *>(r) = eh;
-      *reinterpret_cast<uint2 *>(r + 16) = el;
-      *reinterpret_cast<uint2 *>(r + 32) = oh;
-      *reinterpret_cast<uint2 *>(r + 48) = ol;
+      unsigned short *r = srow + (long long)f * Kf * 4 + (j0 / FOLD_KC) * (FOLD_ROWB / 2);
+      if (p.fold_f32) {  // MISPEC_PREC_F32: stage row = [E 16 floats | O 16 floats]
+        float *fr = reinterpret_cast<float *>(r) + (j0 % FOLD_KC);
+        const f32x4v ev = {e[f][0], e[f][1], e[f][2], e[f][3]}, ov = {o[f][0], o[f][1], o[f][2], o[f][3]};
+        *reinterpret_cast<f32x4v *>(fr) = ev;
+        *reinterpret_cast<f32x4v *>(fr + 16) = ov;
+      } else {
+        uint2 eh, el, oh, ol;
+        bf16_split2(e[f][0], e[f][1], eh.x, el.x);
+        bf16_split2(e[f][2], e[f][3], eh.y, el.y);
+        bf16_split2(o[f][0], o[f][1], oh.x, ol.x);
+        bf16_split2(o[f][2], o[f][3], oh.y, ol.y);
+        r += j0 % FOLD_KC;
+        *reinterpret_cast<uint2 *>(r) = eh;
+        *reinterpret_cast<uint2 *>(r + 16) = el;
+        *reinterpret_cast<uint2 *>(r + 32) = oh;
+        *reinterpret_cast<uint2 *>(r + 48) = ol;
+      }
     }
   }
   __syncthreads();
@@ -281,7 +295,11 @@ __device__ __forceinline__ void lds_dma_barrier_keep() {
 // One tile of the contraction: 128 bins x (64 * NR) frames.  NR = 4 is the kernel described above;
 // NR = 2 (128 frames: 32 KB stages, 4 DMA pieces per wave, half the MFMAs per barrier) serves the
 // frames left over behind the last whole round of workgroups -- see framed_fold_kernel.
-template <int NR>
+// F32 = the same kernel in the exact arithmetic (MISPEC_PREC_F32): stage rows of [re | im] resp.
+// [E | O] fp32 taps, a lane's fragment = taps 8 lh .. 8 lh + 7 (two 16-byte chunks), eight
+// v_mfma_f32_32x32x2_f32 per 16 taps and frame tile (MFMA p contracts taps p and 8 + p) instead of
+// three bf16 ones: the dense fp32 kernel's MFMA count halved, everything else unchanged.
+template <int NR, bool F32>
 __device__ __forceinline__ void framed_fold_body(const KParams &p, const int tile_m, const long long n0) {
   constexpr int WM = 4, WN = 2, NW = 8;
   constexpr int BN = WN * NR * 32;                       // frames of the tile
@@ -353,7 +371,7 @@ __device__ __forceinline__ void framed_fold_body(const KParams &p, const int til
     const unsigned char *st = smem_raw + buf * STAGE;
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) {
-      const int off = 16 * ((4 * HALF + 2 * pl + lh) ^ fsw);
+      const int off = 16 * ((F32 ? 4 * HALF + 2 * lh + pl : 4 * HALF + 2 * pl + lh) ^ fsw);
       fa[HALF][pl] = *reinterpret_cast<const bf16x8 *>(st + a_row + off);
 #pragma unroll
       for (int n = 0; n < NR; ++n)
@@ -363,6 +381,17 @@ __device__ __forceinline__ void framed_fold_body(const KParams &p, const int til
   // the 3 * NR MFMAs of one half; small terms first, an accumulator is revisited after NR - 1 others
   auto mfma_half = [&](auto half_tag) __attribute__((always_inline)) {
     constexpr int HALF = decltype(half_tag)::value;
+    if (F32) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+          const float a = __builtin_bit_cast(f32x4v, fa[HALF][t >> 2])[t & 3];
+          const float x = __builtin_bit_cast(f32x4v, fx[HALF][t >> 2][n])[t & 3];
+          acc[HALF][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, a, acc[HALF][n], 0, 0, 0);
+        }
+      return;
+    }
 #pragma unroll
     for (int term = 0; term < 3; ++term)
 #pragma unroll
@@ -388,7 +417,7 @@ __device__ __forceinline__ void framed_fold_body(const KParams &p, const int til
   using std::integral_constant;
   typedef integral_constant<int, 0> i0;
   typedef integral_constant<int, 1> i1;
-  typedef integral_constant<int, 3 * NR> n_mfma;
+  typedef integral_constant<int, (F32 ? 8 : 3) * NR> n_mfma;
   typedef integral_constant<int, 2 * (1 + NR)> n_reads;
   typedef integral_constant<int, DMA_PER_WAVE> n_dma;
 
@@ -473,7 +502,8 @@ __device__ __forceinline__ void framed_fold_body(const KParams &p, const int til
 // problems of less than half a round double their parallelism (STFT cfg2's shape at B = 4: 0.10 ->
 // 0.07 ms).  A 128-frame tile costs ~0.8 of a 256-frame one, so the host (launch_fold) uses them
 // only where that still pays: cfg3 -4 %, cfg2 (6.75 rounds) unchanged.
-__global__ void __launch_bounds__(512) framed_fold_kernel(const KParams p) {
+template <bool F32>
+__device__ __forceinline__ void framed_fold_grid(const KParams &p) {
   const int b = blockIdx.x;
   if (b < p.fold_main) {
     // ---- XCD-aware tile order (as framed_gemm_body)
@@ -502,14 +532,17 @@ __global__ void __launch_bounds__(512) framed_fold_kernel(const KParams p) {
       }
     }
     tile_n += p.fold_tile0;  // (this launch's chunk of frame tiles)
-    framed_fold_body<4>(p, tile_m, (long long)tile_n * FOLD_BN);
+    framed_fold_body<4, F32>(p, tile_m, (long long)tile_n * FOLD_BN);
   } else {
     // bin blocks fastest: the workgroups that run side by side share their frame rows in L2
     const int t = b - p.fold_main;
     const int tile_n = t / p.n_tiles_m, tile_m = t - tile_n * p.n_tiles_m;
-    framed_fold_body<2>(p, tile_m, p.fold_tail_frame0 + (long long)tile_n * (FOLD_BN / 2));
+    framed_fold_body<2, F32>(p, tile_m, p.fold_tail_frame0 + (long long)tile_n * (FOLD_BN / 2));
   }
 }
+
+__global__ void __launch_bounds__(512) framed_fold_kernel(const KParams p) { framed_fold_grid<false>(p); }
+__global__ void __launch_bounds__(512) framed_fold32_kernel(const KParams p) { framed_fold_grid<true>(p); }
 
 // ---------------------------------------------------------------------------------
 // Role-split variant of the contraction (same tile, same LDS stages, same operands): waves 0-3

@@ -153,6 +153,7 @@ struct KParams {
   int fold_tap0;           // tap 0 is carried as folded tap kernel/2
   int fold_clip0;          // pre-pass launch: first clip; contraction launch: first frame tile
   int fold_tile0;
+  int fold_f32;                // MISPEC_PREC_F32: fp32 stage rows ([re | im], [E | O])
   int fold_main;               // workgroups on 256-frame tiles; the rest take 128-frame tiles
   long long fold_tail_frame0;  //   from this flat frame on
 };
@@ -2276,7 +2277,7 @@ struct FoldPlan {
 
 FoldPlan plan_fold(const mispec_framed_gemm_args *a, const KParams &p) {
   FoldPlan f{};
-  if (a->precision != MISPEC_PREC_BF16X3 || !a->basis_fold || a->tile != MISPEC_TILE_AUTO) return f;
+  if (!a->basis_fold || a->tile != MISPEC_TILE_AUTO) return f;  // (either precision: the planes' format follows it)
   if (MISPEC_DBG(p, 0x100000)) return f;  // A/B runs: the dense kernel
   if (!p.a_im || p.row_support || (p.K & 1) || p.K < 64) return f;
   if ((long long)p.hop * 8 < p.K) return f;  // folded frames cost 8 B per folded tap and frame
@@ -2312,6 +2313,7 @@ int launch_fold(KParams p, const mispec_framed_gemm_args *a, const FoldPlan &f, 
   const unsigned short *bf = static_cast<const unsigned short *>(a->basis_fold);
   p.Ks = f.kf;
   p.fold_tap0 = f.with_tap0;
+  p.fold_f32 = a->precision == MISPEC_PREC_F32;
   p.as = bf;
   p.xs = xf;
   const float *last_rows = reinterpret_cast<const float *>(bf + (long long)p.n_bins * f.kf * 4);
@@ -2333,15 +2335,15 @@ int launch_fold(KParams p, const mispec_framed_gemm_args *a, const FoldPlan &f, 
   if (tn * p.n_tiles_m > 0x7fffffffLL) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
   int g = (32 + p.n_tiles_m / 2) / p.n_tiles_m;  // one workgroup per CU, 32 CUs per XCD
   g = g < 1 ? 1 : g;
-  auto kern = framed_fold_kernel;
-  static std::atomic<unsigned long long> configured{0};
-  int rc = configure_lds(kern, 160 * 1024, configured);
+  auto kern = p.fold_f32 ? framed_fold32_kernel : framed_fold_kernel;
+  static std::atomic<unsigned long long> configured{0}, configured32{0};
+  int rc = configure_lds(kern, 160 * 1024, p.fold_f32 ? configured32 : configured);
   if (rc != MISPEC_OK) return rc;
 #ifdef MISPEC_ABLATE
   {  // A/B runs: the role-split variant (see framed_fold.inl), for the epilogues it serves
     const bool pow_sq = p.epilogue == MISPEC_EPI_POWER && p.power == 2.0f && p.eps == 0.f;
     const bool pow_1 = p.epilogue == MISPEC_EPI_POWER && p.power == 1.0f;
-    if (MISPEC_DBG(p, 0x400000) && (p.fb != nullptr || p.epilogue == MISPEC_EPI_COMPLEX ||
+    if (MISPEC_DBG(p, 0x400000) && !p.fold_f32 && (p.fb != nullptr || p.epilogue == MISPEC_EPI_COMPLEX ||
                                     p.epilogue == MISPEC_EPI_MAGNITUDE || pow_sq || pow_1)) {
       kern = framed_fold_split_kernel;
       static std::atomic<unsigned long long> configured2{0};
@@ -2383,7 +2385,8 @@ int launch_fold(KParams p, const mispec_framed_gemm_args *a, const FoldPlan &f, 
     q2.n_tiles_n = (int)(tile1 - tile0);
     long long grid = (tile1 - tile0) * p.n_tiles_m;
     q2.fold_main = (int)grid;
-    if (tile0 == 0 && tile1 == tn && kern == framed_fold_kernel && !MISPEC_DBG(p, 0x8000000)) {
+    if (tile0 == 0 && tile1 == tn && (kern == framed_fold_kernel || kern == framed_fold32_kernel) &&
+        !MISPEC_DBG(p, 0x8000000)) {
       // whole rounds of the device on 256-frame tiles, the frames behind them on 128-frame tiles
       // (framed_fold_kernel); less than half a round: 128-frame tiles throughout
       const int n_cu = device_cus();
@@ -2676,9 +2679,9 @@ int64_t mispec_basis_fold_bytes(int32_t n_bins, int32_t kernel, int32_t with_tap
   return basis_fold_bytes(n_bins, kernel, with_tap0 != 0);
 }
 
-int mispec_fold_basis_bf16(const float *basis_re, const float *basis_im, int64_t basis_row_stride,
-                           int32_t n_bins, int32_t kernel, int32_t with_tap0, void *dst,
-                           int64_t dst_bytes, float *stats, void *stream) {
+static int fold_basis_any(const float *basis_re, const float *basis_im, int64_t basis_row_stride,
+                          int32_t n_bins, int32_t kernel, int32_t with_tap0, void *dst,
+                          int64_t dst_bytes, float *stats, void *stream, int as_f32) {
   if (!basis_re || !basis_im || !dst) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
   if (n_bins <= 0) return fail(MISPEC_E_INVALID, "non-positive size%s");
   if (kernel < 64 || (kernel & 1)) return fail(MISPEC_E_UNSUPPORTED, "the fold needs an even kernel of >= 64 taps%s");
@@ -2696,10 +2699,24 @@ int mispec_fold_basis_bf16(const float *basis_re, const float *basis_im, int64_t
   if (!st) return fail(MISPEC_E_INVALID, "stats must point to 2 device floats%s");
   hipLaunchKernelGGL(fold_basis_kernel, dim3((unsigned)((kf + 255) / 256), (unsigned)n_bins), dim3(256), 0,
                      s, basis_re, basis_im, (long long)basis_row_stride, n_bins, kernel, w0, kf, d,
-                     last_rows, st);
+                     last_rows, st, as_f32);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MISPEC_E_HIP, "basis fold launch: %s", hipGetErrorString(e));
   return MISPEC_OK;
+}
+
+int mispec_fold_basis_bf16(const float *basis_re, const float *basis_im, int64_t basis_row_stride,
+                           int32_t n_bins, int32_t kernel, int32_t with_tap0, void *dst,
+                           int64_t dst_bytes, float *stats, void *stream) {
+  return fold_basis_any(basis_re, basis_im, basis_row_stride, n_bins, kernel, with_tap0, dst, dst_bytes,
+                        stats, stream, 0);
+}
+
+int mispec_fold_basis_f32(const float *basis_re, const float *basis_im, int64_t basis_row_stride,
+                          int32_t n_bins, int32_t kernel, int32_t with_tap0, void *dst,
+                          int64_t dst_bytes, float *stats, void *stream) {
+  return fold_basis_any(basis_re, basis_im, basis_row_stride, n_bins, kernel, with_tap0, dst, dst_bytes,
+                        stats, stream, 1);
 }
 
 int mispec_framed_gemm_group_f32(const mispec_framed_gemm_args *args, int32_t n, void *stream) {

@@ -294,12 +294,13 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
         a.basis_split = basis_split.data_ptr()
         a.basis_split_bytes = basis_split.numel() * basis_split.element_size()
         keep.append(basis_split)
-        if basis_fold is not None:  # (planes, folded taps) from fold_basis(): half the MFMAs
-            planes, taps = basis_fold
-            a.basis_fold = planes.data_ptr()
-            a.basis_fold_bytes = planes.numel() * planes.element_size()
-            a.fold_taps = int(taps)
-            keep.append(planes)
+    if basis_fold is not None and need_workspace:
+        # (planes, folded taps) from fold_basis() in THIS precision: half the MFMAs
+        planes, taps = basis_fold
+        a.basis_fold = planes.data_ptr()
+        a.basis_fold_bytes = planes.numel() * planes.element_size()
+        a.fold_taps = int(taps)
+        keep.append(planes)
     if need_workspace:
         lib = _abi.load_ablate() if a.reserved else _abi.load()
         need = lib.mispec_framed_gemm_workspace_bytes(ctypes.byref(a))
@@ -346,12 +347,13 @@ def split_basis(basis_re, basis_im):
 FOLD_ASYMMETRY_TOL = 2.0 ** -20
 
 
-def fold_basis(basis_re, basis_im):
+def fold_basis(basis_re, basis_im, precision="bf16x3"):
     """``(planes, folded taps)`` for ``framed_gemm(..., basis_fold=...)`` when the basis is even
     (re) / odd (im) about tap K/2 -- every Fourier basis of the reference's STFT -- else None.
-    The symmetry is checked numerically (``mispec_fold_basis_bf16`` reports the largest
+    The symmetry is checked numerically (``mispec_fold_basis_bf16`` / ``_f32`` report the largest
     coefficient the fold would neglect); this reads two scalars back: once per basis (the callers
-    cache the result), never per forward."""
+    cache the result), never per forward.  The planes' format follows ``precision`` (split bf16 or
+    fp32 taps, the same size) and must be handed to ``framed_gemm`` with that precision."""
     dev = _require_device(basis_re, basis_im)
     wr = _rows(basis_re.detach(), "basis_re")
     wi = _rows(basis_im.detach(), "basis_im") if basis_im is not None else None
@@ -370,7 +372,9 @@ def fold_basis(basis_re, basis_im):
     stats = torch.zeros(2, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
-        _abi.check(lib.mispec_fold_basis_bf16(
+        fold = (lib.mispec_fold_basis_bf16 if resolve_precision(precision) == "bf16x3"
+                else lib.mispec_fold_basis_f32)
+        _abi.check(fold(
             wr.data_ptr(), wi.data_ptr(), wr.stride(0), F, K, with_tap0, dst.data_ptr(), need,
             stats.data_ptr(), ctypes.c_void_p(stream)))
     neglected, largest = (float(v) for v in stats.cpu())
@@ -382,14 +386,13 @@ def fold_basis(basis_re, basis_im):
 def prepare_basis(basis_re, basis_im, precision, hop=None):
     """Derived operands of a basis for ``framed_gemm`` in the given arithmetic, as keyword
     arguments (callers with a persistent basis cache this dict, see ``DerivedCache``): for
-    "bf16x3" the split-bf16 planes and, for a basis with the Fourier symmetry, the folded planes
-    (the library uses them when the shape allows, include/mispec.h ``basis_fold``); nothing for
-    "fp32"."""
-    if resolve_precision(precision) != "bf16x3":
-        return {}
-    out = {"basis_split": split_basis(basis_re, basis_im)}
+    "bf16x3" the split-bf16 planes; in either arithmetic, for a basis with the Fourier symmetry,
+    the folded planes (the library uses them when the shape allows, include/mispec.h
+    ``basis_fold``: half the MFMAs)."""
+    bf16 = resolve_precision(precision) == "bf16x3"
+    out = {"basis_split": split_basis(basis_re, basis_im)} if bf16 else {}
     if basis_im is not None and (hop is None or 8 * int(hop) >= basis_re.shape[-1]):
-        folded = fold_basis(basis_re, basis_im)
+        folded = fold_basis(basis_re, basis_im, "bf16x3" if bf16 else "fp32")
         if folded is not None:
             out["basis_fold"] = folded
     return out
@@ -399,6 +402,8 @@ def describe_framed_kernel(precision, prepared):
     """Name of the dominant kernel ``framed_gemm`` launches for a dense complex basis prepared
     with ``prepare_basis`` (bench.py's report)."""
     if resolve_precision(precision) != "bf16x3":
+        if prepared.get("basis_fold") is not None:
+            return "framed_fold32_kernel (v_mfma_f32_32x32x2_f32, K/2 folded taps) + fold_frames_kernel"
         return "framed_gemm_kernel<2,2,2,2,framed,rows,unmasked> (v_mfma_f32_32x32x2_f32)"
     if prepared.get("basis_fold") is not None:
         return "framed_fold_kernel (v_mfma_f32_32x32x16_bf16, K/2 folded taps) + fold_frames_kernel"

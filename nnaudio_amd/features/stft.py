@@ -166,11 +166,12 @@ class STFT(nn.Module):
             wsin, wcos = wsin[: self.freq_bins], wcos[: self.freq_bins]
         precision = engine.resolve_precision(self.precision)
         prep = {}
-        if precision == "bf16x3" and not engine.compiling():
-            # split planes + (the window being symmetric) the folded planes, cached per basis
+        if not engine.compiling():
+            # bf16x3: split planes; either arithmetic, the window being symmetric: the folded planes
+            # (half the MFMAs) -- cached per basis and precision
             prep = self._split.get((self.wcos, self.wsin),
-                                   lambda: engine.prepare_basis(wcos, wsin, "bf16x3", hop=self.stride),
-                                   extra=(self.freq_bins, self.stride))
+                                   lambda: engine.prepare_basis(wcos, wsin, precision, hop=self.stride),
+                                   extra=(self.freq_bins, self.stride, precision))
         if fb is not None:
             return engine.framed_gemm(
                 x, wcos, wsin, hop=self.stride, pad=pad, pad_mode=mode, epilogue=epilogue,

@@ -26,8 +26,9 @@ _prep_cache = {}  # id(basis_re) -> (weakref, DerivedCache)
 
 def _prepared(basis_re, basis_im, precision, hop):
     """Split / folded planes of a basis for the op's run-time tensors (cached per tensor object)."""
-    if engine.resolve_precision(precision) != "bf16x3" or basis_im is None:
+    if basis_im is None:
         return {}
+    precision = engine.resolve_precision(precision)
     key = id(basis_re)
     hit = _prep_cache.get(key)
     if hit is None or hit[0]() is not basis_re:
@@ -36,7 +37,8 @@ def _prepared(basis_re, basis_im, precision, hop):
     else:
         cache = hit[1]
     return cache.get((basis_re, basis_im),
-                     lambda: engine.prepare_basis(basis_re, basis_im, "bf16x3", hop=hop), extra=int(hop))
+                     lambda: engine.prepare_basis(basis_re, basis_im, precision, hop=hop),
+                     extra=(int(hop), precision))
 
 
 _support_cache = {}  # id(basis_re) -> (weakref, SupportCache)

@@ -847,9 +847,11 @@ def _fourier_like_basis(rng, F, K, tap0):
     (1, 70000, 65, 8192, 2048, 4096, 1, True),    # the longest kernel the fold takes
 ])
 @pytest.mark.parametrize("epi", ["complex", "magnitude", "power2", "phase"])
-def test_symmetric_fold_kernel(shape, epi):
-    """precision="bf16x3" with ``basis_fold``: the contraction over K/2 folded taps of
-    x[n] +- x[K-n] (framed_fold.inl) against the float64 evaluation of the dense contraction."""
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+def test_symmetric_fold_kernel(shape, epi, precision):
+    """``basis_fold`` in either arithmetic: the contraction over K/2 folded taps of x[n] +- x[K-n]
+    (framed_fold.inl; split-bf16 or fp32 taps) against the float64 evaluation of the dense
+    contraction."""
     from nnaudio_amd import engine
 
     B, L, F, K, hop, pad, mode, tap0 = shape
@@ -859,14 +861,15 @@ def test_symmetric_fold_kernel(shape, epi):
     scale = rng.uniform(0.5, 2.0, F).astype(np.float32)
     re, im = _np_framed(x, wr, wi, hop, pad, mode, scale)
     xd, wrd, wid, sd = (torch.as_tensor(a).to(DEV) for a in (x, wr, wi, scale))
-    prep = engine.prepare_basis(wrd, wid, "bf16x3", hop=hop)
+    prep = engine.prepare_basis(wrd, wid, precision, hop=hop)
     assert "basis_fold" in prep and prep["basis_fold"][1] == (K // 2 + (16 if tap0 else 0) + 15) // 16 * 16
+    assert ("basis_split" in prep) == (precision == "bf16x3")
     kw = dict(hop=hop, pad=pad, pad_mode=mode, row_scale=sd)
     e = {"complex": engine.EPI_COMPLEX, "magnitude": engine.EPI_MAGNITUDE, "power2": engine.EPI_POWER,
          "phase": engine.EPI_PHASE_ATAN2}[epi]
-    y = engine.framed_gemm(xd, wrd, wid, precision="bf16x3", epilogue=e, **kw, **prep)
-    ydense = engine.framed_gemm(xd, wrd, wid, precision="bf16x3", epilogue=e, **kw,
-                                basis_split=prep["basis_split"])
+    y = engine.framed_gemm(xd, wrd, wid, precision=precision, epilogue=e, **kw, **prep)
+    ydense = engine.framed_gemm(xd, wrd, wid, precision=precision, epilogue=e, **kw,
+                                **{k: v for k, v in prep.items() if k == "basis_split"})
     torch.cuda.synchronize()
     y, ydense = y.cpu().numpy(), ydense.cpu().numpy()
     if F > 128:
@@ -874,7 +877,8 @@ def test_symmetric_fold_kernel(shape, epi):
     if epi == "complex":
         ref = np.stack((re, im), -1)
         assert_parity(y, ref, rel=1e-4, what="fold %s" % (shape,))
-        assert np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max()  # the split's own budget
+        # the split's own budget; the fp32 taps: the dense fp32 kernel's
+        assert np.abs(y - ref).max() <= (2e-5 if precision == "bf16x3" else 3e-6) * np.abs(ref).max()
     elif epi == "magnitude":
         assert_parity(y, np.sqrt(re * re + im * im), rel=1e-4, what="fold %s" % (shape,))
     elif epi == "power2":
@@ -1376,7 +1380,7 @@ def test_torch_compile_runs_the_custom_ops(cls, ctor, precision):
 
 def test_integration_stub_computes_an_stft():
     """The ctypes stub printed in INTEGRATION.md, executed as is against the in-tree library:
-    framed() in fp32, bf16x3 and bf16x3 + fold_basis reproduces the module."""
+    framed() in fp32 (dense and folded), bf16x3 and bf16x3 + fold_basis reproduces the module."""
     import re
 
     from nnaudio_amd import _abi, features
@@ -1392,12 +1396,16 @@ def test_integration_stub_computes_an_stft():
     with torch.no_grad():
         want = m(x)
         y32 = ns["framed"](x, m.wcos, m.wsin, 128, 256, 2, 1)
+        fold32 = ns["fold_basis"](m.wcos, m.wsin, bf16x3=False)
+        y32f = ns["framed"](x, m.wcos, m.wsin, 128, 256, 2, 1, fold=fold32)
         split = ns["split_basis"](m.wcos, m.wsin)
         fold = ns["fold_basis"](m.wcos, m.wsin)
         yb = ns["framed"](x, m.wcos, m.wsin, 128, 256, 2, 1, split=split)
         yf = ns["framed"](x, m.wcos, m.wsin, 128, 256, 2, 1, split=split, fold=fold)
     torch.cuda.synchronize()
-    assert fold is not None and torch.equal(y32, want)
+    # the module's fp32 forward IS the folded fp32 contraction; the dense one differs by rounding
+    assert fold is not None and fold32 is not None and torch.equal(y32f, want)
+    assert not torch.equal(y32, want) and (y32 - want).abs().max().item() <= 5e-6 * want.abs().max().item()
     for y in (yb, yf):
         assert (y - want).abs().max().item() <= 2e-5 * want.abs().max().item()
     assert not torch.equal(yb, yf)

@@ -134,7 +134,8 @@ typedef struct mispec_framed_gemm_args {
 
   int32_t precision;           /* MISPEC_PREC_*: the LOWEST precision the caller accepts   */
   int32_t reserved2;           /* must be 0                                                */
-  const void *basis_split;     /* MISPEC_PREC_BF16X3: output of mispec_split_basis_bf16()  */
+  const void *basis_split;     /* MISPEC_PREC_BF16X3: output of mispec_split_basis_bf16();  */
+                               /* MISPEC_PREC_F32 (optional): of mispec_frag_basis_f32()    */
   int64_t basis_split_bytes;   /* for this (basis_re, basis_im, n_bins, kernel); else NULL */
 
   /* Fused filterbank reduction (mel.py:184-189: matmul(mel_basis, spec ** power)) -- optional.
@@ -210,6 +211,17 @@ int64_t mispec_basis_split_bytes(int32_t n_bins, int32_t kernel, int32_t has_im)
 int mispec_split_basis_bf16(const float *basis_re, const float *basis_im,
                             int64_t basis_row_stride, int32_t n_bins, int32_t kernel,
                             void *dst, int64_t dst_bytes, void *stream);
+
+/*
+ * MISPEC_PREC_F32 counterpart for bases with supports (CQT banks): the fp32 taps in the strip
+ * kernel's fragment order [16-bin tile][16-tap step][part][lane][4 taps].  Handed over in
+ * `basis_split` (with precision = MISPEC_PREC_F32, row_support and row_support_host) it lets the
+ * exact arithmetic run on the strip kernel too; without it the fp32 tile kernels run.
+ */
+int64_t mispec_basis_frag_bytes(int32_t n_bins, int32_t kernel);
+int mispec_frag_basis_f32(const float *basis_re, const float *basis_im, int64_t basis_row_stride,
+                          int32_t n_bins, int32_t kernel, void *dst, int64_t dst_bytes,
+                          void *stream);
 
 /*
  * Symmetric fold of a Fourier-type basis (see basis_fold above).  Folded tap j stands for the pair

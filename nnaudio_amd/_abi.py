@@ -31,6 +31,8 @@ EXPORTS = (
     "mispec_strip_plan",
     "mispec_basis_split_bytes",
     "mispec_split_basis_bf16",
+    "mispec_basis_frag_bytes",
+    "mispec_frag_basis_f32",
     "mispec_fold_taps",
     "mispec_basis_fold_bytes",
     "mispec_fold_basis_bf16",
@@ -217,6 +219,11 @@ def _load(path, how):
                                                  ctypes.c_void_p]
     lib.mispec_framed_gemm_workspace_bytes.restype = ctypes.c_int64
     lib.mispec_framed_gemm_workspace_bytes.argtypes = [ctypes.POINTER(FramedGemmArgs)]
+    lib.mispec_basis_frag_bytes.restype = ctypes.c_int64
+    lib.mispec_basis_frag_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32]
+    lib.mispec_frag_basis_f32.restype = ctypes.c_int
+    lib.mispec_frag_basis_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                          ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
     lib.mispec_strip_plan.restype = ctypes.c_int32
     lib.mispec_strip_plan.argtypes = [ctypes.POINTER(FramedGemmArgs), ctypes.c_int32, ctypes.c_void_p,
                                       ctypes.c_int32]

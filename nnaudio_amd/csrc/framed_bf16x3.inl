@@ -53,13 +53,22 @@ __global__ void __launch_bounds__(256) split_basis_kernel(const float *__restric
                                                           const float *__restrict__ im,
                                                           long long row_stride, int n_bins, int K,
                                                           int Ks, unsigned short *__restrict__ dst,
-                                                          unsigned short *__restrict__ frag) {
+                                                          unsigned short *__restrict__ frag,
+                                                          float *__restrict__ frag32) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= Ks) return;
   const int bin = blockIdx.y;
   const int z = blockIdx.z;
   const float *src = z ? im : re;
   const float v = k < K ? src[(long long)bin * row_stride + k] : 0.f;
+  if (frag32) {
+    // MISPEC_PREC_F32: fragment order of the strip kernel with fp32 taps -- tile of 16 bins (row =
+    // 2 * bin + component), 16-tap step, part = tap / 4 % 2, lane = row + 32 * (tap / 8 % 2), 4 taps
+    const long long tile = bin >> 4;
+    const int lane = 2 * (bin & 15) + z + 32 * ((k >> 3) & 1);
+    frag32[(((tile * (Ks >> 4) + (k >> 4)) * 2 + ((k >> 2) & 1)) * 64 + lane) * 4 + (k & 3)] = v;
+    return;
+  }
   unsigned hi, lo;
   bf16_split(v, hi, lo);
   const long long plane = (long long)n_bins * Ks;
@@ -102,6 +111,11 @@ __global__ void __launch_bounds__(256) split_signal_kernel(const KParams p,
         t = fetch_sample(p.x, (long long)c * p.x_clip_stride, (int)q, p.n_samples, p.pad_mode, true);
       v[e] = t;
     }
+  }
+  if (p.split_f32) {  // MISPEC_PREC_F32 (strip kernel): the padded clip itself, fp32
+    const f32x4v t = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4v *>(reinterpret_cast<float *>(dst) + (long long)c * p.xs_clip_stride + i0) = t;
+    return;
   }
   u16x4 h, l;
 #pragma unroll

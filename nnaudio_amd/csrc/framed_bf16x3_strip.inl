@@ -85,7 +85,15 @@ __device__ __forceinline__ void strip_barrier(int younger_units) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-__global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KParams p, const StripPlan plan) {
+// F32 = the same kernel in the exact arithmetic (MISPEC_PREC_F32; same plan, same LDS layout,
+// same job structure): the slab holds fp32 samples -- a row's 32 taps as two 64-byte halves in the
+// two planes (taps 0-15 | 16-31: the DMA reads both from the padded fp32 copy of the clip, 64 bytes
+// apart), a lane's fragments of a 16-tap step are taps 8 lh .. 8 lh + 3 and .. + 7 of the step's
+// plane (chunks 2 lh and 2 lh + 1 where the split arithmetic reads the hi and the lo plane) -- the
+// basis fragments are fp32 in the same [tile][16-tap step][part][lane][16 bytes] order, and a
+// step is 8 x 4 v_mfma_f32_32x32x2_f32 (MFMA t of a frame tile contracts taps t and 8 + t).
+template <bool F32>
+__device__ __forceinline__ void framed_strip_body(const KParams &p, const StripPlan &plan) {
   constexpr int NW = STRIP_NW;
   constexpr int ROWB = KC * 2;                    // bytes of one slab row of one plane
   constexpr int SL_PL = STRIP_MAX_ROWS * ROWB;    // hi -> lo plane of a slab buffer
@@ -116,7 +124,10 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
   const int SPH = hop / KC;
   const int C = p.n_super;
   const int n_tiles_n = plan.n_tiles_n;
-  const long long xs_plane = p.xs_plane;
+  // bytes from a slab row's first plane to its second one in the source (split arithmetic: the lo
+  // plane of the split signal; fp32: the second 16 taps of the row), and per 32-tap sub-stage
+  const long long src_plane_bytes = F32 ? 64 : p.xs_plane * 2;
+  constexpr int SRC_STAGE_BYTES = F32 ? 128 : 64;
   // benchmarking build only (constants otherwise): 8 no slab DMA, 16 no reduction / epilogue, 32 no
   // units (the unit loop itself is the product's: ablation branches inside it change its schedule)
   const bool ab_dma = MISPEC_DBG(p, 8), ab_epi = MISPEC_DBG(p, 16);
@@ -200,12 +211,12 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
     }
     __syncthreads();
     STRIP_STAMP(1)
-    const unsigned short *sptr[STRIP_SJ];
+    const char *sptr[STRIP_SJ];
 #pragma unroll
     for (int j = 0; j < STRIP_SJ; ++j) {
       const int pj = j * NW + wave;
       const int row = (pj < spieces ? pj : 0) * 16 + row16;
-      sptr[j] = p.xs + sRowOff[row] + 8 * cg;
+      sptr[j] = reinterpret_cast<const char *>(p.xs) + sRowOff[row] * (F32 ? 4 : 2) + 16 * cg;
     }
     int xrow[4];  // slab row of this lane's frame of frame tile f at super-stage jbase
 #pragma unroll
@@ -226,10 +237,10 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
         for (int j = 0; j < STRIP_SJ; ++j) {
           const int pj = j * NW + wave;
           if (pj < spieces) {
-            const unsigned short *src = sptr[j] + KC * s;
+            const char *src = sptr[j] + SRC_STAGE_BYTES * s;
             const unsigned d = lds0 + buf * SLAB + (sub * slab_rows + pj * 16) * ROWB;
             strip_lds_dma16(src, d);
-            strip_lds_dma16(src + xs_plane, d + SL_PL);
+            strip_lds_dma16(src + src_plane_bytes, d + SL_PL);
           }
         }
       }
@@ -292,15 +303,20 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
         const int row = xrow[f] + dj;  // (the slabs of a buffer start at multiples of 16 rows: same swizzle)
-        dst[f] = base + row * ROWB + 16 * (lh ^ ((row >> 2) & 3));
+        dst[f] = base + row * ROWB + 16 * ((F32 ? 2 * lh : lh) ^ ((row >> 2) & 3));
       }
+    };
+    // address of fragment `part` of step q: split arithmetic -- chunk 2 q + lh of the hi (part 0) /
+    // lo (part 1) plane; fp32 -- chunk 2 lh + part of plane q
+    auto x_frag = [&](unsigned a0, int q, int part) __attribute__((always_inline)) -> unsigned {
+      return F32 ? (a0 ^ (16 * part)) + q * SL_PL : (a0 ^ (32 * q)) + part * SL_PL;
     };
     auto load_set = [&](auto q_tag, const unsigned (&a0)[4]) __attribute__((always_inline)) {
       constexpr int Q = decltype(q_tag)::value;
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        xh[Q][f] = *(lfrag_t)(a0[f] ^ (32 * Q));
-        xl[Q][f] = *(lfrag_t)((a0[f] ^ (32 * Q)) + SL_PL);
+        xh[Q][f] = *(lfrag_t)x_frag(a0[f], Q, 0);
+        xl[Q][f] = *(lfrag_t)x_frag(a0[f], Q, 1);
       }
     };
     f32x16 acc[4];
@@ -316,24 +332,30 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
     // front of the MFMAs they cost 2 x 125 cycles per unit, and the lo fragments, requested inside
     // their own step, another 2 x 150 of waiting); left to hipcc's scheduler the MFMAs get
     // reordered into dependent pairs.
-    auto step = [&](auto slot_tag, auto q_tag, const unsigned (&an)[4], auto nx_tag, auto &&tail)
+    auto step = [&](auto slot_tag, auto q_tag, const unsigned (&an)[4], auto &&tail)
                     __attribute__((always_inline)) {
       constexpr int S = decltype(slot_tag)::value;
       constexpr int Q = decltype(q_tag)::value;
       constexpr int NQ = 1 - Q;
-      constexpr unsigned NX = decltype(nx_tag)::value;
+      constexpr int NM = F32 ? 32 : 12;  // MFMAs of the step
 #pragma unroll
-      for (int i = 0; i < 12; ++i) {
-        const int f = i & 3;
-        if (i < 4)
+      for (int i = 0; i < NM; ++i) {
+        const int f = i & 3, t = i >> 2;
+        if (F32) {
+          // MFMA t contracts taps t and 8 + t of the step: element t & 3 of part t >> 2
+          const f32x4v a = __builtin_bit_cast(f32x4v, t < 4 ? ah[S][Q] : al[S][Q]);
+          const f32x4v x = __builtin_bit_cast(f32x4v, t < 4 ? xh[Q][f] : xl[Q][f]);
+          acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t & 3], x[t & 3], acc[f], 0, 0, 0);
+        } else if (t == 0) {
           acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[S][Q], xh[Q][f], acc[f], 0, 0, 0);
-        else if (i < 8)
+        } else if (t == 1) {
           acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[S][Q], xh[Q][f], acc[f], 0, 0, 0);
-        else
+        } else {
           acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[S][Q], xl[Q][f], acc[f], 0, 0, 0);
-        if (i < 4) xh[NQ][f] = *(lfrag_t)(an[f] ^ NX);
-        else if (i < 8) xl[NQ][f] = *(lfrag_t)((an[f] ^ NX) + SL_PL);
-        if (i >= 8) tail(f);
+        }
+        if (i < 4) xh[NQ][f] = *(lfrag_t)x_frag(an[f], NQ, 0);
+        else if (i < 8) xl[NQ][f] = *(lfrag_t)x_frag(an[f], NQ, 1);
+        if (i >= NM - 4) tail(f);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -387,15 +409,15 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
       const int djn = same ? n1.j - jbase : dj;
       const unsigned basen = x_base(same ? n1.s : (cur.valid ? cur.s : 0));
       __builtin_amdgcn_sched_barrier(0);
-      step(slot_tag, i0{}, xa, std::integral_constant<unsigned, 32>{}, [&](int f) __attribute__((always_inline)) {
+      step(slot_tag, i0{}, xa, [&](int f) __attribute__((always_inline)) {
         const int row = xrow[f] + djn;
-        xn[f] = basen + row * ROWB + 16 * (lh ^ ((row >> 2) & 3));
+        xn[f] = basen + row * ROWB + 16 * ((F32 ? 2 * lh : lh) ^ ((row >> 2) & 3));
       });
       // ---- step 1 (+ the reads of the next unit's step 0, + this slot's next basis fragments)
       const unsigned short *asrc = a_src(n3);
-      // (the last four MFMAs still read ah[S][1]: it is reloaded behind the very last one)
-      step(slot_tag, i1{}, xn, std::integral_constant<unsigned, 0>{}, [&](int f) __attribute__((always_inline)) {
-        load_a1(slot_tag, asrc, f == 2 ? 3 : (f == 3 ? 2 : f));
+      // (the last four MFMAs still read ah[S][1] -- fp32: al[S][1] --, reloaded behind the very last one)
+      step(slot_tag, i1{}, xn, [&](int f) __attribute__((always_inline)) {
+        load_a1(slot_tag, asrc, F32 ? f : (f == 2 ? 3 : (f == 3 ? 2 : f)));
       });
       ++done_in_s;
       if (!same) {
@@ -524,4 +546,11 @@ __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KPara
     __syncthreads();
     job = __builtin_amdgcn_readfirstlane(sJob[0]);
   }
+}
+
+__global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KParams p, const StripPlan plan) {
+  framed_strip_body<false>(p, plan);
+}
+__global__ void __launch_bounds__(256, 2) framed_f32_strip_kernel(const KParams p, const StripPlan plan) {
+  framed_strip_body<true>(p, plan);
 }

@@ -142,6 +142,7 @@ struct KParams {
   int row_split;  // framed_bf16x3_narrow: workgroups per frame tile (each takes every row_split-th row tile)
   unsigned *job_counter;  // framed_bf16x3_strip: next job; zeroed by the signal split of the same call
   const unsigned short *afrag;  // framed_bf16x3_strip: the basis in fragment order, or NULL
+  int split_f32;                // split_signal_kernel writes the padded clip in fp32 (fp32 strip kernel)
   // fused filterbank reduction (bf16x3_epilogue_fb): out[c, m, t] += sum_bin fb[m, bin] * |X|^power
   const float *fb;
   const int *fb_support;
@@ -1901,7 +1902,7 @@ double strip_alloc(const StripTile *t, int k, int *waves) {
   return m;
 }
 
-bool plan_strip(const KParams &p, const int32_t *sup, int n_slots, StripPlan &plan) {
+bool plan_strip(const KParams &p, const int32_t *sup, int n_slots, StripPlan &plan, bool f32 = false) {
   if (!sup || !p.a_im || !p.row_support) return false;
   if (p.hop % KC != 0 || p.hop > 64 * KC || p.Ks < 2 * p.hop || p.n_frames < STRIP_BN) return false;
   const int hop = p.hop, sph = hop / KC;
@@ -1941,7 +1942,9 @@ bool plan_strip(const KParams &p, const int32_t *sup, int n_slots, StripPlan &pl
   // clock).  (Charging the ~1.2 us of barrier + refill per sub-stage as well -- 12 + 1.45 * sph --
   // merges tiles 1 and 2 into one pass of 3 + 1 waves: measured 4 % slower, the single wave of
   // tile 2 then sets the pace of every sub-stage.)
-  const double ovh = 0.75 * sph;
+  // (a unit of the fp32 kernel -- 128 fp32 MFMAs -- takes five times as long: the same ~10 us are
+  // fewer units)
+  const double ovh = (f32 ? 0.15 : 0.75) * sph;
   // slab reach of a group: span of super-stages
   auto span_of = [&](int a, int k) {
     int lo = 1 << 30, hi = -1;
@@ -2063,8 +2066,9 @@ struct StripPlanKey {
   unsigned long long hash;
   int n_bins, hop, Ks, K, n_frames, n_cu;
   long long n_cols;
+  int f32, pad;
 };
-bool strip_plan_cached(const KParams &p, const int32_t *sup, int n_cu, StripPlan &plan) {
+bool strip_plan_cached(const KParams &p, const int32_t *sup, int n_cu, StripPlan &plan, bool f32 = false) {
   static std::mutex mu;
   struct Entry {
     StripPlanKey key;
@@ -2075,7 +2079,7 @@ bool strip_plan_cached(const KParams &p, const int32_t *sup, int n_cu, StripPlan
   static std::vector<Entry> cache;
   unsigned long long h = 1469598103934665603ull;
   for (int i = 0; i < 2 * p.n_bins; ++i) h = (h ^ (unsigned)sup[i]) * 1099511628211ull;
-  const StripPlanKey key{h, p.n_bins, p.hop, p.Ks, p.K, p.n_frames, n_cu, p.n_cols};
+  const StripPlanKey key{h, p.n_bins, p.hop, p.Ks, p.K, p.n_frames, n_cu, p.n_cols, f32 ? 1 : 0, 0};
   std::lock_guard<std::mutex> lock(mu);
   for (const Entry &e : cache)
     if (memcmp(&e.key, &key, sizeof(key)) == 0 &&
@@ -2087,7 +2091,7 @@ bool strip_plan_cached(const KParams &p, const int32_t *sup, int n_cu, StripPlan
   memset(&e.key, 0, sizeof(e.key));
   e.key = key;
   e.sup.assign(sup, sup + 2 * p.n_bins);
-  e.ok = plan_strip(p, sup, n_cu, e.plan);
+  e.ok = plan_strip(p, sup, n_cu, e.plan, f32);
   if (cache.size() >= 32) cache.erase(cache.begin());
   cache.push_back(e);
   plan = e.plan;
@@ -2564,6 +2568,52 @@ int fir_params(KParams &p, const float *x, int64_t x_clip_stride, int32_t n_clip
 
 }  // namespace
 
+// ---- fp32 strip kernel (MISPEC_PREC_F32 with supports, their host copy and the fp32 fragment-order
+// copy of the basis in basis_split): applicability and launch
+bool strip32_ok(const mispec_framed_gemm_args *a, const KParams &p, int n_cu, StripPlan &plan) {
+  if (a->precision != MISPEC_PREC_F32 || !a->basis_split || !a->row_support || !a->row_support_host ||
+      !p.a_im || a->tile != MISPEC_TILE_AUTO || p.fb || MISPEC_DBG(p, 0x800000))
+    return false;
+  if (!basis_has_frags(p.n_bins, true) ||
+      a->basis_split_bytes < (long long)((p.n_bins + 15) / 16) * round_up_kc(p.K) * 128 + 4096)
+    return false;
+  if (p.n_bins * 2 <= 128) return false;  // (as the split arithmetic: narrow problems stay on the tile kernels)
+  KParams q = p;
+  q.Ks = round_up_kc(p.K);
+  return strip_plan_cached(q, a->row_support_host, 2 * n_cu, plan, true);
+}
+
+int launch_strip32(KParams p, const mispec_framed_gemm_args *a, const StripPlan &plan, int n_cu,
+                   hipStream_t stream) {
+  const EdgePlan e = plan_edges(p.n_samples, p.K, p.hop, p.pad, p.n_frames);
+  const SplitPlan sp = plan_split(p, e);
+  if (!a->workspace || a->workspace_bytes < sp.edge_bytes + sp.bytes)
+    return fail(MISPEC_E_INVALID, "workspace too small: size it with the *_workspace_bytes query%s");
+  float *xs = reinterpret_cast<float *>(static_cast<char *>(a->workspace) + sp.edge_bytes);
+  p.xs = reinterpret_cast<const unsigned short *>(xs);
+  p.xs_clip_stride = sp.slot;
+  p.xs_plane = 0;
+  p.split_f32 = 1;
+  p.job_counter = reinterpret_cast<unsigned *>(xs + sp.slot * p.n_clips);
+  p.Ks = round_up_kc(p.K);
+  p.afrag = static_cast<const unsigned short *>(a->basis_split);
+  const unsigned gx = (unsigned)((sp.slot + 1023) / 1024);
+  hipLaunchKernelGGL(split_signal_kernel, dim3(gx, (unsigned)p.n_clips), dim3(256), 0, stream, p,
+                     reinterpret_cast<unsigned short *>(xs));
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail(MISPEC_E_HIP, "signal pad launch: %s", hipGetErrorString(err));
+  p.n_super = (p.Ks + p.hop - 1) / p.hop;
+  auto kern = framed_f32_strip_kernel;
+  static std::atomic<unsigned long long> configured{0};
+  int rc = configure_lds(kern, 160 * 1024, configured);
+  if (rc != MISPEC_OK) return rc;
+  const unsigned grid = (unsigned)(plan.n_jobs < 2 * n_cu ? plan.n_jobs : 2 * n_cu);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(STRIP_NW * 64), (size_t)STRIP_LDS_BYTES, stream, p, plan);
+  err = hipGetLastError();
+  if (err != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(err));
+  return MISPEC_OK;
+}
+
 extern "C" {
 
 int mispec_version(void) { return MISPEC_ABI_VERSION; }
@@ -2581,6 +2631,13 @@ int64_t mispec_framed_gemm_workspace_bytes(const mispec_framed_gemm_args *args) 
     const SplitPlan sp = plan_split(p, e);
     return sp.edge_bytes + sp.bytes;
   }
+  {
+    StripPlan plan;
+    if (strip32_ok(args, p, device_cus(), plan)) {  // the padded fp32 copy of the clips
+      const SplitPlan sp = plan_split(p, e);
+      return sp.edge_bytes + sp.bytes;
+    }
+  }
   return e.stride * p.n_clips * (int64_t)sizeof(float);
 }
 
@@ -2590,12 +2647,16 @@ int32_t mispec_strip_plan(const mispec_framed_gemm_args *args, int32_t n_cu, int
   int rc = fill_params(args, p);
   if (rc != MISPEC_OK) return rc;
   if (n_cu <= 0 || cap < 0 || (cap > 0 && !plan_out)) return fail(MISPEC_E_INVALID, "bad plan buffer%s");
-  if (!bf16x3_ok(args, p) || !args->row_support || !args->row_support_host ||
-      args->tile != MISPEC_TILE_AUTO || !basis_has_frags(p.n_bins, p.a_im != nullptr))
-    return 0;
-  p.Ks = round_up_kc(p.K);
   StripPlan plan;
-  if (!plan_strip(p, args->row_support_host, 2 * n_cu, plan)) return 0;
+  if (args->precision == MISPEC_PREC_F32) {
+    if (!strip32_ok(args, p, n_cu, plan)) return 0;
+  } else {
+    if (!bf16x3_ok(args, p) || !args->row_support || !args->row_support_host ||
+        args->tile != MISPEC_TILE_AUTO || !basis_has_frags(p.n_bins, p.a_im != nullptr))
+      return 0;
+    p.Ks = round_up_kc(p.K);
+    if (!plan_strip(p, args->row_support_host, 2 * n_cu, plan)) return 0;
+  }
   int n = 0;
   auto put = [&](int v) {
     if (n < cap) plan_out[n] = v;
@@ -2623,6 +2684,11 @@ int mispec_framed_gemm_f32(const mispec_framed_gemm_args *args, void *stream) {
   const FoldPlan fold = plan_fold(args, p);
   if (fold.ok) return launch_fold(p, args, fold, s);
   const bool bf16x3 = bf16x3_ok(args, p);
+  if (!bf16x3) {
+    StripPlan plan;
+    const int n_cu = device_cus();
+    if (strip32_ok(args, p, n_cu, plan)) return launch_strip32(p, args, plan, n_cu, s);
+  }
   // (the bf16x3 kernels read the padded split signal, not the fp32 path's edge workspace)
   if (!bf16x3 || plan_bf16x3_rows(p, args->tile).fp32_leftover) {
     rc = setup_edges(p, args->workspace, args->workspace_bytes, s);
@@ -2662,9 +2728,34 @@ int mispec_split_basis_bf16(const float *basis_re, const float *basis_im,
                                               basis_im ? 2u : 1u),
                      dim3(256), 0, static_cast<hipStream_t>(stream), basis_re, basis_im,
                      (long long)basis_row_stride, n_bins, kernel, ks,
-                     static_cast<unsigned short *>(dst), frag);
+                     static_cast<unsigned short *>(dst), frag, static_cast<float *>(nullptr));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MISPEC_E_HIP, "basis split launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+
+int64_t mispec_basis_frag_bytes(int32_t n_bins, int32_t kernel) {
+  if (n_bins <= 0 || kernel <= 0) return fail(MISPEC_E_INVALID, "non-positive size%s");
+  if (!basis_has_frags(n_bins, true)) return fail(MISPEC_E_UNSUPPORTED, "more than 1024 bins%s");
+  return (long long)((n_bins + 15) / 16) * round_up_kc(kernel) * 128 + 4096;
+}
+
+int mispec_frag_basis_f32(const float *basis_re, const float *basis_im, int64_t basis_row_stride,
+                          int32_t n_bins, int32_t kernel, void *dst, int64_t dst_bytes, void *stream) {
+  if (!basis_re || !basis_im || !dst) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
+  const int64_t need = mispec_basis_frag_bytes(n_bins, kernel);
+  if (need < 0) return (int)need;
+  if (dst_bytes < need) return fail(MISPEC_E_INVALID, "dst too small: size it with mispec_basis_frag_bytes%s");
+  const int ks = round_up_kc(kernel);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // (rows past the last bin of the last 16-bin tile, and the block behind the tiles, stay zero)
+  if (hipMemsetAsync(dst, 0, (size_t)need, s) != hipSuccess) return fail(MISPEC_E_HIP, "hipMemsetAsync failed%s");
+  hipLaunchKernelGGL(split_basis_kernel, dim3((unsigned)((ks + 255) / 256), (unsigned)n_bins, 2u), dim3(256), 0,
+                     s, basis_re, basis_im, (long long)basis_row_stride, n_bins, kernel, ks,
+                     static_cast<unsigned short *>(nullptr), static_cast<unsigned short *>(nullptr),
+                     static_cast<float *>(dst));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "basis fragment launch: %s", hipGetErrorString(e));
   return MISPEC_OK;
 }
 

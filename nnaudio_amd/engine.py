@@ -294,6 +294,11 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
         a.basis_split = basis_split.data_ptr()
         a.basis_split_bytes = basis_split.numel() * basis_split.element_size()
         keep.append(basis_split)
+    elif basis_split is not None and need_workspace and row_support is not None:
+        # fp32 with the fragment-order copy of a bank with supports (frag_basis_f32): the strip kernel
+        a.basis_split = basis_split.data_ptr()
+        a.basis_split_bytes = basis_split.numel() * basis_split.element_size()
+        keep.append(basis_split)
     if basis_fold is not None and need_workspace:
         # (planes, folded taps) from fold_basis() in THIS precision: half the MFMAs
         planes, taps = basis_fold
@@ -338,6 +343,27 @@ def split_basis(basis_re, basis_im):
         _abi.check(lib.mispec_split_basis_bf16(
             wr.data_ptr(), wi.data_ptr() if wi is not None else None, wr.stride(0), F, K,
             dst.data_ptr(), need, ctypes.c_void_p(stream)))
+    return dst
+
+
+def frag_basis_f32(basis_re, basis_im):
+    """The fp32 taps of a complex bank in the strip kernel's fragment order
+    (mispec_frag_basis_f32), or None for banks of more than 1024 bins: with it, the supports and
+    their host copy, ``precision="fp32"`` contractions of CQT banks run on the strip kernel."""
+    dev = _require_device(basis_re, basis_im)
+    wr, wi = _rows(basis_re, "basis_re"), _rows(basis_im, "basis_im")
+    if wi.shape != wr.shape or wi.stride(0) != wr.stride(0):
+        raise RuntimeError("real / imaginary bases must have identical shape and layout")
+    lib = _abi.load()
+    F, K = wr.shape
+    need = lib.mispec_basis_frag_bytes(F, K)
+    if need < 0:
+        return None
+    dst = torch.empty(need // 4, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _abi.check(lib.mispec_frag_basis_f32(wr.data_ptr(), wi.data_ptr(), wr.stride(0), F, K,
+                                             dst.data_ptr(), need, ctypes.c_void_p(stream)))
     return dst
 
 

@@ -112,9 +112,11 @@ class CQT1992v2(nn.Module):
         sup = None if self.trainable else self._support.get(self.cqt_kernels_real,
                                                             self.cqt_kernels_imag)
         split = None
+        kr, ki = self.cqt_kernels_real, self.cqt_kernels_imag
         if precision == "bf16x3":
-            kr, ki = self.cqt_kernels_real, self.cqt_kernels_imag
-            split = self._split.get((kr, ki), lambda: engine.split_basis(kr, ki))
+            split = self._split.get((kr, ki), lambda: engine.split_basis(kr, ki), extra=precision)
+        elif sup is not None:  # fp32 with supports: the fragment-order copy for the strip kernel
+            split = self._split.get((kr, ki), lambda: engine.frag_basis_f32(kr, ki), extra=precision)
         return engine.framed_gemm_autograd(
             x, self.cqt_kernels_real, self.cqt_kernels_imag, hop=self.hop_length, pad=pad,
             pad_mode=mode, epilogue=epi, im_sign=-1.0, eps=1e-8 if self.trainable else 0.0,

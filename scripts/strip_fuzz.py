@@ -1,5 +1,5 @@
 """Random shapes through the strip kernel against the one-thread-per-output device kernel:
-python scripts/strip_fuzz.py [cases] [seed]"""
+python scripts/strip_fuzz.py [cases] [seed] [bf16x3|fp32]"""
 import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,6 +7,7 @@ from nnaudio_amd import _abi, engine
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+PREC = sys.argv[3] if len(sys.argv) > 3 else "bf16x3"
 DEV = "cuda"
 taken = 0
 for case in range(n_cases):
@@ -39,14 +40,17 @@ for case in range(n_cases):
     sc = torch.as_tensor(rng.uniform(0.5, 2.0, F).astype(np.float32)).to(DEV)
     epi = int(rng.choice([engine.EPI_COMPLEX, engine.EPI_MAGNITUDE, engine.EPI_POWER, engine.EPI_PHASE_COSSIN]))
     kw = dict(hop=hop, pad=pad, pad_mode=mode, epilogue=epi, row_scale=sc)
-    a, _o, _d, _k = engine._framed_args(x, wr, wi, precision="bf16x3", row_support=sup, **kw)
+    if PREC == "fp32":
+        kw["basis_split"] = engine.frag_basis_f32(wr, wi)
+    a, _o, _d, _k = engine._framed_args(x, wr, wi, precision=PREC, row_support=sup, **kw)
     n_pass = _abi.load().mispec_strip_plan(ctypes.byref(a), 256, None, 0)
     taken += n_pass > 0
-    ref = engine.framed_gemm(x, wr, wi, reference_kernel=True, **kw)
-    y = engine.framed_gemm(x, wr, wi, precision="bf16x3", row_support=sup, **kw)
+    rkw = {k: v for k, v in kw.items() if k != "basis_split"}
+    ref = engine.framed_gemm(x, wr, wi, reference_kernel=True, **rkw)
+    y = engine.framed_gemm(x, wr, wi, precision=PREC, row_support=sup, **kw)
     torch.cuda.synchronize()
     if epi == engine.EPI_PHASE_COSSIN:
-        z = engine.framed_gemm(x, wr, wi, reference_kernel=True, **dict(kw, epilogue=engine.EPI_COMPLEX))
+        z = engine.framed_gemm(x, wr, wi, reference_kernel=True, **dict(rkw, epilogue=engine.EPI_COMPLEX))
         mag = torch.sqrt(z[..., 0] ** 2 + z[..., 1] ** 2)
         strong = mag > 0.05 * mag.max()
         err = float((y - ref)[strong].abs().max()) if bool(strong.any()) else 0.0
@@ -54,7 +58,7 @@ for case in range(n_cases):
     else:
         scale = float(ref.abs().max())
         err = float((y - ref).abs().max()) / max(scale, 1e-30)
-        ok = err <= 1e-4 and bool(torch.isfinite(y).all())
+        ok = err <= (1e-4 if PREC == "bf16x3" else 1e-5) and bool(torch.isfinite(y).all())
     print("case %2d hop %3d K %5d F %3d B %d T %3d pad %d epi %d passes %d: err %.2e %s"
           % (case, hop, K, F, B, T, mode, epi, n_pass, err, "ok" if ok else "FAIL"))
     if not ok:

@@ -113,6 +113,10 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert lib.mispec_basis_split_bytes(0, 16, 1) == -1 and lib.mispec_basis_split_bytes(4, 48, 0) == 2 * 4 * 64 * 2
     # complex banks: four planes + the fragment-order copy of one 16-bin tile + its block of zeros
     assert lib.mispec_basis_split_bytes(4, 48, 1) == 4 * 4 * 64 * 2 + 1 * 64 * 128 + 4096
+    # the fp32 fragment-order copy alone (MISPEC_PREC_F32 on the strip kernel): 17 bins = 2 tiles
+    assert lib.mispec_basis_frag_bytes(17, 48) == 2 * 64 * 128 + 4096 and lib.mispec_basis_frag_bytes(0, 48) == -1
+    assert lib.mispec_basis_frag_bytes(1025, 64) == -2
+    assert lib.mispec_frag_basis_f32(None, None, 0, 4, 48, None, 0, None) == -1
     # the fused filterbank fields are validated with the rest of the block (fake non-NULL pointers:
     # nothing is dereferenced on the host)
     a = _abi.FramedGemmArgs()

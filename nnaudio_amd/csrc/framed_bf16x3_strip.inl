@@ -1,5 +1,5 @@
-// framed_bf16x3_strip.inl -- bf16x3 kernel for bases with per-row supports (CQT banks) whose
-// basis fragments never pass through LDS.  Included by mispec.hip after framed_fold.inl; the
+// framed_bf16x3_strip.inl -- kernel for bases with per-row supports (CQT banks) whose basis
+// fragments never pass through LDS; split-bf16 (bf16x3) and, same code, fp32 arithmetic.  Included by mispec.hip after framed_fold.inl; the
 // hop-periodic K order (tap k = j*hop + 32*s, one LDS slab per sub-stage s) is explained in
 // framed_bf16x3_slab.inl, the predecessor of this kernel in framed_bf16x3_narrow.inl.
 //
@@ -10,15 +10,17 @@
 // tile's super-stages:
 //   * its basis fragments are used by no other wave of the workgroup, so they are loaded straight
 //     from global memory (L2: the non-zero part of a CQT bank is a few MB) into registers, 16 taps
-//     x 32 rows per instruction, two units ahead -- no LDS traffic, no barrier for the basis;
+//     x 32 rows per instruction, three units ahead -- no LDS traffic, no barrier for the basis;
 //   * one fragment pair of the basis serves four frame tiles: 8 LDS reads per 12 MFMAs;
 //   * the only shared data is the slab of the signal (128 + span - 1 rows of 32 taps), double
-//     buffered, one barrier per sub-stage.
+//     buffered, one barrier per sub-stage (per two where two slabs fit one buffer).
 // The four waves of a workgroup take strips of the SAME 128 frames: a host-made plan (plan_strip,
 // mispec.hip) groups the row tiles into passes and deals the waves of a pass out in proportion to
-// the tiles' K ranges (cfg4: tile 0 on four waves, tile 1 on four, tiles 2-3 as 2 + 2, ...).
+// the tiles' K ranges (cfg4: tile 0 on four waves, tile 1 on four, tile 2 on four, tiles 3-5 as
+// 2 + 1 + 1).
 // Waves that share a row tile add their partial sums through LDS at the end of the pass; the
-// pointwise epilogue is the one of the other bf16x3 kernels.  Jobs (pass, frame tile) are handed
+// complex / magnitude / power epilogues are formed in registers, the phase ones go through the
+// shared bf16x3_epilogue (one code instance of the transcendentals).  Jobs (pass, frame tile) are handed
 // out longest first through an atomic counter to TWO persistent workgroups per CU (76 KB of LDS
 // each): every SIMD hosts one wave of each, so the serial parts of a job -- tables, the first slab,
 // the barrier of every sub-stage, reduction and epilogue -- run under the other workgroup's MFMAs

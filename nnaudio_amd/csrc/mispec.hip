@@ -1963,13 +1963,18 @@ bool plan_strip(const KParams &p, const int32_t *sup, int n_slots, StripPlan &pl
   caps[n_caps++] = 1e30;
   double best_est = 1e300;
   int best_cut[STRIP_NW * STRIP_MAX_PASS], best_np = 0;
+  // (the search charges `sovh` per pass; when the true overhead is too small to keep a bank of many
+  // tiles within STRIP_MAX_PASS passes it is raised until a grouping fits -- the estimate that ranks
+  // the groupings always uses the true one)
+  for (double sovh = ovh; best_np == 0 && sovh < 1e6; sovh = sovh * 2 + 1)
   for (int ci = 0; ci < n_caps; ++ci) {
     const double cap = caps[ci] + 1e-9;
     // dp[i]: cheapest way to cover the first i tiles (sorted) with passes whose share is <= cap
-    double dp[STRIP_NW * STRIP_MAX_PASS + 1], dmax[STRIP_NW * STRIP_MAX_PASS + 1];
+    double dp[STRIP_NW * STRIP_MAX_PASS + 1], dmax[STRIP_NW * STRIP_MAX_PASS + 1], dsum[STRIP_NW * STRIP_MAX_PASS + 1];
     int from[STRIP_NW * STRIP_MAX_PASS + 1], np[STRIP_NW * STRIP_MAX_PASS + 1];
     dp[0] = 0;
     dmax[0] = 0;
+    dsum[0] = 0;
     np[0] = 0;
     for (int i = 1; i <= M; ++i) {
       dp[i] = 1e300;
@@ -1979,18 +1984,19 @@ bool plan_strip(const KParams &p, const int32_t *sup, int n_slots, StripPlan &pl
         const double share = strip_alloc(t + i - k, k, waves);
         const int rows = (STRIP_BN + 2 * (span_of(i - k, k) - 1) + 15) / 16 * 16;
         if (share > cap || rows > STRIP_MAX_ROWS) continue;
-        const double c = dp[i - k] + share + ovh;
+        const double c = dp[i - k] + share + sovh;
         if (c < dp[i]) {
           dp[i] = c;
           from[i] = i - k;
           const double mx = share + ovh;
           dmax[i] = dmax[i - k] > mx ? dmax[i - k] : mx;
+          dsum[i] = dsum[i - k] + share + ovh;
           np[i] = np[i - k] + 1;
         }
       }
     }
     if (dp[M] >= 1e300 || np[M] > STRIP_MAX_PASS) continue;
-    const double total = dp[M] * (double)n_tiles_n / n_slots;
+    const double total = dsum[M] * (double)n_tiles_n / n_slots;
     const double jobs = (double)np[M] * n_tiles_n;
     const double est = jobs <= n_slots ? dmax[M] : (total > dmax[M] ? total : dmax[M]) + 0.5 * dmax[M];
     if (est < best_est) {

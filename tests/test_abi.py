@@ -232,7 +232,7 @@ def test_filterbank_support_tables():
     assert not engine.fused_filterbank_ok(2.0, cov, 300)    # > 256 filters
 
 
-def _plan_args(m, B, L, keep):
+def _plan_args(m, B, L, keep, precision="bf16x3"):
     """Argument block of CQT1992v2's contraction with fake device pointers (nothing is dereferenced
     by the host-only planning query) and the real supports."""
     from nnaudio_amd import _abi, engine
@@ -251,8 +251,12 @@ def _plan_args(m, B, L, keep):
     a.basis_row_stride, a.n_bins, a.kernel = K, F, K
     a.epilogue, a.im_sign = engine.EPI_MAGNITUDE, -1.0
     a.out_clip_stride, a.out_row_stride = F * a.n_frames, a.n_frames
-    a.precision = engine.PREC_BF16X3
-    a.basis_split_bytes = _abi.load().mispec_basis_split_bytes(F, K, 1)
+    if precision == "bf16x3":
+        a.precision = engine.PREC_BF16X3
+        a.basis_split_bytes = _abi.load().mispec_basis_split_bytes(F, K, 1)
+    else:  # fp32: the fragment-order copy of the bank in basis_split
+        a.precision = engine.PREC_F32
+        a.basis_split_bytes = _abi.load().mispec_basis_frag_bytes(F, K)
     a.row_support_host = sup.host_copy.ctypes.data
     keep.append(sup)
     return a, sup.host_copy
@@ -265,7 +269,8 @@ def _plan_args(m, B, L, keep):
     dict(sr=22050, hop_length=512, n_bins=120, bins_per_octave=36, fmin=110.0, B=2, L=80000),
     dict(sr=16000, hop_length=128, n_bins=70, bins_per_octave=12, fmin=55.0, B=5, L=33000),
 ])
-def test_strip_plan_covers_every_row_tile_once(cfg):
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+def test_strip_plan_covers_every_row_tile_once(cfg, precision):
     """Host logic of the strip kernel's launch plan (mispec_strip_plan, no GPU): every 16-bin row
     tile sits in exactly one pass, its waves cut its super-stages into consecutive runs, the
     reduction masks of a group cover the four frame tiles once, the slab holds the pass."""
@@ -275,7 +280,7 @@ def test_strip_plan_covers_every_row_tile_once(cfg):
     B, L = cfg.pop("B"), cfg.pop("L")
     m = features.CQT1992v2(verbose=False, **cfg)
     keep = []
-    a, sup = _plan_args(m, B, L, keep)
+    a, sup = _plan_args(m, B, L, keep, precision)
     lib = _abi.load()
     buf = (ctypes.c_int32 * (1 + 8 * 36))()
     n_pass = lib.mispec_strip_plan(ctypes.byref(a), 256, buf, len(buf))

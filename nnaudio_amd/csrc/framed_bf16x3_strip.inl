@@ -59,7 +59,8 @@ struct StripPass {
   int group;        // sub-stages per slab buffer (2 when two slabs fit: half the barriers), else 1
 };
 struct StripPlan {
-  int n_pass, n_tiles_n, n_jobs, reserved;
+  int n_pass, n_tiles_n, n_jobs;
+  int nf;  // frame tiles of a job (4: 128 frames; 2: 64)
   StripPass pass[STRIP_MAX_PASS];
 };
 static_assert(sizeof(StripPlan) <= 1280, "STRIP_PLAN_BYTES");
@@ -94,9 +95,10 @@ __device__ __forceinline__ void strip_barrier(int younger_units) {
 // plane (chunks 2 lh and 2 lh + 1 where the split arithmetic reads the hi and the lo plane) -- the
 // basis fragments are fp32 in the same [tile][16-tap step][part][lane][16 bytes] order, and a
 // step is 8 x 4 v_mfma_f32_32x32x2_f32 (MFMA t of a frame tile contracts taps t and 8 + t).
-template <bool F32>
+template <bool F32, int NF>
 __device__ __forceinline__ void framed_strip_body(const KParams &p, const StripPlan &plan) {
   constexpr int NW = STRIP_NW;
+  constexpr int BN = 32 * NF;  // frame columns of a job: NF frame tiles per wave (4; 2 for small problems)
   constexpr int ROWB = KC * 2;                    // bytes of one slab row of one plane
   constexpr int SL_PL = STRIP_MAX_ROWS * ROWB;    // hi -> lo plane of a slab buffer
   constexpr int SLAB = 2 * SL_PL;
@@ -178,14 +180,14 @@ __device__ __forceinline__ void framed_strip_body(const KParams &p, const StripP
     const int fmask = tile_m < 0 ? 0 : __builtin_amdgcn_readfirstlane(wv.fmask);
 
     // ---- the frame tile's (at most two) runs of consecutive frames, slab row table
-    const long long n0 = (long long)tile_n * STRIP_BN;
+    const long long n0 = (long long)tile_n * BN;
     // (n_cols < 2^31: launch_bf16x3_strip)
     const int c0 = (int)((unsigned)n0 / (unsigned)n_frames);
     const int t0 = (int)((unsigned)n0 - (unsigned)c0 * (unsigned)n_frames);
-    const int len0 = (n_frames - t0) < STRIP_BN ? (n_frames - t0) : STRIP_BN;
+    const int len0 = (n_frames - t0) < BN ? (n_frames - t0) : BN;
     {
       const int rows0 = len0 + span - 1;
-      if (tid < STRIP_BN) sColRow[tid] = tid < len0 ? tid : tid + (span - 1);
+      if (tid < BN) sColRow[tid] = tid < len0 ? tid : tid + (span - 1);
       for (int r = tid; r < slab_rows; r += NW * 64) {
         int c = c0, f = t0 + r + jbase;
         if (r >= rows0) {
@@ -220,9 +222,9 @@ __device__ __forceinline__ void framed_strip_body(const KParams &p, const StripP
       const int row = (pj < spieces ? pj : 0) * 16 + row16;
       sptr[j] = reinterpret_cast<const char *>(p.xs) + sRowOff[row] * (F32 ? 4 : 2) + 16 * cg;
     }
-    int xrow[4];  // slab row of this lane's frame of frame tile f at super-stage jbase
+    int xrow[NF];  // slab row of this lane's frame of frame tile f at super-stage jbase
 #pragma unroll
-    for (int f = 0; f < 4; ++f) xrow[f] = sColRow[32 * f + li];
+    for (int f = 0; f < NF; ++f) xrow[f] = sColRow[32 * f + li];
 
     // ---- the strip's basis fragments: (tile, 16-tap step) -> [hi | lo][lane][8 taps], so a unit
     // (two steps) is 4 KB of consecutive memory and every load a contiguous kilobyte
@@ -295,15 +297,15 @@ __device__ __forceinline__ void framed_strip_body(const KParams &p, const StripP
     // hi fragment of frame tile f; step 1 is the same address with bit 5 flipped (chunk 2q + lh,
     // XOR-swizzled), the lo plane SL_PL further.
     typedef __attribute__((address_space(3))) const bf16x8 *lfrag_t;
-    bf16x8 xh[2][4], xl[2][4];
-    unsigned xa[4];
+    bf16x8 xh[2][NF], xl[2][NF];
+    unsigned xa[NF];
     auto x_base = [&](int s) __attribute__((always_inline)) -> unsigned {  // slab of sub-stage s
       return lds0 + ((s >> gsh) & 1) * SLAB + (s & gsh) * slab_rows * ROWB;
     };
-    auto x_addrs = [&](unsigned (&dst)[4], int s, int dj) __attribute__((always_inline)) {
+    auto x_addrs = [&](unsigned (&dst)[NF], int s, int dj) __attribute__((always_inline)) {
       const unsigned base = x_base(s);
 #pragma unroll
-      for (int f = 0; f < 4; ++f) {
+      for (int f = 0; f < NF; ++f) {
         const int row = xrow[f] + dj;  // (the slabs of a buffer start at multiples of 16 rows: same swizzle)
         dst[f] = base + row * ROWB + 16 * ((F32 ? 2 * lh : lh) ^ ((row >> 2) & 3));
       }
@@ -313,17 +315,17 @@ __device__ __forceinline__ void framed_strip_body(const KParams &p, const StripP
     auto x_frag = [&](unsigned a0, int q, int part) __attribute__((always_inline)) -> unsigned {
       return F32 ? (a0 ^ (16 * part)) + q * SL_PL : (a0 ^ (32 * q)) + part * SL_PL;
     };
-    auto load_set = [&](auto q_tag, const unsigned (&a0)[4]) __attribute__((always_inline)) {
+    auto load_set = [&](auto q_tag, const unsigned (&a0)[NF]) __attribute__((always_inline)) {
       constexpr int Q = decltype(q_tag)::value;
 #pragma unroll
-      for (int f = 0; f < 4; ++f) {
+      for (int f = 0; f < NF; ++f) {
         xh[Q][f] = *(lfrag_t)x_frag(a0[f], Q, 0);
         xl[Q][f] = *(lfrag_t)x_frag(a0[f], Q, 1);
       }
     };
-    f32x16 acc[4];
+    f32x16 acc[NF];
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < NF; ++f)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[f][e] = 0.f;
     // One step = 12 MFMAs of (slot S, step Q) in a fixed order -- frame tile innermost, so that
@@ -334,15 +336,15 @@ __device__ __forceinline__ void framed_strip_body(const KParams &p, const StripP
     // front of the MFMAs they cost 2 x 125 cycles per unit, and the lo fragments, requested inside
     // their own step, another 2 x 150 of waiting); left to hipcc's scheduler the MFMAs get
     // reordered into dependent pairs.
-    auto step = [&](auto slot_tag, auto q_tag, const unsigned (&an)[4], auto &&tail)
+    auto step = [&](auto slot_tag, auto q_tag, const unsigned (&an)[NF], auto &&tail)
                     __attribute__((always_inline)) {
       constexpr int S = decltype(slot_tag)::value;
       constexpr int Q = decltype(q_tag)::value;
       constexpr int NQ = 1 - Q;
-      constexpr int NM = F32 ? 32 : 12;  // MFMAs of the step
+      constexpr int NM = (F32 ? 8 : 3) * NF;  // MFMAs of the step
 #pragma unroll
       for (int i = 0; i < NM; ++i) {
-        const int f = i & 3, t = i >> 2;
+        const int f = i % NF, t = i / NF;
         if (F32) {
           // MFMA t contracts taps t and 8 + t of the step: element t & 3 of part t >> 2
           const f32x4v a = __builtin_bit_cast(f32x4v, t < 4 ? ah[S][Q] : al[S][Q]);
@@ -355,9 +357,9 @@ __device__ __forceinline__ void framed_strip_body(const KParams &p, const StripP
         } else {
           acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[S][Q], xl[Q][f], acc[f], 0, 0, 0);
         }
-        if (i < 4) xh[NQ][f] = *(lfrag_t)x_frag(an[f], NQ, 0);
-        else if (i < 8) xl[NQ][f] = *(lfrag_t)x_frag(an[f], NQ, 1);
-        if (i >= NM - 4) tail(f);
+        if (i < NF) xh[NQ][i] = *(lfrag_t)x_frag(an[i], NQ, 0);
+        else if (i < 2 * NF) xl[NQ][i - NF] = *(lfrag_t)x_frag(an[i - NF], NQ, 1);
+        if (i >= NM - 4) tail(i - (NM - 4));  // four slots behind the last four MFMAs
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -407,19 +409,21 @@ __device__ __forceinline__ void framed_strip_body(const KParams &p, const StripP
       // ---- step 0 (+ the reads of step 1, + the addresses of the next unit's step 0: its own row
       // once more when the next unit opens another slab -- a branch here makes hipcc keep both
       // generations of a fragment set alive, with copies)
-      unsigned xn[4];
+      unsigned xn[NF];
       const int djn = same ? n1.j - jbase : dj;
       const unsigned basen = x_base(same ? n1.s : (cur.valid ? cur.s : 0));
       __builtin_amdgcn_sched_barrier(0);
-      step(slot_tag, i0{}, xa, [&](int f) __attribute__((always_inline)) {
-        const int row = xrow[f] + djn;
-        xn[f] = basen + row * ROWB + 16 * ((F32 ? 2 * lh : lh) ^ ((row >> 2) & 3));
+      step(slot_tag, i0{}, xa, [&](int k) __attribute__((always_inline)) {
+        if (k < NF) {
+          const int row = xrow[k] + djn;
+          xn[k] = basen + row * ROWB + 16 * ((F32 ? 2 * lh : lh) ^ ((row >> 2) & 3));
+        }
       });
       // ---- step 1 (+ the reads of the next unit's step 0, + this slot's next basis fragments)
       const unsigned short *asrc = a_src(n3);
       // (the last four MFMAs still read ah[S][1] -- fp32: al[S][1] --, reloaded behind the very last one)
-      step(slot_tag, i1{}, xn, [&](int f) __attribute__((always_inline)) {
-        load_a1(slot_tag, asrc, F32 ? f : (f == 2 ? 3 : (f == 3 ? 2 : f)));
+      step(slot_tag, i1{}, xn, [&](int k) __attribute__((always_inline)) {
+        load_a1(slot_tag, asrc, F32 ? k : (k == 2 ? 3 : (k == 3 ? 2 : k)));
       });
       ++done_in_s;
       if (!same) {
@@ -431,7 +435,7 @@ __device__ __forceinline__ void framed_strip_body(const KParams &p, const StripP
         }
       }
 #pragma unroll
-      for (int f = 0; f < 4; ++f) xa[f] = xn[f];
+      for (int f = 0; f < NF; ++f) xa[f] = xn[f];
       cur = n1;
       n1 = n2;
       n2 = n3;
@@ -533,11 +537,14 @@ __device__ __forceinline__ void framed_strip_body(const KParams &p, const StripP
         bf16x3_epilogue<1, 8, 1, 1>(p, a1, mine ? tile_m * 32 : (1 << 24), n0 + 32 * f - 32 * wave, smem_raw);
       };
       typedef std::integral_constant<int, 3> i3;
-      put(i0{}), put(i1{}), put(i2{}), put(i3{});
+      put(i0{}), put(i1{});
+      if constexpr (NF > 2) put(i2{}), put(i3{});
       __syncthreads();
-      sum(i0{}), sum(i1{}), sum(i2{}), sum(i3{});
+      sum(i0{}), sum(i1{});
+      if constexpr (NF > 2) sum(i2{}), sum(i3{});
       __syncthreads();  // the partial sums are dead: the epilogue's LDS path may use their place
-      store(i0{}), store(i1{}), store(i2{}), store(i3{});
+      store(i0{}), store(i1{});
+      if constexpr (NF > 2) store(i2{}), store(i3{});
     }
     __syncthreads();  // the epilogue is done with the LDS
     STRIP_STAMP(21)
@@ -550,9 +557,17 @@ __device__ __forceinline__ void framed_strip_body(const KParams &p, const StripP
   }
 }
 
+// (NF = 2: jobs of 64 frames -- twice as many, half as long -- for problems whose 128-frame jobs
+// would not fill the device's workgroup slots, and for banks whose slab needs the rows)
 __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KParams p, const StripPlan plan) {
-  framed_strip_body<false>(p, plan);
+  framed_strip_body<false, 4>(p, plan);
+}
+__global__ void __launch_bounds__(256, 2) framed_bf16x3_strip64_kernel(const KParams p, const StripPlan plan) {
+  framed_strip_body<false, 2>(p, plan);
 }
 __global__ void __launch_bounds__(256, 2) framed_f32_strip_kernel(const KParams p, const StripPlan plan) {
-  framed_strip_body<true>(p, plan);
+  framed_strip_body<true, 4>(p, plan);
+}
+__global__ void __launch_bounds__(256, 2) framed_f32_strip64_kernel(const KParams p, const StripPlan plan) {
+  framed_strip_body<true, 2>(p, plan);
 }

@@ -1902,9 +1902,10 @@ double strip_alloc(const StripTile *t, int k, int *waves) {
   return m;
 }
 
-bool plan_strip(const KParams &p, const int32_t *sup, int n_slots, StripPlan &plan, bool f32 = false) {
+bool plan_strip(const KParams &p, const int32_t *sup, int n_slots, StripPlan &plan, bool f32 = false,
+                int bn = STRIP_BN) {
   if (!sup || !p.a_im || !p.row_support) return false;
-  if (p.hop % KC != 0 || p.hop > 64 * KC || p.Ks < 2 * p.hop || p.n_frames < STRIP_BN) return false;
+  if (p.hop % KC != 0 || p.hop > 64 * KC || p.Ks < 2 * p.hop || p.n_frames < bn) return false;
   const int hop = p.hop, sph = hop / KC;
   const int M = (p.n_bins + 15) / 16;
   if (M > STRIP_NW * STRIP_MAX_PASS) return false;
@@ -1936,8 +1937,8 @@ bool plan_strip(const KParams &p, const int32_t *sup, int n_slots, StripPlan &pl
       t[j] = t[j - 1];
       t[j - 1] = tmp;
     }
-  const long long n_tiles_n = (p.n_cols + STRIP_BN - 1) / STRIP_BN;
-  if (n_tiles_n * STRIP_MAX_PASS > 0x7fffffffLL || p.n_cols + STRIP_BN > 0x7fffffffLL) return false;
+  const long long n_tiles_n = (p.n_cols + bn - 1) / bn;
+  if (n_tiles_n * STRIP_MAX_PASS > 0x7fffffffLL || p.n_cols + bn > 0x7fffffffLL) return false;
   // per-pass cost of tables, first slab, reduction and epilogue: ~10 us = 12 units at cfg4 (phase
   // clock).  (Charging the ~1.2 us of barrier + refill per sub-stage as well -- 12 + 1.45 * sph --
   // merges tiles 1 and 2 into one pass of 3 + 1 waves: measured 4 % slower, the single wave of
@@ -1982,7 +1983,7 @@ bool plan_strip(const KParams &p, const int32_t *sup, int n_slots, StripPlan &pl
         if (dp[i - k] >= 1e300) continue;
         int waves[STRIP_NW];
         const double share = strip_alloc(t + i - k, k, waves);
-        const int rows = (STRIP_BN + 2 * (span_of(i - k, k) - 1) + 15) / 16 * 16;
+        const int rows = (bn + 2 * (span_of(i - k, k) - 1) + 15) / 16 * 16;
         if (share > cap || rows > STRIP_MAX_ROWS) continue;
         const double c = dp[i - k] + share + sovh;
         if (c < dp[i]) {
@@ -2012,6 +2013,7 @@ bool plan_strip(const KParams &p, const int32_t *sup, int n_slots, StripPlan &pl
   if (best_np == 0) return false;
   memset(&plan, 0, sizeof(plan));
   plan.n_pass = best_np;
+  plan.nf = bn / 32;
   plan.n_tiles_n = (int)n_tiles_n;
   plan.n_jobs = (int)(n_tiles_n * best_np);
   for (int q = 0; q < best_np; ++q) {
@@ -2029,7 +2031,7 @@ bool plan_strip(const KParams &p, const int32_t *sup, int n_slots, StripPlan &pl
     if (hi < lo) lo = hi = 0;
     ps.jbase = lo;
     ps.span = hi - lo + 1;
-    ps.slab_rows = (STRIP_BN + 2 * (ps.span - 1) + 15) / 16 * 16;
+    ps.slab_rows = (bn + 2 * (ps.span - 1) + 15) / 16 * 16;
     ps.group = 2 * ps.slab_rows <= STRIP_MAX_ROWS && sph >= 2 ? 2 : 1;  // two slabs per buffer: half the barriers
     int w = 0;
     for (int i = a; i < b; ++i) {
@@ -2097,7 +2099,29 @@ bool strip_plan_cached(const KParams &p, const int32_t *sup, int n_cu, StripPlan
   memset(&e.key, 0, sizeof(e.key));
   e.key = key;
   e.sup.assign(sup, sup + 2 * p.n_bins);
-  e.ok = plan_strip(p, sup, n_cu, e.plan, f32);
+  // 128-frame jobs; 64-frame ones when those would not fill the workgroup slots (small batches: twice
+  // the jobs, half as long) or do not fit the slab (kernels of more than ~80 hops)
+  e.ok = plan_strip(p, sup, n_cu, e.plan, f32, STRIP_BN);
+  {
+    StripPlan half;
+    if (plan_strip(p, sup, n_cu, half, f32, STRIP_BN / 2)) {
+      // makespan estimate: all jobs spread over the slots, but never less than the longest job; a
+      // 64-frame unit is half the MFMAs of a 128-frame one at ~15 % less efficiency
+      auto estimate = [&](const StripPlan &pl) {
+        double sum = 0, longest = 0;
+        for (int i = 0; i < pl.n_pass; ++i) {
+          sum += pl.pass[i].cost;
+          longest = pl.pass[i].cost > longest ? pl.pass[i].cost : longest;
+        }
+        const double spread = sum * pl.n_tiles_n / n_cu;
+        return (spread > longest ? spread : longest) * pl.nf * (pl.nf == 2 ? 1.15 : 1.0);
+      };
+      if (!e.ok || estimate(half) < estimate(e.plan)) {
+        e.plan = half;
+        e.ok = true;
+      }
+    }
+  }
   if (cache.size() >= 32) cache.erase(cache.begin());
   cache.push_back(e);
   plan = e.plan;
@@ -2115,9 +2139,9 @@ int device_cus() {
 
 int launch_bf16x3_strip(KParams p, const StripPlan &plan, int n_cu, hipStream_t stream) {
   p.n_super = (p.Ks + p.hop - 1) / p.hop;
-  auto kern = framed_bf16x3_strip_kernel;
-  static std::atomic<unsigned long long> configured{0};
-  int rc = configure_lds(kern, 160 * 1024, configured);
+  auto kern = plan.nf == 2 ? framed_bf16x3_strip64_kernel : framed_bf16x3_strip_kernel;
+  static std::atomic<unsigned long long> configured{0}, configured64{0};
+  int rc = configure_lds(kern, 160 * 1024, plan.nf == 2 ? configured64 : configured);
   if (rc != MISPEC_OK) return rc;
   unsigned grid = (unsigned)(plan.n_jobs < 2 * n_cu ? plan.n_jobs : 2 * n_cu);  // two per CU
   size_t smem = STRIP_LDS_BYTES;
@@ -2609,9 +2633,9 @@ int launch_strip32(KParams p, const mispec_framed_gemm_args *a, const StripPlan 
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(MISPEC_E_HIP, "signal pad launch: %s", hipGetErrorString(err));
   p.n_super = (p.Ks + p.hop - 1) / p.hop;
-  auto kern = framed_f32_strip_kernel;
-  static std::atomic<unsigned long long> configured{0};
-  int rc = configure_lds(kern, 160 * 1024, configured);
+  auto kern = plan.nf == 2 ? framed_f32_strip64_kernel : framed_f32_strip_kernel;
+  static std::atomic<unsigned long long> configured{0}, configured64{0};
+  int rc = configure_lds(kern, 160 * 1024, plan.nf == 2 ? configured64 : configured);
   if (rc != MISPEC_OK) return rc;
   const unsigned grid = (unsigned)(plan.n_jobs < 2 * n_cu ? plan.n_jobs : 2 * n_cu);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(STRIP_NW * 64), (size_t)STRIP_LDS_BYTES, stream, p, plan);
@@ -2661,7 +2685,7 @@ int32_t mispec_strip_plan(const mispec_framed_gemm_args *args, int32_t n_cu, int
         args->tile != MISPEC_TILE_AUTO || !basis_has_frags(p.n_bins, p.a_im != nullptr))
       return 0;
     p.Ks = round_up_kc(p.K);
-    if (!plan_strip(p, args->row_support_host, 2 * n_cu, plan)) return 0;
+    if (!strip_plan_cached(p, args->row_support_host, 2 * n_cu, plan)) return 0;
   }
   int n = 0;
   auto put = [&](int v) {

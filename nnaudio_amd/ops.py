@@ -24,9 +24,8 @@ from . import engine
 _prep_cache = {}  # id(basis_re) -> (weakref, DerivedCache)
 
 
-def _prepared(basis_re, basis_im, precision, hop, support=False):
-    """Split / folded planes (and, for fp32 banks with supports, the fragment-order copy) of a basis
-    for the op's run-time tensors (cached per tensor object)."""
+def _prepared(basis_re, basis_im, precision, hop):
+    """Split / folded planes of a basis for the op's run-time tensors (cached per tensor object)."""
     if basis_im is None:
         return {}
     precision = engine.resolve_precision(precision)
@@ -37,15 +36,9 @@ def _prepared(basis_re, basis_im, precision, hop, support=False):
         _prep_cache[key] = (weakref.ref(basis_re, lambda _r, k=key: _prep_cache.pop(k, None)), cache)
     else:
         cache = hit[1]
-    def build():
-        prep = engine.prepare_basis(basis_re, basis_im, precision, hop=hop)
-        if support and precision == "fp32":
-            frag = engine.frag_basis_f32(basis_re, basis_im)
-            if frag is not None:
-                prep = dict(prep, basis_split=frag)
-        return prep
-
-    return cache.get((basis_re, basis_im), build, extra=(int(hop), precision, bool(support)))
+    return cache.get((basis_re, basis_im),
+                     lambda: engine.prepare_basis(basis_re, basis_im, precision, hop=hop),
+                     extra=(int(hop), precision))
 
 
 _support_cache = {}  # id(basis_re) -> (weakref, SupportCache)
@@ -70,7 +63,7 @@ def framed_gemm(x: torch.Tensor, basis_re: torch.Tensor, basis_im: Optional[torc
                 pad: int, pad_mode: int, epilogue: int, im_sign: float, eps: float, power: float,
                 row_scale: Optional[torch.Tensor], support: bool, precision: str) -> torch.Tensor:
     """``support``: skip the zero taps outside every row's [start, stop) (CQT banks)."""
-    prep = _prepared(basis_re, basis_im, precision, hop, support)
+    prep = _prepared(basis_re, basis_im, precision, hop)
     sup = _supports(basis_re, basis_im) if support and basis_im is not None else None
     return engine.framed_gemm(x, basis_re, basis_im, hop=hop, pad=pad, pad_mode=pad_mode,
                               epilogue=epilogue, im_sign=im_sign, eps=eps, power=power,

@@ -15,7 +15,7 @@ for case in range(n_cases):
     K = int(rng.integers(2 * hop, min(80 * hop, 12000)))
     F = int(rng.integers(65, 220))
     B = int(rng.integers(1, 5))
-    T = int(rng.integers(128, 400))
+    T = int(rng.integers(64, 400))
     center = bool(rng.integers(0, 2))
     pad = K // 2 if center else 0
     mode = int(rng.choice([1, 2])) if center else 0

@@ -286,11 +286,13 @@ def test_strip_plan_covers_every_row_tile_once(cfg, precision):
     n_pass = lib.mispec_strip_plan(ctypes.byref(a), 256, buf, len(buf))
     assert 1 <= n_pass <= 8, _abi.load().mispec_last_error()
     hop, K, F = a.hop, a.kernel, a.n_bins
-    assert buf[0] == -(-B * a.n_frames // 128)
+    # jobs of 128 frames, or of 64 when the 128-frame ones would not fill the workgroup slots
+    bn = 128 if buf[0] == -(-B * a.n_frames // 128) else 64
+    assert buf[0] == -(-B * a.n_frames // bn)
     seen = {}
     for i in range(n_pass):
         cost, jbase, span, rows = buf[1 + 36 * i:5 + 36 * i]
-        assert rows % 16 == 0 and 128 + 2 * (span - 1) <= rows <= 288
+        assert rows % 16 == 0 and bn + 2 * (span - 1) <= rows <= 288
         waves = [buf[5 + 36 * i + 8 * w:13 + 36 * i + 8 * w] for w in range(4)]
         groups = {}
         for w, (tile, kb, ke, ja, jb, g0, gsize, fmask) in enumerate(waves):
@@ -331,11 +333,15 @@ def test_strip_plan_declines_what_the_kernel_does_not_cover():
     a.hop = 500  # not a multiple of 32 taps
     a.n_frames = 441000 // 500 + 1
     assert lib.mispec_strip_plan(ctypes.byref(a), 256, buf, 300) == 0
-    a, _ = _plan_args(m, 1, 40000, keep)  # 79 frames: a 128-frame tile would straddle several clips
+    a, _ = _plan_args(m, 1, 30000, keep)  # 59 frames: even a 64-frame job would straddle several clips
     assert lib.mispec_strip_plan(ctypes.byref(a), 256, buf, 300) == 0
-    # kernels of 90 hops: the slab of a 128-frame tile would need more than 288 rows
+    # kernels of 90 hops: the slab of a 128-frame job would need more than 288 rows -- 64-frame jobs fit
     m2 = features.CQT1992v2(sr=22050, hop_length=256, n_bins=96, bins_per_octave=24, verbose=False)
     a, _ = _plan_args(m2, 3, 70000, keep)
+    assert lib.mispec_strip_plan(ctypes.byref(a), 256, buf, 300) > 0 and buf[0] == -(-3 * a.n_frames // 64)
+    # ... and kernels of 180 hops do not
+    m3 = features.CQT1992v2(sr=22050, hop_length=128, n_bins=96, bins_per_octave=24, verbose=False)
+    a, _ = _plan_args(m3, 3, 70000, keep)
     assert lib.mispec_strip_plan(ctypes.byref(a), 256, buf, 300) == 0
     a, _ = _plan_args(m, 4, 441000, keep)
     assert lib.mispec_strip_plan(ctypes.byref(a), 0, buf, 300) == -1

@@ -688,7 +688,7 @@ def test_bf16x3_kernel_shapes(shape, support):
         sup = torch.as_tensor(np.stack([lo, hi], 1).astype(np.int32)).to(DEV)
         if str(support).startswith("strip"):
             # with a host copy of the supports the library may plan the strip kernel (whenever the
-            # shape allows: hop % 32 == 0, >= 128 frames per clip, kernels of >= 2 hops)
+            # shape allows: hop % 32 == 0, >= 64 frames per clip, kernels of >= 2 hops)
             sup.host_copy = np.ascontiguousarray(np.stack([lo, hi], 1).astype(np.int32))
     re, im = _np_framed(x, wr, wi, hop, pad, mode)
     ref = np.stack((re, im), -1)
@@ -704,7 +704,7 @@ def test_bf16x3_kernel_shapes(shape, support):
 
         n_pass = _abi.load().mispec_strip_plan(ctypes.byref(a), 256, None, 0)
         T = (L + 2 * pad - K) // hop + 1
-        assert (n_pass > 0) == (hop % 32 == 0 and T >= 128 and -(-K // 32) * 32 >= 2 * hop)
+        assert (n_pass > 0) == (hop % 32 == 0 and T >= 64 and -(-K // 32) * 32 >= 2 * hop)
     if hop % 2:
         assert torch.equal(y, y32)  # fell back to the fp32 kernel
     else:

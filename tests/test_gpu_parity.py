@@ -1411,7 +1411,7 @@ def test_integration_stub_computes_an_stft():
     assert not torch.equal(yb, yf)
 
 
-@pytest.mark.parametrize("name", ["stft", "mel", "cqt1992v2", "cqt2010v2"])
+@pytest.mark.parametrize("name", ["stft", "mel", "mfcc", "cqt1992v2", "cqt2010v2"])
 def test_forward_is_hip_graph_capturable(bf16x3, name):
     """A forward (after one eager warm-up call, which builds the cached operands) records into a
     HIP graph -- no host synchronisation, no allocation outside the capture pool, the strip
@@ -1425,6 +1425,9 @@ def test_forward_is_hip_graph_capturable(bf16x3, name):
         L = 40000
     elif name == "mel":
         m = features.MelSpectrogram(sr=22050, n_fft=1024, hop_length=256, n_mels=64, verbose=False)
+        L = 40000
+    elif name == "mfcc":
+        m = features.MFCC(sr=22050, n_mfcc=20, n_fft=1024, hop_length=256, n_mels=64, verbose=False)
         L = 40000
     elif name == "cqt1992v2":
         m = features.CQT1992v2(sr=22050, hop_length=256, n_bins=72, bins_per_octave=12, fmin=65.4, verbose=False)

@@ -421,13 +421,15 @@ __device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_
   constexpr int LROW = GLDS ? KC : LDT;
   constexpr int A_STAGE = BM * LROW;
   constexpr int B_STAGE = (BMODE == BMODE_FRAMED) ? BN * LROW : KC * BN;
-  constexpr int PPASS = KC * BN / NT;  // planar mode: scalar elements per thread
-  static_assert(BMODE == BMODE_FRAMED || NT % BN == 0 || BN % NT == 0, "planar loader shape");
+  // planar loader: a thread moves quads of 4 consecutive columns (one 16-byte load when the
+  // four columns are adjacent in memory, four scalar loads otherwise, decided per thread once);
+  // QPR quads per K row, RPP K rows per pass, VPASS passes per stage
+  constexpr int QPR = BN / 4;
+  constexpr int RPP = NT / QPR;
+  constexpr int VPASS = KC / RPP;
+  static_assert(BMODE == BMODE_FRAMED || (NT % QPR == 0 && KC % RPP == 0 && VPASS >= 1), "planar loader shape");
   constexpr int STORE_MODE = (AMODE == AMODE_TOEPLITZ || BMODE == BMODE_PLANAR_T) ? STORE_ROWS_INNER
                                                                                : STORE_FRAMES_INNER;
-  // planar loader: which (k row, column) a thread moves in pass ps
-  constexpr int KPP = (NT >= BN) ? NT / BN : 1;
-  constexpr int JPP = (NT >= BN) ? 1 : BN / NT;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float *sA = reinterpret_cast<float *>(smem_raw);
@@ -566,21 +568,21 @@ __device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_
       aptr[ps] = src + (long long)bin * p.a_row_stride + 4 * cg;
     }
   }
-  const float *bptr[(BMODE == BMODE_FRAMED) ? BPASS : PPASS];
+  const float *bptr[(BMODE == BMODE_FRAMED) ? BPASS : 4];
+  const int pq = 4 * (tid % QPR);  // planar: first column of this thread's quad
+  const int pk = tid / QPR;        // planar: its K row inside a pass
+  bool quad = false;               // planar: the quad's columns are adjacent in memory
   if (BMODE == BMODE_FRAMED) {
 #pragma unroll
     for (int ps = 0; ps < BPASS; ++ps) bptr[ps] = sColPtr[ps * 32 + r32] + 4 * cg;
   } else {
 #pragma unroll
-    for (int ps = 0; ps < PPASS; ++ps) {
-      const int j = (NT >= BN) ? tid % BN : (ps % JPP) * NT + tid;
-      bptr[ps] = sColPtr[j];
-    }
+    for (int e = 0; e < 4; ++e) bptr[e] = sColPtr[pq + e];
+    quad = bptr[1] == bptr[0] + 1 && bptr[2] == bptr[0] + 2 && bptr[3] == bptr[0] + 3;
   }
 
   f32x4v ra[APASS];
-  f32x4v rb[(BMODE == BMODE_FRAMED) ? BPASS : 1];
-  float rp[(BMODE != BMODE_FRAMED) ? PPASS : 1];
+  f32x4v rb[(BMODE == BMODE_FRAMED) ? BPASS : VPASS];
   unsigned toep_bits = 0;  // Toeplitz A: which of the 4*APASS loaded taps are inside the band
 
   // ---- stage loads: no control flow, every address is valid memory by construction.
@@ -592,14 +594,18 @@ __device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_
         rb[ps] = *reinterpret_cast<const f32x4u *>(bptr[ps] + kc);
     } else {
 #pragma unroll
-      for (int ps = 0; ps < PPASS; ++ps) {
-        const int kl = (NT >= BN) ? ps * KPP + tid / BN : ps / JPP;
-        int kk = kc + kl;
+      for (int ps = 0; ps < VPASS; ++ps) {
+        int kk = kc + ps * RPP + pk;
         kk = kk < p.K ? kk : p.K - 1;  // K tail: any finite value, the A side is zero there
         long long ko = (long long)kk * p.x_k_stride;
         if (p.k_split && kk >= p.k_split) ko = (long long)(kk - p.k_split) * p.x_k_stride + p.k_split_off;
         if (p.k_offsets) ko = p.k_offsets[kk];
-        rp[ps] = bptr[ps][ko];
+        if (quad) {
+          rb[ps] = *reinterpret_cast<const f32x4u *>(bptr[0] + ko);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) rb[ps][e] = bptr[e][ko];
+        }
       }
     }
   };
@@ -647,11 +653,8 @@ __device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_
         *reinterpret_cast<f32x4v *>(b + (ps * 32 + r32) * LROW + 4 * c4) = rb[ps];
     } else {
 #pragma unroll
-      for (int ps = 0; ps < PPASS; ++ps) {
-        const int kl = (NT >= BN) ? ps * KPP + tid / BN : ps / JPP;
-        const int j = (NT >= BN) ? tid % BN : (ps % JPP) * NT + tid;
-        b[kl * BN + j] = rp[ps];
-      }
+      for (int ps = 0; ps < VPASS; ++ps)
+        *reinterpret_cast<f32x4v *>(b + (ps * RPP + pk) * BN + pq) = rb[ps];
     }
   };
 

@@ -135,50 +135,98 @@ __global__ void __launch_bounds__(256) fold_basis_kernel(const float *__restrict
 }
 
 // ---------------------------------------------------------------------------------
-// Pre-pass: one workgroup per FOLD_FR consecutive frames of a clip.  Thread i owns folded taps
-// 4 i .. 4 i + 3 (+ 1024 per trip) of each of them: 16-byte loads of x_t[n ..] forwards and
+// Pre-pass: one workgroup per FOLD_FR * G consecutive frames of a clip, G = fold_groups(Kf) thread
+// groups of 256 / G threads with FOLD_FR frames each (short frames: 1024 taps keep one group of 256
+// threads busy, 512 taps two groups of 128, ...).  Thread i of a group owns folded taps 4 i .. 4 i + 3
+// (+ 4 * group size per trip) of each of its frames: 16-byte loads of x_t[n ..] forwards and
 // x_t[N-n ..] backwards, all frames' loads issued before the first use (element-wise with the
 // virtual padding for the frames that touch a clip edge), E / O in fp32, split, assembled in LDS and
-// stored as consecutive 16-byte pieces (a frame's 8 Kf bytes are one run of memory).  With
-// p.fold_last the LAST bin (Nyquist) is evaluated here too, in plain fp32 FMAs on the same E / O,
-// through the full pointwise epilogue -- instead of a row block of its own in the contraction.
+// stored as consecutive 16-byte pieces (a frame's 8 Kf bytes are one run of memory).  The LDS
+// staging rows (128 B = all 32 banks) keep their 16-byte pieces XOR-swizzled by row & 7: a wave's
+// 8-byte writes cover 16 rows x the same two pieces, unswizzled a 16-way bank conflict (3.7e7
+// conflict cycles per cfg3 step).  With p.fold_last the LAST bin (Nyquist) is evaluated here too, in
+// plain fp32 FMAs on the same E / O, through the full pointwise epilogue -- instead of a row block
+// of its own in the contraction.
 // ---------------------------------------------------------------------------------
 constexpr int FOLD_FR = 4;
 
+// sum over the 64 lanes, the same value in every lane: quad permutes, half-row and row mirrors (DPP,
+// no LDS crossbar), then the four rows through scalar registers
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#define FOLD_DPP_ADD(ctrl) \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+  FOLD_DPP_ADD(0xB1);   // quad_perm [1, 0, 3, 2]
+  FOLD_DPP_ADD(0x4E);   // quad_perm [2, 3, 0, 1]
+  FOLD_DPP_ADD(0x141);  // row_half_mirror
+  FOLD_DPP_ADD(0x140);  // row_mirror
+#undef FOLD_DPP_ADD
+  const int b = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) +
+         __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16)) +
+         __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) +
+         __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+}
+
+__host__ __device__ inline int fold_groups(int Kf) { return Kf <= 256 ? 4 : (Kf <= 512 ? 2 : 1); }
+
 __global__ void __launch_bounds__(256) fold_frames_kernel(const KParams p,
                                                           unsigned short *__restrict__ dst) {
-  const int c = p.fold_clip0 + blockIdx.y;
-  const int t0 = blockIdx.x * FOLD_FR;
-  const int nf = p.n_frames - t0 < FOLD_FR ? p.n_frames - t0 : FOLD_FR;  // frames of this block
   const int N = p.K, H = N >> 1, Kf = p.Ks;
+  const int G = fold_groups(Kf), TG = 256 / G;
+  const int grp = threadIdx.x / TG, gt = threadIdx.x - grp * TG;
+  const int c = p.fold_clip0 + blockIdx.y;
+  const int tw0 = blockIdx.x * (FOLD_FR * G);  // first frame of the workgroup
+  const int nfw = p.n_frames - tw0 < FOLD_FR * G ? p.n_frames - tw0 : FOLD_FR * G;
+  const int t0 = tw0 + grp * FOLD_FR;          // first frame of this thread's group
+  int nf = p.n_frames - t0;                    // frames of the group (<= 0: an idle group of the last block)
+  nf = nf < FOLD_FR ? nf : FOLD_FR;
   const float *x = p.x + (long long)c * p.x_clip_stride;
-  const long long col0 = (long long)c * p.n_frames + t0;
+  const long long col0 = (long long)c * p.n_frames + tw0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  unsigned short *srow = reinterpret_cast<unsigned short *>(smem_raw);  // [FOLD_FR][4 Kf]
-  const float *le = p.fold_last, *lo = p.fold_last ? p.fold_last + Kf : nullptr;
+  // (benchmarking build, 0x200: without the Nyquist bin)
+  const float *le = MISPEC_DBG(p, 0x200) ? nullptr : p.fold_last, *lo = le ? le + Kf : nullptr;
   float pe[FOLD_FR], po[FOLD_FR];
 #pragma unroll
   for (int f = 0; f < FOLD_FR; ++f) pe[f] = po[f] = 0.f;
-  // all frames of the block interior? (then every load is a plain 16-byte run)
+  // all frames of the group interior? (then every load is a plain 16-byte run)
   const long long qa = (long long)t0 * p.hop - p.pad;
   const bool interior = qa >= 0 && qa + (long long)(nf - 1) * p.hop + N <= p.n_samples;
-  for (int j0 = 4 * threadIdx.x; j0 < Kf; j0 += 1024) {
+  const int rows_f = Kf / FOLD_KC;  // staging rows per frame
+  for (int j0 = 4 * gt; j0 < Kf && nf > 0; j0 += 4 * TG) {
     float e[FOLD_FR][4], o[FOLD_FR][4];
-    if (interior && j0 + 4 < H) {  // taps n = j0+1 .. j0+4 < N/2: all paired
+    if (interior && j0 + 4 <= H) {  // taps n = j0+1 .. j0+4 <= N/2: paired, except n = N/2 itself
       f32x4u fw[FOLD_FR], bw[FOLD_FR];
 #pragma unroll
       for (int f = 0; f < FOLD_FR; ++f) {
         const long long q0 = qa + (long long)(f < nf ? f : 0) * p.hop;
+        if (MISPEC_DBG(p, 0x80)) {  // benchmarking build: no global loads
+          fw[f] = f32x4u{(float)j0, 1.f, 2.f, (float)f};
+          bw[f] = f32x4u{3.f, (float)gt, 2.f, 1.f};
+          continue;
+        }
         fw[f] = *reinterpret_cast<const f32x4u *>(x + q0 + j0 + 1);
         bw[f] = *reinterpret_cast<const f32x4u *>(x + q0 + N - j0 - 4);
       }
+      // (the quad that ends at n = N/2 used to take the element-wise path below: one lane per
+      // frame group, but its wave then walked 32 dependent loads in every workgroup -- the pre-pass
+      // ran at the same speed with all its other loads and stores removed)
+      const bool mid = j0 + 4 == H;  // tap N/2 has no partner: E = O = the sample itself
 #pragma unroll
       for (int f = 0; f < FOLD_FR; ++f)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           e[f][i] = fw[f][i] + bw[f][3 - i];
           o[f][i] = fw[f][i] - bw[f][3 - i];
+          if (i == 3 && mid) e[f][i] = o[f][i] = fw[f][i];
         }
+    } else if (interior && j0 >= H) {  // behind the paired taps: tap 0 (if carried), then zero padding
+#pragma unroll
+      for (int f = 0; f < FOLD_FR; ++f) {
+        const long long q0 = qa + (long long)(f < nf ? f : 0) * p.hop;
+        const float a = (j0 == H && p.fold_tap0) ? x[q0] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[f][i] = o[f][i] = i == 0 ? a : 0.f;
+      }
     } else {
 #pragma unroll
       for (int f = 0; f < FOLD_FR; ++f) {
@@ -212,72 +260,89 @@ __global__ void __launch_bounds__(256) fold_frames_kernel(const KParams p,
         pe[f] = fmaf(we[i], e[f][i], pe[f]);
         po[f] = fmaf(wo[i], o[f][i], po[f]);
       }
-      unsigned short *r = srow + (long long)f * Kf * 4 + (j0 / FOLD_KC) * (FOLD_ROWB / 2);
-      if (p.fold_f32) {  // MISPEC_PREC_F32: stage row = [E 16 floats | O 16 floats]
-        float *fr = reinterpret_cast<float *>(r) + (j0 % FOLD_KC);
+      // staging row of (frame, stage) and its swizzle; u = first of this thread's 4 taps in the stage
+      const int R = (grp * FOLD_FR + f) * rows_f + j0 / FOLD_KC, sw = R & 7, u = j0 % FOLD_KC;
+      unsigned char *r = smem_raw + (size_t)R * FOLD_ROWB;
+      if (p.fold_f32) {  // MISPEC_PREC_F32: stage row = [E 16 floats | O 16 floats], pieces of 4 floats
         const f32x4v ev = {e[f][0], e[f][1], e[f][2], e[f][3]}, ov = {o[f][0], o[f][1], o[f][2], o[f][3]};
-        *reinterpret_cast<f32x4v *>(fr) = ev;
-        *reinterpret_cast<f32x4v *>(fr + 16) = ov;
-      } else {
+        *reinterpret_cast<f32x4v *>(r + (((u >> 2)) ^ sw) * 16) = ev;
+        *reinterpret_cast<f32x4v *>(r + ((4 + (u >> 2)) ^ sw) * 16) = ov;
+      } else {  // [E_hi 16 | E_lo 16 | O_hi 16 | O_lo 16] bf16: plane P = pieces 2P, 2P+1 of 8 taps
         uint2 eh, el, oh, ol;
         bf16_split2(e[f][0], e[f][1], eh.x, el.x);
         bf16_split2(e[f][2], e[f][3], eh.y, el.y);
         bf16_split2(o[f][0], o[f][1], oh.x, ol.x);
         bf16_split2(o[f][2], o[f][3], oh.y, ol.y);
-        r += j0 % FOLD_KC;
-        *reinterpret_cast<uint2 *>(r) = eh;
-        *reinterpret_cast<uint2 *>(r + 16) = el;
-        *reinterpret_cast<uint2 *>(r + 32) = oh;
-        *reinterpret_cast<uint2 *>(r + 48) = ol;
+        const int h = u >> 3, sub = (u & 4) * 2;
+        *reinterpret_cast<uint2 *>(r + ((0 + h) ^ sw) * 16 + sub) = eh;
+        *reinterpret_cast<uint2 *>(r + ((2 + h) ^ sw) * 16 + sub) = el;
+        *reinterpret_cast<uint2 *>(r + ((4 + h) ^ sw) * 16 + sub) = oh;
+        *reinterpret_cast<uint2 *>(r + ((6 + h) ^ sw) * 16 + sub) = ol;
+      }
+    }
+  }
+  // the last bin's partial sums: wave totals to LDS before the barrier the staging needs anyway
+  float(*red)[4][FOLD_FR] =
+      reinterpret_cast<float(*)[4][FOLD_FR]>(smem_raw + (size_t)FOLD_FR * G * Kf * 8);
+  if (le) {
+#pragma unroll
+    for (int f = 0; f < FOLD_FR; ++f) {
+      const float se = wave_sum_f32(pe[f]), so = wave_sum_f32(po[f]);
+      if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6][f] = se;
+        red[1][threadIdx.x >> 6][f] = so;
       }
     }
   }
   __syncthreads();
   {
     f32x4v *out = reinterpret_cast<f32x4v *>(dst + col0 * ((long long)Kf * 4));
-    const int pieces = nf * (Kf / 2);  // Kf * 8 bytes per frame = Kf / 2 pieces of 16
-    for (int i = threadIdx.x; i < pieces; i += 256) out[i] = reinterpret_cast<const f32x4v *>(srow)[i];
+    const int pieces = nfw * (Kf / 2);  // Kf * 8 bytes per frame = Kf / 2 pieces of 16
+    const f32x4v *src = reinterpret_cast<const f32x4v *>(smem_raw);
+    for (int i = threadIdx.x; i < pieces; i += 256) {
+      if (MISPEC_DBG(p, 0x40) && src[i][0] != 12345.678f) continue;  // benchmarking build: no global stores
+      out[i] = src[i ^ ((i >> 3) & 7)];
+    }
   }
   if (!le) return;
-  float(*red)[4][FOLD_FR] = reinterpret_cast<float(*)[4][FOLD_FR]>(smem_raw + (size_t)FOLD_FR * Kf * 8);
-#pragma unroll
-  for (int f = 0; f < FOLD_FR; ++f) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      pe[f] += __shfl_xor(pe[f], d);
-      po[f] += __shfl_xor(po[f], d);
-    }
-    if ((threadIdx.x & 63) == 0) {
-      red[0][threadIdx.x >> 6][f] = pe[f];
-      red[1][threadIdx.x >> 6][f] = po[f];
-    }
-  }
-  __syncthreads();
   const int bin = p.fold_last_bin;  // relative to the problem's first bin
   const float sc = p.row_scale ? p.row_scale[bin] : 1.f;
-  for (int f = 0; f < nf; ++f) {
-    const int t = t0 + f;
-    const float re = (red[0][0][f] + red[0][1][f] + red[0][2][f] + red[0][3][f]) * sc;
-    const float im = p.im_sign * (red[1][0][f] + red[1][1][f] + red[1][2][f] + red[1][3][f]) * sc;
-    if (p.fb) {
-      // fused filterbank: out[c, m, t] += fb[m, bin] * |z|^power for the filters that weigh this
-      // bin (the main kernel treats their bands as crossing a tile boundary: atomic addends there too)
-      const float s2 = re * re + im * im + p.eps;
-      const float pw = p.power == 2.0f ? s2 : sqrtf(s2);
-      const int babs = p.out_row_offset + bin;
-      for (int m = threadIdx.x; m < p.n_fb; m += 256) {
-        if (p.fb_support[2 * m] <= babs && babs < p.fb_support[2 * m + 1]) {
-          const float w = p.fb[(long long)m * p.fb_row_stride + babs];
-          if (w != 0.f)
-            unsafeAtomicAdd(p.out + (long long)c * p.out_clip_stride + (long long)m * p.out_row_stride + t, w * pw);
+  const int wpg = 4 / G;  // waves per group
+  auto frame_value = [&](int fw, float &re, float &im) __attribute__((always_inline)) {
+    const int g = fw / FOLD_FR, f = fw - g * FOLD_FR;
+    re = im = 0.f;
+    for (int w = g * wpg; w < (g + 1) * wpg; ++w) {
+      re += red[0][w][f];
+      im += red[1][w][f];
+    }
+    re *= sc;
+    im *= p.im_sign * sc;
+  };
+  if (p.fb) {
+    // fused filterbank: out[c, m, t] += fb[m, bin] * |z|^power for the filters that weigh this
+    // bin (the main kernel treats their bands as crossing a tile boundary: atomic addends there too)
+    const int babs = p.out_row_offset + bin;
+    for (int m = threadIdx.x; m < p.n_fb; m += 256) {
+      if (p.fb_support[2 * m] <= babs && babs < p.fb_support[2 * m + 1]) {
+        const float w = p.fb[(long long)m * p.fb_row_stride + babs];
+        if (w != 0.f) {
+          for (int fw = 0; fw < nfw; ++fw) {
+            float re, im;
+            frame_value(fw, re, im);
+            const float s2 = re * re + im * im + p.eps;
+            const float pw = p.power == 2.0f ? s2 : sqrtf(s2);
+            unsafeAtomicAdd(p.out + (long long)c * p.out_clip_stride + (long long)m * p.out_row_stride + tw0 + fw, w * pw);
+          }
         }
       }
-    } else if (threadIdx.x == 0) {
-      const int E = epilogue_width(p.epilogue);
-      float *d = p.out + (long long)c * p.out_clip_stride +
-                 (long long)(p.out_row_offset + bin) * p.out_row_stride + (long long)t * E;
-      epilogue_store(p, d, re, im);
     }
+  } else if ((int)threadIdx.x < nfw) {  // one thread per frame
+    float re, im;
+    frame_value(threadIdx.x, re, im);
+    const int E = epilogue_width(p.epilogue);
+    float *d = p.out + (long long)c * p.out_clip_stride +
+               (long long)(p.out_row_offset + bin) * p.out_row_stride + (long long)(tw0 + threadIdx.x) * E;
+    epilogue_store(p, d, re, im);
   }
 }
 

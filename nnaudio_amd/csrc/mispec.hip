@@ -2358,7 +2358,8 @@ int launch_fold(KParams p, const mispec_framed_gemm_args *a, const FoldPlan &f, 
   KParams pre = p;
   pre.fold_last = f.last_in_prepass ? last_rows : nullptr;
   pre.fold_last_bin = p.n_bins - 1;
-  const size_t pre_smem = (size_t)FOLD_FR * f.kf * 8 + 8 * FOLD_FR * sizeof(float);
+  const int pre_frames = FOLD_FR * fold_groups(f.kf);  // frames per pre-pass workgroup
+  const size_t pre_smem = (size_t)pre_frames * f.kf * 8 + 8 * FOLD_FR * sizeof(float);
   {
     static std::atomic<unsigned long long> configured_pre{0};
     int rc0 = configure_lds(fold_frames_kernel, 160 * 1024, configured_pre);
@@ -2411,7 +2412,7 @@ int launch_fold(KParams p, const mispec_framed_gemm_args *a, const FoldPlan &f, 
       KParams q1 = pre;
       q1.fold_clip0 = clip0;
       hipLaunchKernelGGL(fold_frames_kernel,
-                         dim3((unsigned)((p.n_frames + FOLD_FR - 1) / FOLD_FR), (unsigned)(clip1 - clip0)),
+                         dim3((unsigned)((p.n_frames + pre_frames - 1) / pre_frames), (unsigned)(clip1 - clip0)),
                          dim3(256), pre_smem, stream, q1, xf);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) return fail(MISPEC_E_HIP, "fold pre-pass launch: %s", hipGetErrorString(e));

@@ -27,6 +27,6 @@ for prec in ("fp32", "bf16x3"):
     m = features.MFCC(sr=22050, n_mfcc=20, n_fft=1024, n_mels=128, hop_length=512, verbose=False).to("cuda")
     nnaudio_amd.set_precision(prec)
     print("mfcc 256x5s      %-7s %.3f ms" % (prec, timeit(lambda: m(x2))))
-    s = features.STFT(n_fft=1024, hop_length=512, output_format="Complex", verbose=False).to("cuda")
+    s = features.STFT(n_fft=1024, hop_length=512, output_format="Complex", iSTFT=True, verbose=False).to("cuda")
     spec = s(x2[:64])
     print("istft 64x5s      %-7s %.3f ms" % (prec, timeit(lambda: s.inverse(spec, onesided=True, length=110250))))

@@ -282,14 +282,16 @@ __device__ __forceinline__ void bf16x3_epilogue(const KParams &p, f32x16 (&acc)[
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
-template <int WM, int WN, int NR>
+// (wm, wn): the 32-bin block and the NR*32-frame block of the workgroup tile that `acc` holds -- the
+// wave's own coordinates in the dense kernel; the folded kernel's waves own two bin blocks and call
+// this once per block.
+template <int NR>
 __device__ __forceinline__ void bf16x3_epilogue_planar(const KParams &p, f32x16 (&acc)[2][NR], const int m0,
-                                                       const long long n0, unsigned char *smem_raw) {
+                                                       const long long n0, unsigned char *smem_raw,
+                                                       const int wm, const int wn) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN;
-  const int wn = wave % WN;
   const int li = lane & 31;
   const int lh = lane >> 5;
   const bool cplx = p.a_im != nullptr;
@@ -452,6 +454,34 @@ __device__ __forceinline__ void bf16x3_epilogue_planar(const KParams &p, f32x16 
 // filterbank_from_tile (mispec.hip) then reduces it over the bins of every filter's band.
 // Bins are absolute: p.out_row_offset is the first bin of a leftover-row problem.
 // ---------------------------------------------------------------------------------
+// One wave's part of the |X|^power tile: its bins b0 + 32 wm + li, its frames 32 (wn NR + n) + ...
+template <int RS, int NR>
+__device__ __forceinline__ void bf16x3_fb_write(const KParams &p, f32x16 (&acc)[2][NR], float *P, const int b0,
+                                                const int wm, const int wn) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+  const int bl = wm * 32 + li;
+  const bool bin_ok = b0 + bl < p.n_bins;
+  const float sc = (p.row_scale && bin_ok) ? p.row_scale[b0 + bl] : 1.f;
+  const bool sq = p.power == 2.0f;
+#pragma unroll
+  for (int n = 0; n < NR; ++n) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float re = acc[0][n][4 * g + i] * sc;
+        const float im = acc[1][n][4 * g + i] * sc;
+        const float s2 = re * re + im * im + p.eps;
+        v[i] = bin_ok ? (sq ? s2 : sqrtf(s2)) : 0.f;
+      }
+      *reinterpret_cast<f32x4 *>(P + bl * RS + (wn * NR + n) * 32 + 8 * g + 4 * lh) = v;
+    }
+  }
+}
+
 template <int WM, int WN, int NR>
 __device__ __forceinline__ void bf16x3_epilogue_fb(const KParams &p, f32x16 (&acc)[2][NR], const int m0,
                                                    const long long n0, unsigned char *smem_raw) {
@@ -460,36 +490,10 @@ __device__ __forceinline__ void bf16x3_epilogue_fb(const KParams &p, f32x16 (&ac
   constexpr int RS = BN + 4;    // patch row stride in floats
   constexpr int NT = WM * WN * 64;
   static_assert(NT % (BN / 4) == 0, "a thread keeps its frame quad over all its items");
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN;
-  const int wn = wave % WN;
-  const int li = lane & 31;
-  const int lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float *const P = reinterpret_cast<float *>(smem_raw);
   const int b0 = m0 >> 1;  // first bin of the tile (relative to this problem's first bin)
-  {
-    const int bl = wm * 32 + li;
-    const bool bin_ok = b0 + bl < p.n_bins;
-    const float sc = (p.row_scale && bin_ok) ? p.row_scale[b0 + bl] : 1.f;
-    const bool sq = p.power == 2.0f;
-#pragma unroll
-    for (int n = 0; n < NR; ++n) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 v;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float re = acc[0][n][4 * g + i] * sc;
-          const float im = acc[1][n][4 * g + i] * sc;
-          const float s2 = re * re + im * im + p.eps;
-          v[i] = bin_ok ? (sq ? s2 : sqrtf(s2)) : 0.f;
-        }
-        *reinterpret_cast<f32x4 *>(P + bl * RS + (wn * NR + n) * 32 + 8 * g + 4 * lh) = v;
-      }
-    }
-  }
+  bf16x3_fb_write<RS, NR>(p, acc, P, b0, wave / WN, wave % WN);
   filterbank_from_tile<BB, BN, NT>(p, P, b0, n0);
 }
 
@@ -789,7 +793,7 @@ __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int w
     if (p.fb)
       bf16x3_epilogue_fb<WM, WN, NR>(p, acc, m0, n0, smem_raw);
     else
-      bf16x3_epilogue_planar<WM, WN, NR>(p, acc, m0, n0, smem_raw);
+      bf16x3_epilogue_planar<NR>(p, acc, m0, n0, smem_raw, wave / WN, wave % WN);
   }
   else
     bf16x3_epilogue<WM, WN, MR, NR>(p, acc, m0, n0, smem_raw);

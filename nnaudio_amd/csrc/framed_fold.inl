@@ -366,8 +366,14 @@ __device__ __forceinline__ void lds_dma_barrier_keep() {
 // three bf16 ones: the dense fp32 kernel's MFMA count halved, everything else unchanged.
 template <int NR, bool F32>
 __device__ __forceinline__ void framed_fold_body(const KParams &p, const int tile_m, const long long n0) {
-  constexpr int WM = 4, WN = 2, NW = 8;
-  constexpr int BN = WN * NR * 32;                       // frames of the tile
+  // wave layout: 2 x 4 waves, a wave owns MRW = 2 bin tiles x NRW = NR / 2 frame tiles (64 bins x 64
+  // frames of the 256-frame tile), re and im accumulators of both: per stage and wave 2 (MRW + NRW)
+  // = 8 fragment reads per half for 12 MFMAs.  (Until round 2's last day: 4 x 2 waves of 32 bins x
+  // 128 frames, 10 reads per half -- with the stage DMA more LDS cycles than MFMA cycles.)
+  constexpr int MRW = 2, WM = 2, WN = 4, NW = 8;
+  constexpr int BN = 64 * NR;                            // frames of the tile
+  constexpr int NRW = BN / (32 * WN);                    // frame tiles per wave
+  static_assert(NRW >= 1, "tile too narrow for 4 wave columns");
   constexpr int X_ST = BN * FOLD_ROWB;                   // bytes of the frame rows of a stage
   constexpr int STAGE = FOLD_A_ST + X_ST;
   constexpr int XJ = BN / 64;                            // frame-row DMA pieces per wave
@@ -417,54 +423,63 @@ __device__ __forceinline__ void framed_fold_body(const KParams &p, const int til
                                        (lptr_t)(st + FOLD_A_ST + (j * NW + wave) * 1024), 16, 0, 0);
   };
 
-  f32x16 acc[2][NR];
+  f32x16 acc[MRW][2][NRW];  // [bin tile][re / im][frame tile]
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < MRW; ++m)
 #pragma unroll
-    for (int n = 0; n < NR; ++n)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+      for (int n = 0; n < NRW; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][h][n][e] = 0.f;
 
   // ---- fragments.  Lane (li, lh) supplies row li and taps 8 lh .. 8 lh + 7 of the step: chunk
   // 2 * plane + lh of the row, at slot  chunk ^ ((li >> 1) & 7)
   const int fsw = (li >> 1) & 7;
-  const int a_row = (wm * 32 + li) * FOLD_ROWB;
-  const int x_row = FOLD_A_ST + ((wn * NR) * 32 + li) * FOLD_ROWB;
-  bf16x8 fa[2][2], fx[2][2][NR];  // [half][hi / lo]
+  const int a_row = ((wm * MRW) * 32 + li) * FOLD_ROWB;
+  const int x_row = FOLD_A_ST + ((wn * NRW) * 32 + li) * FOLD_ROWB;
+  bf16x8 fa[2][2][MRW], fx[2][2][NRW];  // [half][hi / lo][tile]
   auto load_frags = [&](int buf, auto half_tag) __attribute__((always_inline)) {
     constexpr int HALF = decltype(half_tag)::value;  // 0: (A_re, E), 1: (A_im, O)
     const unsigned char *st = smem_raw + buf * STAGE;
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) {
       const int off = 16 * ((F32 ? 4 * HALF + 2 * lh + pl : 4 * HALF + 2 * pl + lh) ^ fsw);
-      fa[HALF][pl] = *reinterpret_cast<const bf16x8 *>(st + a_row + off);
 #pragma unroll
-      for (int n = 0; n < NR; ++n)
+      for (int m = 0; m < MRW; ++m)
+        fa[HALF][pl][m] = *reinterpret_cast<const bf16x8 *>(st + a_row + m * 32 * FOLD_ROWB + off);
+#pragma unroll
+      for (int n = 0; n < NRW; ++n)
         fx[HALF][pl][n] = *reinterpret_cast<const bf16x8 *>(st + x_row + n * 32 * FOLD_ROWB + off);
     }
   };
-  // the 3 * NR MFMAs of one half; small terms first, an accumulator is revisited after NR - 1 others
+  // the 3 * MRW * NRW MFMAs of one half; small terms first, an accumulator is revisited after
+  // MRW * NRW - 1 others
   auto mfma_half = [&](auto half_tag) __attribute__((always_inline)) {
     constexpr int HALF = decltype(half_tag)::value;
     if (F32) {
 #pragma unroll
       for (int t = 0; t < 8; ++t)
 #pragma unroll
-        for (int n = 0; n < NR; ++n) {
-          const float a = __builtin_bit_cast(f32x4v, fa[HALF][t >> 2])[t & 3];
-          const float x = __builtin_bit_cast(f32x4v, fx[HALF][t >> 2][n])[t & 3];
-          acc[HALF][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, a, acc[HALF][n], 0, 0, 0);
-        }
+        for (int m = 0; m < MRW; ++m)
+#pragma unroll
+          for (int n = 0; n < NRW; ++n) {
+            const float a = __builtin_bit_cast(f32x4v, fa[HALF][t >> 2][m])[t & 3];
+            const float x = __builtin_bit_cast(f32x4v, fx[HALF][t >> 2][n])[t & 3];
+            acc[m][HALF][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, a, acc[m][HALF][n], 0, 0, 0);
+          }
       return;
     }
 #pragma unroll
     for (int term = 0; term < 3; ++term)
 #pragma unroll
-      for (int n = 0; n < NR; ++n) {
-        const bf16x8 a = fa[HALF][term == 0 ? 1 : 0];
-        const bf16x8 x = fx[HALF][term == 1 ? 1 : 0][n];
-        acc[HALF][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, a, acc[HALF][n], 0, 0, 0);
-      }
+      for (int m = 0; m < MRW; ++m)
+#pragma unroll
+        for (int n = 0; n < NRW; ++n) {
+          const bf16x8 a = fa[HALF][term == 0 ? 1 : 0][m];
+          const bf16x8 x = fx[HALF][term == 1 ? 1 : 0][n];
+          acc[m][HALF][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, a, acc[m][HALF][n], 0, 0, 0);
+        }
   };
   auto interleave = [&](auto n_mfma_tag, auto n_ds_tag, auto n_vm_tag) __attribute__((always_inline)) {
     constexpr int NM = decltype(n_mfma_tag)::value;
@@ -482,8 +497,8 @@ __device__ __forceinline__ void framed_fold_body(const KParams &p, const int til
   using std::integral_constant;
   typedef integral_constant<int, 0> i0;
   typedef integral_constant<int, 1> i1;
-  typedef integral_constant<int, (F32 ? 8 : 3) * NR> n_mfma;
-  typedef integral_constant<int, 2 * (1 + NR)> n_reads;
+  typedef integral_constant<int, (F32 ? 8 : 3) * MRW * NRW> n_mfma;
+  typedef integral_constant<int, 2 * (MRW + NRW)> n_reads;
   typedef integral_constant<int, DMA_PER_WAVE> n_dma;
 
   // One iteration = stage c out of buffer `buf`.  Waves w and w + 4 share a SIMD (a workgroup's
@@ -546,18 +561,29 @@ __device__ __forceinline__ void framed_fold_body(const KParams &p, const int til
   if (MISPEC_DBG(p, 0x40000)) {  // ablation: no epilogue (keep the accumulators alive)
     float sum = 0.f;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MRW; ++m)
 #pragma unroll
-      for (int n = 0; n < NR; ++n)
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) sum += acc[m][n][e];
+        for (int n = 0; n < NRW; ++n)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) sum += acc[m][h][n][e];
     if (sum == 12345.678f) p.out[0] = sum;
     return;
   }
-  if (p.fb)
-    bf16x3_epilogue_fb<WM, WN, NR>(p, acc, 2 * b0, n0, smem_raw);
-  else
-    bf16x3_epilogue_planar<WM, WN, NR>(p, acc, 2 * b0, n0, smem_raw);
+  // the epilogues of the dense planar kernel, once per bin tile of the wave (32-bin block
+  // wm MRW + m, frame block wn of NRW tiles)
+  if (p.fb) {
+    constexpr int RS = BN + 4;
+    float *const P = reinterpret_cast<float *>(smem_raw);
+#pragma unroll
+    for (int m = 0; m < MRW; ++m) bf16x3_fb_write<RS, NRW>(p, acc[m], P, b0, wm * MRW + m, wn);
+    filterbank_from_tile<FOLD_BINS, BN, NW * 64>(p, P, b0, n0);
+  } else {
+#pragma unroll
+    for (int m = 0; m < MRW; ++m)
+      bf16x3_epilogue_planar<NRW>(p, acc[m], 2 * b0, n0, smem_raw, wm * MRW + m, wn);
+  }
 }
 
 
@@ -609,288 +635,3 @@ __device__ __forceinline__ void framed_fold_grid(const KParams &p) {
 __global__ void __launch_bounds__(512) framed_fold_kernel(const KParams p) { framed_fold_grid<false>(p); }
 __global__ void __launch_bounds__(512) framed_fold32_kernel(const KParams p) { framed_fold_grid<true>(p); }
 
-// ---------------------------------------------------------------------------------
-// Role-split variant of the contraction (same tile, same LDS stages, same operands): waves 0-3
-// accumulate the RE part of 64 bins x 128 frames each (basis re rows x E), waves 4-7 the IM part
-// of the same regions (basis im rows x O).  A wave then needs the fragments of ONE component:
-// 4 basis + 8 frame reads per 24 MFMAs instead of 4 + 16 (the E and O fragments cannot be shared
-// between the two halves of a wave that owns both parts of its bins; the fragment reads were the
-// largest term of the K loop's ablation).  The price is paid once per tile: the im waves hand
-// their accumulators to the re waves through LDS, which then run the planar epilogue.
-// Serves the register-formed epilogues (Complex, Magnitude, |.|^2, |.|) and the fused filterbank.
-//
-// BENCHMARKING BUILD ONLY (debug bit 0x400000 selects it): measured on the MI355X it ties with
-// framed_fold_kernel (cfg2 contraction 0.616 vs 0.61 ms, fused mel 0.357 vs 0.353 ms).  Ablations
-// (kbench fold): the fragment reads do cost less (0.05 instead of 0.15 ms), but the epilogue
-// doubles (0.118 vs 0.062 ms: exchange through LDS, four waves storing) and the bare MFMA loop
-// runs 20 % slower (basis fragments single-buffered: a second set does not fit beside 128
-// accumulator registers).  Kept as the starting point for a symmetric exchange (re waves finish
-// bin tile 0, im waves bin tile 1).
-// ---------------------------------------------------------------------------------
-#ifdef MISPEC_ABLATE
-__global__ void __launch_bounds__(512) framed_fold_split_kernel(const KParams p) {
-  constexpr int NW = 8, NRT = 4;  // frame tiles per wave
-  typedef __attribute__((address_space(1))) const void *gptr_t;
-  typedef __attribute__((address_space(3))) void *lptr_t;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int role = wave >> 2;      // 0: re (E), 1: im (O)
-  const int wb = (wave >> 1) & 1;  // 64-bin half of the tile
-  const int wf = wave & 1;         // 128-frame half of the tile
-  const int li = lane & 31;
-  const int lh = lane >> 5;
-
-  // ---- XCD-aware tile order (as framed_gemm_body)
-  int tile;
-  {
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7;
-    const int xcd = b & 7, idx = b >> 3;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  int tile_m, tile_n;
-  {
-    const int G = p.n_group;
-    const int per_group = G * p.n_tiles_m;
-    const int full = (p.n_tiles_n / G) * per_group;
-    if (tile < full) {
-      const int g = tile / per_group;
-      const int rest = tile - g * per_group;
-      tile_m = rest / G;
-      tile_n = g * G + (rest - tile_m * G);
-    } else {
-      const int Gt = p.n_tiles_n % G;
-      const int rest = tile - full;
-      tile_m = rest / Gt;
-      tile_n = (p.n_tiles_n / G) * G + (rest - tile_m * Gt);
-    }
-  }
-  const int b0 = tile_m * FOLD_BINS;
-  tile_n += p.fold_tile0;
-  const long long n0 = (long long)tile_n * FOLD_BN;
-  const int nst = p.Ks / FOLD_KC;
-  const long long row_el = (long long)nst * (FOLD_ROWB / 2);
-
-  // ---- DMA geometry (as framed_fold_kernel)
-  const int r8 = lane >> 3, slot = lane & 7;
-  const unsigned short *aptr[2], *xptr[4];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = (j * NW + wave) * 8 + r8;
-    int bin = b0 + row;
-    bin = bin < p.n_bins ? bin : p.n_bins - 1;
-    aptr[j] = p.as + (long long)bin * row_el + 8 * (slot ^ ((row >> 1) & 7));
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = (j * NW + wave) * 8 + r8;
-    long long col = n0 + row;
-    col = col < p.n_cols ? col : 0;
-    xptr[j] = p.xs + col * row_el + 8 * (slot ^ ((row >> 1) & 7));
-  }
-  auto dma_stage = [&](int s, int buf) __attribute__((always_inline)) {
-    unsigned char *st = smem_raw + buf * FOLD_STAGE;
-    const int so = s * (FOLD_ROWB / 2);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(aptr[j] + so), (lptr_t)(st + (j * NW + wave) * 1024), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(xptr[j] + so),
-                                       (lptr_t)(st + FOLD_A_ST + (j * NW + wave) * 1024), 16, 0, 0);
-  };
-
-  f32x16 acc[2][NRT];  // [bin tile m][frame tile n] of this wave's component
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int n = 0; n < NRT; ++n)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
-
-  // ---- fragments: chunk 4 role + 2 plane + lh of the row, at slot chunk ^ ((li >> 1) & 7)
-  const int fsw = (li >> 1) & 7;
-  const int a_row = (wb * 64 + li) * FOLD_ROWB;
-  const int x_row = FOLD_A_ST + (wf * 128 + li) * FOLD_ROWB;
-  const int ch_hi = 16 * ((4 * role + lh) ^ fsw), ch_lo = 16 * ((4 * role + 2 + lh) ^ fsw);
-  bf16x8 fa[2][2];    // [m][hi / lo]
-  bf16x8 fx[NRT][2];  // [n][hi / lo]
-  auto load_a = [&](int buf) __attribute__((always_inline)) {
-    const unsigned char *st = smem_raw + buf * FOLD_STAGE + a_row;
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      fa[m][0] = *reinterpret_cast<const bf16x8 *>(st + m * 32 * FOLD_ROWB + ch_hi);
-      fa[m][1] = *reinterpret_cast<const bf16x8 *>(st + m * 32 * FOLD_ROWB + ch_lo);
-    }
-  };
-  auto load_x = [&](int buf, auto n0_tag) __attribute__((always_inline)) {
-    constexpr int N0 = decltype(n0_tag)::value;
-    const unsigned char *st = smem_raw + buf * FOLD_STAGE + x_row;
-#pragma unroll
-    for (int n = N0; n < N0 + 2; ++n) {
-      fx[n][0] = *reinterpret_cast<const bf16x8 *>(st + n * 32 * FOLD_ROWB + ch_hi);
-      fx[n][1] = *reinterpret_cast<const bf16x8 *>(st + n * 32 * FOLD_ROWB + ch_lo);
-    }
-  };
-  // the 3 * 2 * 2 MFMAs of frame tiles N0, N0 + 1; small terms first
-  auto mfma_half = [&](auto n0_tag) __attribute__((always_inline)) {
-    constexpr int N0 = decltype(n0_tag)::value;
-#pragma unroll
-    for (int term = 0; term < 3; ++term)
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = N0; n < N0 + 2; ++n) {
-          const bf16x8 a = fa[m][term == 0 ? 1 : 0];
-          const bf16x8 x = fx[n][term == 1 ? 1 : 0];
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, a, acc[m][n], 0, 0, 0);
-        }
-  };
-  using std::integral_constant;
-  typedef integral_constant<int, 0> i0;
-  typedef integral_constant<int, 2> i2;
-
-  // iteration = stage c: frame tiles 0, 1 (X23 read meanwhile) -> barrier -> frame tiles 2, 3 (stage
-  // c+1's X01 fragments read meanwhile), then stage c+1's basis fragments into the registers the
-  // last MFMAs have just read (one buffer: a second set would not fit beside 128 accumulator
-  // registers; the partner wave on the SIMD covers the read latency).  DMA staggered between the
-  // waves that share a SIMD exactly as in framed_fold_kernel.
-  const bool late = wave >= NW / 2;
-  auto stage_iter = [&](int c, int buf, int buf_prev, int buf_next, bool dma_late, bool dma_early,
-                        auto next_tag, auto keep_tag) __attribute__((always_inline)) {
-    constexpr bool NEXT = decltype(next_tag)::value;
-    if (!MISPEC_DBG(p, 8)) load_x(buf, i2{});
-    if (dma_late && !MISPEC_DBG(p, 1)) dma_stage(c + 2, buf_prev);
-    mfma_half(i0{});
-    if (!MISPEC_DBG(p, 4)) lds_dma_barrier_keep<decltype(keep_tag)::value>();
-    if (dma_early && !MISPEC_DBG(p, 1)) dma_stage(c + FOLD_NBUF, buf);
-    if (NEXT && !MISPEC_DBG(p, 8)) load_x(buf_next, i0{});
-    mfma_half(i2{});
-    if (NEXT && !MISPEC_DBG(p, 8)) load_a(buf_next);
-  };
-  typedef integral_constant<bool, true> yes;
-  typedef integral_constant<bool, false> no;
-  typedef integral_constant<int, FOLD_DMA_PER_WAVE> keep1;
-  if (nst > 0) {
-    dma_stage(0, 0);
-    if (nst > 1) dma_stage(1, 1);
-    if (nst > 2) dma_stage(2, 2);
-    if (nst > 2)
-      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (nst > 1)
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    load_a(0);
-    load_x(0, i0{});
-    auto nxt = [](int b) { return b == FOLD_NBUF - 1 ? 0 : b + 1; };
-    auto prv = [](int b) { return b == 0 ? FOLD_NBUF - 1 : b - 1; };
-    int c = 0, buf = 0;
-    for (; c + 2 < nst; ++c) {  // stages c+1 and c+2 exist; c+2 is in flight at the barrier
-      stage_iter(c, buf, prv(buf), nxt(buf), late && c >= 1, !late && c + FOLD_NBUF < nst, yes{}, keep1{});
-      buf = nxt(buf);
-    }
-    if (c + 1 < nst) {  // only c+1 left: wait for everything
-      stage_iter(c, buf, prv(buf), nxt(buf), false, false, yes{}, i0{});
-      buf = nxt(buf);
-      ++c;
-    }
-    stage_iter(c, buf, buf, buf, false, false, no{}, i0{});
-    __syncthreads();  // every wave is done with the stage buffers (the epilogue reuses them)
-  }
-
-  // ---- epilogue.  acc[m][n][e] of a wave = its component of bin b0 + 64 wb + 32 m + li at flat frame
-  // n0 + 128 wf + 32 n + 8 (e >> 2) + 4 lh + (e & 3)  (the layout of bf16x3_epilogue_planar, per wave)
-  if (MISPEC_DBG(p, 0x40000)) {  // ablation: no epilogue (keep the accumulators alive)
-    float sum = 0.f;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int n = 0; n < NRT; ++n)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sum += acc[m][n][e];
-    if (sum == 12345.678f) p.out[0] = sum;
-    return;
-  }
-  if (p.fb) {
-    // fused filterbank: P[bin][frame] = |z|^power assembled by the re waves, then the im waves
-    constexpr int RS = FOLD_BN + 4;
-    float *const P = reinterpret_cast<float *>(smem_raw);
-    const bool sq = p.power == 2.0f;
-#pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-      if (role == pass) {
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          const int bl = wb * 64 + m * 32 + li;
-          const bool bin_ok = b0 + bl < p.n_bins;
-          const float sc = (p.row_scale && bin_ok) ? p.row_scale[b0 + bl] : 1.f;
-#pragma unroll
-          for (int n = 0; n < NRT; ++n)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              float *d = P + bl * RS + wf * 128 + n * 32 + 8 * g + 4 * lh;
-              f32x4 v;
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                const float t = acc[m][n][4 * g + i] * sc;
-                v[i] = t * t;
-              }
-              if (pass == 1) {
-                const f32x4 q = *reinterpret_cast<const f32x4 *>(d);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                  const float s2 = q[i] + v[i] + p.eps;
-                  v[i] = bin_ok ? (sq ? s2 : sqrtf(s2)) : 0.f;
-                }
-              }
-              *reinterpret_cast<f32x4 *>(d) = v;
-            }
-        }
-      }
-      __syncthreads();
-    }
-    filterbank_from_tile<FOLD_BINS, FOLD_BN, 512>(p, P, b0, n0);
-    return;
-  }
-  // the im waves hand their accumulators over, one bin tile (16 KB per wave) at a time; the re waves
-  // pair them with their own and run the planar epilogue of a 2 x 2 wave layout on their quarter
-  unsigned char *const dump = smem_raw;               // 4 x 16 KB
-  unsigned char *const patches = smem_raw + 4 * 16384;  // 4 x 32 x 132 floats
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    if (role == 1) {
-      unsigned char *d = dump + (wave & 3) * 16384 + lane * 16;
-#pragma unroll
-      for (int n = 0; n < NRT; ++n)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x16 &a = acc[m][n];
-          *reinterpret_cast<f32x4 *>(d + (n * 4 + g) * 1024) = f32x4{a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
-        }
-    }
-    __syncthreads();
-    if (role == 0) {
-      f32x16 pair[2][NRT];
-      const unsigned char *d = dump + wave * 16384 + lane * 16;
-#pragma unroll
-      for (int n = 0; n < NRT; ++n) {
-        pair[0][n] = acc[m][n];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 q = *reinterpret_cast<const f32x4 *>(d + (n * 4 + g) * 1024);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) pair[1][n][4 * g + i] = q[i];
-        }
-      }
-      // a 2 x 2 wave layout (wm = wb, wn = wf) whose 32-bin rows start at b0 + 32 wb + 32 m + 32 wm
-      bf16x3_epilogue_planar<2, 2, NRT>(p, pair, 2 * (b0 + 32 * wb + 32 * m), n0, patches);
-    }
-    __syncthreads();
-  }
-}
-#endif  // MISPEC_ABLATE

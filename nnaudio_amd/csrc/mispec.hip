@@ -41,7 +41,8 @@
 // generic Toeplitz decimator, 0x2000 no pair launch, 0x4000 bf16x3: staged kernel instead of the
 // hop-periodic ones, 0x8000 one slab buffer, 0x20000 masked 192x256 slab tiles instead of narrow
 // tiles, 0x40000 no epilogue, 0x80000 two K stages only, 0x100000 bf16x3: dense (unfolded) kernel,
-// 0x200000 fold: chunks of clips, 0x400000 fold: role-split waves (framed_fold_split_kernel).
+// 0x200000 fold: chunks of clips; fold pre-pass: 0x40 no global stores, 0x80 no global loads, 0x200
+// without the last bin.
 // In the product library MISPEC_DBG() is the constant false (the branches compile away) and a
 // non-zero `reserved` is rejected.
 //
@@ -2377,19 +2378,6 @@ int launch_fold(KParams p, const mispec_framed_gemm_args *a, const FoldPlan &f, 
   static std::atomic<unsigned long long> configured{0}, configured32{0};
   int rc = configure_lds(kern, 160 * 1024, p.fold_f32 ? configured32 : configured);
   if (rc != MISPEC_OK) return rc;
-#ifdef MISPEC_ABLATE
-  {  // A/B runs: the role-split variant (see framed_fold.inl), for the epilogues it serves
-    const bool pow_sq = p.epilogue == MISPEC_EPI_POWER && p.power == 2.0f && p.eps == 0.f;
-    const bool pow_1 = p.epilogue == MISPEC_EPI_POWER && p.power == 1.0f;
-    if (MISPEC_DBG(p, 0x400000) && !p.fold_f32 && (p.fb != nullptr || p.epilogue == MISPEC_EPI_COMPLEX ||
-                                    p.epilogue == MISPEC_EPI_MAGNITUDE || pow_sq || pow_1)) {
-      kern = framed_fold_split_kernel;
-      static std::atomic<unsigned long long> configured2{0};
-      rc = configure_lds(kern, 160 * 1024, configured2);
-      if (rc != MISPEC_OK) return rc;
-    }
-  }
-#endif
   // the epilogues reuse the stage ring (patches: 8 waves x 32 x 132 floats, or the 128 x 260 power
   // tile + band table of the fused filterbank)
   const size_t smem = (size_t)FOLD_NBUF * FOLD_STAGE;

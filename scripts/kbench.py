@@ -65,8 +65,6 @@ def fold():
     for dbg, what in ((0, "full step (pre-pass + contraction)"), (1, "no LDS-DMA in the loop"),
                       (8, "no fragment reads"), (1 + 8, "no DMA, no fragment reads (MFMA + barrier)"),
                       (1 + 8 + 4, "MFMAs only"), (0x40000, "no epilogue"), (0x40000 + 1, "no epilogue, no DMA"),
-                      (0x400000, "role-split waves (framed_fold_split_kernel)"), (0x400000 + 1, "  no DMA"),
-                      (0x400000 + 8, "  no fragment reads"), (0x400000 + 0x40000, "  no epilogue"),
                       (0x100000, "dense (unfolded) kernel")):
         ms = timeit(lambda: engine.framed_gemm(x, m.wcos, m.wsin, hop=512, pad=1024, pad_mode=2,
                                                epilogue=engine.EPI_MAGNITUDE, precision="bf16x3",

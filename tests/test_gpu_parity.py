@@ -845,6 +845,9 @@ def _fourier_like_basis(rng, F, K, tap0):
     (5, 700, 130, 128, 32, 64, 2, False),      # many short clips: tiles span several clips
     (1, 40000, 129, 4096, 1024, 2048, 2, False),  # n_fft = 4096: 64 KB of LDS per pre-pass block
     (1, 70000, 65, 8192, 2048, 4096, 1, True),    # the longest kernel the fold takes
+    (2, 6000, 130, 402, 100, 201, 2, False),   # K/2 odd: the quad that straddles tap K/2 (element-wise path)
+    (3, 9000, 129, 1000, 250, 500, 2, False),  # 512 folded taps: two thread groups in the pre-pass + last bin
+    (1, 3000, 129, 500, 125, 250, 1, True),    # 256 folded taps incl. tap 0: four thread groups in the pre-pass
 ])
 @pytest.mark.parametrize("epi", ["complex", "magnitude", "power2", "phase"])
 @pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
@@ -862,7 +865,7 @@ def test_symmetric_fold_kernel(shape, epi, precision):
     re, im = _np_framed(x, wr, wi, hop, pad, mode, scale)
     xd, wrd, wid, sd = (torch.as_tensor(a).to(DEV) for a in (x, wr, wi, scale))
     prep = engine.prepare_basis(wrd, wid, precision, hop=hop)
-    assert "basis_fold" in prep and prep["basis_fold"][1] == (K // 2 + (16 if tap0 else 0) + 15) // 16 * 16
+    assert "basis_fold" in prep and prep["basis_fold"][1] == (K // 2 + (1 if tap0 else 0) + 15) // 16 * 16
     assert ("basis_split" in prep) == (precision == "bf16x3")
     kw = dict(hop=hop, pad=pad, pad_mode=mode, row_scale=sd)
     e = {"complex": engine.EPI_COMPLEX, "magnitude": engine.EPI_MAGNITUDE, "power2": engine.EPI_POWER,

@@ -23,8 +23,8 @@
 // Folded tap j <-> n = j + 1 for j < N/2 (n = 1 .. N/2), j = N/2 <-> n = 0 (only when some basis row
 // has a non-zero tap 0, i.e. a window with w[0] != 0), then zero taps up to a multiple of 16.
 //
-// Main kernel: 128 bins x 256 frames per workgroup, 8 waves (wave = 32 bins x 128 frames, re and im
-// accumulators of the same bins: acc[0][n] / acc[1][n]), K stage = 16 folded taps = ONE MFMA step,
+// Main kernel: 128 bins x 256 frames per workgroup, 8 waves as 2 x 4 (wave = 64 bins x 64 frames, re
+// and im accumulators of the same bins: acc[m][0][n] / acc[m][1][n]), K stage = 16 folded taps = ONE MFMA step,
 // LDS stage = 128 A rows + 256 X rows of 128 B (48 KB), ring of 3.  An iteration is two halves:
 //     re half : 12 MFMAs acc[0][n] += E x A_re   (3 split terms x 4 frame tiles) while the im-half
 //               fragments of this stage are read

@@ -26,11 +26,11 @@
 // Main kernel: 128 bins x 256 frames per workgroup, 8 waves as 2 x 4 (wave = 64 bins x 64 frames, re
 // and im accumulators of the same bins: acc[m][0][n] / acc[m][1][n]), K stage = 16 folded taps = ONE MFMA step,
 // LDS stage = 128 A rows + 256 X rows of 128 B (48 KB), ring of 3.  An iteration is two halves:
-//     re half : 12 MFMAs acc[0][n] += E x A_re   (3 split terms x 4 frame tiles) while the im-half
+//     re half : 12 MFMAs acc[m][0][n] += E x A_re   (3 split terms x 2 x 2 tiles) while the im-half
 //               fragments of this stage are read
 //     barrier : stage c+1 has landed (s_waitcnt vmcnt(6): stage c+2 may still be in flight), every
 //               wave has read what it needs from stage c
-//     im half : 12 MFMAs acc[1][n] += O x A_im while stage c+3 is DMA'd into the buffer of stage c and
+//     im half : 12 MFMAs acc[m][1][n] += O x A_im while stage c+3 is DMA'd into the buffer of stage c and
 //               the re-half fragments of stage c+1 are read
 // Rows are XOR-swizzled in 16-byte chunks by (row >> 1) & 7 (applied to the DMA source address and to
 // the fragment reads): conflict-free ds_read_b128 (MI355X_MICROARCH.md, LDS table).

@@ -3172,8 +3172,8 @@ int mispec_filterbank_f32(const float *fb, int32_t n_filters, int32_t n_freq, co
   p.out_clip_stride = (long long)n_filters * n_frames;
   p.out_row_stride = n_frames;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (n_filters <= 32) return launch_cfg<1, 4, 1, 2, BMODE_PLANAR, AMODE_ROWS, false>(p, s);
-  if (n_filters <= 64) return launch_cfg<1, 4, 2, 1, BMODE_PLANAR, AMODE_ROWS, false>(p, s);
+  if (n_filters <= 32) return launch_cfg<1, 4, 1, 1, BMODE_PLANAR, AMODE_ROWS, false>(p, s);
+  if (n_filters <= 64) return launch_cfg<2, 2, 1, 1, BMODE_PLANAR, AMODE_ROWS, false>(p, s);
   return launch_cfg<2, 2, 2, 2, BMODE_PLANAR, AMODE_ROWS, false>(p, s);
 }
 

@@ -42,7 +42,8 @@
 // hop-periodic ones, 0x8000 one slab buffer, 0x20000 masked 192x256 slab tiles instead of narrow
 // tiles, 0x40000 no epilogue, 0x80000 two K stages only, 0x100000 bf16x3: dense (unfolded) kernel,
 // 0x200000 fold: chunks of clips; fold pre-pass: 0x40 no global stores, 0x80 no global loads, 0x200
-// without the last bin.
+// without the last bin; fused filterbank: 0x400 no walk, 0x10000 walk without stores, 0x400000 plain
+// stores instead of atomics.
 // In the product library MISPEC_DBG() is the constant false (the branches compile away) and a
 // non-zero `reserved` is rejected.
 //
@@ -355,6 +356,7 @@ __device__ __forceinline__ void filterbank_from_tile(const KParams &p, float *P,
       }
     }
   }
+  if (MISPEC_DBG(p, 0x400)) return;  // benchmarking build: no walk
 #pragma unroll 1
   for (int m = tid / QPR; m < p.n_fb; m += NT / QPR) {
     const int2 band = sBand[m];
@@ -379,7 +381,8 @@ __device__ __forceinline__ void filterbank_from_tile(const KParams &p, float *P,
         for (int i = 0; i < 4; ++i) sum[i] += wb[u] * q[u][i];
     }
     float *const orow = p.out + (long long)m * p.out_row_stride;
-    if (whole) {
+    if (MISPEC_DBG(p, 0x10000) && sum[0] != 12345.678f) continue;  // benchmarking build: walk, no stores
+    if (whole || MISPEC_DBG(p, 0x400000)) {  // (0x400000: plain stores instead of atomics)
       if (col + 3 < p.n_cols && cc[3] == cc[0]) {
         *reinterpret_cast<f32x4u *>(orow + (long long)cc[0] * p.out_clip_stride + tt[0]) = sum;
       } else {

@@ -23,6 +23,9 @@ kw = dict(hop=512, pad=512, pad_mode=2, epilogue=engine.EPI_POWER, power=2.0, pr
 A = 0x10000000  # (a bit nothing reads: routes the call to the benchmarking build)
 print("fused mel step            %.3f ms" % timeit(lambda: engine.framed_gemm(x, st.wcos, st.wsin, fb=m.mel_basis, fb_support=sup, _debug=A, **kw, **prep)))
 print("  ... without epilogue    %.3f ms" % timeit(lambda: engine.framed_gemm(x, st.wcos, st.wsin, fb=m.mel_basis, fb_support=sup, _debug=A | 0x40000, **kw, **prep)))
+print("  ... without the walk   %.3f ms" % timeit(lambda: engine.framed_gemm(x, st.wcos, st.wsin, fb=m.mel_basis, fb_support=sup, _debug=A | 0x400, **kw, **prep)))
+print("  ... walk, no stores    %.3f ms" % timeit(lambda: engine.framed_gemm(x, st.wcos, st.wsin, fb=m.mel_basis, fb_support=sup, _debug=A | 0x10000, **kw, **prep)))
+print("  ... stores, no atomics %.3f ms" % timeit(lambda: engine.framed_gemm(x, st.wcos, st.wsin, fb=m.mel_basis, fb_support=sup, _debug=A | 0x400000, **kw, **prep)))
 print("power spectrum (no mel)   %.3f ms" % timeit(lambda: engine.framed_gemm(x, st.wcos, st.wsin, _debug=A, **kw, **prep)))
 print("  ... without epilogue    %.3f ms" % timeit(lambda: engine.framed_gemm(x, st.wcos, st.wsin, _debug=A | 0x40000, **kw, **prep)))
 print("module forward            %.3f ms" % timeit(lambda: m(x)))

@@ -3296,9 +3296,13 @@ int mispec_octave_pyramid_f32(const mispec_octave_args *a, void *stream) {
   }
   p.nf = nf;
   p.n_chunks = (a->n_frames + nf - 1) / nf;
-  auto kern = octave_pyramid_kernel;
-  static std::atomic<unsigned long long> configured{0};
-  int rc = configure_lds(kern, 80 * 1024, configured);
+  // kernel rows resident in registers: 6 steps (192 taps) when every level fits, else 8
+  int max_steps = 0;
+  for (int l = 0; l < D; ++l) max_steps = p.lv[l].Ks / 32 > max_steps ? p.lv[l].Ks / 32 : max_steps;
+  const bool six = max_steps <= 6;
+  auto kern = six ? octave_pyramid_kernel<6> : octave_pyramid_kernel<8>;
+  static std::atomic<unsigned long long> configured6{0}, configured8{0};
+  int rc = configure_lds(kern, 80 * 1024, six ? configured6 : configured8);
   if (rc != MISPEC_OK) return rc;
   // persistent workgroups, two per CU
   int dev = 0, cus = 256;

@@ -102,6 +102,10 @@ __device__ __forceinline__ int pyr_addr(int i) {
   return row * PYR_ROW + ((((i & 63) >> 3) ^ ((row >> 1) & 7)) << 4) + ((i & 7) << 1);
 }
 
+// MAXS = 32-tap steps of the kernel rows a wave keeps in registers (8: banks up to 256 taps; 6: up to
+// 192 -- the reference's banks once their zero margins are trimmed -- 32 VGPRs fewer); wider banks
+// stream the remaining steps from L2.
+template <int MAXS>
 __global__ void __launch_bounds__(256, 2) octave_pyramid_kernel(const PyrParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
@@ -133,7 +137,6 @@ __global__ void __launch_bounds__(256, 2) octave_pyramid_kernel(const PyrParams 
 
   // ---- once per workgroup: this wave's level in phase C (the waves are dealt to the contracting
   // levels)
-  constexpr int MAXS = 8;  // K <= 256 resident; wider banks stream the rest per step
   int my_level = -1, my_rank = 0, my_peers = 1;
   {
     int nc = 0;

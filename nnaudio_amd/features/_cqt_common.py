@@ -64,6 +64,20 @@ class SupportCache:
         return self._cache.get((real, imag), lambda: self._build(real, imag))
 
 
+def zero_margin(re, im):
+    """Taps that can be cut off BOTH ends of a bank ``(rows, K)`` without touching a non-zero
+    coefficient: a multiple of 16, the kernel stays centred, a multiple of 32 wide and at least 32
+    taps (0 for widths that are not a multiple of 32).  One host read per call."""
+    K = re.shape[1]
+    if K % 32 or K < 64 or re.shape[0] == 0:
+        return 0
+    idx = torch.nonzero(((re != 0) | (im != 0)).any(0)).flatten()
+    if not idx.numel():
+        return 0
+    m = min(int(idx[0]), K - 1 - int(idx[-1])) // 16 * 16
+    return max(0, min(m, (K - 32) // 32 * 16))
+
+
 class OctaveCache:
     """Per-module derived operands of the octave recursion for ``precision="bf16x3"``: the split
     planes of every octave's bank rows (see ``engine.DerivedCache``: rebuilt when the buffers
@@ -90,12 +104,7 @@ class OctaveCache:
         def build():
             r = kr.reshape(kr.shape[0], -1)[first:]
             im = ki.reshape(ki.shape[0], -1)[first:]
-            K, m = r.shape[1], 0
-            if K % 32 == 0 and K >= 64 and r.shape[0] > 0:
-                idx = torch.nonzero(((r != 0) | (im != 0)).any(0)).flatten()
-                if idx.numel():  # (one host read per bank and buffer version)
-                    m = min(int(idx[0]), K - 1 - int(idx[-1])) // 16 * 16
-                    m = max(0, min(m, (K - 32) // 32 * 16))
+            K, m = r.shape[1], zero_margin(r, im)
             if m:
                 r, im = r[:, m:K - m].contiguous(), im[:, m:K - m].contiguous()
             return engine.split_basis(r, im), K - 2 * m

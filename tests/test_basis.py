@@ -71,3 +71,32 @@ def test_cqt_alias():
     from nnaudio_amd import features
 
     assert issubclass(features.CQT, features.CQT1992v2)
+
+
+def test_octave_bank_zero_margin():
+    """The margin ``OctaveCache.bank`` cuts off both ends of an octave's kernels: zeros only, a
+    multiple of 16, the kernel stays centred and a multiple of 32 wide; the reference's own
+    CQT2010v2 bank (cqt.py:1023-1040: kernels centred in a power-of-two width) loses a quarter."""
+    import torch
+    from nnaudio_amd import features
+    from nnaudio_amd.features._cqt_common import zero_margin
+
+    re = torch.zeros(3, 256)
+    im = torch.zeros(3, 256)
+    assert zero_margin(re, im) == 0                      # nothing to centre on
+    re[1, 40:217] = 1.0
+    assert zero_margin(re, im) == 32                     # 40 / 39 zeros -> 32 each side, 192 left
+    im[2, 17] = 1.0
+    assert zero_margin(re, im) == 16
+    im[0, 3] = 1.0
+    assert zero_margin(re, im) == 0
+    assert zero_margin(torch.zeros(2, 48), torch.zeros(2, 48)) == 0   # width not a multiple of 32
+    one = torch.zeros(1, 64)
+    one[0, 32] = 1.0
+    assert zero_margin(one, one) == 16                   # never below 32 taps
+    m = features.CQT2010v2(sr=44100, hop_length=512, n_bins=96, verbose=False)
+    kr = m.cqt_kernels_real.reshape(m.cqt_kernels_real.shape[0], -1)
+    ki = m.cqt_kernels_imag.reshape(m.cqt_kernels_imag.shape[0], -1)
+    K, mg = kr.shape[1], zero_margin(kr, ki)
+    assert K == 256 and mg == 32
+    assert not kr[:, :mg].any() and not kr[:, K - mg:].any() and not ki[:, :mg].any() and not ki[:, K - mg:].any()

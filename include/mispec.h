@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MISPEC_ABI_VERSION 6
+#define MISPEC_ABI_VERSION 7
 
 enum {
   MISPEC_OK = 0,
@@ -82,6 +82,12 @@ enum {
                          /* a_hi*x_hi + a_hi*x_lo + a_lo*x_hi on v_mfma_f32_32x32x16_bf16 with fp32   */
                          /* accumulate: ~16 operand mantissa bits, error ~5e-6 of the spectrum peak. */
                          /* Needs basis_split; shapes it does not cover run in MISPEC_PREC_F32.      */
+  , MISPEC_PREC_F16X3 = 2 /* the same three products on v_mfma_f32_32x32x16_f16 with (hi, lo) fp16 pairs */
+                         /* of power-of-two SCALED operands (fp16 has 11 significant bits: 22 per      */
+                         /* operand instead of bf16x3's 16; the scales keep the pairs inside fp16's     */
+                         /* 5-bit exponent and are undone on the accumulators): error ~1e-7 of the     */
+                         /* spectrum peak, i.e. fp32 class, at the bf16x3 MFMA count.  Served where     */
+                         /* basis_fold2 applies; other shapes run in MISPEC_PREC_F32.                   */
 };
 
 /*
@@ -173,6 +179,20 @@ typedef struct mispec_framed_gemm_args {
    * workgroup are dealt out to the 16-bin row tiles in proportion to their tap ranges.  The
    * CALLER vouches that the two copies agree; without the host copy the narrow-tile kernel runs. */
   const int32_t *row_support_host;
+
+  /* Second symmetric fold (optional, any precision): for a basis that is  window x DFT
+   * (basis_re[k, n] = w[n] cos(2 pi k n / kernel), basis_im[k, n] = w[n] sin(...), k = 0 .. n_bins-1:
+   * stft.py:230-245 with freq_scale='no') the contraction runs over kernel/4 (+1) taps of the four
+   * combinations of  w x  at n, kernel-n, kernel/2-n, kernel/2+n  -- even and odd bins use different
+   * combinations -- a QUARTER of the dense MFMAs.  basis_fold2 is the output of mispec_fold2_basis() for
+   * this (basis_re, basis_im, n_bins, kernel) in this `precision`; the CALLER vouches that the basis
+   * has that form (the routine reports how far it is from it).  fold2_wmax = max |w| (stats[2]).  Used
+   * when the shape allows (kernel % 64 == 0, 128 .. 8192, >= 128 bins, hop >= kernel/8, no supports / row
+   * scale / fused filterbank, automatic tile); takes precedence over basis_fold. */
+  const void *basis_fold2;     /* or NULL                                                  */
+  int64_t basis_fold2_bytes;
+  float fold2_wmax;
+  int32_t reserved5;           /* must be 0                                                */
 } mispec_framed_gemm_args;
 
 /*
@@ -246,6 +266,18 @@ int mispec_fold_basis_bf16(const float *basis_re, const float *basis_im, int64_t
 int mispec_fold_basis_f32(const float *basis_re, const float *basis_im, int64_t basis_row_stride,
                           int32_t n_bins, int32_t kernel, int32_t with_tap0, void *dst,
                           int64_t dst_bytes, float *stats, void *stream);
+
+/*
+ * Second fold of a window x DFT basis (see basis_fold2 above): the quarter-folded coefficient planes
+ * from the analytic DFT, in the format of `precision` (MISPEC_PREC_*).  stats (device, 3 floats):
+ *   [0] max |basis[k, n] - w[n] * dft(k, n)| over every coefficient, w = row 0 of basis_re
+ *   [1] max |basis coefficient|     [2] max |w|
+ * Offer the result only when [0] is rounding noise against [1] (nnaudio_amd.engine: <= 2^-20).
+ */
+int64_t mispec_basis_fold2_bytes(int32_t n_bins, int32_t kernel);
+int mispec_fold2_basis(const float *basis_re, const float *basis_im, int64_t basis_row_stride,
+                       int32_t n_bins, int32_t kernel, int32_t precision, void *dst, int64_t dst_bytes,
+                       float *stats, void *stream);
 
 /* Launch the MFMA framed contraction.  Replaces stft.py:278-316, cqt.py:740-780,
  * utils.py:498-521 (one call per octave).                                             */

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmispec.so")
 ABLATE_LIB_PATH = os.path.join(_HERE, "csrc", "libmispec_ablate.so")  # benchmarking build
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 E_INVALID, E_UNSUPPORTED, E_HIP = -1, -2, -3
 
 # enums (mirror include/mispec.h)
@@ -19,7 +19,7 @@ PAD_NONE, PAD_ZERO, PAD_REFLECT = 0, 1, 2
 EPI_COMPLEX, EPI_MAGNITUDE, EPI_POWER, EPI_PHASE_ATAN2, EPI_PHASE_COSSIN, EPI_REAL = range(6)
 (TILE_AUTO, TILE_128x128, TILE_32x256, TILE_64x256, TILE_128x128_TALL, TILE_192x128, TILE_256x128,
  TILE_256x128_SQ, TILE_128x256_SQ, TILE_256x256) = range(10)
-PREC_F32, PREC_BF16X3 = 0, 1
+PREC_F32, PREC_BF16X3, PREC_F16X3 = 0, 1, 2
 
 EXPORTS = (
     "mispec_version",
@@ -37,6 +37,8 @@ EXPORTS = (
     "mispec_basis_fold_bytes",
     "mispec_fold_basis_bf16",
     "mispec_fold_basis_f32",
+    "mispec_basis_fold2_bytes",
+    "mispec_fold2_basis",
     "mispec_filterbank_f32",
     "mispec_istft_grad_signal_f32",
     "mispec_power_to_db_f32",
@@ -102,6 +104,10 @@ class FramedGemmArgs(ctypes.Structure):
         ("fold_taps", ctypes.c_int32),
         ("reserved4", ctypes.c_int32),
         ("row_support_host", ctypes.c_void_p),
+        ("basis_fold2", ctypes.c_void_p),
+        ("basis_fold2_bytes", ctypes.c_int64),
+        ("fold2_wmax", ctypes.c_float),
+        ("reserved5", ctypes.c_int32),
     ]
 
 
@@ -245,6 +251,13 @@ def _load(path, how):
     ]
     lib.mispec_fold_basis_f32.restype = ctypes.c_int
     lib.mispec_fold_basis_f32.argtypes = [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+        ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+    ]
+    lib.mispec_basis_fold2_bytes.restype = ctypes.c_int64
+    lib.mispec_basis_fold2_bytes.argtypes = [ctypes.c_int32] * 2
+    lib.mispec_fold2_basis.restype = ctypes.c_int
+    lib.mispec_fold2_basis.argtypes = [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
         ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
     ]

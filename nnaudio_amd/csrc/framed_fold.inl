@@ -35,6 +35,7 @@
 // Rows are XOR-swizzled in 16-byte chunks by (row >> 1) & 7 (applied to the DMA source address and to
 // the fragment reads): conflict-free ds_read_b128 (MI355X_MICROARCH.md, LDS table).
 
+enum { FOLD_BF16X3 = 0, FOLD_F32 = 1, FOLD_F16X3 = 2 };  // arithmetic of the folded contraction
 constexpr int FOLD_KC = 16;                 // folded taps per stage
 constexpr int FOLD_ROWB = 128;              // bytes of one stage row: 4 planes x 16 bf16
 constexpr int FOLD_BINS = 128;              // bins per workgroup
@@ -48,6 +49,8 @@ constexpr int FOLD_DMA_PER_WAVE = (FOLD_STAGE / 1024) / 8;  // LDS-DMA pieces pe
 // (hi, lo) of two floats with the hardware conversion (v_cvt_pk_bf16_f32, round to nearest even):
 // the same values as bf16_split for every finite input inside the bf16 range
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void bf16_split2(float a, float b, unsigned &hi, unsigned &lo) {
   const f32x2 v = {a, b};
@@ -364,8 +367,12 @@ __device__ __forceinline__ void lds_dma_barrier_keep() {
 // [E | O] fp32 taps, a lane's fragment = taps 8 lh .. 8 lh + 7 (two 16-byte chunks), eight
 // v_mfma_f32_32x32x2_f32 per 16 taps and frame tile (MFMA p contracts taps p and 8 + p) instead of
 // three bf16 ones: the dense fp32 kernel's MFMA count halved, everything else unchanged.
-template <int NR, bool F32>
+// ARITH = FOLD_F16X3: the bf16x3 kernel on v_mfma_f32_32x32x16_f16 -- the operands are (hi, lo) fp16
+// pairs of power-of-two scaled values (22 significant bits instead of 16; framed_fold2.inl), and the
+// accumulators are multiplied by the frames' col_unscale before the epilogue.
+template <int NR, int ARITH>
 __device__ __forceinline__ void framed_fold_body(const KParams &p, const int tile_m, const long long n0) {
+  constexpr bool F32 = ARITH == FOLD_F32;
   // wave layout: 2 x 4 waves, a wave owns MRW = 2 bin tiles x NRW = NR / 2 frame tiles (64 bins x 64
   // frames of the 256-frame tile), re and im accumulators of both: per stage and wave 2 (MRW + NRW)
   // = 8 fragment reads per half for 12 MFMAs.  (Until round 2's last day: 4 x 2 waves of 32 bins x
@@ -478,7 +485,11 @@ __device__ __forceinline__ void framed_fold_body(const KParams &p, const int til
         for (int n = 0; n < NRW; ++n) {
           const bf16x8 a = fa[HALF][term == 0 ? 1 : 0][m];
           const bf16x8 x = fx[HALF][term == 1 ? 1 : 0][n];
-          acc[m][HALF][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, a, acc[m][HALF][n], 0, 0, 0);
+          if (ARITH == FOLD_F16X3)
+            acc[m][HALF][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                __builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, a), acc[m][HALF][n], 0, 0, 0);
+          else
+            acc[m][HALF][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, a, acc[m][HALF][n], 0, 0, 0);
         }
   };
   auto interleave = [&](auto n_mfma_tag, auto n_ds_tag, auto n_vm_tag) __attribute__((always_inline)) {
@@ -571,6 +582,28 @@ __device__ __forceinline__ void framed_fold_body(const KParams &p, const int til
     if (sum == 12345.678f) p.out[0] = sum;
     return;
   }
+  if (ARITH == FOLD_F16X3) {
+    // undo the operand scaling: acc[..][n][4 g + i] belongs to frame 32 n + 8 g + 4 lh + i of the wave's block
+#pragma unroll
+    for (int n = 0; n < NRW; ++n)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const long long col = n0 + (wn * NRW + n) * 32 + 8 * g + 4 * lh;
+        f32x4v u;
+        if (col + 3 < p.n_cols) {
+          u = *reinterpret_cast<const f32x4v *>(p.col_unscale + col);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) u[i] = p.col_unscale[col + i < p.n_cols ? col + i : 0];
+        }
+#pragma unroll
+        for (int m = 0; m < MRW; ++m)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[m][h][n][4 * g + i] *= u[i];
+      }
+  }
   // the epilogues of the dense planar kernel, once per bin tile of the wave (32-bin block
   // wm MRW + m, frame block wn of NRW tiles)
   if (p.fb) {
@@ -593,7 +626,28 @@ __device__ __forceinline__ void framed_fold_body(const KParams &p, const int til
 // problems of less than half a round double their parallelism (STFT cfg2's shape at B = 4: 0.10 ->
 // 0.07 ms).  A 128-frame tile costs ~0.8 of a 256-frame one, so the host (launch_fold) uses them
 // only where that still pays: cfg3 -4 %, cfg2 (6.75 rounds) unchanged.
-template <bool F32>
+// p.fold2: the row tiles are those of two problems, the even bins (operands: the even folded rows /
+// frames, output rows 0, 2, ..) and the odd bins (rows 1, 3, ..) -- see framed_fold2.inl
+template <int NR, int ARITH>
+__device__ __forceinline__ void framed_fold_tile(const KParams &p, int tile_m, const long long n0) {
+  if (!p.fold2) {
+    framed_fold_body<NR, ARITH>(p, tile_m, n0);
+    return;
+  }
+  KParams q = p;
+  q.out_row_stride = 2 * p.out_row_stride;
+  q.n_bins = p.fold2_bins_e;
+  if (tile_m >= p.fold2_tiles_e) {
+    tile_m -= p.fold2_tiles_e;
+    q.n_bins = p.fold2_bins_o;
+    q.as = p.as + p.fold2_as_odd;
+    q.xs = p.xs + p.fold2_xs_odd;
+    q.out = p.out + p.out_row_stride;
+  }
+  framed_fold_body<NR, ARITH>(q, tile_m, n0);
+}
+
+template <int ARITH>
 __device__ __forceinline__ void framed_fold_grid(const KParams &p) {
   const int b = blockIdx.x;
   if (b < p.fold_main) {
@@ -623,15 +677,16 @@ __device__ __forceinline__ void framed_fold_grid(const KParams &p) {
       }
     }
     tile_n += p.fold_tile0;  // (this launch's chunk of frame tiles)
-    framed_fold_body<4, F32>(p, tile_m, (long long)tile_n * FOLD_BN);
+    framed_fold_tile<4, ARITH>(p, tile_m, (long long)tile_n * FOLD_BN);
   } else {
     // bin blocks fastest: the workgroups that run side by side share their frame rows in L2
     const int t = b - p.fold_main;
     const int tile_n = t / p.n_tiles_m, tile_m = t - tile_n * p.n_tiles_m;
-    framed_fold_body<2, F32>(p, tile_m, p.fold_tail_frame0 + (long long)tile_n * (FOLD_BN / 2));
+    framed_fold_tile<2, ARITH>(p, tile_m, p.fold_tail_frame0 + (long long)tile_n * (FOLD_BN / 2));
   }
 }
 
-__global__ void __launch_bounds__(512) framed_fold_kernel(const KParams p) { framed_fold_grid<false>(p); }
-__global__ void __launch_bounds__(512) framed_fold32_kernel(const KParams p) { framed_fold_grid<true>(p); }
+__global__ void __launch_bounds__(512) framed_fold_kernel(const KParams p) { framed_fold_grid<FOLD_BF16X3>(p); }
+__global__ void __launch_bounds__(512) framed_fold32_kernel(const KParams p) { framed_fold_grid<FOLD_F32>(p); }
+__global__ void __launch_bounds__(512) framed_fold16_kernel(const KParams p) { framed_fold_grid<FOLD_F16X3>(p); }
 

@@ -159,6 +159,16 @@ struct KParams {
   int fold_f32;                // MISPEC_PREC_F32: fp32 stage rows ([re | im], [E | O])
   int fold_main;               // workgroups on 256-frame tiles; the rest take 128-frame tiles
   long long fold_tail_frame0;  //   from this flat frame on
+  // second fold (framed_fold2.inl): even bins contract (Ep, Om), odd bins (Em, Op) over kernel/4 taps
+  int fold2;                 // contraction launch: row tiles >= fold2_tiles_e belong to the odd bins
+  int fold2_tiles_e;
+  int fold2_bins_e;          // even / odd bins the contraction takes
+  int fold2_bins_o;
+  long long fold2_as_odd;    // elements from the even bins' folded rows to the odd bins'
+  long long fold2_xs_odd;    // the same for the folded frames
+  int fold_arith;            // FOLD_BF16X3 / FOLD_F32 / FOLD_F16X3: format of the folded operands
+  float fold_wmax;           // FOLD_F16X3: max |window| (bounds the folded samples of a frame)
+  float *col_unscale;        // FOLD_F16X3: per flat frame, what undoes the operand scaling (pre-pass writes, contraction reads)
 };
 
 // ---------------------------------------------------------------------------------
@@ -973,6 +983,7 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
 #include "framed_bf16x3_slab.inl"
 #include "framed_bf16x3_narrow.inl"
 #include "framed_fold.inl"
+#include "framed_fold2.inl"
 #include "framed_bf16x3_strip.inl"
 #include "octave_pyramid.inl"
 
@@ -2452,6 +2463,135 @@ int launch_fold(KParams p, const mispec_framed_gemm_args *a, const FoldPlan &f, 
   return MISPEC_OK;
 }
 
+// ---------------------------------------------------------------------------------
+// second fold (framed_fold2.inl): applicability, workspace, launch
+// ---------------------------------------------------------------------------------
+long long basis_fold2_bytes(int n_bins, int kernel) {
+  const long long kf = fold2_taps(kernel);
+  return (long long)n_bins * kf * 8 + 2 * kf * (long long)sizeof(float);
+}
+
+inline bool fold2_kernel_ok(int kernel) { return kernel >= 128 && kernel <= 8192 && kernel % 64 == 0; }
+
+inline int fold_arith_of(int precision) {
+  return precision == MISPEC_PREC_F32 ? FOLD_F32 : (precision == MISPEC_PREC_F16X3 ? FOLD_F16X3 : FOLD_BF16X3);
+}
+
+struct Fold2Plan {
+  bool ok;
+  int kf, ne, no, main_e;
+  bool last_in_prepass;
+  long long ws_bytes, unscale_off;
+};
+
+Fold2Plan plan_fold2(const mispec_framed_gemm_args *a, const KParams &p) {
+  Fold2Plan f{};
+  if (!a->basis_fold2 || a->tile != MISPEC_TILE_AUTO) return f;
+  if (MISPEC_DBG(p, 0x100000) || MISPEC_DBG(p, 0x10000000)) return f;  // A/B runs: dense / single fold
+  if (!p.a_im || p.row_support || p.row_scale || p.fb || !fold2_kernel_ok(p.K)) return f;
+  if ((long long)p.hop * 8 < p.K) return f;  // the folded frames cost 4 K bytes per frame
+  if (a->basis_fold2_bytes < basis_fold2_bytes(p.n_bins, p.K)) return f;
+  if (p.n_bins < 128) return f;  // two 128-bin tiles would be mostly empty
+  f.kf = fold2_taps(p.K);
+  f.ne = (p.n_bins + 1) / 2;
+  f.no = p.n_bins / 2;
+  f.last_in_prepass = f.ne > FOLD_BINS && f.ne % FOLD_BINS == 1;
+  f.main_e = f.last_in_prepass ? f.ne - 1 : f.ne;
+  f.unscale_off = 2 * p.n_cols * (long long)f.kf * 8;
+  f.ws_bytes = f.unscale_off + (a->precision == MISPEC_PREC_F16X3 ? p.n_cols * (long long)sizeof(float) : 0);
+  f.ok = true;
+  return f;
+}
+
+int launch_fold2(KParams p, const mispec_framed_gemm_args *a, const Fold2Plan &f, hipStream_t stream) {
+  if (!a->workspace || a->workspace_bytes < f.ws_bytes)
+    return fail(MISPEC_E_INVALID, "workspace too small: size it with the *_workspace_bytes query%s");
+  if (p.n_cols > 0x7fffffffLL) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
+  unsigned short *xf = static_cast<unsigned short *>(a->workspace);
+  const unsigned short *bf = static_cast<const unsigned short *>(a->basis_fold2);
+  p.Ks = f.kf;
+  p.fold_arith = fold_arith_of(a->precision);
+  p.fold_f32 = p.fold_arith == FOLD_F32;
+  p.fold_wmax = a->fold2_wmax > 0.f ? a->fold2_wmax : 1.f;
+  p.as = bf;
+  p.xs = xf;
+  p.fold2_as_odd = (long long)f.ne * f.kf * 4;
+  p.fold2_xs_odd = p.n_cols * (long long)f.kf * 4;
+  p.col_unscale = p.fold_arith == FOLD_F16X3
+                      ? reinterpret_cast<float *>(static_cast<char *>(a->workspace) + f.unscale_off)
+                      : nullptr;
+  // output rows: the problem's block starts at out_row_offset; even / odd bins interleave from there
+  p.out += (long long)p.out_row_offset * p.out_row_stride;
+  p.out_row_offset = 0;
+  const float *last_rows = reinterpret_cast<const float *>(bf + (long long)p.n_bins * f.kf * 4);
+  KParams pre = p;
+  pre.fold_last = f.last_in_prepass ? last_rows : nullptr;
+  pre.fold_last_bin = 2 * (f.ne - 1);
+  const int pre_frames = FOLD2_FR * (256 / fold2_tg(p.K));
+  const size_t pre_smem = (size_t)pre_frames * 2 * f.kf * 8 + (2 * 4 * FOLD2_FR + 4) * sizeof(float);
+  {
+    static std::atomic<unsigned long long> configured_pre{0};
+    int rc0 = configure_lds(fold2_frames_kernel, 160 * 1024, configured_pre);
+    if (rc0 != MISPEC_OK) return rc0;
+  }
+  hipLaunchKernelGGL(fold2_frames_kernel,
+                     dim3((unsigned)((p.n_frames + pre_frames - 1) / pre_frames), (unsigned)p.n_clips), dim3(256),
+                     pre_smem, stream, pre, xf);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "fold pre-pass launch: %s", hipGetErrorString(e));
+
+  p.fold2 = 1;
+  p.fold2_bins_e = f.main_e;
+  p.fold2_bins_o = f.no;
+  p.fold2_tiles_e = (f.main_e + FOLD_BINS - 1) / FOLD_BINS;
+  p.n_tiles_m = p.fold2_tiles_e + (f.no + FOLD_BINS - 1) / FOLD_BINS;
+  const long long tn = (p.n_cols + FOLD_BN - 1) / FOLD_BN;
+  if (tn * p.n_tiles_m > 0x7fffffffLL) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
+  int g = (32 + p.n_tiles_m / 2) / p.n_tiles_m;  // one workgroup per CU, 32 CUs per XCD
+  g = g < 1 ? 1 : g;
+  auto kern = p.fold_arith == FOLD_F32 ? framed_fold32_kernel
+                                       : (p.fold_arith == FOLD_F16X3 ? framed_fold16_kernel : framed_fold_kernel);
+  static std::atomic<unsigned long long> configured[3] = {{0}, {0}, {0}};
+  int rc = configure_lds(kern, 160 * 1024, configured[p.fold_arith]);
+  if (rc != MISPEC_OK) return rc;
+  const size_t smem = (size_t)FOLD_NBUF * FOLD_STAGE;
+  p.fold_tile0 = 0;
+  p.n_tiles_n = (int)tn;
+  long long grid = tn * p.n_tiles_m;
+  p.fold_main = (int)grid;
+  {
+    // whole rounds of the device on 256-frame tiles, the frames behind them on 128-frame tiles (as
+    // launch_fold)
+    const int n_cu = device_cus();
+    const double rounds = (double)grid / n_cu;
+    long long main_tn = tn;
+    if (rounds <= 0.5) {
+      main_tn = 0;
+    } else if (rounds > 1.0) {
+      const long long whole = (long long)rounds * n_cu / p.n_tiles_m;
+      if (whole < tn) {
+        const long long half = (p.n_cols - whole * FOLD_BN + FOLD_BN / 2 - 1) / (FOLD_BN / 2) * p.n_tiles_m;
+        const double tail = 0.8 * (double)half / n_cu;
+        const double mixed = (double)(whole * p.n_tiles_m) / n_cu + (tail > 0.8 ? tail : 0.8);
+        if (mixed < (double)(long long)(rounds + 0.999) - 0.05) main_tn = whole;
+      }
+    }
+    if (main_tn < tn) {
+      p.n_tiles_n = (int)main_tn;
+      p.fold_main = (int)(main_tn * p.n_tiles_m);
+      p.fold_tail_frame0 = main_tn * FOLD_BN;
+      const long long tail_tn = (p.n_cols - p.fold_tail_frame0 + FOLD_BN / 2 - 1) / (FOLD_BN / 2);
+      grid = p.fold_main + tail_tn * p.n_tiles_m;
+    }
+  }
+  p.n_group = g > p.n_tiles_n ? p.n_tiles_n : g;
+  if (p.n_group < 1) p.n_group = 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, stream, p);
+  e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+
 // attach the edge workspace to p and enqueue the fill pre-pass
 int setup_edges(KParams &p, void *workspace, long long workspace_bytes, hipStream_t stream) {
   const EdgePlan e = plan_edges(p.n_samples, p.K, p.hop, p.pad, p.n_frames);
@@ -2533,9 +2673,10 @@ int fill_params(const mispec_framed_gemm_args *a, KParams &p) {
   if (a->reserved != 0)
     return fail(MISPEC_E_INVALID, "reserved must be 0 (ablation bits exist only in libmispec_ablate.so)%s");
 #endif
-  if (a->precision != MISPEC_PREC_F32 && a->precision != MISPEC_PREC_BF16X3)
+  if (a->precision != MISPEC_PREC_F32 && a->precision != MISPEC_PREC_BF16X3 &&
+      a->precision != MISPEC_PREC_F16X3)
     return fail(MISPEC_E_INVALID, "bad precision%s");
-  if (a->reserved2 != 0 || a->reserved3 != 0 || a->reserved4 != 0)
+  if (a->reserved2 != 0 || a->reserved3 != 0 || a->reserved4 != 0 || a->reserved5 != 0)
     return fail(MISPEC_E_INVALID, "reserved fields must be 0%s");
   if (a->fb) {
     if (!a->fb_support || a->n_fb <= 0)
@@ -2639,6 +2780,17 @@ int launch_strip32(KParams p, const mispec_framed_gemm_args *a, const StripPlan 
   return MISPEC_OK;
 }
 
+// MISPEC_PREC_F16X3 exists on the second fold only: every other shape runs in MISPEC_PREC_F32 (then
+// with basis_fold, if given, in the fp32 format)
+static bool f16_downgrade(const mispec_framed_gemm_args *a, const KParams &p, mispec_framed_gemm_args &local) {
+  if (a->precision != MISPEC_PREC_F16X3 || plan_fold2(a, p).ok) return false;
+  local = *a;
+  local.precision = MISPEC_PREC_F32;
+  local.basis_fold2 = nullptr;
+  local.basis_fold2_bytes = 0;
+  return true;
+}
+
 extern "C" {
 
 int mispec_version(void) { return MISPEC_ABI_VERSION; }
@@ -2649,6 +2801,10 @@ int64_t mispec_framed_gemm_workspace_bytes(const mispec_framed_gemm_args *args) 
   KParams p;
   int rc = fill_params(args, p);
   if (rc != MISPEC_OK) return rc;
+  mispec_framed_gemm_args local;
+  if (f16_downgrade(args, p, local)) args = &local;
+  const Fold2Plan f2 = plan_fold2(args, p);
+  if (f2.ok) return f2.ws_bytes;
   const FoldPlan f = plan_fold(args, p);
   if (f.ok) return f.ws_bytes;
   const EdgePlan e = plan_edges(p.n_samples, p.K, p.hop, p.pad, p.n_frames);
@@ -2672,6 +2828,8 @@ int32_t mispec_strip_plan(const mispec_framed_gemm_args *args, int32_t n_cu, int
   int rc = fill_params(args, p);
   if (rc != MISPEC_OK) return rc;
   if (n_cu <= 0 || cap < 0 || (cap > 0 && !plan_out)) return fail(MISPEC_E_INVALID, "bad plan buffer%s");
+  mispec_framed_gemm_args local;
+  if (f16_downgrade(args, p, local)) args = &local;
   StripPlan plan;
   if (args->precision == MISPEC_PREC_F32) {
     if (!strip32_ok(args, p, n_cu, plan)) return 0;
@@ -2704,8 +2862,12 @@ int mispec_framed_gemm_f32(const mispec_framed_gemm_args *args, void *stream) {
   int rc = fill_params(args, p);
   if (rc != MISPEC_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  mispec_framed_gemm_args local;
+  if (f16_downgrade(args, p, local)) args = &local;
   if (p.fb && (args->tile != MISPEC_TILE_AUTO || MISPEC_DBG(p, 0x2000)))
     return fail(MISPEC_E_UNSUPPORTED, "fused filterbank needs the automatic tile choice%s");
+  const Fold2Plan fold2 = plan_fold2(args, p);
+  if (fold2.ok) return launch_fold2(p, args, fold2, s);
   const FoldPlan fold = plan_fold(args, p);
   if (fold.ok) return launch_fold(p, args, fold, s);
   const bool bf16x3 = bf16x3_ok(args, p);
@@ -2833,6 +2995,39 @@ int mispec_fold_basis_f32(const float *basis_re, const float *basis_im, int64_t 
                           int64_t dst_bytes, float *stats, void *stream) {
   return fold_basis_any(basis_re, basis_im, basis_row_stride, n_bins, kernel, with_tap0, dst, dst_bytes,
                         stats, stream, 1);
+}
+
+int64_t mispec_basis_fold2_bytes(int32_t n_bins, int32_t kernel) {
+  if (n_bins <= 0) return fail(MISPEC_E_INVALID, "non-positive size%s");
+  if (!fold2_kernel_ok(kernel))
+    return fail(MISPEC_E_UNSUPPORTED, "the second fold needs a kernel of 128 .. 8192 taps, a multiple of 64%s");
+  return basis_fold2_bytes(n_bins, kernel);
+}
+
+int mispec_fold2_basis(const float *basis_re, const float *basis_im, int64_t basis_row_stride,
+                       int32_t n_bins, int32_t kernel, int32_t precision, void *dst, int64_t dst_bytes,
+                       float *stats, void *stream) {
+  if (!basis_re || !basis_im || !dst || !stats) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
+  if (n_bins <= 0) return fail(MISPEC_E_INVALID, "non-positive size%s");
+  if (!fold2_kernel_ok(kernel))
+    return fail(MISPEC_E_UNSUPPORTED, "the second fold needs a kernel of 128 .. 8192 taps, a multiple of 64%s");
+  if (precision != MISPEC_PREC_F32 && precision != MISPEC_PREC_BF16X3 && precision != MISPEC_PREC_F16X3)
+    return fail(MISPEC_E_INVALID, "bad precision%s");
+  if (dst_bytes < basis_fold2_bytes(n_bins, kernel))
+    return fail(MISPEC_E_INVALID, "dst too small: size it with mispec_basis_fold2_bytes%s");
+  const int kf = fold2_taps(kernel);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  unsigned short *d = static_cast<unsigned short *>(dst);
+  float *last_rows = reinterpret_cast<float *>(d + (long long)n_bins * kf * 4);
+  if (hipMemsetAsync(stats, 0, 3 * sizeof(float), s) != hipSuccess)
+    return fail(MISPEC_E_HIP, "hipMemsetAsync failed%s");
+  const int ne = (n_bins + 1) / 2;
+  hipLaunchKernelGGL(fold2_basis_kernel, dim3((unsigned)((kf + 255) / 256), (unsigned)n_bins), dim3(256), 0, s,
+                     basis_re, basis_im, (long long)basis_row_stride, n_bins, kernel, kf, d, last_rows,
+                     2 * (ne - 1), reinterpret_cast<unsigned *>(stats), fold_arith_of(precision));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "basis fold launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
 }
 
 int mispec_framed_gemm_group_f32(const mispec_framed_gemm_args *args, int32_t n, void *stream) {

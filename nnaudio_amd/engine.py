@@ -15,7 +15,7 @@ import torch
 from . import _abi
 from ._abi import (  # noqa: F401  (re-exported for the feature modules)
     EPI_COMPLEX, EPI_MAGNITUDE, EPI_PHASE_ATAN2, EPI_PHASE_COSSIN, EPI_POWER, EPI_REAL,
-    PAD_NONE, PAD_REFLECT, PAD_ZERO, PREC_BF16X3, PREC_F32, TILE_AUTO,
+    PAD_NONE, PAD_REFLECT, PAD_ZERO, PREC_BF16X3, PREC_F16X3, PREC_F32, TILE_AUTO,
 )
 from .basis import decimated_length
 
@@ -23,7 +23,10 @@ from .basis import decimated_length
 #   "fp32"   fp32 MFMA, bit-for-bit an fmaf chain like the reference's conv1d (default)
 #   "bf16x3" split-bf16 operands on the 16x faster bf16 MFMA, fp32 accumulate: ~5e-6 of the
 #            spectrum peak, inside the 1e-4 bar; problems it does not cover run in fp32
-_PRECISIONS = {"fp32": PREC_F32, "bf16x3": PREC_BF16X3}
+#   "f16x3"  the same three MFMAs per product on (hi, lo) fp16 pairs of power-of-two scaled
+#            operands: 22 operand bits, ~1e-7 of the peak (fp32 class, ~160 dB of dynamic range
+#            where bf16x3 has ~105); problems it does not cover run in fp32
+_PRECISIONS = {"fp32": PREC_F32, "bf16x3": PREC_BF16X3, "f16x3": PREC_F16X3}
 _default_precision = os.environ.get("MISPEC_PRECISION", "fp32")
 
 
@@ -204,7 +207,7 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
                  eps=0.0, power=2.0, row_scale=None, row_support=None, out=None,
                  out_rows_total=None, out_row_offset=0, tile=TILE_AUTO, _debug=0,
                  need_workspace=True, precision=None, basis_split=None, basis_fold=None, fb=None,
-                 fb_support=None):
+                 fb_support=None, basis_fold2=None):
     """Validate one framed-contraction problem and fill its C argument block.
     Returns (args, out, device, keepalive tensors)."""
     dev = _require_device(x, basis_re, basis_im, row_scale, row_support, out, fb, fb_support)
@@ -299,6 +302,15 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
         a.basis_split = basis_split.data_ptr()
         a.basis_split_bytes = basis_split.numel() * basis_split.element_size()
         keep.append(basis_split)
+    if basis_fold2 is not None and need_workspace:
+        # (planes, max |window|) from fold2_basis() in THIS precision: a quarter of the MFMAs
+        planes, wmax = basis_fold2
+        a.basis_fold2 = planes.data_ptr()
+        a.basis_fold2_bytes = planes.numel() * planes.element_size()
+        a.fold2_wmax = float(wmax)
+        keep.append(planes)
+    if resolve_precision(precision) == "f16x3" and need_workspace:
+        a.precision = PREC_F16X3  # (the library runs what the second fold does not cover in fp32)
     if basis_fold is not None and need_workspace:
         # (planes, folded taps) from fold_basis() in THIS precision: half the MFMAs
         planes, taps = basis_fold
@@ -409,16 +421,53 @@ def fold_basis(basis_re, basis_im, precision="bf16x3"):
     return dst, int(taps)
 
 
+def fold2_basis(basis_re, basis_im, precision):
+    """``(planes, max |window|)`` for ``framed_gemm(..., basis_fold2=...)`` when the basis is
+    window x DFT with rows = bins 0, 1, 2, .. -- the reference's STFT basis with
+    ``freq_scale='no'`` (stft.py:230-245) -- else None.  ``mispec_fold2_basis`` builds the
+    quarter-folded planes from the analytic DFT and reports how far the buffers are from
+    ``basis_re[0] x dft``; offered only when that is rounding noise.  Reads three scalars back,
+    once per basis (the callers cache the result)."""
+    dev = _require_device(basis_re, basis_im)
+    wr = _rows(basis_re.detach(), "basis_re")
+    wi = _rows(basis_im.detach(), "basis_im") if basis_im is not None else None
+    if wi is None or wi.shape != wr.shape or wi.stride(0) != wr.stride(0):
+        return None
+    F, K = wr.shape
+    lib = _abi.load()
+    if K % 64 or not 128 <= K <= 8192 or F < 128:
+        return None
+    need = lib.mispec_basis_fold2_bytes(F, K)
+    if need < 0:
+        return None
+    dst = torch.empty(need // 2, dtype=torch.int16, device=dev)
+    stats = torch.zeros(3, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _abi.check(lib.mispec_fold2_basis(
+            wr.data_ptr(), wi.data_ptr(), wr.stride(0), F, K, _PRECISIONS[resolve_precision(precision)],
+            dst.data_ptr(), need, stats.data_ptr(), ctypes.c_void_p(stream)))
+    mismatch, largest, wmax = (float(v) for v in stats.cpu())
+    if not largest > 0.0 or not wmax > 0.0 or mismatch > FOLD_ASYMMETRY_TOL * largest:
+        return None
+    return dst, wmax
+
+
 def prepare_basis(basis_re, basis_im, precision, hop=None):
     """Derived operands of a basis for ``framed_gemm`` in the given arithmetic, as keyword
     arguments (callers with a persistent basis cache this dict, see ``DerivedCache``): for
-    "bf16x3" the split-bf16 planes; in either arithmetic, for a basis with the Fourier symmetry,
-    the folded planes (the library uses them when the shape allows, include/mispec.h
-    ``basis_fold``: half the MFMAs)."""
-    bf16 = resolve_precision(precision) == "bf16x3"
-    out = {"basis_split": split_basis(basis_re, basis_im)} if bf16 else {}
+    "bf16x3" the split-bf16 planes; in any arithmetic, for a window x DFT basis the quarter-folded
+    planes (``basis_fold2``) and for a basis with the Fourier symmetry the folded planes
+    (``basis_fold``) -- the library uses them when the shape allows (include/mispec.h): a quarter /
+    half of the MFMAs.  "f16x3" is served by the second fold only; what that does not cover runs
+    in fp32 (so its ``basis_fold`` planes are the fp32 ones)."""
+    precision = resolve_precision(precision)
+    out = {"basis_split": split_basis(basis_re, basis_im)} if precision == "bf16x3" else {}
     if basis_im is not None and (hop is None or 8 * int(hop) >= basis_re.shape[-1]):
-        folded = fold_basis(basis_re, basis_im, "bf16x3" if bf16 else "fp32")
+        folded2 = fold2_basis(basis_re, basis_im, precision)
+        if folded2 is not None:
+            out["basis_fold2"] = folded2
+        folded = fold_basis(basis_re, basis_im, "bf16x3" if precision == "bf16x3" else "fp32")
         if folded is not None:
             out["basis_fold"] = folded
     return out
@@ -427,7 +476,13 @@ def prepare_basis(basis_re, basis_im, precision, hop=None):
 def describe_framed_kernel(precision, prepared):
     """Name of the dominant kernel ``framed_gemm`` launches for a dense complex basis prepared
     with ``prepare_basis`` (bench.py's report)."""
-    if resolve_precision(precision) != "bf16x3":
+    precision = resolve_precision(precision)
+    if prepared.get("basis_fold2") is not None:
+        kern, mfma = {"fp32": ("framed_fold32_kernel", "v_mfma_f32_32x32x2_f32"),
+                      "bf16x3": ("framed_fold_kernel", "v_mfma_f32_32x32x16_bf16"),
+                      "f16x3": ("framed_fold16_kernel", "v_mfma_f32_32x32x16_f16")}[precision]
+        return "%s (%s, K/4 folded taps, even / odd bins) + fold2_frames_kernel" % (kern, mfma)
+    if precision != "bf16x3":
         if prepared.get("basis_fold") is not None:
             return "framed_fold32_kernel (v_mfma_f32_32x32x2_f32, K/2 folded taps) + fold_frames_kernel"
         return "framed_gemm_kernel<2,2,2,2,framed,rows,unmasked> (v_mfma_f32_32x32x2_f32)"
@@ -848,7 +903,8 @@ class _FramedGemmFn(torch.autograd.Function):
         zkw = dict(kw, epilogue=EPI_COMPLEX, precision="fp32", row_support=None, out=None,
                    out_rows_total=None, out_row_offset=0)
         zkw.pop("basis_split", None)
-        zkw.pop("basis_fold", None)
+        zkw.pop("basis_fold", None)   # (planes in the forward's precision, not in fp32)
+        zkw.pop("basis_fold2", None)
         z = framed_gemm(xs, wr, wi, **zkw)
         T = z.shape[2]
         go = _f32(grad_out, "grad_output").contiguous()
@@ -1046,7 +1102,10 @@ def compiling():
 
 
 def framed_gemm_autograd(x, basis_re, basis_im, **kw):
-    """``framed_gemm`` that records a graph when the input or the bases require gradients."""
+    """``framed_gemm`` that records a graph when the input or the bases require gradients.
+    ``support`` (CQT1992v2 under torch.compile: look the row supports up inside the custom op) is
+    consumed here: neither ``framed_gemm`` nor the autograd function knows it."""
+    support = bool(kw.pop("support", False))
     if torch.is_grad_enabled() and (x.requires_grad or basis_re.requires_grad
                                     or (basis_im is not None and basis_im.requires_grad)):
         if basis_im is None:
@@ -1058,18 +1117,6 @@ def framed_gemm_autograd(x, basis_re, basis_im, **kw):
         return ops.framed_gemm(
             x, basis_re, basis_im, int(kw["hop"]), int(kw["pad"]), int(kw["pad_mode"]),
             int(kw["epilogue"]), float(kw.get("im_sign", -1.0)), float(kw.get("eps", 0.0)),
-            float(kw.get("power", 2.0)), kw.get("row_scale"), bool(kw.get("support", False)),
+            float(kw.get("power", 2.0)), kw.get("row_scale"), support,
             resolve_precision(kw.get("precision")))
-    kw.pop("support", None)
     return framed_gemm(x, basis_re, basis_im, **kw)
-
-
-def grad_guard(module, x):
-    """Modules without a backward pass (CQT2010v2 / VQT octave recursion, MFCC's dB + DCT stage,
-    the inverse STFT): refuse to silently drop a graph."""
-    if needs_grad(module, x):
-        raise NotImplementedError(
-            "%s: backward through this module's HIP kernels is not implemented yet (trainable "
-            "bases / requires_grad inputs). Call under torch.no_grad() for inference."
-            % type(module).__name__
-        )

@@ -1405,10 +1405,17 @@ def test_integration_stub_computes_an_stft():
         fold = ns["fold_basis"](m.wcos, m.wsin)
         yb = ns["framed"](x, m.wcos, m.wsin, 128, 256, 2, 1, split=split)
         yf = ns["framed"](x, m.wcos, m.wsin, 128, 256, 2, 1, split=split, fold=fold)
+        fold2_32 = ns["fold2_basis"](m.wcos, m.wsin, 0)
+        y32q = ns["framed"](x, m.wcos, m.wsin, 128, 256, 2, 1, fold=fold32, fold2=fold2_32)
+        fold2_16 = ns["fold2_basis"](m.wcos, m.wsin, 2)
+        y16 = ns["framed"](x, m.wcos, m.wsin, 128, 256, 2, 1, fold2=fold2_16, f16x3=True)
     torch.cuda.synchronize()
-    # the module's fp32 forward IS the folded fp32 contraction; the dense one differs by rounding
-    assert fold is not None and fold32 is not None and torch.equal(y32f, want)
-    assert not torch.equal(y32, want) and (y32 - want).abs().max().item() <= 5e-6 * want.abs().max().item()
+    # the module's fp32 forward IS the twice-folded fp32 contraction; the others differ by rounding
+    assert fold is not None and fold32 is not None and fold2_32 is not None and fold2_16 is not None
+    assert torch.equal(y32q, want)
+    for y in (y32, y32f):
+        assert not torch.equal(y, want) and (y - want).abs().max().item() <= 5e-6 * want.abs().max().item()
+    assert (y16 - want).abs().max().item() <= 3e-6 * want.abs().max().item()
     for y in (yb, yf):
         assert (y - want).abs().max().item() <= 2e-5 * want.abs().max().item()
     assert not torch.equal(yb, yf)

@@ -87,7 +87,8 @@ enum {
                          /* operand instead of bf16x3's 16; the scales keep the pairs inside fp16's     */
                          /* 5-bit exponent and are undone on the accumulators): error ~1e-7 of the     */
                          /* spectrum peak, i.e. fp32 class, at the bf16x3 MFMA count.  Served where     */
-                         /* basis_fold2 applies; other shapes run in MISPEC_PREC_F32.                   */
+                         /* basis_fold2 applies and, with basis_split = mispec_frag_basis_f16(), for    */
+                         /* banks with supports (strip kernel); other shapes run in MISPEC_PREC_F32.    */
 };
 
 /*
@@ -240,6 +241,18 @@ int mispec_split_basis_bf16(const float *basis_re, const float *basis_im,
  */
 int64_t mispec_basis_frag_bytes(int32_t n_bins, int32_t kernel);
 int mispec_frag_basis_f32(const float *basis_re, const float *basis_im, int64_t basis_row_stride,
+                          int32_t n_bins, int32_t kernel, void *dst, int64_t dst_bytes,
+                          void *stream);
+
+/*
+ * MISPEC_PREC_F16X3 counterpart for bases with supports (CQT banks): (hi, lo) fp16 pairs of every row
+ * multiplied by a power of two (its largest |tap| ends up in [2^13, 2^14)), in the strip kernel's
+ * fragment order, followed by the per-row inverse factors the epilogue applies.  Handed over in
+ * `basis_split` with precision = MISPEC_PREC_F16X3, row_support and row_support_host.  The signal is
+ * scaled per clip (from its largest |sample|, found by a pre-pass) and split the same way.
+ */
+int64_t mispec_basis_frag16_bytes(int32_t n_bins, int32_t kernel);
+int mispec_frag_basis_f16(const float *basis_re, const float *basis_im, int64_t basis_row_stride,
                           int32_t n_bins, int32_t kernel, void *dst, int64_t dst_bytes,
                           void *stream);
 

@@ -33,6 +33,8 @@ EXPORTS = (
     "mispec_split_basis_bf16",
     "mispec_basis_frag_bytes",
     "mispec_frag_basis_f32",
+    "mispec_basis_frag16_bytes",
+    "mispec_frag_basis_f16",
     "mispec_fold_taps",
     "mispec_basis_fold_bytes",
     "mispec_fold_basis_bf16",
@@ -229,6 +231,11 @@ def _load(path, how):
     lib.mispec_basis_frag_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32]
     lib.mispec_frag_basis_f32.restype = ctypes.c_int
     lib.mispec_frag_basis_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                          ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+    lib.mispec_basis_frag16_bytes.restype = ctypes.c_int64
+    lib.mispec_basis_frag16_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32]
+    lib.mispec_frag_basis_f16.restype = ctypes.c_int
+    lib.mispec_frag_basis_f16.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                                           ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
     lib.mispec_strip_plan.restype = ctypes.c_int32
     lib.mispec_strip_plan.argtypes = [ctypes.POINTER(FramedGemmArgs), ctypes.c_int32, ctypes.c_void_p,

@@ -54,13 +54,25 @@ __global__ void __launch_bounds__(256) split_basis_kernel(const float *__restric
                                                           long long row_stride, int n_bins, int K,
                                                           int Ks, unsigned short *__restrict__ dst,
                                                           unsigned short *__restrict__ frag,
-                                                          float *__restrict__ frag32) {
+                                                          float *__restrict__ frag32,
+                                                          const float *__restrict__ row_scale = nullptr) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= Ks) return;
   const int bin = blockIdx.y;
   const int z = blockIdx.z;
   const float *src = z ? im : re;
   const float v = k < K ? src[(long long)bin * row_stride + k] : 0.f;
+  if (row_scale) {
+    // MISPEC_PREC_F16X3: fragment order only, (hi, lo) fp16 pairs of the row x its power of two
+    unsigned h2, l2;
+    f16_split2(v * row_scale[bin], 0.f, h2, l2);
+    const long long tile = bin >> 4;
+    const int lane = 2 * (bin & 15) + z + 32 * ((k >> 3) & 1);
+    const long long f = (((tile * (Ks >> 4) + (k >> 4)) * 2) * 64 + lane) * 8 + (k & 7);
+    frag[f] = (unsigned short)(h2 & 0xffff);
+    frag[f + 64 * 8] = (unsigned short)(l2 & 0xffff);
+    return;
+  }
   if (frag32) {
     // MISPEC_PREC_F32: fragment order of the strip kernel with fp32 taps -- tile of 16 bins (row =
     // 2 * bin + component), 16-tap step, part = tap / 4 % 2, lane = row + 32 * (tap / 8 % 2), 4 taps
@@ -117,6 +129,16 @@ __global__ void __launch_bounds__(256) split_signal_kernel(const KParams p,
     *reinterpret_cast<f32x4v *>(reinterpret_cast<float *>(dst) + (long long)c * p.xs_clip_stride + i0) = t;
     return;
   }
+  if (p.split_f16) {  // MISPEC_PREC_F16X3: (hi, lo) fp16 pairs of the clip x its power of two
+    const float sc = clip_scale_of(p.clip_absmax[c]);
+    uint2 h2, l2;
+    f16_split2(v[0] * sc, v[1] * sc, h2.x, l2.x);
+    f16_split2(v[2] * sc, v[3] * sc, h2.y, l2.y);
+    unsigned short *o16 = dst + (long long)c * p.xs_clip_stride + i0;
+    *reinterpret_cast<uint2 *>(o16) = h2;
+    *reinterpret_cast<uint2 *>(o16 + p.xs_plane) = l2;
+    return;
+  }
   u16x4 h, l;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -128,6 +150,52 @@ __global__ void __launch_bounds__(256) split_signal_kernel(const KParams p,
   unsigned short *o = dst + (long long)c * p.xs_clip_stride + i0;
   *reinterpret_cast<u16x4 *>(o) = h;
   *reinterpret_cast<u16x4 *>(o + p.xs_plane) = l;
+}
+
+// MISPEC_PREC_F16X3: bit pattern of max |x[c, :]| per clip (the padding mirrors or zero-fills the
+// clip: the same bound holds for the padded clip).  grid (chunks of 4096 samples, n_clips); dst is
+// zeroed by the caller (hipMemsetAsync) -- positive floats order like their bit patterns.
+__global__ void __launch_bounds__(256) clip_absmax_kernel(const float *__restrict__ x, long long clip_stride,
+                                                          int n_samples, unsigned *__restrict__ dst) {
+  const int c = blockIdx.y;
+  const float *xc = x + (long long)c * clip_stride;
+  const long long q0 = (long long)blockIdx.x * 4096 + 4 * threadIdx.x;
+  float m = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long long q = q0 + 1024 * u;
+    if (q + 4 <= n_samples) {
+      const f32x4u v = *reinterpret_cast<const f32x4u *>(xc + q);
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    } else {
+      for (long long i = q; i < n_samples; ++i) m = fmaxf(m, fabsf(xc[i]));
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(dst + c, __float_as_uint(m));
+}
+
+// MISPEC_PREC_F16X3: per basis row (bin), the power of two that puts its largest |re|, |im| below
+// 2^14 and its inverse.  grid (n_bins), one workgroup per row.
+__global__ void __launch_bounds__(256) row_scale_kernel(const float *__restrict__ re, const float *__restrict__ im,
+                                                        long long row_stride, int K, float *__restrict__ scale,
+                                                        float *__restrict__ unscale) {
+  const int bin = blockIdx.x;
+  float m = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256)
+    m = fmaxf(m, fmaxf(fabsf(re[(long long)bin * row_stride + k]), fabsf(im[(long long)bin * row_stride + k])));
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+  __shared__ float sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    const int e = absmax_exponent(m);
+    scale[bin] = pow2f(F16_TOP - e);
+    unscale[bin] = pow2f(e - F16_TOP);
+  }
 }
 
 // ---------------------------------------------------------------------------------

@@ -95,8 +95,14 @@ __device__ __forceinline__ void strip_barrier(int younger_units) {
 // plane (chunks 2 lh and 2 lh + 1 where the split arithmetic reads the hi and the lo plane) -- the
 // basis fragments are fp32 in the same [tile][16-tap step][part][lane][16 bytes] order, and a
 // step is 8 x 4 v_mfma_f32_32x32x2_f32 (MFMA t of a frame tile contracts taps t and 8 + t).
-template <bool F32, int NF>
+// ARITH = FOLD_F16X3 (MISPEC_PREC_F16X3): the split kernel on v_mfma_f32_32x32x16_f16 -- the planes of
+// the signal are (hi, lo) fp16 pairs of the padded clip x a power of two chosen per clip from its largest
+// |sample| (clip_absmax_kernel), the fragment-order basis holds fp16 pairs of each row x a power of two
+// (row_scale_kernel); the direct epilogues multiply by the two inverse factors (the phase epilogues
+// do not care about a positive common factor of re and im).
+template <int ARITH, int NF>
 __device__ __forceinline__ void framed_strip_body(const KParams &p, const StripPlan &plan) {
+  constexpr bool F32 = ARITH == FOLD_F32;
   constexpr int NW = STRIP_NW;
   constexpr int BN = 32 * NF;  // frame columns of a job: NF frame tiles per wave (4; 2 for small problems)
   constexpr int ROWB = KC * 2;                    // bytes of one slab row of one plane
@@ -350,6 +356,11 @@ __device__ __forceinline__ void framed_strip_body(const KParams &p, const StripP
           const f32x4v a = __builtin_bit_cast(f32x4v, t < 4 ? ah[S][Q] : al[S][Q]);
           const f32x4v x = __builtin_bit_cast(f32x4v, t < 4 ? xh[Q][f] : xl[Q][f]);
           acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t & 3], x[t & 3], acc[f], 0, 0, 0);
+        } else if (ARITH == FOLD_F16X3) {
+          const bf16x8 a = t == 0 ? al[S][Q] : ah[S][Q];
+          const bf16x8 x = t == 2 ? xl[Q][f] : xh[Q][f];
+          acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
+                                                         __builtin_bit_cast(f16x8, x), acc[f], 0, 0, 0);
         } else if (t == 0) {
           acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[S][Q], xh[Q][f], acc[f], 0, 0, 0);
         } else if (t == 1) {
@@ -505,11 +516,14 @@ __device__ __forceinline__ void framed_strip_body(const KParams &p, const StripP
         const int bin0 = tile_m * 16 + 2 * lh;
         float *ob = p.out + (long long)c * p.out_clip_stride + (long long)t * E +
                     (long long)(p.out_row_offset + bin0) * p.out_row_stride;
+        float cu = 1.f;  // FOLD_F16X3: what undoes the clip's operand scale
+        if (ARITH == FOLD_F16X3) cu = clip_unscale_of(p.clip_absmax[c < p.n_clips ? c : 0]);
 #pragma unroll
         for (int e2 = 0; e2 < 8; ++e2) {
           const int db = (e2 & 1) + 4 * (e2 >> 1);
           const bool ok = col_ok && bin0 + db < p.n_bins;
-          const float sc = (p.row_scale && ok) ? p.row_scale[bin0 + db] : 1.f;
+          float sc = (p.row_scale && ok) ? p.row_scale[bin0 + db] : 1.f;
+          if (ARITH == FOLD_F16X3) sc *= cu * (ok ? p.row_unscale[bin0 + db] : 1.f);
           const float re = acc[f][2 * e2] * sc;
           const float im = p.im_sign * acc[f][2 * e2 + 1] * sc;
           float *dst = ob + (long long)db * p.out_row_stride;
@@ -560,14 +574,20 @@ __device__ __forceinline__ void framed_strip_body(const KParams &p, const StripP
 // (NF = 2: jobs of 64 frames -- twice as many, half as long -- for problems whose 128-frame jobs
 // would not fill the device's workgroup slots, and for banks whose slab needs the rows)
 __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip_kernel(const KParams p, const StripPlan plan) {
-  framed_strip_body<false, 4>(p, plan);
+  framed_strip_body<FOLD_BF16X3, 4>(p, plan);
 }
 __global__ void __launch_bounds__(256, 2) framed_bf16x3_strip64_kernel(const KParams p, const StripPlan plan) {
-  framed_strip_body<false, 2>(p, plan);
+  framed_strip_body<FOLD_BF16X3, 2>(p, plan);
 }
 __global__ void __launch_bounds__(256, 2) framed_f32_strip_kernel(const KParams p, const StripPlan plan) {
-  framed_strip_body<true, 4>(p, plan);
+  framed_strip_body<FOLD_F32, 4>(p, plan);
 }
 __global__ void __launch_bounds__(256, 2) framed_f32_strip64_kernel(const KParams p, const StripPlan plan) {
-  framed_strip_body<true, 2>(p, plan);
+  framed_strip_body<FOLD_F32, 2>(p, plan);
+}
+__global__ void __launch_bounds__(256, 2) framed_f16x3_strip_kernel(const KParams p, const StripPlan plan) {
+  framed_strip_body<FOLD_F16X3, 4>(p, plan);
+}
+__global__ void __launch_bounds__(256, 2) framed_f16x3_strip64_kernel(const KParams p, const StripPlan plan) {
+  framed_strip_body<FOLD_F16X3, 2>(p, plan);
 }

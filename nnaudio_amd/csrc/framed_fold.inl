@@ -35,7 +35,6 @@
 // Rows are XOR-swizzled in 16-byte chunks by (row >> 1) & 7 (applied to the DMA source address and to
 // the fragment reads): conflict-free ds_read_b128 (MI355X_MICROARCH.md, LDS table).
 
-enum { FOLD_BF16X3 = 0, FOLD_F32 = 1, FOLD_F16X3 = 2 };  // arithmetic of the folded contraction
 constexpr int FOLD_KC = 16;                 // folded taps per stage
 constexpr int FOLD_ROWB = 128;              // bytes of one stage row: 4 planes x 16 bf16
 constexpr int FOLD_BINS = 128;              // bins per workgroup
@@ -49,8 +48,6 @@ constexpr int FOLD_DMA_PER_WAVE = (FOLD_STAGE / 1024) / 8;  // LDS-DMA pieces pe
 // (hi, lo) of two floats with the hardware conversion (v_cvt_pk_bf16_f32, round to nearest even):
 // the same values as bf16_split for every finite input inside the bf16 range
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void bf16_split2(float a, float b, unsigned &hi, unsigned &lo) {
   const f32x2 v = {a, b};

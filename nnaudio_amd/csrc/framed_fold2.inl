@@ -42,15 +42,6 @@ __host__ __device__ inline int fold2_tg(int kernel) {
   return quads <= 64 ? 64 : (quads <= 128 ? 128 : 256);
 }
 
-__device__ __forceinline__ void f16_split2(float a, float b, unsigned &hi, unsigned &lo) {
-  const f32x2 v = {a, b};
-  const f16x2 h = __builtin_convertvector(v, f16x2);
-  const f32x2 r = v - __builtin_convertvector(h, f32x2);
-  const f16x2 l = __builtin_convertvector(r, f16x2);
-  hi = __builtin_bit_cast(unsigned, h);
-  lo = __builtin_bit_cast(unsigned, l);
-}
-
 // ---------------------------------------------------------------------------------
 // basis -> quarter-folded planes from the ANALYTIC DFT (+ how far the buffers are from
 // window x DFT).  grid (ceil(Kf / 256), n_bins).  stats[0] = max |buffer - w * dft| over all
@@ -190,11 +181,9 @@ __global__ void __launch_bounds__(256) fold2_frames_kernel(const KParams p, unsi
               fmaxf(red[2 * 4 * FOLD2_FR + 2], red[2 * 4 * FOLD2_FR + 3]));
     m *= p.fold_wmax;
     // m = f 2^e, f in [0.5, 1): the four-sample combinations stay below 2^(e+2); scale 2^(13-e)
-    int e = (int)((__float_as_uint(m) >> 23) & 0xff) - 126;
-    e = e < -80 ? -80 : (e > 100 ? 100 : e);
-    scale = __uint_as_float((unsigned)(13 - e + 127) << 23);
-    if ((int)threadIdx.x < nfw)
-      p.col_unscale[col0 + threadIdx.x] = __uint_as_float((unsigned)(e - 27 + 127) << 23);  // 2^-(13-e) 2^-14
+    const int e = absmax_exponent(m);
+    scale = pow2f(13 - e);
+    if ((int)threadIdx.x < nfw) p.col_unscale[col0 + threadIdx.x] = pow2f(e - 13 - 14);  // also the basis' 2^14
   }
 
   for (int j0 = 4 * gt; j0 < Kf && nf > 0; j0 += 4 * TG) {

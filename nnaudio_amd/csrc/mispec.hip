@@ -73,6 +73,37 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // arbitrary); the hardware handles dword-aligned 16-byte global loads.
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// arithmetic of the split kernels (strip, fold): the operands' format
+enum { FOLD_BF16X3 = 0, FOLD_F32 = 1, FOLD_F16X3 = 2 };
+
+// (hi, lo) fp16 pairs of two floats (round to nearest even): for MISPEC_PREC_F16X3, whose operands are
+// scaled by powers of two so that the pairs stay inside fp16's exponent range
+__device__ __forceinline__ void f16_split2(float a, float b, unsigned &hi, unsigned &lo) {
+  const f32x2 v = {a, b};
+  const f16x2 h = __builtin_convertvector(v, f16x2);
+  const f32x2 r = v - __builtin_convertvector(h, f32x2);
+  const f16x2 l = __builtin_convertvector(r, f16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+// A power-of-two scale from the largest magnitude m = f 2^e, f in [0.5, 1), of what it multiplies:
+// 2^(top - e) puts the values below 2^top; exponents clamped so that scale and inverse are normal.
+__device__ __forceinline__ int absmax_exponent(float m) {
+  int e = (int)((__float_as_uint(m) >> 23) & 0xff) - 126;
+  return e < -80 ? -80 : (e > 100 ? 100 : e);
+}
+__device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
+constexpr int F16_TOP = 14;  // scaled operands of the strip kernel stay below 2^14
+__device__ __forceinline__ float clip_scale_of(unsigned absmax_bits) {
+  return pow2f(F16_TOP - absmax_exponent(__uint_as_float(absmax_bits)));
+}
+__device__ __forceinline__ float clip_unscale_of(unsigned absmax_bits) {
+  return pow2f(absmax_exponent(__uint_as_float(absmax_bits)) - F16_TOP);
+}
+
 constexpr int KC = 32;   // K depth of one LDS stage
 constexpr int LDT = 36;  // LDS row stride in floats: 16-B aligned rows, conflict-free ds_read_b128
 
@@ -169,6 +200,10 @@ struct KParams {
   int fold_arith;            // FOLD_BF16X3 / FOLD_F32 / FOLD_F16X3: format of the folded operands
   float fold_wmax;           // FOLD_F16X3: max |window| (bounds the folded samples of a frame)
   float *col_unscale;        // FOLD_F16X3: per flat frame, what undoes the operand scaling (pre-pass writes, contraction reads)
+  // MISPEC_PREC_F16X3 on the strip kernel
+  unsigned *clip_absmax;     // per clip: bit pattern of max |sample| (clip_absmax_kernel; atomicMax)
+  const float *row_unscale;  // per bin: inverse of the power of two its basis row was multiplied with
+  int split_f16;             // split_signal_kernel writes scaled fp16 pairs
 };
 
 // ---------------------------------------------------------------------------------
@@ -2780,14 +2815,78 @@ int launch_strip32(KParams p, const mispec_framed_gemm_args *a, const StripPlan 
   return MISPEC_OK;
 }
 
-// MISPEC_PREC_F16X3 exists on the second fold only: every other shape runs in MISPEC_PREC_F32 (then
-// with basis_fold, if given, in the fp32 format)
+// ---- MISPEC_PREC_F16X3 on the strip kernel (complex banks with supports and their host copy, basis_split
+// = mispec_frag_basis_f16()): applicability and launch
+long long basis_frag16_bytes(int n_bins, int kernel) {
+  return (long long)((n_bins + 15) / 16) * round_up_kc(kernel) * 128 + 4096 + 2LL * n_bins * (long long)sizeof(float);
+}
+
+bool strip16_ok(const mispec_framed_gemm_args *a, const KParams &p, int n_cu, StripPlan &plan) {
+  if (a->precision != MISPEC_PREC_F16X3 || !a->basis_split || !a->row_support || !a->row_support_host ||
+      !p.a_im || a->tile != MISPEC_TILE_AUTO || p.fb)
+    return false;
+  if (!basis_has_frags(p.n_bins, true) || a->basis_split_bytes < basis_frag16_bytes(p.n_bins, p.K)) return false;
+  if (p.n_bins * 2 <= 128 || (p.hop & 1)) return false;  // (as bf16x3: narrow problems stay on the fp32 tile kernels)
+  KParams q = p;
+  q.Ks = round_up_kc(p.K);
+  return strip_plan_cached(q, a->row_support_host, 2 * n_cu, plan);
+}
+
+// workspace: [edge spans (unused here) | (hi, lo) planes + job counter | per-clip absmax bits]
+long long strip16_ws_bytes(const KParams &p, const SplitPlan &sp) {
+  return sp.edge_bytes + sp.bytes + round_up_ll(p.n_clips * (long long)sizeof(unsigned), 256);
+}
+
+int launch_strip16(KParams p, const mispec_framed_gemm_args *a, const StripPlan &plan, int n_cu,
+                   hipStream_t stream) {
+  const EdgePlan e = plan_edges(p.n_samples, p.K, p.hop, p.pad, p.n_frames);
+  const SplitPlan sp = plan_split(p, e);
+  if (!a->workspace || a->workspace_bytes < strip16_ws_bytes(p, sp))
+    return fail(MISPEC_E_INVALID, "workspace too small: size it with the *_workspace_bytes query%s");
+  unsigned short *xs = reinterpret_cast<unsigned short *>(static_cast<char *>(a->workspace) + sp.edge_bytes);
+  p.xs = xs;
+  p.xs_clip_stride = sp.slot;
+  p.xs_plane = sp.slot * p.n_clips;
+  p.job_counter = reinterpret_cast<unsigned *>(xs + 2 * sp.slot * p.n_clips);
+  p.clip_absmax = reinterpret_cast<unsigned *>(static_cast<char *>(a->workspace) + sp.edge_bytes + sp.bytes);
+  p.split_f16 = 1;
+  p.Ks = round_up_kc(p.K);
+  p.afrag = static_cast<const unsigned short *>(a->basis_split);
+  p.row_unscale = reinterpret_cast<const float *>(
+      static_cast<const char *>(a->basis_split) + (long long)((p.n_bins + 15) / 16) * p.Ks * 128 + 4096);
+  if (hipMemsetAsync(p.clip_absmax, 0, p.n_clips * sizeof(unsigned), stream) != hipSuccess)
+    return fail(MISPEC_E_HIP, "hipMemsetAsync failed%s");
+  hipLaunchKernelGGL(clip_absmax_kernel, dim3((unsigned)((p.n_samples + 4095) / 4096), (unsigned)p.n_clips),
+                     dim3(256), 0, stream, p.x, p.x_clip_stride, p.n_samples, p.clip_absmax);
+  const unsigned gx = (unsigned)((sp.slot + 1023) / 1024);
+  hipLaunchKernelGGL(split_signal_kernel, dim3(gx, (unsigned)p.n_clips), dim3(256), 0, stream, p, xs);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail(MISPEC_E_HIP, "signal split launch: %s", hipGetErrorString(err));
+  p.n_super = (p.Ks + p.hop - 1) / p.hop;
+  auto kern = plan.nf == 2 ? framed_f16x3_strip64_kernel : framed_f16x3_strip_kernel;
+  static std::atomic<unsigned long long> configured{0}, configured64{0};
+  int rc = configure_lds(kern, 160 * 1024, plan.nf == 2 ? configured64 : configured);
+  if (rc != MISPEC_OK) return rc;
+  const unsigned grid = (unsigned)(plan.n_jobs < 2 * n_cu ? plan.n_jobs : 2 * n_cu);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(STRIP_NW * 64), (size_t)STRIP_LDS_BYTES, stream, p, plan);
+  err = hipGetLastError();
+  if (err != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(err));
+  return MISPEC_OK;
+}
+
+// MISPEC_PREC_F16X3 exists on the second fold and on the strip kernel: every other shape runs in
+// MISPEC_PREC_F32 (then with basis_fold, if given, in the fp32 format; a basis_split made for
+// MISPEC_PREC_F16X3 is not offered to the fp32 kernels)
 static bool f16_downgrade(const mispec_framed_gemm_args *a, const KParams &p, mispec_framed_gemm_args &local) {
   if (a->precision != MISPEC_PREC_F16X3 || plan_fold2(a, p).ok) return false;
+  StripPlan plan;
+  if (strip16_ok(a, p, device_cus(), plan)) return false;
   local = *a;
   local.precision = MISPEC_PREC_F32;
   local.basis_fold2 = nullptr;
   local.basis_fold2_bytes = 0;
+  local.basis_split = nullptr;
+  local.basis_split_bytes = 0;
   return true;
 }
 
@@ -2814,6 +2913,10 @@ int64_t mispec_framed_gemm_workspace_bytes(const mispec_framed_gemm_args *args) 
   }
   {
     StripPlan plan;
+    if (strip16_ok(args, p, device_cus(), plan)) return strip16_ws_bytes(p, plan_split(p, e));
+  }
+  {
+    StripPlan plan;
     if (strip32_ok(args, p, device_cus(), plan)) {  // the padded fp32 copy of the clips
       const SplitPlan sp = plan_split(p, e);
       return sp.edge_bytes + sp.bytes;
@@ -2831,7 +2934,9 @@ int32_t mispec_strip_plan(const mispec_framed_gemm_args *args, int32_t n_cu, int
   mispec_framed_gemm_args local;
   if (f16_downgrade(args, p, local)) args = &local;
   StripPlan plan;
-  if (args->precision == MISPEC_PREC_F32) {
+  if (args->precision == MISPEC_PREC_F16X3) {
+    if (!strip16_ok(args, p, n_cu, plan)) return 0;
+  } else if (args->precision == MISPEC_PREC_F32) {
     if (!strip32_ok(args, p, n_cu, plan)) return 0;
   } else {
     if (!bf16x3_ok(args, p) || !args->row_support || !args->row_support_host ||
@@ -2874,6 +2979,7 @@ int mispec_framed_gemm_f32(const mispec_framed_gemm_args *args, void *stream) {
   if (!bf16x3) {
     StripPlan plan;
     const int n_cu = device_cus();
+    if (strip16_ok(args, p, n_cu, plan)) return launch_strip16(p, args, plan, n_cu, s);
     if (strip32_ok(args, p, n_cu, plan)) return launch_strip32(p, args, plan, n_cu, s);
   }
   // (the bf16x3 kernels read the padded split signal, not the fp32 path's edge workspace)
@@ -2941,6 +3047,34 @@ int mispec_frag_basis_f32(const float *basis_re, const float *basis_im, int64_t 
                      s, basis_re, basis_im, (long long)basis_row_stride, n_bins, kernel, ks,
                      static_cast<unsigned short *>(nullptr), static_cast<unsigned short *>(nullptr),
                      static_cast<float *>(dst));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "basis fragment launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+
+int64_t mispec_basis_frag16_bytes(int32_t n_bins, int32_t kernel) {
+  if (n_bins <= 0 || kernel <= 0) return fail(MISPEC_E_INVALID, "non-positive size%s");
+  if (!basis_has_frags(n_bins, true)) return fail(MISPEC_E_UNSUPPORTED, "more than 1024 bins%s");
+  return basis_frag16_bytes(n_bins, kernel);
+}
+
+int mispec_frag_basis_f16(const float *basis_re, const float *basis_im, int64_t basis_row_stride,
+                          int32_t n_bins, int32_t kernel, void *dst, int64_t dst_bytes, void *stream) {
+  if (!basis_re || !basis_im || !dst) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
+  const int64_t need = mispec_basis_frag16_bytes(n_bins, kernel);
+  if (need < 0) return (int)need;
+  if (dst_bytes < need) return fail(MISPEC_E_INVALID, "dst too small: size it with mispec_basis_frag16_bytes%s");
+  const int ks = round_up_kc(kernel);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(dst, 0, (size_t)need, s) != hipSuccess) return fail(MISPEC_E_HIP, "hipMemsetAsync failed%s");
+  float *unscale = reinterpret_cast<float *>(static_cast<char *>(dst) + (long long)((n_bins + 15) / 16) * ks * 128 + 4096);
+  float *scale = unscale + n_bins;
+  hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)n_bins), dim3(256), 0, s, basis_re, basis_im,
+                     (long long)basis_row_stride, kernel, scale, unscale);
+  hipLaunchKernelGGL(split_basis_kernel, dim3((unsigned)((ks + 255) / 256), (unsigned)n_bins, 2u), dim3(256), 0,
+                     s, basis_re, basis_im, (long long)basis_row_stride, n_bins, kernel, ks,
+                     static_cast<unsigned short *>(nullptr), static_cast<unsigned short *>(dst),
+                     static_cast<float *>(nullptr), static_cast<const float *>(scale));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MISPEC_E_HIP, "basis fragment launch: %s", hipGetErrorString(e));
   return MISPEC_OK;

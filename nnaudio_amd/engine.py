@@ -27,23 +27,37 @@ from .basis import decimated_length
 #            operands: 22 operand bits, ~1e-7 of the peak (fp32 class, ~160 dB of dynamic range
 #            where bf16x3 has ~105); problems it does not cover run in fp32
 _PRECISIONS = {"fp32": PREC_F32, "bf16x3": PREC_BF16X3, "f16x3": PREC_F16X3}
-_default_precision = os.environ.get("MISPEC_PRECISION", "fp32")
+# Process-wide override (nnaudio_amd.set_precision, or the MISPEC_PRECISION environment variable at
+# import); None: every module uses its own default -- the fastest arithmetic that meets the
+# reference's own fixtures for that module (tests/test_gpu_parity.py::test_reference_ground_truths):
+#   STFT (and MelSpectrogram / Gammatonegram / MFCC through it)   "f16x3"
+#   CQT1992v2                                                      "fp32" (the reference's summation order)
+#   CQT2010v2 / VQT                                                "fp32"
+_default_precision = os.environ.get("MISPEC_PRECISION") or None
+if _default_precision is not None and _default_precision not in _PRECISIONS:
+    raise ValueError("MISPEC_PRECISION must be one of %s" % sorted(_PRECISIONS))
 
 
 def set_precision(name):
-    """Process-wide default for modules whose ``precision`` attribute is None."""
+    """Process-wide arithmetic for modules whose ``precision`` attribute is None; ``None`` (or
+    "auto") returns to the per-module defaults."""
     global _default_precision
-    if name not in _PRECISIONS:
-        raise ValueError("precision must be one of %s" % sorted(_PRECISIONS))
+    if name == "auto":
+        name = None
+    if name is not None and name not in _PRECISIONS:
+        raise ValueError("precision must be None or one of %s" % sorted(_PRECISIONS))
     _default_precision = name
 
 
 def get_precision():
+    """The process-wide override, or None when the modules use their own defaults."""
     return _default_precision
 
 
-def resolve_precision(name=None):
-    name = name or _default_precision
+def resolve_precision(name=None, default="fp32"):
+    """``name`` (a module's attribute / a call's argument), else the process-wide override, else
+    ``default`` (the caller's own default)."""
+    name = name or _default_precision or default
     if name not in _PRECISIONS:
         raise ValueError("precision must be one of %s, got %r" % (sorted(_PRECISIONS), name))
     return name
@@ -375,6 +389,28 @@ def frag_basis_f32(basis_re, basis_im):
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
         _abi.check(lib.mispec_frag_basis_f32(wr.data_ptr(), wi.data_ptr(), wr.stride(0), F, K,
+                                             dst.data_ptr(), need, ctypes.c_void_p(stream)))
+    return dst
+
+
+def frag_basis_f16(basis_re, basis_im):
+    """Scaled (hi, lo) fp16 pairs of a complex bank in the strip kernel's fragment order + the
+    per-row inverse scales (mispec_frag_basis_f16), or None for banks of more than 1024 bins: with
+    it, the supports and their host copy, ``precision="f16x3"`` contractions of CQT banks run on
+    the strip kernel with fp32-class accuracy."""
+    dev = _require_device(basis_re, basis_im)
+    wr, wi = _rows(basis_re, "basis_re"), _rows(basis_im, "basis_im")
+    if wi.shape != wr.shape or wi.stride(0) != wr.stride(0):
+        raise RuntimeError("real / imaginary bases must have identical shape and layout")
+    lib = _abi.load()
+    F, K = wr.shape
+    need = lib.mispec_basis_frag16_bytes(F, K)
+    if need < 0:
+        return None
+    dst = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _abi.check(lib.mispec_frag_basis_f16(wr.data_ptr(), wi.data_ptr(), wr.stride(0), F, K,
                                              dst.data_ptr(), need, ctypes.c_void_p(stream)))
     return dst
 

@@ -115,6 +115,8 @@ class CQT1992v2(nn.Module):
         kr, ki = self.cqt_kernels_real, self.cqt_kernels_imag
         if precision == "bf16x3":
             split = self._split.get((kr, ki), lambda: engine.split_basis(kr, ki), extra=precision)
+        elif precision == "f16x3" and sup is not None:
+            split = self._split.get((kr, ki), lambda: engine.frag_basis_f16(kr, ki), extra=precision)
         # (fp32 stays on the tile kernels, which sum the taps in the reference's order: the strip
         # kernel also exists in fp32 -- engine.frag_basis_f32, 20-50 % faster -- but its hop-periodic
         # order leaves different rounding noise in the near-silent bins, and 4.7 % of them then miss

@@ -132,8 +132,9 @@ class STFT(nn.Module):
             self.register_buffer("wsin", wsin)
             self.register_buffer("wcos", wcos)
         self.register_buffer("window_mask", win.unsqueeze(0).unsqueeze(-1))
-        # not a constructor argument (the signature stays the reference's): set the attribute,
-        # or nnaudio_amd.set_precision(...), to "bf16x3" for the split-bf16 matrix pipe
+        # not a constructor argument (the signature stays the reference's): None = the module's
+        # default, "f16x3" (scaled fp16 pairs on the f16 matrix pipe, fp32-class accuracy), unless
+        # nnaudio_amd.set_precision(...) overrides it; or "fp32" / "bf16x3" / "f16x3"
         self.precision = None
         self._split = engine.DerivedCache()
 
@@ -164,7 +165,7 @@ class STFT(nn.Module):
         wsin, wcos = self.wsin, self.wcos
         if self.freq_bins is not None:
             wsin, wcos = wsin[: self.freq_bins], wcos[: self.freq_bins]
-        precision = engine.resolve_precision(self.precision)
+        precision = engine.resolve_precision(self.precision, "f16x3")
         prep = {}
         if not engine.compiling():
             # bf16x3: split planes; either arithmetic, the window being symmetric: the folded planes

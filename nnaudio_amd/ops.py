@@ -24,7 +24,14 @@ from . import engine
 _prep_cache = {}  # id(basis_re) -> (weakref, DerivedCache)
 
 
-def _prepared(basis_re, basis_im, precision, hop):
+def _prepare(basis_re, basis_im, precision, hop, support):
+    if support and precision == "f16x3":  # banks with supports: the strip kernel's scaled fp16 fragments
+        frag = engine.frag_basis_f16(basis_re, basis_im)
+        return {"basis_split": frag} if frag is not None else {}
+    return engine.prepare_basis(basis_re, basis_im, precision, hop=hop)
+
+
+def _prepared(basis_re, basis_im, precision, hop, support=False):
     """Split / folded planes of a basis for the op's run-time tensors (cached per tensor object)."""
     if basis_im is None:
         return {}
@@ -37,8 +44,8 @@ def _prepared(basis_re, basis_im, precision, hop):
     else:
         cache = hit[1]
     return cache.get((basis_re, basis_im),
-                     lambda: engine.prepare_basis(basis_re, basis_im, precision, hop=hop),
-                     extra=(int(hop), precision))
+                     lambda: _prepare(basis_re, basis_im, precision, hop, support),
+                     extra=(int(hop), precision, bool(support)))
 
 
 _support_cache = {}  # id(basis_re) -> (weakref, SupportCache)
@@ -63,7 +70,7 @@ def framed_gemm(x: torch.Tensor, basis_re: torch.Tensor, basis_im: Optional[torc
                 pad: int, pad_mode: int, epilogue: int, im_sign: float, eps: float, power: float,
                 row_scale: Optional[torch.Tensor], support: bool, precision: str) -> torch.Tensor:
     """``support``: skip the zero taps outside every row's [start, stop) (CQT banks)."""
-    prep = _prepared(basis_re, basis_im, precision, hop)
+    prep = _prepared(basis_re, basis_im, precision, hop, support and basis_im is not None)
     sup = _supports(basis_re, basis_im) if support and basis_im is not None else None
     return engine.framed_gemm(x, basis_re, basis_im, hop=hop, pad=pad, pad_mode=pad_mode,
                               epilogue=epilogue, im_sign=im_sign, eps=eps, power=power,

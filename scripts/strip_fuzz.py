@@ -1,5 +1,5 @@
 """Random shapes through the strip kernel against the one-thread-per-output device kernel:
-python scripts/strip_fuzz.py [cases] [seed] [bf16x3|fp32]"""
+python scripts/strip_fuzz.py [cases] [seed] [bf16x3|fp32|f16x3]"""
 import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -42,6 +42,11 @@ for case in range(n_cases):
     kw = dict(hop=hop, pad=pad, pad_mode=mode, epilogue=epi, row_scale=sc)
     if PREC == "fp32":
         kw["basis_split"] = engine.frag_basis_f32(wr, wi)
+    if PREC == "f16x3":  # the operand scaling: any level of signal and bank must do
+        x = x * float(10.0 ** rng.uniform(-6, 4))
+        g = float(10.0 ** rng.uniform(-5, 3))
+        wr, wi = wr * g, wi * g
+        kw["basis_split"] = engine.frag_basis_f16(wr, wi)
     a, _o, _d, _k = engine._framed_args(x, wr, wi, precision=PREC, row_support=sup, **kw)
     n_pass = _abi.load().mispec_strip_plan(ctypes.byref(a), 256, None, 0)
     taken += n_pass > 0

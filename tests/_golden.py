@@ -181,7 +181,7 @@ def assert_phase_parity(y, ref, mag, what="", floor=1e-3, tol=1e-3, min_frac=0.5
     assert d[mask].max() <= tol, "%s phase err %.3e" % (what, d[mask].max())
 
 
-def check_ground_truth(y, gt, fmt, eps, gt_complex=None, what=""):
+def check_ground_truth(y, gt, fmt, eps, gt_complex=None, what="", max_miss=5e-3, phase_floor=1e-3):
     """Compare a transform of the reference's chirp inputs with one of the reference's own
     ground-truth arrays (reference tests/test_cqt.py:94-262, rtol = atol = 1e-3).
 
@@ -195,7 +195,9 @@ def check_ground_truth(y, gt, fmt, eps, gt_complex=None, what=""):
                   ground-truth magnitude exceeds 1 % of the peak (there the log is conditioned
                   against 7e-6-of-peak noise); on all
                   elements the linear-domain parity bar |X - X_gt| <= 1e-4 * max|X_gt| ; and
-                  at most 0.5 % of the elements may miss the verbatim log assertion.
+                  at most `max_miss` (0.5 %) of the elements may miss the verbatim log assertion
+                  (returned).  An exact float64 evaluation misses 0.13 % / 0.0 % (log / linear
+                  sweep): that much of the fixture is the reference's own float32 noise.
       Phase     : (cos, sin) compared (atol 1e-3) where the bin carries energy
                   (|z_gt| > 1e-3 * max|z_gt|); elsewhere the phase is rounding noise."""
     y = np.asarray(y)
@@ -208,9 +210,10 @@ def check_ground_truth(y, gt, fmt, eps, gt_complex=None, what=""):
         yl = np.log(y + eps)
         ok = np.isclose(yl, gt, rtol=1e-3, atol=1e-3)
         assert ok[lin > 1e-2 * lin.max()].all(), what + " (log, conditioned bins)"
-        assert (~ok).mean() <= 5e-3, what + " (log, fraction)"
+        assert (~ok).mean() <= max_miss, what + " (log, fraction %.4f)" % (~ok).mean()
+        return float((~ok).mean())
     elif fmt == "Phase":
         mag = np.hypot(gt_complex[..., 0], gt_complex[..., 1]).reshape(y.shape[:-1])
-        assert_phase_parity(y, gt, mag, what=what, floor=1e-3, tol=1e-3, min_frac=0.05)
+        assert_phase_parity(y, gt, mag, what=what, floor=phase_floor, tol=1e-3, min_frac=0.05)
     else:
         raise ValueError(fmt)

@@ -49,3 +49,19 @@ def test_ops_are_registered_with_fake_implementations():
     y = torch.ops.mispec.framed_gemm(x, w, w, 16, 32, 2, 0, -1.0, 0.0, 2.0, None, False, "bf16x3")
     assert y.shape == (2, 33, 63, 2) and y.device.type == "meta"
     assert torch.ops.mispec.fir_decimate(x, torch.empty(256, device="meta"), 2).shape == (2, 500)
+
+
+@pytest.mark.parametrize("trainable,x_grad", [(True, False), (False, True)])
+def test_cqt1992v2_compile_with_a_graph_reaches_the_autograd_function(trainable, x_grad):
+    """Grad mode on + trainable kernels (or a differentiable input) under torch.compile: the
+    ``support`` hint of the compile branch must be consumed before the autograd function sees the
+    keyword arguments (it used to reach ``_framed_args`` and raise TypeError, which dynamo does not
+    turn into a graph break).  On CPU the call must get as far as the device check."""
+    mod = build_module(dict(cls="CQT1992v2", ctor=dict(sr=16000, hop_length=64, fmin=110, n_bins=24,
+                                                       trainable=trainable), fwd={}))
+    x = torch.randn(2, 4000, requires_grad=x_grad)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(RuntimeError, match="GPU only"):
+            torch.compile(mod, backend="eager")(x)
+    torch._dynamo.reset()

@@ -84,15 +84,41 @@ GT_CASES = [
 ]
 
 
+# What each arithmetic may miss of the reference's verbatim log(X + eps) assertion (fraction of
+# elements; the conditioned ones -- above 1 % of the peak -- must all pass in every arithmetic),
+# and from which energy its phase is compared.  The near-silent bins of a sweep carry 1e-9 of the
+# peak; the fixture there records the rounding noise of the reference's own summation ORDER:
+#   fp32   the tile kernels sum the taps in the reference's order: 0.03 % miss -- the fixture bar
+#          (0.5 %; an exact float64 evaluation misses 0.13 %)
+#   f16x3  fp32-class operands (2e-6 of the peak at most, see test_cfg4_*), but CQT1992v2 runs on the
+#          strip kernel, whose hop-periodic tap order leaves partial sums of ~0.3 x peak in silent
+#          bins (aliases of the sweep): 2.7 % / 0.1 % miss on the MI355X (log / linear sweep; exact
+#          operands in that order with fp32 accumulation: 1.3 %, scripts/split_emulation.py).  That
+#          is why CQT1992v2's default precision stays fp32.  CQT2010v2 (octave path) meets the bar.
+#   bf16x3 5e-6 of the peak is the size of those bins: 57 % / 74 %
+# The measured fractions are pinned (with margin) so that they cannot grow unnoticed.
+GT_MAX_MISS = {"fp32": {"1992": 5e-3, "2010": 5e-3}, "f16x3": {"1992": 0.04, "2010": 5e-3},
+               "bf16x3": {"1992": 0.80, "2010": 0.80}}
+GT_PHASE_FLOOR = {"fp32": 1e-3, "f16x3": 1e-3, "bf16x3": 1e-2}
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "bf16x3"])
 @pytest.mark.parametrize("sweep,method,cls,tagc,fmt,tag", GT_CASES)
-def test_reference_ground_truths(golden, sweep, method, cls, tagc, fmt, tag):
+def test_reference_ground_truths(golden, sweep, method, cls, tagc, fmt, tag, precision):
+    """reference tests/test_cqt.py:94-262 (rtol = atol = 1e-3 on log(X + eps) / Complex / Phase) in
+    every arithmetic the modules offer."""
     case = dict(cls=cls, ctor=dict(sr=44100, fmin=55, n_bins=207, bins_per_octave=24,
                                    output_format=fmt), fwd={})
-    y = run(build_module(case, DEV), _chirp(method))
+    mod = build_module(case, DEV)
+    mod.precision = precision
+    y = run(mod, _chirp(method))
     gt = golden.ground_truth("%s-sweep-cqt-%s-%s-ground-truth.npy" % (sweep, tagc, tag))
     gtc = golden.ground_truth("%s-sweep-cqt-%s-complex-ground-truth.npy" % (sweep, tagc))
-    check_ground_truth(y, gt, fmt, 1e-5 if tagc == "1992" else 1e-2, gtc,
-                       what="%s %s %s" % (sweep, cls, fmt))
+    miss = check_ground_truth(y, gt, fmt, 1e-5 if tagc == "1992" else 1e-2, gtc,
+                              what="%s %s %s %s" % (sweep, cls, fmt, precision),
+                              max_miss=GT_MAX_MISS[precision][tagc], phase_floor=GT_PHASE_FLOOR[precision])
+    if miss is not None:
+        print("ground truth %s %s %s: %.4f of the elements miss log(X + eps)" % (sweep, cls, precision, miss))
 
 
 def test_vqt_gamma0_is_bit_identical_to_cqt2010v2(golden):
@@ -376,7 +402,7 @@ def test_cfg3_mel_full_size_sampled():
     assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
 
 
-@pytest.mark.parametrize("precision,B", [("fp32", 16), ("bf16x3", 16), ("bf16x3", 64)])
+@pytest.mark.parametrize("precision,B", [("fp32", 16), ("bf16x3", 16), ("bf16x3", 64), ("f16x3", 16), ("f16x3", 64)])
 def test_cfg4_cqt1992v2_full_size_sampled(precision, B):
     from nnaudio_amd import features
     from oracle import spectral_oracle as O
@@ -398,8 +424,9 @@ def test_cfg4_cqt1992v2_full_size_sampled(precision, B):
     s = np.sqrt(m.lenghts.cpu().numpy().astype(np.float64))[None, :]
     got = y[torch.as_tensor(cb), :, torch.as_tensor(ct)].cpu().numpy()
     peak = max(np.abs(re * s).max(), np.abs(im * s).max())
-    assert np.abs(got[..., 0] - re * s).max() <= 1e-4 * peak
-    assert np.abs(got[..., 1] - im * s).max() <= 1e-4 * peak
+    tol = 2e-6 if precision == "f16x3" else 1e-4  # f16x3: fp32 class
+    assert np.abs(got[..., 0] - re * s).max() <= tol * peak
+    assert np.abs(got[..., 1] - im * s).max() <= tol * peak
 
 
 def _octave_banks(mod):
@@ -716,7 +743,8 @@ def test_bf16x3_kernel_shapes(shape, support):
     (2, 70001, 70, 2048, 128, 1024, 1),   # last row tile holds 6 bins; 547 frames
     (7, 17000, 100, 1024, 96, 0, 0),      # hop of 3 sub-stages, center=False, 167 frames
 ])
-def test_strip_kernel_epilogues(shape):
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x3"])
+def test_strip_kernel_epilogues(shape, precision):
     """Every epilogue through the strip kernel (framed_bf16x3_strip.inl: banks with supports and a
     host copy of them) against the one-thread-per-output device kernel: partial sums of the waves
     that share a row tile, the register and the LDS path of the shared epilogue, row scales, row
@@ -735,8 +763,9 @@ def test_strip_kernel_epilogues(shape):
     sup.host_copy = np.ascontiguousarray(np.stack([lo, hi], 1).astype(np.int32))
     sc = torch.as_tensor(rng.uniform(0.5, 2.0, F).astype(np.float32)).to(DEV)
     base = dict(hop=hop, pad=pad, pad_mode=mode)
-    a, _o, _d, _k = engine._framed_args(xd, wr, wi, precision="bf16x3", row_support=sup,
-                                        epilogue=engine.EPI_MAGNITUDE, **base)
+    split = {"basis_split": engine.frag_basis_f16(wr, wi)} if precision == "f16x3" else {}
+    a, _o, _d, _k = engine._framed_args(xd, wr, wi, precision=precision, row_support=sup,
+                                        epilogue=engine.EPI_MAGNITUDE, **base, **split)
     assert _abi.load().mispec_strip_plan(ctypes.byref(a), 256, None, 0) > 0
     z = engine.framed_gemm(xd, wr, wi, reference_kernel=True, epilogue=engine.EPI_COMPLEX, row_scale=sc,
                            **base)
@@ -748,7 +777,7 @@ def test_strip_kernel_epilogues(shape):
     for epi, extra in cases:
         kw = dict(base, epilogue=epi, row_scale=sc, **extra)
         ref = engine.framed_gemm(xd, wr, wi, reference_kernel=True, **kw)
-        y = engine.framed_gemm(xd, wr, wi, precision="bf16x3", row_support=sup, **kw)
+        y = engine.framed_gemm(xd, wr, wi, precision=precision, row_support=sup, **kw, **split)
         assert y.shape == ref.shape
         what = "strip epilogue %d %s %s" % (epi, extra, shape)
         if epi == engine.EPI_PHASE_ATAN2:
@@ -757,12 +786,12 @@ def test_strip_kernel_epilogues(shape):
         elif epi == engine.EPI_PHASE_COSSIN:
             assert (y - ref)[strong].abs().max().item() < 2e-3, what
         else:
-            assert (y - ref).abs().max().item() <= 1e-4 * ref.abs().max().item(), what
+            assert (y - ref).abs().max().item() <= (1e-4 if precision == "bf16x3" else 1e-5) * ref.abs().max().item(), what
     # a row block of a taller output (octave assembly): rows outside it stay untouched
     T = z.shape[2]
     out = torch.full((B, F + 9, T), -7.0, device=DEV)
-    engine.framed_gemm(xd, wr, wi, precision="bf16x3", row_support=sup, epilogue=engine.EPI_MAGNITUDE,
-                       row_scale=sc, out=out, out_rows_total=F + 9, out_row_offset=5, **base)
+    engine.framed_gemm(xd, wr, wi, precision=precision, row_support=sup, epilogue=engine.EPI_MAGNITUDE,
+                       row_scale=sc, out=out, out_rows_total=F + 9, out_row_offset=5, **base, **split)
     ref = engine.framed_gemm(xd, wr, wi, reference_kernel=True, epilogue=engine.EPI_MAGNITUDE, row_scale=sc,
                              **base)
     assert (out[:, 5:5 + F] - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
@@ -1395,6 +1424,7 @@ def test_integration_stub_computes_an_stft():
     ns = {}
     exec(compile(code, "INTEGRATION.md", "exec"), ns)
     m = features.STFT(n_fft=512, hop_length=128, output_format="Magnitude", verbose=False).to(DEV)
+    m.precision = "fp32"
     x = torch.randn(5, 1, 20000, generator=torch.Generator().manual_seed(2)).to(DEV)
     with torch.no_grad():
         want = m(x)
@@ -1416,6 +1446,9 @@ def test_integration_stub_computes_an_stft():
     for y in (y32, y32f):
         assert not torch.equal(y, want) and (y - want).abs().max().item() <= 5e-6 * want.abs().max().item()
     assert (y16 - want).abs().max().item() <= 3e-6 * want.abs().max().item()
+    m.precision = None  # the module's own default is that f16x3 call
+    with torch.no_grad():
+        assert torch.equal(m(x), y16)
     for y in (yb, yf):
         assert (y - want).abs().max().item() <= 2e-5 * want.abs().max().item()
     assert not torch.equal(yb, yf)
@@ -1465,7 +1498,7 @@ def test_forward_is_hip_graph_capturable(bf16x3, name):
             assert torch.equal(y, want), name
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32", "f16x3"])
 def test_strip_kernel_random_shapes(precision):
     """40 random problems (hop, kernel length, bins, clips, frames, padding, epilogue; supports of
     random length AND position, some empty) through the strip kernel's planner and kernel -- the

@@ -10,24 +10,35 @@ The batch shards across ranks as independent clips (nnaudio_amd.dist); computing
 collective, so the timed region has none; the RCCL all-gather that reassembles the output
 tensor is timed separately and reported under "gather" (never in `value`).
 
-The step runs with ``--precision bf16x3`` by default: fp32 operands split into bf16 (hi, lo)
-pairs, three bf16 MFMAs per product, fp32 accumulate (include/mispec.h MISPEC_PREC_BF16X3;
-~5e-6 of the spectrum peak, same 1e-4 parity tests as the fp32 path).  The fp32-MFMA path
-(the modules' default) is timed in the same run and reported under "paths".
+The step runs with ``--precision f16x3`` by default -- the STFT module's own default arithmetic:
+fp32 operands scaled by powers of two and split into (hi, lo) fp16 pairs, three f16 MFMAs per
+product, fp32 accumulate (include/mispec.h MISPEC_PREC_F16X3; ~1e-7 of the spectrum peak, fp32
+class).  "bf16x3" (split bf16, ~5e-6 of the peak) and "fp32" (fp32 MFMA) are timed in the same
+run and reported under "paths", each with the dynamic range measured on this device.
+
+``python bench.py --gpus N`` without a torch.distributed environment starts its own N ranks
+(``python -m torch.distributed.run``, one per GPU, RCCL) and relays rank 0's line.
 
 Rank 0 prints ONE JSON line: metric = spectrogram frames/s (whole job), plus
-  "roofline":        the STFT step against the MFMA peak of the precision used, in ALGORITHMIC
-                     flops (bf16x3 = 2500 / 3 = 833 TFLOP/s, fp32 157.3): 2 flop
-                     per tap of the dense contraction the reference performs, whatever the
-                     kernels execute, / the step's device time (HIP events on the launch
-                     stream); "traffic" = fabric-side bytes per step from rocprofv3 PMC passes
-                     (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes, + WRITE_SIZE) run
-                     live on this binary by this script (``--traffic live``), or null;
+  "roofline":        the STFT step on the matrix pipe: "achieved" = the flops the kernels EXECUTE
+                     (MFMA instructions x 2 M N K; counted by the SQ_INSTS_VALU_MFMA_MOPS_* PMCs in
+                     the live rocprofv3 passes when available, else from the tiling) / the step's
+                     device time (HIP events on the launch stream); "peak" = the raw dense MFMA
+                     peak of the instruction used (2500 TFLOP/s bf16 / f16, 157.3 fp32); "frac" =
+                     achieved / peak, bounded by 1.  "algorithmic_frac" is the contract's figure:
+                     2 flop per tap of the DENSE contraction the reference performs
+                     / time / (peak / MFMAs per product) -- it exceeds 1 once symmetric folds
+                     skip work, which is why it is not "frac".  "traffic" = fabric-side bytes per
+                     step from rocprofv3 PMC passes (FETCH_SIZE doubled as MI355X_MICROARCH.md
+                     prescribes, + WRITE_SIZE) run live on this binary by this script
+                     (``--traffic live``), or null;
   "roofline_cqt84":  the same block for the other half of BASELINE.json's metric (CQT1992v2,
                      84 bins, B = 64), support-aware useful flops;
-  "extra":           Mel cfg3, and one rank's shard of cfg5 (CQT2010v2 and VQT, 64 x 30 s), each
-                     timed with the same pre-warm and step count as the headline and priced
-                     against both rooflines;
+  "extra":           Mel cfg3, Gammatonegram, and one rank's shard of cfg5 (CQT2010v2 and VQT,
+                     64 x 30 s), each in its module's default arithmetic unless --precision is
+                     given, timed with the same pre-warm and step count as the headline and priced
+                     against both rooflines (with live traffic); at N > 1 also cfg4's real shard
+                     (CQT1992v2, 16 clips per rank);
   "cpu_baseline":    the numpy port of the reference algorithm (oracle/, float32 BLAS) timed on
                      this host on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -53,10 +64,13 @@ if ROOT not in sys.path:
 PEAK_F32_MFMA = 157.3e12  # FLOP/s, MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
 PEAK_BF16_MFMA = 2.5e15   # FLOP/s dense, MI355X_MICROARCH.md (v_mfma_f32_32x32x16_bf16)
 PEAK_HBM = 8.0e12         # B/s spec
-MFMAS_PER_PRODUCT = {"fp32": 1, "bf16x3": 3}
+MFMAS_PER_PRODUCT = {"fp32": 1, "bf16x3": 3, "f16x3": 3}
+RAW_PEAK = {"fp32": PEAK_F32_MFMA, "bf16x3": PEAK_BF16_MFMA, "f16x3": PEAK_BF16_MFMA}  # f16 = bf16 rate
 # peak for the precision used, in ALGORITHMIC flops ("bf16x3" = the dense bf16 MFMA
 # peak / 3 MFMAs per product = 833 TFLOP/s, cfg2 floor 0.56 ms; fp32 MFMA 157.3, floor 2.95 ms)
-PEAK = {"fp32": PEAK_F32_MFMA, "bf16x3": PEAK_BF16_MFMA / 3}
+PEAK = {k: RAW_PEAK[k] / MFMAS_PER_PRODUCT[k] for k in RAW_PEAK}
+PRECISIONS = ("f16x3", "bf16x3", "fp32")
+MOPS_COUNTERS = ("SQ_INSTS_VALU_MFMA_MOPS_F16", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_VALU_MFMA_MOPS_F32")
 
 
 def log(*a):
@@ -73,12 +87,29 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def workload(name, device):
+def fold_geometry(n_bins, K, fused_fb):
+    """(bins inside whole MFMA tiles, folded taps per component) of the folded STFT contraction for
+    an n_fft/2+1-bin Fourier basis -- mirror of plan_fold2 / plan_fold in csrc/mispec.hip: the second
+    fold (K/4 + 1 taps rounded to 16, even and odd bins in 128-bin tiles, the Nyquist bin in the
+    pre-pass) unless the filterbank is fused (then the single fold, K/2 taps)."""
+    up = lambda v, m: (v + m - 1) // m * m
+    if not fused_fb and K % 64 == 0 and n_bins >= 128:
+        ne, no = (n_bins + 1) // 2, n_bins // 2
+        if ne > 128 and ne % 128 == 1:
+            ne -= 1
+        return up(ne, 128) + up(no, 128), up(K // 4 + 1, 16)
+    nb = n_bins - 1 if (n_bins > 128 and n_bins % 128 == 1) else n_bins
+    return up(nb, 128), up(K // 2, 16)
+
+
+def workload(name, device, B=None):
     """-> (module, make_input(seed), meta) ; meta: algorithmic flops / bytes per launch."""
     from nnaudio_amd import features
 
+    B0 = B
+    up = lambda v, m: (v + m - 1) // m * m
     if name == "stft":
-        B, L, K, hop = 64, 441000, 2048, 512
+        B, L, K, hop = B0 or 64, 441000, 2048, 512
         F, T = K // 2 + 1, L // hop + 1
         m = features.STFT(n_fft=K, hop_length=hop, window="hann", output_format="Magnitude",
                           verbose=False).to(device)
@@ -86,32 +117,40 @@ def workload(name, device):
         byts = 4.0 * (B * L + B * F * T + 2 * F * K)
         tag = "STFT n_fft=2048 hop=512 hann, B=64 x 10 s @ 44.1 kHz, Magnitude (configs[1])"
         bound = "mfma"
-        executed = 0.5 * flops  # symmetric fold: K/2 taps of x[n] +- x[K-n] (both precisions)
-    elif name == "mel":
-        B, L, K, hop, M = 256, 110250, 1024, 512, 128
+        bins, taps = fold_geometry(F, K, False)
+        executed = 2.0 * (2 * bins) * taps * up(B * T, 128)  # products; x 3 MFMAs for the split arithmetics
+    elif name in ("mel", "gammatone"):
+        B, L, K, hop, M = (B0 or 256, 110250, 1024, 512, 128) if name == "mel" else (B0 or 64, 441000, 2048, 512, 64)
         F, T = K // 2 + 1, L // hop + 1
-        m = features.MelSpectrogram(sr=22050, n_fft=K, n_mels=M, hop_length=hop,
-                                    verbose=False).to(device)
+        if name == "mel":
+            m = features.MelSpectrogram(sr=22050, n_fft=K, n_mels=M, hop_length=hop,
+                                        verbose=False).to(device)
+            tag = "MelSpectrogram n_fft=1024 hop=512 n_mels=128, B=%d x 5 s @ 22.05 kHz (configs[2])" % B
+        else:
+            m = features.Gammatonegram(sr=44100, n_fft=K, n_bins=M, hop_length=hop, verbose=False).to(device)
+            tag = "Gammatonegram n_fft=2048 hop=512 64 bins, B=%d x 10 s @ 44.1 kHz (configs[1]'s batch)" % B
         flops = 2.0 * (2 * F) * K * B * T + 2.0 * M * F * B * T
         byts = 4.0 * (B * L + B * M * T + 2 * F * K + M * F)
-        tag = "MelSpectrogram n_fft=1024 hop=512 n_mels=128, B=256 x 5 s @ 22.05 kHz (configs[2])"
         bound = "mfma"
-        executed = 0.5 * 2.0 * (2 * F) * K * B * T  # folded STFT; the banded mel reduction runs on the VALU
+        # the folded STFT (the banded mel reduction runs on the VALU inside its epilogue; the dense
+        # gammatone reduction is a second, fp32-MFMA launch: not counted here)
+        bins, taps = fold_geometry(F, K, name == "mel")
+        executed = 2.0 * (2 * bins) * taps * up(B * T, 128)
     elif name == "cqt":
-        B, L, hop = 64, 441000, 512
+        B, L, hop = B0 or 64, 441000, 512
         m = features.CQT1992v2(sr=44100, hop_length=hop, fmin=32.70, n_bins=84, bins_per_octave=12,
                                verbose=False).to(device)
         T = L // hop + 1
         useful = float(m.lenghts.sum().item())
         flops = 2.0 * 2 * useful * B * T  # support-aware ("useful") flops
         byts = 4.0 * (B * L + B * 84 * T + 2 * useful)
-        tag = "CQT1992v2 84 bins / 12 bpo hop=512, B=64 x 10 s @ 44.1 kHz, Magnitude"
+        tag = "CQT1992v2 84 bins / 12 bpo hop=512, B=%d x 10 s @ 44.1 kHz, Magnitude" % B
         bound = "mfma"
         # executed: 16-bin row tiles over the tap range of their longest bin (zero padding included)
         lens = m.lenghts.detach().cpu().numpy()
         executed = 2.0 * sum(32 * float(lens[i:i + 16].max()) for i in range(0, 84, 16)) * B * T
     elif name in ("cqt2010", "vqt"):
-        B, L, hop = 64, 1323000, 512
+        B, L, hop = B0 or 64, 1323000, 512
         if name == "cqt2010":
             m = features.CQT2010v2(sr=44100, hop_length=hop, n_bins=96, verbose=False).to(device)
         else:
@@ -133,7 +172,7 @@ def workload(name, device):
         return torch.randn(B, L, generator=g, dtype=torch.float32).to(device)
 
     return m, make_input, dict(B=B, L=L, T=T, frames=B * T, flops=flops, bytes=byts, tag=tag,
-                               bound=bound, executed=executed)
+                               bound=bound, executed=executed, name=name)
 
 
 def prewarm(module, x, ms):
@@ -169,26 +208,48 @@ def timed_steps(module, x, steps, warmup, sync):
     return t1 - t0, e0.elapsed_time(e1) * 1e-3
 
 
-def roofline_block(meta, dev_step_s, precision, traffic=None, kernel=""):
-    """The line's roofline object for one workload (per launch = per step)."""
+def module_precision(name, precision):
+    """The arithmetic a workload's module runs in: --precision when given, else the module's own
+    default (STFT family: f16x3; the CQT modules: fp32 -- nnaudio_amd.engine)."""
+    if precision:
+        return precision
+    return "f16x3" if name in ("stft", "mel", "gammatone") else "fp32"
+
+
+def executed_flops(meta, precision):
+    """MFMA flops the kernels execute per step, from the tiling (None: no model for this workload)."""
+    if not meta.get("executed"):
+        return None
+    return meta["executed"] * MFMAS_PER_PRODUCT[precision]
+
+
+def roofline_block(meta, dev_step_s, precision, traffic=None, kernel="", executed=None, executed_source="tiling"):
+    """The line's roofline object for one workload (per launch = per step).  MFMA-bound workloads:
+    achieved = EXECUTED flops / time against the raw MFMA peak (frac <= 1); the contract's
+    algorithmic figure (2 flop per tap of the dense contraction) sits beside it."""
     fl = meta["flops"] / dev_step_s
     by = meta["bytes"] / dev_step_s
     blk = {"bound": meta["bound"], "unit": "TFLOP/s" if meta["bound"] == "mfma" else "GB/s",
            "traffic": traffic, "kernel": kernel, "step_device_ms": dev_step_s * 1e3,
            "algorithmic_flops_per_launch": meta["flops"],
            "algorithmic_bytes_per_launch": meta["bytes"],
-           "mfma_frac": fl / PEAK[precision], "hbm_frac_on_algorithmic_bytes": by / PEAK_HBM,
-           "algorithmic_frac_of_dense_mfma_peak":
-               fl / (PEAK_BF16_MFMA if precision == "bf16x3" else PEAK_F32_MFMA)}
-    if meta.get("executed"):
-        # what the matrix pipe actually executes (approximate, from the tiling): the folded STFT runs
-        # half the taps, the CQT tiles include their zero padding; bf16x3 issues 3 bf16 MFMAs per
-        # product.  `frac` above stays the algorithmic one the roofline contract asks for.
-        ex = meta["executed"] * (3.0 if precision == "bf16x3" else 1.0) / dev_step_s
-        blk["executed_mfma_tflops"] = ex / 1e12
-        blk["executed_frac_of_raw_mfma_peak"] = ex / (PEAK_BF16_MFMA if precision == "bf16x3" else PEAK_F32_MFMA)
-    if meta["bound"] == "mfma":
-        blk.update(achieved=fl / 1e12, peak=PEAK[precision] / 1e12, frac=fl / PEAK[precision])
+           "algorithmic_tflops": fl / 1e12,
+           "algorithmic_frac": fl / PEAK[precision],
+           "algorithmic_frac_what": "2 flop per tap of the dense contraction / time / (raw MFMA peak / MFMAs per "
+                                    "product): the SURVEY 8d figure; > 1 is possible because the symmetric folds skip work",
+           "hbm_frac_on_algorithmic_bytes": by / PEAK_HBM}
+    if executed is None:
+        executed = executed_flops(meta, precision)
+        executed_source = "tiling"
+    if executed:
+        ex = executed / dev_step_s
+        blk.update(executed_flops_per_launch=executed, executed_source=executed_source,
+                   executed_mfma_tflops=ex / 1e12, executed_frac_of_raw_mfma_peak=ex / RAW_PEAK[precision])
+    if meta["bound"] == "mfma" and executed:
+        blk.update(achieved=executed / dev_step_s / 1e12, peak=RAW_PEAK[precision] / 1e12,
+                   frac=executed / dev_step_s / RAW_PEAK[precision])
+    elif meta["bound"] == "mfma":
+        blk.update(achieved=fl / 1e12, peak=PEAK[precision] / 1e12, frac=min(1.0, fl / PEAK[precision]))
     else:
         blk.update(achieved=by / 1e9, peak=PEAK_HBM / 1e9, frac=by / PEAK_HBM)
     return blk
@@ -203,7 +264,7 @@ def pmc_child(name, precision, steps):
 
     device = torch.device("cuda", 0)
     torch.cuda.set_device(0)
-    nnaudio_amd.set_precision(precision)
+    nnaudio_amd.set_precision(precision or None)
     module, make_input, _ = workload(name, device)
     x = make_input(0)
     with torch.no_grad():
@@ -218,36 +279,48 @@ def _ours(kernel_name):
 
 
 def measure_traffic(name, precision, steps=4, timeout=150):
-    """-> dict(bytes_per_step, fetch_bytes, write_bytes, per_kernel, method) or raises."""
+    """-> dict(bytes_per_step, fetch_bytes, write_bytes, mfma_flops, per_kernel, method) or raises.
+    Three rocprofv3 passes (counters only) over a child process running `steps` forwards:
+    FETCH_SIZE, WRITE_SIZE, and the MFMA op counters (SQ_INSTS_VALU_MFMA_MOPS_*: 512 flops each)."""
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
         raise RuntimeError("rocprofv3 not found")
     res = {}
     per_kernel = {}
     env = dict(os.environ, TMPDIR="/tmp")
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    for env_key in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(env_key, None)
+    passes = [("FETCH_SIZE",), ("WRITE_SIZE",), MOPS_COUNTERS]
+    for counters in passes:
         d = tempfile.mkdtemp(prefix="mispec_pmc_", dir="/tmp")
         try:
-            cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+            cmd = [prof, "--pmc", *counters, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
                    sys.executable, os.path.abspath(__file__), "--pmc-child", name,
-                   "--precision", precision, "--steps", str(steps)]
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL,
-                           stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+                   "--precision", precision or "auto", "--steps", str(steps)]
+            try:
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+            except Exception:
+                if counters is MOPS_COUNTERS:  # the op counters are a bonus: the byte passes decide
+                    continue
+                raise
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if not files:
-                raise RuntimeError("no counter_collection.csv from the %s pass" % counter)
-            total = 0.0
+                if counters is MOPS_COUNTERS:
+                    continue
+                raise RuntimeError("no counter_collection.csv from the %s pass" % (counters,))
             for f in files:
                 for r in csv.DictReader(open(f)):
-                    if r.get("Counter_Name") != counter or not _ours(r.get("Kernel_Name", "")):
+                    counter = r.get("Counter_Name")
+                    if counter not in counters or not _ours(r.get("Kernel_Name", "")):
                         continue
-                    v = float(r.get("Counter_Value") or 0.0) * 1024.0  # the counters are in KB
-                    total += v
+                    v = float(r.get("Counter_Value") or 0.0)
+                    v *= 512.0 if counter in MOPS_COUNTERS else 1024.0  # MFMA ops -> flops; KB -> bytes
+                    res[counter] = res.get(counter, 0.0) + v / steps
                     k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
                     k = k.split("(")[0].split("<")[0][-60:]
                     per_kernel.setdefault(k, {}).setdefault(counter, 0.0)
                     per_kernel[k][counter] += v / steps
-            res[counter] = total / steps
         finally:
             shutil.rmtree(d, ignore_errors=True)
     # gfx950: FETCH_SIZE tallies 64 B per 128-B request of a 16 B/lane stream (MI355X_MICROARCH.md,
@@ -256,11 +329,29 @@ def measure_traffic(name, precision, steps=4, timeout=150):
     for k in per_kernel:
         if "FETCH_SIZE" in per_kernel[k]:
             per_kernel[k]["FETCH_SIZE"] *= 2.0
+    mfma = {c: res[c] for c in MOPS_COUNTERS if c in res}
     return {"bytes_per_step": fetch + res["WRITE_SIZE"], "fetch_bytes": fetch,
-            "write_bytes": res["WRITE_SIZE"], "per_kernel": per_kernel,
-            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over %d steps of this "
-                      "binary, run by bench.py; FETCH_SIZE x2 (gfx950 16 B/lane streams); fabric-side "
-                      "bytes (Infinity-Cache hits included)" % steps}
+            "write_bytes": res["WRITE_SIZE"], "mfma_flops": sum(mfma.values()) if mfma else None,
+            "mfma_flops_by_type": mfma, "per_kernel": per_kernel,
+            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU_MFMA_MOPS_{F16,BF16,F32} (x 512 flops), "
+                      "separate passes over %d steps of this binary, run by bench.py; FETCH_SIZE x2 (gfx950 "
+                      "16 B/lane streams); fabric-side bytes (Infinity-Cache hits included)" % steps}
+
+
+def dynamic_range_db(device, precision):
+    """What the arithmetic leaves in the silent bins of a pure tone, relative to the peak (dB): STFT
+    n_fft=2048 of a sine exactly on bin 400, bins more than 20 away from it, interior frames."""
+    from nnaudio_amd import features
+
+    m = features.STFT(n_fft=2048, hop_length=512, output_format="Complex", verbose=False).to(device)
+    m.precision = precision
+    n = torch.arange(40 * 512, dtype=torch.float64)
+    x = torch.cos(2 * np.pi * 400 * n / 2048 + 0.3).to(torch.float32)[None, :].to(device)
+    with torch.no_grad():
+        y = m(x)[0, :, 4:-4].double()
+    mag = torch.sqrt(y[..., 0] ** 2 + y[..., 1] ** 2)
+    silent = torch.cat((mag[:380], mag[420:]))
+    return float(20 * torch.log10(silent.max() / mag.max() + 1e-300))
 
 
 def cpu_baseline(budget_s=15.0):
@@ -334,34 +425,54 @@ def cpu_baseline(budget_s=15.0):
     return out
 
 
+def self_launch(args):
+    """``python bench.py --gpus N`` outside torch.distributed.run: start N ranks (one per GPU, RCCL)
+    of this script with the same arguments and relay rank 0's JSON line."""
+    import socket
+
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_dev < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, n_dev))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="stft", choices=["stft", "mel", "cqt", "cqt2010", "vqt"])
+    ap.add_argument("--workload", default="stft", choices=["stft", "mel", "gammatone", "cqt", "cqt2010", "vqt"])
     ap.add_argument("--extras", type=int, default=1,
-                    help="also time the fp32 path, CQT84, Mel cfg3, the cfg5 shard and the gather")
+                    help="also time the other arithmetics, CQT84, Mel cfg3, Gammatonegram, the cfg5 shard and the gather")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="untimed start-up work before the warm-up steps (GPU out of its idle clocks)")
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32"],
-                    help="arithmetic of the timed step (the other path is reported under 'paths')")
+    ap.add_argument("--precision", default="auto", choices=["auto"] + list(PRECISIONS),
+                    help="arithmetic of every timed module; auto = each module's own default (STFT family "
+                         "f16x3, the CQT modules fp32; CQT84 is additionally reported in f16x3 and bf16x3)")
     ap.add_argument("--traffic", default="live", choices=["live", "off"],
                     help="live: rocprofv3 PMC passes over a child process (N=1 only); off: null")
     ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    forced = None if args.precision == "auto" else args.precision
 
     if args.pmc_child:
-        pmc_child(args.pmc_child, args.precision, args.steps)
+        pmc_child(args.pmc_child, forced, args.steps)
         return
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("bench.py --gpus %d inside a torch.distributed job of %d ranks" % (args.gpus, world))
     import torch.distributed as dist
 
     if not torch.cuda.is_available():
@@ -393,17 +504,18 @@ def main():
         """Time `steps` forwards in one arithmetic; whole-job numbers (max over ranks)."""
         nnaudio_amd.set_precision(precision)
         wall, dev_s = timed_steps(mod, xin, steps, warmup, sync)
+        nnaudio_amd.set_precision(forced)
         wall, dev_s = max_over_ranks(wall, dev_s)
+        per = dev_s / steps
         res = {"frames_per_s": me["frames"] * world * steps / wall, "ms_per_step": wall / steps * 1e3,
-               "step_device_ms": dev_s / steps * 1e3,
-               "algorithmic_tflops": me["flops"] / (dev_s / steps) / 1e12,
-               "mfma_frac": me["flops"] / (dev_s / steps) / PEAK[precision],
-               "hbm_frac_on_algorithmic_bytes": me["bytes"] / (dev_s / steps) / PEAK_HBM}
-        if me.get("executed"):  # (algorithmic > executed for the folded STFT: mfma_frac can exceed 1)
-            ex = me["executed"] * (3.0 if precision == "bf16x3" else 1.0) / (dev_s / steps)
-            res["executed_mfma_tflops"] = ex / 1e12
-            res["executed_frac_of_raw_mfma_peak"] = ex / (PEAK_BF16_MFMA if precision == "bf16x3"
-                                                          else PEAK_F32_MFMA)
+               "step_device_ms": per * 1e3,
+               "algorithmic_tflops": me["flops"] / per / 1e12,
+               "algorithmic_frac": me["flops"] / per / PEAK[precision],
+               "hbm_frac_on_algorithmic_bytes": me["bytes"] / per / PEAK_HBM}
+        ex = executed_flops(me, precision)
+        if ex:
+            res["executed_mfma_tflops"] = ex / per / 1e12
+            res["mfma_frac"] = ex / per / RAW_PEAK[precision]  # executed flops / raw MFMA peak: <= 1
         return wall, dev_s, res
 
     def dominant_kernel(precision):
@@ -420,27 +532,42 @@ def main():
         _, d = timed_steps(_M(), x, args.steps, 2, sync)
         fl = 2.0 * 2048 * 2048 * meta["frames"]
         per = d / args.steps
+        bins, taps = fold_geometry(1024, 2048, False)
+        ex = 2.0 * (2 * bins) * taps * ((meta["frames"] + 127) // 128 * 128) * MFMAS_PER_PRODUCT[precision]
         return {"name": engine.describe_framed_kernel(precision, prep), "avg_ms": per * 1e3,
-                "algorithmic_flops": fl, "tflops": fl / per / 1e12, "frac_of_peak": fl / per / PEAK[precision]}
+                "algorithmic_flops": fl, "algorithmic_tflops": fl / per / 1e12,
+                "algorithmic_frac": fl / per / PEAK[precision],
+                "executed_flops": ex, "executed_tflops": ex / per / 1e12, "frac_of_raw_mfma_peak": ex / per / RAW_PEAK[precision]}
 
-    prec = args.precision
-    other = "fp32" if prec == "bf16x3" else "bf16x3"
-    nnaudio_amd.set_precision(prec)
+    prec = module_precision(args.workload, forced)
+    nnaudio_amd.set_precision(forced)
     prewarm_ms = prewarm(module, x, args.prewarm_ms)
     wall, dev_s, primary = run_path(module, x, meta, prec, args.steps, args.warmup)
     paths = {prec: primary}
     dominant = None
     if args.workload == "stft":
         dominant = dominant_kernel(prec)
-    if args.extras:
-        _, _, paths[other] = run_path(module, x, meta, other, max(3, args.steps // 2), 2)
-        if args.workload == "stft":
+    if args.extras and args.workload == "stft":
+        for other in PRECISIONS:
+            if other == prec:
+                continue
+            _, _, paths[other] = run_path(module, x, meta, other, max(3, args.steps // 2), 2)
             paths[other]["dominant_kernel"] = dominant_kernel(other)
-    nnaudio_amd.set_precision(prec)
+        for pr in paths:  # what each arithmetic leaves in silent bins, relative to the peak
+            try:
+                paths[pr]["dynamic_range_db"] = dynamic_range_db(device, pr)
+            except Exception as e:
+                paths[pr]["dynamic_range_db"] = None
+                log("dynamic range (%s): %r" % (pr, e))
 
     frames_total = meta["frames"] * world * args.steps
     kern_s = dev_s / args.steps
     src_sha = kernel_source_sha()
+    what = {"f16x3": "f16x3: fp32 operands scaled by powers of two and split into fp16 hi+lo, 3 f16 MFMAs per "
+                     "product, fp32 accumulate (err ~1e-7 of peak: fp32 class); the STFT module's default",
+            "bf16x3": "bf16x3: fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate "
+                      "(err ~5e-6 of peak, 1e-4 parity bar)",
+            "fp32": "fp32 MFMA, fp32 accumulate"}[prec]
     out = {
         "metric": "spectrogram frames/sec",
         "value": frames_total / wall,
@@ -452,54 +579,62 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "bf16x3" if prec == "bf16x3" else "f32",
+        "dtype": "f32" if prec == "fp32" else prec,
         "data": "synthetic",
         "prewarm_ms": prewarm_ms,
         "kernel_source_sha": src_sha,
+        "dynamic_range_db": paths[prec].get("dynamic_range_db"),
         "config": {"workload": meta["tag"], "global_batch": meta["B"] * world,
                    "clip_samples": meta["L"], "frames_per_clip": meta["T"],
-                   "precision": ("bf16x3: fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per "
-                                 "product, fp32 accumulate (err ~5e-6 of peak, 1e-4 parity bar)"
-                                 if prec == "bf16x3" else "fp32 MFMA, fp32 accumulate"),
+                   "precision": what,
                    "parallelism": "batch-sharded x%d, no data-path collective" % world},
         "roofline": roofline_block(
             meta, kern_s, prec,
-            kernel="one step = pre-pass + main contraction; achieved = algorithmic flops (2 per tap "
-                   "of the dense contraction the reference performs) / step device time; peak = MFMA "
-                   "peak of the precision used in algorithmic flops (bf16x3: 2500 dense bf16 / 3 "
-                   "MFMAs per product)"),
+            kernel="one step = pre-pass + main contraction; achieved = EXECUTED MFMA flops (the folded kernels run "
+                   "a quarter of the dense taps, x 3 MFMAs per product for the split arithmetics) / step device "
+                   "time; peak = raw dense MFMA peak of the instruction"),
         "paths": paths,
     }
     out["roofline"]["dominant_kernel"] = dominant
 
     extra = {}
-    traffic_jobs = [(args.workload, "roofline")]
+    traffic_jobs = [(args.workload, forced, out, "roofline")]
     if args.extras:
         del x
         torch.cuda.empty_cache()
         n2 = max(20, args.steps)  # every extra under the headline's rules: pre-warm + >= 20 steps
-        for name in ("cqt", "mel", "cqt2010", "vqt"):
+        jobs = [("cqt", "f16x3", None), ("cqt", "bf16x3", None), ("cqt", "fp32", None),
+                ("mel", None, None), ("gammatone", None, None), ("cqt2010", None, None), ("vqt", None, None)]
+        if world > 1:  # cfg4's real shard: 128 clips over 8 ranks
+            jobs.append(("cqt", "f16x3", 16))
+        for name, pr2, b2 in jobs:
             if name == args.workload:
                 continue
+            key = name if pr2 is None else ("%s_%s" % (name, pr2) + ("_cfg4_shard" if b2 else ""))
             try:
-                m2, mk2, me2 = workload(name, device)
+                pr = pr2 or module_precision(name, forced)
+                m2, mk2, me2 = workload(name, device, B=b2)
+                m2.precision = pr2  # (None: the module's default / the process-wide override)
                 x2 = mk2(100 + rank)
-                nnaudio_amd.set_precision(prec)
                 prewarm(m2, x2, args.prewarm_ms)
-                w2, d2, r2 = run_path(m2, x2, me2, prec, n2, max(5, args.warmup // 2))
-                blk = roofline_block(me2, d2 / n2, prec)
-                r2.update(workload=me2["tag"], precision=prec, steps=n2, roofline=blk)
-                extra[name] = r2
-                if name == "cqt":
-                    blk["kernel"] = ("one step = split pre-pass + framed_bf16x3_strip_kernel; useful "
-                                     "(support-aware) flops 2*2*sum(lenghts) per frame / step device time")
-                    out["roofline_cqt84"] = dict(blk, workload=me2["tag"], frames_per_s=r2["frames_per_s"],
+                w2, d2, r2 = run_path(m2, x2, me2, pr, n2, max(5, args.warmup // 2))
+                blk = roofline_block(me2, d2 / n2, pr)
+                r2.update(workload=me2["tag"], precision=pr, steps=n2, roofline=blk)
+                extra[key] = r2
+                if name == "cqt" and pr == "f16x3" and not b2:
+                    blk["kernel"] = ("one step = clip absmax + split pre-passes + framed_f16x3_strip_kernel; achieved = "
+                                     "executed MFMA flops (16-bin row tiles over the tap range of their longest bin) / "
+                                     "step device time; algorithmic = useful (support-aware) flops 2*2*sum(lenghts) per frame")
+                    out["roofline_cqt84"] = dict(blk, workload=me2["tag"], precision=pr,
+                                                 frames_per_s=r2["frames_per_s"],
                                                  ms_per_step=r2["ms_per_step"], steps=n2)
-                    traffic_jobs.append(("cqt", "roofline_cqt84"))
+                    traffic_jobs.append(("cqt", "f16x3", out, "roofline_cqt84"))
+                elif pr2 is None:
+                    traffic_jobs.append((name, forced, extra[key], "roofline"))
                 del m2, x2
                 torch.cuda.empty_cache()
             except Exception as e:  # extras must never take the primary number down
-                extra[name] = {"error": repr(e)}
+                extra[key] = {"error": repr(e)}
         out["extra"] = extra
 
     # output reassembly over xGMI (RCCL all-gather), outside the reported value: the step with the
@@ -534,16 +669,27 @@ def main():
 
     if rank == 0 and world == 1 and args.traffic == "live":
         torch.cuda.empty_cache()
-        for name, key in traffic_jobs:
-            if key not in out:
+        for name, pr, holder, key in traffic_jobs:
+            if key not in holder:
                 continue
+            blk = holder[key]
             try:
-                t = measure_traffic(name, prec)
-                out[key]["traffic"] = t["bytes_per_step"]
-                out[key]["traffic_detail"] = {k: t[k] for k in ("fetch_bytes", "write_bytes", "per_kernel", "method")}
+                t = measure_traffic(name, pr)
+                blk["traffic"] = t["bytes_per_step"]
+                blk["traffic_detail"] = {k: t[k] for k in ("fetch_bytes", "write_bytes", "per_kernel", "method")}
+                if t.get("mfma_flops") and blk.get("bound") == "mfma":
+                    # the counted MFMA flops replace the tiling model behind achieved / frac
+                    per = blk["step_device_ms"] * 1e-3
+                    raw = RAW_PEAK[module_precision(name, pr)]
+                    blk.update(executed_flops_per_launch=t["mfma_flops"], executed_source="pmc",
+                               executed_mfma_tflops=t["mfma_flops"] / per / 1e12,
+                               executed_frac_of_raw_mfma_peak=t["mfma_flops"] / per / raw,
+                               executed_by_instruction=t["mfma_flops_by_type"],
+                               achieved=t["mfma_flops"] / per / 1e12, peak=raw / 1e12,
+                               frac=min(1.0, t["mfma_flops"] / per / raw))
             except Exception as e:
-                out[key]["traffic"] = None
-                out[key]["traffic_detail"] = {"error": repr(e)[:300]}
+                blk["traffic"] = None
+                blk["traffic_detail"] = {"error": repr(e)[:300]}
 
     if rank == 0 and world == 1 and args.cpu_baseline:
         try:

@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(256) split_signal_kernel(const KParams p,
     return;
   }
   if (p.split_f16) {  // MISPEC_PREC_F16X3: (hi, lo) fp16 pairs of the clip x its power of two
-    const float sc = clip_scale_of(p.clip_absmax[c]);
+    const float sc = clip_scale_of(p.clip_absmax[(long long)c * CLIP_ABSMAX_STRIDE]);
     uint2 h2, l2;
     f16_split2(v[0] * sc, v[1] * sc, h2.x, l2.x);
     f16_split2(v[2] * sc, v[3] * sc, h2.y, l2.y);
@@ -153,27 +153,40 @@ __global__ void __launch_bounds__(256) split_signal_kernel(const KParams p,
 }
 
 // MISPEC_PREC_F16X3: bit pattern of max |x[c, :]| per clip (the padding mirrors or zero-fills the
-// clip: the same bound holds for the padded clip).  grid (chunks of 4096 samples, n_clips); dst is
-// zeroed by the caller (hipMemsetAsync) -- positive floats order like their bit patterns.
+// clip: the same bound holds for the padded clip).  grid (chunks of ABSMAX_CHUNK samples, n_clips), ONE
+// atomic per workgroup, every clip's word in a 128-byte line of its own (CLIP_ABSMAX_STRIDE): with an
+// atomic per wave on adjacent words the kernel spent 0.2 ms queueing 27 000 device-scope atomics on
+// two cache lines.  dst is zeroed by the caller (hipMemsetAsync) -- positive floats order like their
+// bit patterns.
 __global__ void __launch_bounds__(256) clip_absmax_kernel(const float *__restrict__ x, long long clip_stride,
                                                           int n_samples, unsigned *__restrict__ dst) {
   const int c = blockIdx.y;
   const float *xc = x + (long long)c * clip_stride;
-  const long long q0 = (long long)blockIdx.x * 4096 + 4 * threadIdx.x;
+  const long long q0 = (long long)blockIdx.x * ABSMAX_CHUNK + 4 * threadIdx.x;
   float m = 0.f;
+  f32x4u v[ABSMAX_CHUNK / 1024];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < ABSMAX_CHUNK / 1024; ++u) {
     const long long q = q0 + 1024 * u;
+    v[u] = f32x4u{0.f, 0.f, 0.f, 0.f};
     if (q + 4 <= n_samples) {
-      const f32x4u v = *reinterpret_cast<const f32x4u *>(xc + q);
-      m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+      v[u] = *reinterpret_cast<const f32x4u *>(xc + q);
     } else {
       for (long long i = q; i < n_samples; ++i) m = fmaxf(m, fabsf(xc[i]));
     }
   }
 #pragma unroll
+  for (int u = 0; u < ABSMAX_CHUNK / 1024; ++u)
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u][0]), fabsf(v[u][1]))), fmaxf(fabsf(v[u][2]), fabsf(v[u][3])));
+#pragma unroll
   for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(dst + c, __float_as_uint(m));
+  __shared__ float sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    if (m > 0.f) atomicMax(dst + (long long)c * CLIP_ABSMAX_STRIDE, __float_as_uint(m));
+  }
 }
 
 // MISPEC_PREC_F16X3: per basis row (bin), the power of two that puts its largest |re|, |im| below

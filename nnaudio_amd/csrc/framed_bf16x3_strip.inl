@@ -517,7 +517,7 @@ __device__ __forceinline__ void framed_strip_body(const KParams &p, const StripP
         float *ob = p.out + (long long)c * p.out_clip_stride + (long long)t * E +
                     (long long)(p.out_row_offset + bin0) * p.out_row_stride;
         float cu = 1.f;  // FOLD_F16X3: what undoes the clip's operand scale
-        if (ARITH == FOLD_F16X3) cu = clip_unscale_of(p.clip_absmax[c < p.n_clips ? c : 0]);
+        if (ARITH == FOLD_F16X3) cu = clip_unscale_of(p.clip_absmax[(long long)(c < p.n_clips ? c : 0) * CLIP_ABSMAX_STRIDE]);
 #pragma unroll
         for (int e2 = 0; e2 < 8; ++e2) {
           const int db = (e2 & 1) + 4 * (e2 >> 1);

@@ -157,52 +157,36 @@ __global__ void __launch_bounds__(256) fold2_frames_kernel(const KParams p, unsi
   const long long qa = (long long)t0 * p.hop - p.pad;
   const bool interior = qa >= 0 && qa + (long long)(nf - 1) * p.hop + N <= p.n_samples;
 
-  // ---- FOLD_F16X3: the scale of this workgroup's frames from the largest |sample| they read
-  float scale = 1.f;
-  if (p.fold_arith == FOLD_F16X3) {
-    const long long wa = (long long)tw0 * p.hop - p.pad, wb = wa + (long long)(nfw - 1) * p.hop + N;
-    float m = 0.f;
-    if (wa >= 0 && wb <= p.n_samples) {
-      long long q = wa + 4 * threadIdx.x;
-      for (; q + 4 <= wb; q += 1024) {
-        const f32x4u v = *reinterpret_cast<const f32x4u *>(x + q);
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-      }
-      for (; q < wb; ++q) m = fmaxf(m, fabsf(x[q]));
-    } else {
-      for (long long q = wa + threadIdx.x; q < wb; q += 256)
-        m = fmaxf(m, fabsf(fetch_sample(p.x, (long long)c * p.x_clip_stride, (int)q, p.n_samples, p.pad_mode, true)));
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
-    if ((threadIdx.x & 63) == 0) red[2 * 4 * FOLD2_FR + (threadIdx.x >> 6)] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(red[2 * 4 * FOLD2_FR], red[2 * 4 * FOLD2_FR + 1]),
-              fmaxf(red[2 * 4 * FOLD2_FR + 2], red[2 * 4 * FOLD2_FR + 3]));
-    m *= p.fold_wmax;
-    // m = f 2^e, f in [0.5, 1): the four-sample combinations stay below 2^(e+2); scale 2^(13-e)
-    const int e = absmax_exponent(m);
-    scale = pow2f(13 - e);
-    if ((int)threadIdx.x < nfw) p.col_unscale[col0 + threadIdx.x] = pow2f(e - 13 - 14);  // also the basis' 2^14
-  }
-
-  for (int j0 = 4 * gt; j0 < Kf && nf > 0; j0 += 4 * TG) {
-    float ep[FOLD2_FR][4], em[FOLD2_FR][4], op[FOLD2_FR][4], om[FOLD2_FR][4];
+  // one trip's values: slots j0 .. j0 + 3 of the group's frames
+  // (returns the largest magnitude among them)
+  auto compute = [&](int j0, float (&ep)[FOLD2_FR][4], float (&em)[FOLD2_FR][4], float (&op)[FOLD2_FR][4],
+                     float (&om)[FOLD2_FR][4]) __attribute__((always_inline)) -> float {
+    float mx = 0.f;
     if (j0 + 4 <= Q) {  // slots of n = j0+1 .. j0+4: samples n, N-n, M-n, M+n
       const f32x4u wA = *reinterpret_cast<const f32x4u *>(win + j0 + 1);
       const f32x4u wB = *reinterpret_cast<const f32x4u *>(win + N - j0 - 4);
       const f32x4u wC = *reinterpret_cast<const f32x4u *>(win + M - j0 - 4);
       const f32x4u wD = *reinterpret_cast<const f32x4u *>(win + M + j0 + 1);
-      f32x4u A[FOLD2_FR], B[FOLD2_FR], C[FOLD2_FR], D[FOLD2_FR];
+      float A[FOLD2_FR][4], B[FOLD2_FR][4], C[FOLD2_FR][4], D[FOLD2_FR][4];
       if (interior) {
+        f32x4u va[FOLD2_FR], vb[FOLD2_FR], vc[FOLD2_FR], vd[FOLD2_FR];
 #pragma unroll
         for (int f = 0; f < FOLD2_FR; ++f) {
           const long long q0 = qa + (long long)(f < nf ? f : 0) * p.hop;
-          A[f] = *reinterpret_cast<const f32x4u *>(x + q0 + j0 + 1);
-          B[f] = *reinterpret_cast<const f32x4u *>(x + q0 + N - j0 - 4);
-          C[f] = *reinterpret_cast<const f32x4u *>(x + q0 + M - j0 - 4);
-          D[f] = *reinterpret_cast<const f32x4u *>(x + q0 + M + j0 + 1);
+          va[f] = *reinterpret_cast<const f32x4u *>(x + q0 + j0 + 1);
+          vb[f] = *reinterpret_cast<const f32x4u *>(x + q0 + N - j0 - 4);
+          vc[f] = *reinterpret_cast<const f32x4u *>(x + q0 + M - j0 - 4);
+          vd[f] = *reinterpret_cast<const f32x4u *>(x + q0 + M + j0 + 1);
         }
+#pragma unroll
+        for (int f = 0; f < FOLD2_FR; ++f)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            A[f][i] = va[f][i];
+            B[f][i] = vb[f][i];
+            C[f][i] = vc[f][i];
+            D[f][i] = vd[f][i];
+          }
       } else {
 #pragma unroll
         for (int f = 0; f < FOLD2_FR; ++f) {
@@ -228,6 +212,7 @@ __global__ void __launch_bounds__(256) fold2_frames_kernel(const KParams p, unsi
           em[f][i] = s1 - s2;
           op[f][i] = d1 + d2;
           om[f][i] = d1 - d2;
+          mx = fmaxf(fmaxf(mx, fmaxf(fabsf(ep[f][i]), fabsf(em[f][i]))), fmaxf(fabsf(op[f][i]), fabsf(om[f][i])));
         }
     } else {  // slot Q: n = 0 (samples 0 and M), then the zero padding
 #pragma unroll
@@ -239,14 +224,51 @@ __global__ void __launch_bounds__(256) fold2_frames_kernel(const KParams p, unsi
           y0 = win[0] * fetch_sample(p.x, cb, (int)q0, p.n_samples, p.pad_mode, true);
           yM = win[M] * fetch_sample(p.x, cb, (int)(q0 + M), p.n_samples, p.pad_mode, true);
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          ep[f][i] = i == 0 ? y0 + yM : 0.f;
-          em[f][i] = i == 0 ? y0 - yM : 0.f;
-          op[f][i] = om[f][i] = 0.f;
-        }
+        ep[f][0] = y0 + yM;
+        em[f][0] = y0 - yM;
+        op[f][0] = om[f][0] = 0.f;
+        ep[f][1] = ep[f][2] = ep[f][3] = 0.f;
+        em[f][1] = em[f][2] = em[f][3] = 0.f;
+        op[f][1] = op[f][2] = op[f][3] = 0.f;
+        om[f][1] = om[f][2] = om[f][3] = 0.f;
+        mx = fmaxf(mx, fmaxf(fabsf(ep[f][0]), fabsf(em[f][0])));
       }
     }
+    return mx;
+  };
+  // four slots of the two planes of one staging row R (u = first slot inside the row's stage)
+  auto stage_quad = [&](int R, int u, const float (&c0)[4], const float (&c1)[4], float scale)
+                        __attribute__((always_inline)) {
+    const int sw = R & 7;
+    unsigned char *r = smem_raw + (size_t)R * FOLD_ROWB;
+    if (p.fold_arith == FOLD_F32) {
+      const f32x4v v0 = {c0[0], c0[1], c0[2], c0[3]}, v1 = {c1[0], c1[1], c1[2], c1[3]};
+      *reinterpret_cast<f32x4v *>(r + (((u >> 2)) ^ sw) * 16) = v0;
+      *reinterpret_cast<f32x4v *>(r + ((4 + (u >> 2)) ^ sw) * 16) = v1;
+    } else {
+      uint2 h0, l0, h1, l1;
+      if (p.fold_arith == FOLD_F16X3) {
+        f16_split2(c0[0] * scale, c0[1] * scale, h0.x, l0.x);
+        f16_split2(c0[2] * scale, c0[3] * scale, h0.y, l0.y);
+        f16_split2(c1[0] * scale, c1[1] * scale, h1.x, l1.x);
+        f16_split2(c1[2] * scale, c1[3] * scale, h1.y, l1.y);
+      } else {
+        bf16_split2(c0[0], c0[1], h0.x, l0.x);
+        bf16_split2(c0[2], c0[3], h0.y, l0.y);
+        bf16_split2(c1[0], c1[1], h1.x, l1.x);
+        bf16_split2(c1[2], c1[3], h1.y, l1.y);
+      }
+      const int h = u >> 3, sub = (u & 4) * 2;
+      *reinterpret_cast<uint2 *>(r + ((0 + h) ^ sw) * 16 + sub) = h0;
+      *reinterpret_cast<uint2 *>(r + ((2 + h) ^ sw) * 16 + sub) = l0;
+      *reinterpret_cast<uint2 *>(r + ((4 + h) ^ sw) * 16 + sub) = h1;
+      *reinterpret_cast<uint2 *>(r + ((6 + h) ^ sw) * 16 + sub) = l1;
+    }
+  };
+  // the last even bin's partial sums, the split and the staging of one trip's values
+  auto emit = [&](int j0, const float (&ep)[FOLD2_FR][4], const float (&em)[FOLD2_FR][4],
+                  const float (&op)[FOLD2_FR][4], const float (&om)[FOLD2_FR][4], float scale)
+                  __attribute__((always_inline)) {
     f32x4v we = {0.f, 0.f, 0.f, 0.f}, wo = {0.f, 0.f, 0.f, 0.f};
     if (le) {
       we = *reinterpret_cast<const f32x4v *>(le + j0);
@@ -260,36 +282,66 @@ __global__ void __launch_bounds__(256) fold2_frames_kernel(const KParams p, unsi
         po[f] = fmaf(wo[i], om[f][i], po[f]);
       }
       const int u = j0 % FOLD_KC;
+      // staging rows of (frame, operand, stage); operand 0 = (Ep | Om), 1 = (Em | Op)
+      stage_quad(((grp * FOLD2_FR + f) * 2 + 0) * rows_f + j0 / FOLD_KC, u, ep[f], om[f], scale);
+      stage_quad(((grp * FOLD2_FR + f) * 2 + 1) * rows_f + j0 / FOLD_KC, u, em[f], op[f], scale);
+    }
+  };
+  // workgroup maximum of a per-thread value (the idle groups of the last block take part)
+  auto wg_max = [&](float m) __attribute__((always_inline)) -> float {
 #pragma unroll
-      for (int par = 0; par < 2; ++par) {
-        // staging row of (frame, operand, stage); operand 0 = (Ep | Om), 1 = (Em | Op)
-        const int R = ((grp * FOLD2_FR + f) * 2 + par) * rows_f + j0 / FOLD_KC, sw = R & 7;
-        unsigned char *r = smem_raw + (size_t)R * FOLD_ROWB;
-        const float *c0 = par ? em[f] : ep[f], *c1 = par ? op[f] : om[f];
-        if (p.fold_arith == FOLD_F32) {
-          const f32x4v v0 = {c0[0], c0[1], c0[2], c0[3]}, v1 = {c1[0], c1[1], c1[2], c1[3]};
-          *reinterpret_cast<f32x4v *>(r + (((u >> 2)) ^ sw) * 16) = v0;
-          *reinterpret_cast<f32x4v *>(r + ((4 + (u >> 2)) ^ sw) * 16) = v1;
-        } else {
-          uint2 h0, l0, h1, l1;
-          if (p.fold_arith == FOLD_F16X3) {
-            f16_split2(c0[0] * scale, c0[1] * scale, h0.x, l0.x);
-            f16_split2(c0[2] * scale, c0[3] * scale, h0.y, l0.y);
-            f16_split2(c1[0] * scale, c1[1] * scale, h1.x, l1.x);
-            f16_split2(c1[2] * scale, c1[3] * scale, h1.y, l1.y);
-          } else {
-            bf16_split2(c0[0], c0[1], h0.x, l0.x);
-            bf16_split2(c0[2], c0[3], h0.y, l0.y);
-            bf16_split2(c1[0], c1[1], h1.x, l1.x);
-            bf16_split2(c1[2], c1[3], h1.y, l1.y);
-          }
-          const int h = u >> 3, sub = (u & 4) * 2;
-          *reinterpret_cast<uint2 *>(r + ((0 + h) ^ sw) * 16 + sub) = h0;
-          *reinterpret_cast<uint2 *>(r + ((2 + h) ^ sw) * 16 + sub) = l0;
-          *reinterpret_cast<uint2 *>(r + ((4 + h) ^ sw) * 16 + sub) = h1;
-          *reinterpret_cast<uint2 *>(r + ((6 + h) ^ sw) * 16 + sub) = l1;
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if ((threadIdx.x & 63) == 0) red[2 * 4 * FOLD2_FR + (threadIdx.x >> 6)] = m;
+    __syncthreads();
+    return fmaxf(fmaxf(red[2 * 4 * FOLD2_FR], red[2 * 4 * FOLD2_FR + 1]),
+                 fmaxf(red[2 * 4 * FOLD2_FR + 2], red[2 * 4 * FOLD2_FR + 3]));
+  };
+
+  if (p.fold_arith == FOLD_F16X3 && Kf <= 8 * TG) {
+    // ---- FOLD_F16X3, every thread's slots fit two trips (the paired quads, then slot Q): all values
+    // are formed first, the workgroup's largest magnitude m = f 2^e, f in [0.5, 1), gives the scale
+    // 2^(15-e) that keeps the fp16 pairs below 2^15, then they are split and staged
+    float ep0[FOLD2_FR][4], em0[FOLD2_FR][4], op0[FOLD2_FR][4], om0[FOLD2_FR][4];
+    float ep1[FOLD2_FR][4], em1[FOLD2_FR][4], op1[FOLD2_FR][4], om1[FOLD2_FR][4];
+    const int j0 = 4 * gt, j1 = j0 + 4 * TG;
+    float m = 0.f;
+    const bool live = nf > 0 && j0 < Kf;  // (short kernels: more threads than quads)
+    const bool live1 = live && j1 < Kf;
+    if (live) m = compute(j0, ep0, em0, op0, om0);
+    if (live1) m = fmaxf(m, compute(j1, ep1, em1, op1, om1));
+    m = wg_max(m);
+    const int e = absmax_exponent(m);
+    const float scale = pow2f(15 - e);
+    if ((int)threadIdx.x < nfw) p.col_unscale[col0 + threadIdx.x] = pow2f(e - 15 - 14);  // also the basis' 2^14
+    if (live) emit(j0, ep0, em0, op0, om0, scale);
+    if (live1) emit(j1, ep1, em1, op1, om1, scale);
+  } else {
+    // ---- any other case: FOLD_F16X3 takes its scale from the largest |sample| the workgroup reads
+    // (x max |window|: the four-sample combinations stay below 2^(e+2))
+    float scale = 1.f;
+    if (p.fold_arith == FOLD_F16X3) {
+      const long long wa = (long long)tw0 * p.hop - p.pad, wb = wa + (long long)(nfw - 1) * p.hop + N;
+      float m = 0.f;
+      if (wa >= 0 && wb <= p.n_samples) {
+        long long q = wa + 4 * threadIdx.x;
+        for (; q + 4 <= wb; q += 1024) {
+          const f32x4u v = *reinterpret_cast<const f32x4u *>(x + q);
+          m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         }
+        for (; q < wb; ++q) m = fmaxf(m, fabsf(x[q]));
+      } else {
+        for (long long q = wa + threadIdx.x; q < wb; q += 256)
+          m = fmaxf(m, fabsf(fetch_sample(p.x, (long long)c * p.x_clip_stride, (int)q, p.n_samples, p.pad_mode, true)));
       }
+      m = wg_max(m) * p.fold_wmax;
+      const int e = absmax_exponent(m);
+      scale = pow2f(13 - e);
+      if ((int)threadIdx.x < nfw) p.col_unscale[col0 + threadIdx.x] = pow2f(e - 13 - 14);  // also the basis' 2^14
+    }
+    for (int j0 = 4 * gt; j0 < Kf && nf > 0; j0 += 4 * TG) {
+      float ep[FOLD2_FR][4], em[FOLD2_FR][4], op[FOLD2_FR][4], om[FOLD2_FR][4];
+      (void)compute(j0, ep, em, op, om);
+      emit(j0, ep, em, op, om, scale);
     }
   }
   if (le) {

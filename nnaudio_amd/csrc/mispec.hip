@@ -97,6 +97,8 @@ __device__ __forceinline__ int absmax_exponent(float m) {
 }
 __device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
 constexpr int F16_TOP = 14;  // scaled operands of the strip kernel stay below 2^14
+constexpr int ABSMAX_CHUNK = 16384;     // samples per workgroup of clip_absmax_kernel
+constexpr int CLIP_ABSMAX_STRIDE = 32;  // unsigned words between the clips' absmax words (own cache lines)
 __device__ __forceinline__ float clip_scale_of(unsigned absmax_bits) {
   return pow2f(F16_TOP - absmax_exponent(__uint_as_float(absmax_bits)));
 }
@@ -2834,7 +2836,7 @@ bool strip16_ok(const mispec_framed_gemm_args *a, const KParams &p, int n_cu, St
 
 // workspace: [edge spans (unused here) | (hi, lo) planes + job counter | per-clip absmax bits]
 long long strip16_ws_bytes(const KParams &p, const SplitPlan &sp) {
-  return sp.edge_bytes + sp.bytes + round_up_ll(p.n_clips * (long long)sizeof(unsigned), 256);
+  return sp.edge_bytes + sp.bytes + p.n_clips * (long long)(CLIP_ABSMAX_STRIDE * sizeof(unsigned));
 }
 
 int launch_strip16(KParams p, const mispec_framed_gemm_args *a, const StripPlan &plan, int n_cu,
@@ -2854,9 +2856,9 @@ int launch_strip16(KParams p, const mispec_framed_gemm_args *a, const StripPlan 
   p.afrag = static_cast<const unsigned short *>(a->basis_split);
   p.row_unscale = reinterpret_cast<const float *>(
       static_cast<const char *>(a->basis_split) + (long long)((p.n_bins + 15) / 16) * p.Ks * 128 + 4096);
-  if (hipMemsetAsync(p.clip_absmax, 0, p.n_clips * sizeof(unsigned), stream) != hipSuccess)
+  if (hipMemsetAsync(p.clip_absmax, 0, (size_t)p.n_clips * CLIP_ABSMAX_STRIDE * sizeof(unsigned), stream) != hipSuccess)
     return fail(MISPEC_E_HIP, "hipMemsetAsync failed%s");
-  hipLaunchKernelGGL(clip_absmax_kernel, dim3((unsigned)((p.n_samples + 4095) / 4096), (unsigned)p.n_clips),
+  hipLaunchKernelGGL(clip_absmax_kernel, dim3((unsigned)((p.n_samples + ABSMAX_CHUNK - 1) / ABSMAX_CHUNK), (unsigned)p.n_clips),
                      dim3(256), 0, stream, p.x, p.x_clip_stride, p.n_samples, p.clip_absmax);
   const unsigned gx = (unsigned)((sp.slot + 1023) / 1024);
   hipLaunchKernelGGL(split_signal_kernel, dim3(gx, (unsigned)p.n_clips), dim3(256), 0, stream, p, xs);

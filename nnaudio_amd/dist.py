@@ -41,15 +41,17 @@ def _aliasing_ok(group):
     return dist.get_backend(group) == "nccl"
 
 
-def gather_in_place(full, n_clips, group=None, async_op=False):
+def gather_in_place(full, n_clips, group=None, async_op=False, even_alone=False):
     """All-gather ``full`` (``(n_clips, ...)``, contiguous), whose block ``shard_bounds(rank)``
     this rank has already filled, so that every rank holds every block.  Equal blocks: ONE
     in-place ``all_gather_into_tensor``.  Ragged split (``n_clips % world != 0``): one in-place
     broadcast per rank (no padding, no staging).  Returns the list of async work handles
-    (empty when ``async_op`` is False)."""
+    (empty when ``async_op`` is False).  A single rank has nothing to gather and returns at once,
+    unless ``even_alone`` asks for the collective anyway (the aliased in-place form on RCCL with
+    one rank: tests/test_gpu_parity.py)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    if world == 1:
+    if world == 1 and not even_alone:
         return []
     works = []
     if n_clips % world == 0:
@@ -144,13 +146,18 @@ def sharded_forward(module, x_full, gather=True, group=None, chunks=1, **fwd):
 class ShardedModule(torch.nn.Module):
     """``module`` wrapped so that ``forward(x_full)`` is ``sharded_forward`` with a persistent
     gather buffer: from the second call on (same input shape) the kernels write straight into
-    the buffer's slice and nothing is allocated or copied."""
+    the buffer's slice and nothing is allocated or copied.
 
-    def __init__(self, module, group=None, gather=True):
+    The returned tensor IS that buffer: the next ``forward`` overwrites it (results kept in a list,
+    or handed to a consumer on another stream, must be copied -- or construct with ``clone=True``,
+    which returns a private copy per call at the price of one device copy)."""
+
+    def __init__(self, module, group=None, gather=True, clone=False):
         super().__init__()
         self.module = module
         self.group = group
         self.gather = gather
+        self.clone = clone
         self._full = None
 
     def forward(self, x_full, **fwd):
@@ -163,17 +170,19 @@ class ShardedModule(torch.nn.Module):
         full = self._full
         if full is not None and (full.shape[0] != n or full.device != x_full.device):
             full = None
+        y = None
         if full is not None:
             with engine.output_into(full[lo:hi]) as slot:
                 y = self.module(x_full[lo:hi], **fwd)
             if tuple(y.shape[1:]) != tuple(full.shape[1:]) or y.dtype != full.dtype:
-                full = None  # output format changed: fall through to the allocating path
+                full = None  # output format changed (the slot was not taken): new buffer for this y
             elif not slot.taken or y.data_ptr() != full[lo:hi].data_ptr():
                 full[lo:hi].copy_(y)
         if full is None:
-            y = self.module(x_full[lo:hi], **fwd)
+            if y is None:
+                y = self.module(x_full[lo:hi], **fwd)
             full = torch.empty((n,) + tuple(y.shape[1:]), dtype=y.dtype, device=y.device)
             full[lo:hi].copy_(y)
             self._full = full
         gather_in_place(full, n, group=self.group)
-        return full
+        return full.clone() if self.clone else full

@@ -87,7 +87,7 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def fold_geometry(n_bins, K, fused_fb):
+def fold_geometry(n_bins, K, fused_fb=False):
     """(bins inside whole MFMA tiles, folded taps per component) of the folded STFT contraction for
     an n_fft/2+1-bin Fourier basis -- mirror of plan_fold2 / plan_fold in csrc/mispec.hip: the second
     fold (K/4 + 1 taps rounded to 16, even and odd bins in 128-bin tiles, the Nyquist bin in the

@@ -87,8 +87,9 @@ enum {
                          /* operand instead of bf16x3's 16; the scales keep the pairs inside fp16's     */
                          /* 5-bit exponent and are undone on the accumulators): error ~1e-7 of the     */
                          /* spectrum peak, i.e. fp32 class, at the bf16x3 MFMA count.  Served where     */
-                         /* basis_fold2 applies and, with basis_split = mispec_frag_basis_f16(), for    */
-                         /* banks with supports (strip kernel); other shapes run in MISPEC_PREC_F32.    */
+                         /* basis_fold2 / basis_fold apply and, with basis_split =                       */
+                         /* mispec_frag_basis_f16(), for banks with supports (strip kernel); other       */
+                         /* shapes run in MISPEC_PREC_F32.                                              */
 };
 
 /*
@@ -165,7 +166,7 @@ typedef struct mispec_framed_gemm_args {
    * (basis_im) about tap kernel/2 -- every Fourier basis of stft.py:230-245 -- the contraction runs
    * over kernel/2 (+1) folded taps of  x[n] + x[kernel-n]  and  x[n] - x[kernel-n]  instead of
    * `kernel` taps: half the MFMAs.  basis_fold is the output of mispec_fold_basis_bf16()
-   * (MISPEC_PREC_BF16X3) or mispec_fold_basis_f32() (MISPEC_PREC_F32: same size, fp32 taps) for
+   * (MISPEC_PREC_BF16X3), mispec_fold_basis_f16() (MISPEC_PREC_F16X3) or mispec_fold_basis_f32() (MISPEC_PREC_F32: same size, fp32 taps) for
    * this (basis_re, basis_im, n_bins, kernel) -- the format must match `precision`; the CALLER
    * vouches for the symmetry (the fold routine reports what it neglects).  Used when the shape
    * allows (even kernel, dense complex basis, hop >= kernel/8, automatic tile), otherwise ignored. */
@@ -277,6 +278,10 @@ int mispec_fold_basis_bf16(const float *basis_re, const float *basis_im, int64_t
                            int32_t n_bins, int32_t kernel, int32_t with_tap0, void *dst,
                            int64_t dst_bytes, float *stats, void *stream);
 int mispec_fold_basis_f32(const float *basis_re, const float *basis_im, int64_t basis_row_stride,
+                          int32_t n_bins, int32_t kernel, int32_t with_tap0, void *dst,
+                          int64_t dst_bytes, float *stats, void *stream);
+/* MISPEC_PREC_F16X3: (hi, lo) fp16 pairs of coefficient x 2^14 -- offer it only when stats[1] <= 2 */
+int mispec_fold_basis_f16(const float *basis_re, const float *basis_im, int64_t basis_row_stride,
                           int32_t n_bins, int32_t kernel, int32_t with_tap0, void *dst,
                           int64_t dst_bytes, float *stats, void *stream);
 

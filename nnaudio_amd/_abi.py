@@ -39,6 +39,7 @@ EXPORTS = (
     "mispec_basis_fold_bytes",
     "mispec_fold_basis_bf16",
     "mispec_fold_basis_f32",
+    "mispec_fold_basis_f16",
     "mispec_basis_fold2_bytes",
     "mispec_fold2_basis",
     "mispec_filterbank_f32",
@@ -253,6 +254,11 @@ def _load(path, how):
     lib.mispec_basis_fold_bytes.argtypes = [ctypes.c_int32] * 3
     lib.mispec_fold_basis_bf16.restype = ctypes.c_int
     lib.mispec_fold_basis_bf16.argtypes = [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+        ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+    ]
+    lib.mispec_fold_basis_f16.restype = ctypes.c_int
+    lib.mispec_fold_basis_f16.argtypes = [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
         ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
     ]

@@ -36,6 +36,7 @@
 // the fragment reads): conflict-free ds_read_b128 (MI355X_MICROARCH.md, LDS table).
 
 constexpr int FOLD_KC = 16;                 // folded taps per stage
+constexpr float FOLD_ASCALE = 16384.f;      // FOLD_F16X3: basis coefficients x 2^14 (undone with the frames' scale)
 constexpr int FOLD_ROWB = 128;              // bytes of one stage row: 4 planes x 16 bf16
 constexpr int FOLD_BINS = 128;              // bins per workgroup
 constexpr int FOLD_BN = 256;                // frames per workgroup
@@ -82,7 +83,7 @@ __global__ void __launch_bounds__(256) fold_basis_kernel(const float *__restrict
                                                          int with_tap0, int Kf,
                                                          unsigned short *__restrict__ dst,
                                                          float *__restrict__ last_rows,
-                                                         unsigned *__restrict__ stats, int as_f32) {
+                                                         unsigned *__restrict__ stats, int arith) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int bin = blockIdx.y;
   float asym = 0.f, amax = 0.f;
@@ -105,14 +106,20 @@ __global__ void __launch_bounds__(256) fold_basis_kernel(const float *__restrict
     }
     unsigned short *row = dst + ((long long)bin * (Kf / FOLD_KC) + j / FOLD_KC) * (FOLD_ROWB / 2);
     const int u = j % FOLD_KC;
-    if (as_f32) {  // MISPEC_PREC_F32: the same 128-byte stage rows as [re 16 floats | im 16 floats]
+    if (arith == FOLD_F32) {  // MISPEC_PREC_F32: the same 128-byte stage rows as [re 16 floats | im 16 floats]
       float *frow = reinterpret_cast<float *>(row);
       frow[u] = ae;
       frow[16 + u] = ao;
     } else {
       unsigned eh, el, oh, ol;
-      bf16_split(ae, eh, el);
-      bf16_split(ao, oh, ol);
+      if (arith == FOLD_F16X3) {  // (hi, lo) fp16 pairs of coefficient x 2^14 (the caller checks |c| <= 2)
+        unsigned h2, l2;
+        f16_split2(ae * FOLD_ASCALE, ao * FOLD_ASCALE, h2, l2);
+        eh = h2 & 0xffff, oh = h2 >> 16, el = l2 & 0xffff, ol = l2 >> 16;
+      } else {
+        bf16_split(ae, eh, el);
+        bf16_split(ao, oh, ol);
+      }
       row[u] = (unsigned short)eh;
       row[16 + u] = (unsigned short)el;
       row[32 + u] = (unsigned short)oh;
@@ -192,8 +199,8 @@ __global__ void __launch_bounds__(256) fold_frames_kernel(const KParams p,
   const long long qa = (long long)t0 * p.hop - p.pad;
   const bool interior = qa >= 0 && qa + (long long)(nf - 1) * p.hop + N <= p.n_samples;
   const int rows_f = Kf / FOLD_KC;  // staging rows per frame
-  for (int j0 = 4 * gt; j0 < Kf && nf > 0; j0 += 4 * TG) {
-    float e[FOLD_FR][4], o[FOLD_FR][4];
+  // one trip's values: folded taps j0 .. j0 + 3 of the group's frames (returns their largest magnitude)
+  auto compute = [&](int j0, float (&e)[FOLD_FR][4], float (&o)[FOLD_FR][4]) __attribute__((always_inline)) -> float {
     if (interior && j0 + 4 <= H) {  // taps n = j0+1 .. j0+4 <= N/2: paired, except n = N/2 itself
       f32x4u fw[FOLD_FR], bw[FOLD_FR];
 #pragma unroll
@@ -224,8 +231,9 @@ __global__ void __launch_bounds__(256) fold_frames_kernel(const KParams p,
       for (int f = 0; f < FOLD_FR; ++f) {
         const long long q0 = qa + (long long)(f < nf ? f : 0) * p.hop;
         const float a = (j0 == H && p.fold_tap0) ? x[q0] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) e[f][i] = o[f][i] = i == 0 ? a : 0.f;
+        e[f][0] = o[f][0] = a;
+        e[f][1] = e[f][2] = e[f][3] = 0.f;
+        o[f][1] = o[f][2] = o[f][3] = 0.f;
       }
     } else {
 #pragma unroll
@@ -248,6 +256,18 @@ __global__ void __launch_bounds__(256) fold_frames_kernel(const KParams p,
         }
       }
     }
+    float mx = 0.f;
+    if (p.fold_arith == FOLD_F16X3) {
+#pragma unroll
+      for (int f = 0; f < FOLD_FR; ++f)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mx = fmaxf(mx, fmaxf(fabsf(e[f][i]), fabsf(o[f][i])));
+    }
+    return mx;
+  };
+  // the last bin's partial sums, the split and the staging of one trip's values
+  auto emit = [&](int j0, const float (&e)[FOLD_FR][4], const float (&o)[FOLD_FR][4], float scale)
+                  __attribute__((always_inline)) {
     f32x4v we = {0.f, 0.f, 0.f, 0.f}, wo = {0.f, 0.f, 0.f, 0.f};
     if (le) {
       we = *reinterpret_cast<const f32x4v *>(le + j0);
@@ -267,12 +287,19 @@ __global__ void __launch_bounds__(256) fold_frames_kernel(const KParams p,
         const f32x4v ev = {e[f][0], e[f][1], e[f][2], e[f][3]}, ov = {o[f][0], o[f][1], o[f][2], o[f][3]};
         *reinterpret_cast<f32x4v *>(r + (((u >> 2)) ^ sw) * 16) = ev;
         *reinterpret_cast<f32x4v *>(r + ((4 + (u >> 2)) ^ sw) * 16) = ov;
-      } else {  // [E_hi 16 | E_lo 16 | O_hi 16 | O_lo 16] bf16: plane P = pieces 2P, 2P+1 of 8 taps
+      } else {  // [E_hi 16 | E_lo 16 | O_hi 16 | O_lo 16] bf16 / scaled fp16: plane P = pieces 2P, 2P+1 of 8 taps
         uint2 eh, el, oh, ol;
-        bf16_split2(e[f][0], e[f][1], eh.x, el.x);
-        bf16_split2(e[f][2], e[f][3], eh.y, el.y);
-        bf16_split2(o[f][0], o[f][1], oh.x, ol.x);
-        bf16_split2(o[f][2], o[f][3], oh.y, ol.y);
+        if (p.fold_arith == FOLD_F16X3) {
+          f16_split2(e[f][0] * scale, e[f][1] * scale, eh.x, el.x);
+          f16_split2(e[f][2] * scale, e[f][3] * scale, eh.y, el.y);
+          f16_split2(o[f][0] * scale, o[f][1] * scale, oh.x, ol.x);
+          f16_split2(o[f][2] * scale, o[f][3] * scale, oh.y, ol.y);
+        } else {
+          bf16_split2(e[f][0], e[f][1], eh.x, el.x);
+          bf16_split2(e[f][2], e[f][3], eh.y, el.y);
+          bf16_split2(o[f][0], o[f][1], oh.x, ol.x);
+          bf16_split2(o[f][2], o[f][3], oh.y, ol.y);
+        }
         const int h = u >> 3, sub = (u & 4) * 2;
         *reinterpret_cast<uint2 *>(r + ((0 + h) ^ sw) * 16 + sub) = eh;
         *reinterpret_cast<uint2 *>(r + ((2 + h) ^ sw) * 16 + sub) = el;
@@ -280,10 +307,47 @@ __global__ void __launch_bounds__(256) fold_frames_kernel(const KParams p,
         *reinterpret_cast<uint2 *>(r + ((6 + h) ^ sw) * 16 + sub) = ol;
       }
     }
-  }
-  // the last bin's partial sums: wave totals to LDS before the barrier the staging needs anyway
+  };
   float(*red)[4][FOLD_FR] =
       reinterpret_cast<float(*)[4][FOLD_FR]>(smem_raw + (size_t)FOLD_FR * G * Kf * 8);
+  // workgroup maximum of a per-thread value (slot [2] of the reduction area; idle groups take part)
+  auto wg_max = [&](float m) __attribute__((always_inline)) -> float {
+    float *rm = &red[2][0][0];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if ((threadIdx.x & 63) == 0) rm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    return fmaxf(fmaxf(rm[0], rm[1]), fmaxf(rm[2], rm[3]));
+  };
+  if (p.fold_arith == FOLD_F16X3 && Kf == 4 * TG) {
+    // MISPEC_PREC_F16X3, one trip per thread: the values first, then the scale 2^(15-e) from the
+    // workgroup's largest magnitude m = f 2^e (the fp16 pairs stay below 2^15), then split and stage
+    float e[FOLD_FR][4], o[FOLD_FR][4];
+    float m = 0.f;
+    if (nf > 0) m = compute(4 * gt, e, o);
+    m = wg_max(m);
+    const int ex = absmax_exponent(m);
+    if ((int)threadIdx.x < nfw) p.col_unscale[col0 + threadIdx.x] = pow2f(ex - 15 - 14);  // also the basis' 2^14
+    if (nf > 0) emit(4 * gt, e, o, pow2f(15 - ex));
+  } else {
+    float scale = 1.f;
+    if (p.fold_arith == FOLD_F16X3) {
+      // any other shape: the scale from the largest |sample| the workgroup reads (|E|, |O| <= 2 max)
+      const long long wa = (long long)tw0 * p.hop - p.pad, wb = wa + (long long)(nfw - 1) * p.hop + N;
+      float m = 0.f;
+      for (long long q = wa + threadIdx.x; q < wb; q += 256)
+        m = fmaxf(m, fabsf(fetch_sample(p.x, (long long)c * p.x_clip_stride, (int)q, p.n_samples, p.pad_mode, true)));
+      const int ex = absmax_exponent(wg_max(m));
+      scale = pow2f(14 - ex);
+      if ((int)threadIdx.x < nfw) p.col_unscale[col0 + threadIdx.x] = pow2f(ex - 14 - 14);
+    }
+    for (int j0 = 4 * gt; j0 < Kf && nf > 0; j0 += 4 * TG) {
+      float e[FOLD_FR][4], o[FOLD_FR][4];
+      (void)compute(j0, e, o);
+      emit(j0, e, o, scale);
+    }
+  }
+  // the last bin's partial sums: wave totals to LDS before the barrier the staging needs anyway
   if (le) {
 #pragma unroll
     for (int f = 0; f < FOLD_FR; ++f) {

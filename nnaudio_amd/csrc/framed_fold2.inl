@@ -31,7 +31,6 @@
 // then the odd bins', output rows interleaved (framed_fold_tile).
 
 constexpr int FOLD2_FR = 2;          // frames per thread group of the pre-pass
-constexpr float FOLD2_ASCALE = 16384.f;  // FOLD_F16X3: coefficients (|c| <= 1) x 2^14
 
 __host__ __device__ inline int fold2_taps(int kernel) {
   return (kernel / 4 + 1 + FOLD_KC - 1) / FOLD_KC * FOLD_KC;
@@ -96,7 +95,7 @@ __global__ void __launch_bounds__(256) fold2_basis_kernel(const float *__restric
       unsigned ch, cl, sh, sl;
       if (arith == FOLD_F16X3) {
         unsigned h2, l2;
-        f16_split2(c * FOLD2_ASCALE, s * FOLD2_ASCALE, h2, l2);
+        f16_split2(c * FOLD_ASCALE, s * FOLD_ASCALE, h2, l2);
         ch = h2 & 0xffff, sh = h2 >> 16, cl = l2 & 0xffff, sl = l2 >> 16;
       } else {
         bf16_split(c, ch, cl);

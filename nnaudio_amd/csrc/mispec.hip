@@ -2352,6 +2352,10 @@ int launch_framed_bf16x3(const KParams &p, int tile, hipStream_t stream,
 // ---------------------------------------------------------------------------------
 // symmetric fold (framed_fold.inl): applicability, workspace, launch
 // ---------------------------------------------------------------------------------
+inline int fold_arith_of(int precision) {
+  return precision == MISPEC_PREC_F32 ? FOLD_F32 : (precision == MISPEC_PREC_F16X3 ? FOLD_F16X3 : FOLD_BF16X3);
+}
+
 long long basis_fold_bytes(int n_bins, int kernel, int with_tap0) {
   const long long kf = fold_taps(kernel, with_tap0);
   return (long long)n_bins * kf * 8 + 2 * kf * (long long)sizeof(float);
@@ -2383,7 +2387,8 @@ FoldPlan plan_fold(const mispec_framed_gemm_args *a, const KParams &p) {
   f.with_tap0 = with_tap0;
   f.last_in_prepass = p.n_bins > FOLD_BINS && p.n_bins % FOLD_BINS == 1;
   f.main_bins = f.last_in_prepass ? p.n_bins - 1 : p.n_bins;
-  f.ws_bytes = p.n_cols * (long long)f.kf * 8;
+  f.ws_bytes = p.n_cols * (long long)f.kf * 8 +
+               (a->precision == MISPEC_PREC_F16X3 ? p.n_cols * (long long)sizeof(float) : 0);
   f.ok = true;
   return f;
 }
@@ -2402,16 +2407,20 @@ int launch_fold(KParams p, const mispec_framed_gemm_args *a, const FoldPlan &f, 
   const unsigned short *bf = static_cast<const unsigned short *>(a->basis_fold);
   p.Ks = f.kf;
   p.fold_tap0 = f.with_tap0;
-  p.fold_f32 = a->precision == MISPEC_PREC_F32;
+  p.fold_arith = fold_arith_of(a->precision);
+  p.fold_f32 = p.fold_arith == FOLD_F32;
   p.as = bf;
   p.xs = xf;
+  p.col_unscale = p.fold_arith == FOLD_F16X3
+                      ? reinterpret_cast<float *>(static_cast<char *>(a->workspace) + p.n_cols * (long long)f.kf * 8)
+                      : nullptr;
   const float *last_rows = reinterpret_cast<const float *>(bf + (long long)p.n_bins * f.kf * 4);
   // pre-pass: folded frames (+ the last bin); it sees the whole problem's epilogue fields
   KParams pre = p;
   pre.fold_last = f.last_in_prepass ? last_rows : nullptr;
   pre.fold_last_bin = p.n_bins - 1;
   const int pre_frames = FOLD_FR * fold_groups(f.kf);  // frames per pre-pass workgroup
-  const size_t pre_smem = (size_t)pre_frames * f.kf * 8 + 8 * FOLD_FR * sizeof(float);
+  const size_t pre_smem = (size_t)pre_frames * f.kf * 8 + 12 * FOLD_FR * sizeof(float);
   {
     static std::atomic<unsigned long long> configured_pre{0};
     int rc0 = configure_lds(fold_frames_kernel, 160 * 1024, configured_pre);
@@ -2425,9 +2434,10 @@ int launch_fold(KParams p, const mispec_framed_gemm_args *a, const FoldPlan &f, 
   if (tn * p.n_tiles_m > 0x7fffffffLL) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
   int g = (32 + p.n_tiles_m / 2) / p.n_tiles_m;  // one workgroup per CU, 32 CUs per XCD
   g = g < 1 ? 1 : g;
-  auto kern = p.fold_f32 ? framed_fold32_kernel : framed_fold_kernel;
-  static std::atomic<unsigned long long> configured{0}, configured32{0};
-  int rc = configure_lds(kern, 160 * 1024, p.fold_f32 ? configured32 : configured);
+  auto kern = p.fold_f32 ? framed_fold32_kernel
+                         : (p.fold_arith == FOLD_F16X3 ? framed_fold16_kernel : framed_fold_kernel);
+  static std::atomic<unsigned long long> configured3[3] = {{0}, {0}, {0}};
+  int rc = configure_lds(kern, 160 * 1024, configured3[p.fold_arith]);
   if (rc != MISPEC_OK) return rc;
   // the epilogues reuse the stage ring (patches: 8 waves x 32 x 132 floats, or the 128 x 260 power
   // tile + band table of the fused filterbank)
@@ -2462,7 +2472,7 @@ int launch_fold(KParams p, const mispec_framed_gemm_args *a, const FoldPlan &f, 
     q2.n_tiles_n = (int)(tile1 - tile0);
     long long grid = (tile1 - tile0) * p.n_tiles_m;
     q2.fold_main = (int)grid;
-    if (tile0 == 0 && tile1 == tn && (kern == framed_fold_kernel || kern == framed_fold32_kernel) &&
+    if (tile0 == 0 && tile1 == tn &&
         !MISPEC_DBG(p, 0x8000000)) {
       // whole rounds of the device on 256-frame tiles, the frames behind them on 128-frame tiles
       // (framed_fold_kernel); less than half a round: 128-frame tiles throughout
@@ -2509,10 +2519,6 @@ long long basis_fold2_bytes(int n_bins, int kernel) {
 }
 
 inline bool fold2_kernel_ok(int kernel) { return kernel >= 128 && kernel <= 8192 && kernel % 64 == 0; }
-
-inline int fold_arith_of(int precision) {
-  return precision == MISPEC_PREC_F32 ? FOLD_F32 : (precision == MISPEC_PREC_F16X3 ? FOLD_F16X3 : FOLD_BF16X3);
-}
 
 struct Fold2Plan {
   bool ok;
@@ -2876,17 +2882,18 @@ int launch_strip16(KParams p, const mispec_framed_gemm_args *a, const StripPlan 
   return MISPEC_OK;
 }
 
-// MISPEC_PREC_F16X3 exists on the second fold and on the strip kernel: every other shape runs in
-// MISPEC_PREC_F32 (then with basis_fold, if given, in the fp32 format; a basis_split made for
-// MISPEC_PREC_F16X3 is not offered to the fp32 kernels)
+// MISPEC_PREC_F16X3 exists on the folded contractions and on the strip kernel: every other shape runs in
+// MISPEC_PREC_F32 on the dense kernels (operands prepared for MISPEC_PREC_F16X3 are not offered to them)
 static bool f16_downgrade(const mispec_framed_gemm_args *a, const KParams &p, mispec_framed_gemm_args &local) {
-  if (a->precision != MISPEC_PREC_F16X3 || plan_fold2(a, p).ok) return false;
+  if (a->precision != MISPEC_PREC_F16X3 || plan_fold2(a, p).ok || plan_fold(a, p).ok) return false;
   StripPlan plan;
   if (strip16_ok(a, p, device_cus(), plan)) return false;
   local = *a;
   local.precision = MISPEC_PREC_F32;
   local.basis_fold2 = nullptr;
   local.basis_fold2_bytes = 0;
+  local.basis_fold = nullptr;
+  local.basis_fold_bytes = 0;
   local.basis_split = nullptr;
   local.basis_split_bytes = 0;
   return true;
@@ -3095,7 +3102,7 @@ int64_t mispec_basis_fold_bytes(int32_t n_bins, int32_t kernel, int32_t with_tap
 
 static int fold_basis_any(const float *basis_re, const float *basis_im, int64_t basis_row_stride,
                           int32_t n_bins, int32_t kernel, int32_t with_tap0, void *dst,
-                          int64_t dst_bytes, float *stats, void *stream, int as_f32) {
+                          int64_t dst_bytes, float *stats, void *stream, int arith) {
   if (!basis_re || !basis_im || !dst) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
   if (n_bins <= 0) return fail(MISPEC_E_INVALID, "non-positive size%s");
   if (kernel < 64 || (kernel & 1)) return fail(MISPEC_E_UNSUPPORTED, "the fold needs an even kernel of >= 64 taps%s");
@@ -3113,7 +3120,7 @@ static int fold_basis_any(const float *basis_re, const float *basis_im, int64_t 
   if (!st) return fail(MISPEC_E_INVALID, "stats must point to 2 device floats%s");
   hipLaunchKernelGGL(fold_basis_kernel, dim3((unsigned)((kf + 255) / 256), (unsigned)n_bins), dim3(256), 0,
                      s, basis_re, basis_im, (long long)basis_row_stride, n_bins, kernel, w0, kf, d,
-                     last_rows, st, as_f32);
+                     last_rows, st, arith);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MISPEC_E_HIP, "basis fold launch: %s", hipGetErrorString(e));
   return MISPEC_OK;
@@ -3123,14 +3130,21 @@ int mispec_fold_basis_bf16(const float *basis_re, const float *basis_im, int64_t
                            int32_t n_bins, int32_t kernel, int32_t with_tap0, void *dst,
                            int64_t dst_bytes, float *stats, void *stream) {
   return fold_basis_any(basis_re, basis_im, basis_row_stride, n_bins, kernel, with_tap0, dst, dst_bytes,
-                        stats, stream, 0);
+                        stats, stream, FOLD_BF16X3);
+}
+
+int mispec_fold_basis_f16(const float *basis_re, const float *basis_im, int64_t basis_row_stride,
+                          int32_t n_bins, int32_t kernel, int32_t with_tap0, void *dst,
+                          int64_t dst_bytes, float *stats, void *stream) {
+  return fold_basis_any(basis_re, basis_im, basis_row_stride, n_bins, kernel, with_tap0, dst, dst_bytes,
+                        stats, stream, FOLD_F16X3);
 }
 
 int mispec_fold_basis_f32(const float *basis_re, const float *basis_im, int64_t basis_row_stride,
                           int32_t n_bins, int32_t kernel, int32_t with_tap0, void *dst,
                           int64_t dst_bytes, float *stats, void *stream) {
   return fold_basis_any(basis_re, basis_im, basis_row_stride, n_bins, kernel, with_tap0, dst, dst_bytes,
-                        stats, stream, 1);
+                        stats, stream, FOLD_F32);
 }
 
 int64_t mispec_basis_fold2_bytes(int32_t n_bins, int32_t kernel) {

@@ -446,14 +446,16 @@ def fold_basis(basis_re, basis_im, precision="bf16x3"):
     stats = torch.zeros(2, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
-        fold = (lib.mispec_fold_basis_bf16 if resolve_precision(precision) == "bf16x3"
-                else lib.mispec_fold_basis_f32)
+        fold = {"bf16x3": lib.mispec_fold_basis_bf16, "f16x3": lib.mispec_fold_basis_f16,
+                "fp32": lib.mispec_fold_basis_f32}[resolve_precision(precision)]
         _abi.check(fold(
             wr.data_ptr(), wi.data_ptr(), wr.stride(0), F, K, with_tap0, dst.data_ptr(), need,
             stats.data_ptr(), ctypes.c_void_p(stream)))
     neglected, largest = (float(v) for v in stats.cpu())
     if not largest > 0.0 or neglected > FOLD_ASYMMETRY_TOL * largest:
         return None
+    if resolve_precision(precision) == "f16x3" and largest > 2.0:
+        return None  # (the fp16 pairs hold coefficient x 2^14)
     return dst, int(taps)
 
 
@@ -495,15 +497,15 @@ def prepare_basis(basis_re, basis_im, precision, hop=None):
     "bf16x3" the split-bf16 planes; in any arithmetic, for a window x DFT basis the quarter-folded
     planes (``basis_fold2``) and for a basis with the Fourier symmetry the folded planes
     (``basis_fold``) -- the library uses them when the shape allows (include/mispec.h): a quarter /
-    half of the MFMAs.  "f16x3" is served by the second fold only; what that does not cover runs
-    in fp32 (so its ``basis_fold`` planes are the fp32 ones)."""
+    half of the MFMAs.  "f16x3" is served by the folded kernels (and the strip kernel for CQT banks);
+    what they do not cover runs in fp32 on the dense kernels."""
     precision = resolve_precision(precision)
     out = {"basis_split": split_basis(basis_re, basis_im)} if precision == "bf16x3" else {}
     if basis_im is not None and (hop is None or 8 * int(hop) >= basis_re.shape[-1]):
         folded2 = fold2_basis(basis_re, basis_im, precision)
         if folded2 is not None:
             out["basis_fold2"] = folded2
-        folded = fold_basis(basis_re, basis_im, "bf16x3" if precision == "bf16x3" else "fp32")
+        folded = fold_basis(basis_re, basis_im, precision)
         if folded is not None:
             out["basis_fold"] = folded
     return out

@@ -162,3 +162,4 @@ def test_f16x3_levels_within_a_clip():
     assert err <= 5e-6, err
     err = np.abs(y - ref).max() / np.abs(ref).max()
     assert err <= 5e-6, err
+

@@ -879,7 +879,7 @@ def _fourier_like_basis(rng, F, K, tap0):
     (1, 3000, 129, 500, 125, 250, 1, True),    # 256 folded taps incl. tap 0: four thread groups in the pre-pass
 ])
 @pytest.mark.parametrize("epi", ["complex", "magnitude", "power2", "phase"])
-@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32", "f16x3"])
 def test_symmetric_fold_kernel(shape, epi, precision):
     """``basis_fold`` in either arithmetic: the contraction over K/2 folded taps of x[n] +- x[K-n]
     (framed_fold.inl; split-bf16 or fp32 taps) against the float64 evaluation of the dense
@@ -890,12 +890,15 @@ def test_symmetric_fold_kernel(shape, epi, precision):
     rng = np.random.default_rng(F * 1000 + K + hop)
     x = rng.standard_normal((B, L)).astype(np.float32)
     wr, wi = _fourier_like_basis(rng, F, K, tap0)
+    if precision == "f16x3":  # (the fp16 pairs hold coefficient x 2^14: |coefficient| <= 2; a window is <= 1)
+        wr, wi = 0.3 * wr, 0.3 * wi
+        x = x * np.float32(10.0 ** rng.uniform(-4, 4))  # any signal level must do
     scale = rng.uniform(0.5, 2.0, F).astype(np.float32)
     re, im = _np_framed(x, wr, wi, hop, pad, mode, scale)
     xd, wrd, wid, sd = (torch.as_tensor(a).to(DEV) for a in (x, wr, wi, scale))
     prep = engine.prepare_basis(wrd, wid, precision, hop=hop)
     assert "basis_fold" in prep and prep["basis_fold"][1] == (K // 2 + (1 if tap0 else 0) + 15) // 16 * 16
-    assert ("basis_split" in prep) == (precision == "bf16x3")
+    assert ("basis_split" in prep) == (precision == "bf16x3") and "basis_fold2" not in prep
     kw = dict(hop=hop, pad=pad, pad_mode=mode, row_scale=sd)
     e = {"complex": engine.EPI_COMPLEX, "magnitude": engine.EPI_MAGNITUDE, "power2": engine.EPI_POWER,
          "phase": engine.EPI_PHASE_ATAN2}[epi]

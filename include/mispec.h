@@ -148,8 +148,9 @@ typedef struct mispec_framed_gemm_args {
 
   /* Fused filterbank reduction (mel.py:184-189: matmul(mel_basis, spec ** power)) -- optional.
    * With fb != NULL the epilogue must be MISPEC_EPI_POWER with power 1 or 2, and the launch
-   * ADDS  out[c, m, t] += sum_bin fb[m, bin] * |X[c, bin, t]|^power  for the n_fb filters into
-   * `out` = (n_clips, n_fb, n_frames), which the caller has zeroed (workgroups own 128-bin
+   * computes  out[c, m, t] = sum_bin fb[m, bin] * |X[c, bin, t]|^power  for the n_fb filters into
+   * `out` = (n_clips, n_fb, n_frames), contiguous -- the library clears it itself, in the fold's
+   * pre-pass or with a hipMemsetAsync on `stream`, and the contraction adds (workgroups own 128-bin
    * blocks; a filter whose band crosses a block boundary receives one atomic addend per block,
    * so bands of up to 129 bins sum in an order-independent way).  The band of every filter is
    * walked bin by bin: meant for banded (mel) filterbanks.
@@ -499,6 +500,20 @@ typedef struct mispec_octave_args {
 } mispec_octave_args;
 
 int mispec_octave_pyramid_f32(const mispec_octave_args *args, void *stream);
+
+/*
+ * Host path: the same three operations on HOST pointers, as plain C++ loops (fp32 multiply-adds in tap
+ * order, a few threads) -- so that a module whose input lives in host memory computes there, like the
+ * reference's forward (stft.py:290-293: conv1d runs wherever x lives; BASELINE configs[0] is a CPU
+ * case).  Same argument blocks and checks; workspace, precision, basis_split / basis_fold* are ignored;
+ * no fused filterbank.  Synchronous; meant for plumbing-sized inputs, not for throughput.
+ */
+int mispec_framed_gemm_host_f32(const mispec_framed_gemm_args *args);
+int mispec_filterbank_host_f32(const float *fb, int32_t n_filters, int32_t n_freq, const float *spec,
+                               int32_t n_clips, int32_t n_frames, float *out);
+int mispec_fir_decimate_host_f32(const float *x, int64_t x_clip_stride, int32_t n_clips,
+                                 int32_t n_samples, const float *taps, int32_t n_taps, int32_t stride,
+                                 int32_t pad, float *y, int64_t y_clip_stride, int32_t n_out);
 
 /* Scratch bytes mispec_fir_decimate_f32 needs (zero-padded clip edges); negative = error. */
 int64_t mispec_fir_decimate_workspace_bytes(int32_t n_clips, int32_t n_samples, int32_t n_taps,

@@ -58,6 +58,9 @@ EXPORTS = (
     "mispec_fir_decimate_f32",
     "mispec_fir_decimate_workspace_bytes",
     "mispec_fir_decimate_bwd_f32",
+    "mispec_framed_gemm_host_f32",
+    "mispec_filterbank_host_f32",
+    "mispec_fir_decimate_host_f32",
 )
 
 
@@ -349,6 +352,19 @@ def _load(path, how):
         ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
         ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64,
         ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+    ]
+    lib.mispec_framed_gemm_host_f32.restype = ctypes.c_int
+    lib.mispec_framed_gemm_host_f32.argtypes = [ctypes.POINTER(FramedGemmArgs)]
+    lib.mispec_filterbank_host_f32.restype = ctypes.c_int
+    lib.mispec_filterbank_host_f32.argtypes = [
+        ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+        ctypes.c_int32, ctypes.c_void_p,
+    ]
+    lib.mispec_fir_decimate_host_f32.restype = ctypes.c_int
+    lib.mispec_fir_decimate_host_f32.argtypes = [
+        ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+        ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64,
+        ctypes.c_int32,
     ]
     v = lib.mispec_version()
     if v != ABI_VERSION:

@@ -54,7 +54,9 @@
 #include <cstdio>
 #include <type_traits>
 #include <cstring>
+#include <cmath>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "mispec.h"
@@ -343,6 +345,9 @@ __device__ __forceinline__ void epilogue_store(const KParams &p, float *__restri
 }
 
 __device__ __forceinline__ int epilogue_width(int epi) {
+  return (epi == MISPEC_EPI_COMPLEX || epi == MISPEC_EPI_PHASE_COSSIN) ? 2 : 1;
+}
+inline int epilogue_width_host(int epi) {
   return (epi == MISPEC_EPI_COMPLEX || epi == MISPEC_EPI_PHASE_COSSIN) ? 2 : 1;
 }
 
@@ -2882,6 +2887,61 @@ int launch_strip16(KParams p, const mispec_framed_gemm_args *a, const StripPlan 
   return MISPEC_OK;
 }
 
+// ---- helpers of the host path (mispec_*_host_f32 below)
+namespace {
+template <typename F>
+void host_parallel_for(long long n, F &&fn) {
+  unsigned nt = std::thread::hardware_concurrency();
+  nt = nt == 0 ? 1 : (nt > 16 ? 16 : nt);
+  if (n < 64 || nt == 1) {
+    for (long long i = 0; i < n; ++i) fn(i);
+    return;
+  }
+  std::atomic<long long> next{0};
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; ++t)
+    th.emplace_back([&]() {
+      for (long long i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i);
+    });
+  for (auto &t : th) t.join();
+}
+
+inline float host_sample(const float *x, long long pos, int L, int pad_mode) {
+  if (pad_mode == MISPEC_PAD_REFLECT) {
+    pos = pos < 0 ? -pos : pos;
+    pos = pos >= L ? 2LL * L - 2 - pos : pos;
+  }
+  return (pos >= 0 && pos < L) ? x[pos] : 0.f;
+}
+
+inline void host_epilogue(const mispec_framed_gemm_args *a, float *dst, float re, float im) {
+  switch (a->epilogue) {
+    case MISPEC_EPI_COMPLEX:
+      dst[0] = re;
+      dst[1] = im;
+      break;
+    case MISPEC_EPI_MAGNITUDE:
+      dst[0] = sqrtf(re * re + im * im + a->eps);
+      break;
+    case MISPEC_EPI_POWER: {
+      const float s2 = re * re + im * im + a->eps;
+      dst[0] = (a->power == 2.0f && a->eps == 0.f) ? s2 : (a->power == 1.0f ? sqrtf(s2) : powf(sqrtf(s2), a->power));
+    } break;
+    case MISPEC_EPI_PHASE_ATAN2:
+      dst[0] = atan2f(im + 0.0f, re);
+      break;
+    case MISPEC_EPI_PHASE_COSSIN: {
+      const float ang = atan2f(im, re);
+      dst[0] = cosf(ang);
+      dst[1] = sinf(ang);
+    } break;
+    default:
+      dst[0] = re;
+      break;
+  }
+}
+}  // namespace
+
 // MISPEC_PREC_F16X3 exists on the folded contractions and on the strip kernel: every other shape runs in
 // MISPEC_PREC_F32 on the dense kernels (operands prepared for MISPEC_PREC_F16X3 are not offered to them)
 static bool f16_downgrade(const mispec_framed_gemm_args *a, const KParams &p, mispec_framed_gemm_args &local) {
@@ -2983,7 +3043,9 @@ int mispec_framed_gemm_f32(const mispec_framed_gemm_args *args, void *stream) {
   const Fold2Plan fold2 = plan_fold2(args, p);
   if (fold2.ok) return launch_fold2(p, args, fold2, s);
   const FoldPlan fold = plan_fold(args, p);
-  if (fold.ok) return launch_fold(p, args, fold, s);
+  if (fold.ok) return launch_fold(p, args, fold, s);  // (with a fused filterbank its pre-pass clears the output)
+  if (p.fb && hipMemsetAsync(p.out, 0, (size_t)p.n_clips * p.out_clip_stride * sizeof(float), s) != hipSuccess)
+    return fail(MISPEC_E_HIP, "hipMemsetAsync failed%s");
   const bool bf16x3 = bf16x3_ok(args, p);
   if (!bf16x3) {
     StripPlan plan;
@@ -3177,6 +3239,98 @@ int mispec_fold2_basis(const float *basis_re, const float *basis_im, int64_t bas
                      2 * (ne - 1), reinterpret_cast<unsigned *>(stats), fold_arith_of(precision));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MISPEC_E_HIP, "basis fold launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// Host path (CPU tensors): the same contraction + epilogue as plain C++ loops over HOST pointers, so
+// that the modules run wherever their input lives, like the reference's (stft.py:290-293) -- meant
+// for plumbing-sized inputs (BASELINE configs[0]: STFT 512/128 of 1 s), not for throughput.  fp32
+// multiply-adds in tap order (the reference's conv1d arithmetic); rows are dealt to a few threads.
+// ---------------------------------------------------------------------------------
+int mispec_framed_gemm_host_f32(const mispec_framed_gemm_args *a) {
+  KParams p;
+  int rc = fill_params(a, p);  // (the same argument checks as the device entry)
+  if (rc != MISPEC_OK) return rc;
+  if (a->fb) return fail(MISPEC_E_UNSUPPORTED, "host path: no fused filterbank (use mispec_filterbank_host_f32)%s");
+  const int E = epilogue_width_host(a->epilogue);
+  const long long items = (long long)a->n_clips * a->n_bins;
+  host_parallel_for(items, [&](long long it) {
+    const int c = (int)(it / a->n_bins), f = (int)(it - (long long)c * a->n_bins);
+    const float *x = a->x + (long long)c * a->x_clip_stride;
+    const float *wr = a->basis_re + (long long)f * a->basis_row_stride;
+    const float *wi = a->basis_im ? a->basis_im + (long long)f * a->basis_row_stride : nullptr;
+    int k0 = 0, k1 = a->kernel;
+    if (a->row_support) {
+      k0 = a->row_support[2 * f];
+      k1 = a->row_support[2 * f + 1];
+    }
+    const float sc = a->row_scale ? a->row_scale[f] : 1.f;
+    float *orow = a->out + (long long)c * a->out_clip_stride + (long long)(a->out_row_offset + f) * a->out_row_stride;
+    for (int t = 0; t < a->n_frames; ++t) {
+      const long long q0 = (long long)t * a->hop - a->pad;
+      float re = 0.f, im = 0.f;
+      if (q0 + k0 >= 0 && q0 + k1 <= a->n_samples) {
+        const float *xs = x + q0;
+        for (int k = k0; k < k1; ++k) {
+          re = fmaf(wr[k], xs[k], re);
+          if (wi) im = fmaf(wi[k], xs[k], im);
+        }
+      } else {
+        for (int k = k0; k < k1; ++k) {
+          const float v = host_sample(x, q0 + k, a->n_samples, a->pad_mode);
+          re = fmaf(wr[k], v, re);
+          if (wi) im = fmaf(wi[k], v, im);
+        }
+      }
+      host_epilogue(a, orow + (long long)t * E, re * sc, a->im_sign * im * sc);
+    }
+  });
+  return MISPEC_OK;
+}
+
+int mispec_filterbank_host_f32(const float *fb, int32_t n_filters, int32_t n_freq, const float *spec,
+                               int32_t n_clips, int32_t n_frames, float *out) {
+  if (!fb || !spec || !out) return fail(MISPEC_E_INVALID, "NULL pointer%s");
+  if (n_filters <= 0 || n_freq <= 0 || n_clips <= 0 || n_frames <= 0) return fail(MISPEC_E_INVALID, "non-positive size%s");
+  host_parallel_for((long long)n_clips * n_filters, [&](long long it) {
+    const int c = (int)(it / n_filters), m = (int)(it - (long long)c * n_filters);
+    float *o = out + ((long long)c * n_filters + m) * n_frames;
+    for (int t = 0; t < n_frames; ++t) o[t] = 0.f;
+    for (int f = 0; f < n_freq; ++f) {
+      const float w = fb[(long long)m * n_freq + f];
+      if (w == 0.f) continue;
+      const float *sp = spec + ((long long)c * n_freq + f) * n_frames;
+      for (int t = 0; t < n_frames; ++t) o[t] = fmaf(w, sp[t], o[t]);
+    }
+  });
+  return MISPEC_OK;
+}
+
+int mispec_fir_decimate_host_f32(const float *x, int64_t x_clip_stride, int32_t n_clips, int32_t n_samples,
+                                 const float *taps, int32_t n_taps, int32_t stride, int32_t pad, float *y,
+                                 int64_t y_clip_stride, int32_t n_out) {
+  if (!x || !taps || !y) return fail(MISPEC_E_INVALID, "NULL pointer%s");
+  KParams p;
+  int rc = fir_params(p, x, x_clip_stride, n_clips, n_samples, taps, n_taps, stride, pad, y, y_clip_stride, n_out);
+  if (rc != MISPEC_OK) return rc;
+  const int chunk = 4096;
+  const long long per = (n_out + chunk - 1) / chunk;
+  host_parallel_for((long long)n_clips * per, [&](long long it) {
+    const int c = (int)(it / per);
+    const int i0 = (int)(it - (long long)c * per) * chunk, i1 = i0 + chunk < n_out ? i0 + chunk : n_out;
+    const float *xc = x + (long long)c * x_clip_stride;
+    float *yc = y + (long long)c * y_clip_stride;
+    for (int i = i0; i < i1; ++i) {
+      const long long q0 = (long long)i * stride - pad;
+      float acc = 0.f;
+      for (int n = 0; n < n_taps; ++n) {
+        const long long q = q0 + n;
+        if (q >= 0 && q < n_samples) acc = fmaf(taps[n], xc[q], acc);
+      }
+      yc[i] = acc;
+    }
+  });
   return MISPEC_OK;
 }
 

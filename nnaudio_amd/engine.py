@@ -147,17 +147,35 @@ def alloc_out(shape, device, zero=False):
     return (torch.zeros if zero else torch.empty)(tuple(shape), dtype=torch.float32, device=device)
 
 
-def _require_device(*tensors):
+# Host path: the forward of STFT / MelSpectrogram / Gammatonegram / CQT1992v2 / CQT2010v2 / VQT on CPU
+# tensors runs on libmispec's own host loops (mispec_*_host_f32: plain C++, plumbing-sized inputs --
+# the reference's forward computes wherever its input lives, stft.py:290-293).  Everything else
+# (backward, MFCC, the inverse STFT, the frequency-domain CQTs) needs the GPU; set_host_path(False)
+# makes every CPU tensor raise again.
+_host_path = os.environ.get("MISPEC_HOST_PATH", "1") != "0"
+
+
+def set_host_path(enabled):
+    global _host_path
+    _host_path = bool(enabled)
+
+
+def _gpu_only(t):
+    return RuntimeError(
+        "nnaudio_amd computes on the GPU only (libmispec HIP kernels); got a %s tensor. "
+        "Move the module and its input with .to('cuda') -- there is no CPU fallback for this operation."
+        % t.device)
+
+
+def _require_device(*tensors, host_ok=False):
+    """The common device of the tensors.  CPU tensors raise unless the caller has a host
+    implementation (``host_ok``) and the host path is enabled -- then the CPU device is returned."""
     dev = None
     for t in tensors:
         if t is None:
             continue
-        if not t.is_cuda:
-            raise RuntimeError(
-                "nnaudio_amd computes on the GPU only (libmispec HIP kernels); got a %s tensor. "
-                "Move the module and its input with .to('cuda') -- there is no CPU fallback."
-                % t.device
-            )
+        if not t.is_cuda and not (host_ok and _host_path and t.device.type == "cpu"):
+            raise _gpu_only(t)
         if dev is None:
             dev = t.device
         elif t.device != dev:
@@ -224,7 +242,11 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
                  fb_support=None, basis_fold2=None):
     """Validate one framed-contraction problem and fill its C argument block.
     Returns (args, out, device, keepalive tensors)."""
-    dev = _require_device(x, basis_re, basis_im, row_scale, row_support, out, fb, fb_support)
+    dev = _require_device(x, basis_re, basis_im, row_scale, row_support, out, fb, fb_support,
+                          host_ok=fb is None and not _debug)
+    host = dev.type == "cpu"
+    if host:  # plain loops over host pointers: no workspace, no derived operands, one arithmetic
+        need_workspace, basis_split, basis_fold, basis_fold2 = False, None, None, None
     x = _signal(x)
     wr = _rows(basis_re, "basis_re")
     wi = _rows(basis_im, "basis_im") if basis_im is not None else None
@@ -241,7 +263,7 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
     two = epilogue in (EPI_COMPLEX, EPI_PHASE_COSSIN)
     rows_total = F if out_rows_total is None else out_rows_total
     if fb is not None:
-        # fused filterbank: the launch adds into a zeroed (B, n_fb, T) tensor
+        # fused filterbank: the launch clears and fills a (B, n_fb, T) tensor
         fb = _f32(fb, "filterbank")
         if fb.dim() != 2 or fb.shape[1] != F or fb.stride(1) != 1:
             raise RuntimeError("fused filterbank must be (n_filters, %d) with unit column stride" % F)
@@ -251,7 +273,7 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
         if out is not None or out_rows_total is not None or out_row_offset or two:
             raise RuntimeError("fused filterbank writes its own (B, n_filters, T) output")
         fb_support = fb_support.contiguous()
-        out = alloc_out((B, fb.shape[0], T), dev, zero=True)
+        out = alloc_out((B, fb.shape[0], T), dev)  # (cleared by the library: no ATen launch in a forward)
         rows_total = fb.shape[0]
     elif out is None:
         shape = (B, rows_total, T, 2) if two else (B, rows_total, T)
@@ -500,6 +522,8 @@ def prepare_basis(basis_re, basis_im, precision, hop=None):
     half of the MFMAs.  "f16x3" is served by the folded kernels (and the strip kernel for CQT banks);
     what they do not cover runs in fp32 on the dense kernels."""
     precision = resolve_precision(precision)
+    if not basis_re.is_cuda:
+        return {}  # (the host path contracts the module's buffers as they are)
     out = {"basis_split": split_basis(basis_re, basis_im)} if precision == "bf16x3" else {}
     if basis_im is not None and (hop is None or 8 * int(hop) >= basis_re.shape[-1]):
         folded2 = fold2_basis(basis_re, basis_im, precision)
@@ -540,6 +564,9 @@ def framed_gemm(x, basis_re, basis_im, *, reference_kernel=False, **kw):
     ``(B, n_filters, T)``, see ``fused_filterbank_ok``)."""
     a, out, dev, _keep = _framed_args(x, basis_re, basis_im, need_workspace=not reference_kernel,
                                       **kw)
+    if dev.type == "cpu":
+        _abi.check(_abi.load().mispec_framed_gemm_host_f32(ctypes.byref(a)))
+        return out
     # `_debug` (scripts/kbench.py, scripts/profile.sh) selects the benchmarking build; the product
     # library rejects a non-zero `reserved`
     lib = _abi.load_ablate() if a.reserved else _abi.load()
@@ -583,7 +610,7 @@ def fused_filterbank_plan(mod, fb, x, stft, power):
     """For MelSpectrogram / Gammatonegram: the ``fb_support`` table when this forward can run with
     the filterbank fused into the STFT contraction (no graph needed, banded filters), else
     None."""
-    if needs_grad(mod, x) or stft.freq_bins is not None or compiling():
+    if needs_grad(mod, x) or stft.freq_bins is not None or compiling() or not x.is_cuda:
         return None
     if not hasattr(mod, "_fb_support"):
         mod._fb_support = DerivedCache()
@@ -605,6 +632,10 @@ def framed_gemm_group(problems):
     dev = built[0][2]
     if any(b[2] != dev for b in built):
         raise RuntimeError("grouped problems must live on one device")
+    if dev.type == "cpu":
+        for b in built:
+            _abi.check(lib.mispec_framed_gemm_host_f32(ctypes.byref(b[0])))
+        return
     with torch.cuda.device(dev):
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         for i in range(0, len(built), 8):
@@ -620,7 +651,7 @@ def framed_gemm_group(problems):
 
 def filterbank(fb, spec):
     """(M, F) x (B, F, T) -> (B, M, T)   [torch.matmul(mel_basis, spec), mel.py:188]."""
-    dev = _require_device(fb, spec)
+    dev = _require_device(fb, spec, host_ok=True)
     fb = _f32(fb, "filterbank").contiguous()
     spec = _f32(spec, "spectrogram").contiguous()
     if fb.dim() != 2 or spec.dim() != 3 or fb.shape[1] != spec.shape[1]:
@@ -632,6 +663,9 @@ def filterbank(fb, spec):
     M = fb.shape[0]
     out = alloc_out((B, M, T), dev)
     lib = _abi.load()
+    if dev.type == "cpu":
+        _abi.check(lib.mispec_filterbank_host_f32(fb.data_ptr(), M, F, spec.data_ptr(), B, T, out.data_ptr()))
+        return out
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
         _abi.check(lib.mispec_filterbank_f32(
@@ -806,7 +840,7 @@ def power_to_db_autograd(spec, amin, ref, top_db):
 
 def fir_decimate(x, taps, stride):
     """conv1d(x, taps, stride=stride, padding=(len-1)//2)  [utils.py:73-124] -> (B, n_out)."""
-    dev = _require_device(x, taps)
+    dev = _require_device(x, taps, host_ok=True)
     x = _signal(x)
     taps = _f32(taps, "filter").reshape(-1).contiguous()
     B, L = x.shape
@@ -820,6 +854,10 @@ def fir_decimate(x, taps, stride):
         )
     y = torch.empty((B, n_out), dtype=torch.float32, device=dev)
     lib = _abi.load()
+    if dev.type == "cpu":
+        _abi.check(lib.mispec_fir_decimate_host_f32(x.data_ptr(), x.stride(0), B, L, taps.data_ptr(), nt,
+                                                    int(stride), pad, y.data_ptr(), y.stride(0), n_out))
+        return y
     need = lib.mispec_fir_decimate_workspace_bytes(B, L, nt, int(stride), pad, n_out)
     if need < 0:
         _abi.check(int(need))
@@ -919,6 +957,8 @@ class _FramedGemmFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, basis_re, basis_im, kw):
+        if not x.is_cuda:
+            raise _gpu_only(x)  # (the host path is forward-only)
         ctx.kw = dict(kw)
         ctx.save_for_backward(x, basis_re, basis_im)
         return framed_gemm(x, basis_re, basis_im, **kw)
@@ -1023,6 +1063,8 @@ class _FilterbankFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, fb, spec):
+        if not spec.is_cuda:
+            raise _gpu_only(spec)  # (the host path is forward-only)
         ctx.save_for_backward(fb, spec)
         return filterbank(fb, spec)
 
@@ -1065,6 +1107,8 @@ class _FirDecimateFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, taps, stride):
+        if not x.is_cuda:
+            raise _gpu_only(x)  # (the host path is forward-only)
         ctx.save_for_backward(taps)
         ctx.stride, ctx.shape = int(stride), tuple(x.shape)
         return fir_decimate(x, taps, stride)

@@ -234,7 +234,7 @@ def octave_recursion(x, banks, lenghts, hop, n_bins, lowpass, downsample_factor,
     shape = (x.shape[0], n_bins, T_ref, 2) if two else (x.shape[0], n_bins, T_ref)
     out = engine.alloc_out(shape, x.device)
     done, xd = 0, x
-    if precision == "bf16x3" and cache is not None and not trainable:
+    if precision == "bf16x3" and cache is not None and not trainable and x.is_cuda:
         done, xd = _fused_chain(x, octs, lowpass, epi, im_sign, eps, out, cache)
     launches = []  # the remaining per-octave contractions are independent: one grouped launch
     for o in octs[done:]:  # xd: the fp32 signal of the previous octave (x itself before octave 0)

@@ -113,7 +113,9 @@ class CQT1992v2(nn.Module):
                                                             self.cqt_kernels_imag)
         split = None
         kr, ki = self.cqt_kernels_real, self.cqt_kernels_imag
-        if precision == "bf16x3":
+        if not x.is_cuda:
+            pass  # (host path: the buffers as they are)
+        elif precision == "bf16x3":
             split = self._split.get((kr, ki), lambda: engine.split_basis(kr, ki), extra=precision)
         elif precision == "f16x3" and sup is not None:
             split = self._split.get((kr, ki), lambda: engine.frag_basis_f16(kr, ki), extra=precision)

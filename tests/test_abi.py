@@ -174,16 +174,29 @@ def test_needs_grad_sees_dataparallel_replicas():
     assert engine.needs_grad(frozen, x.clone().requires_grad_(True))
 
 
-def test_cpu_tensors_fail_loudly():
-    from nnaudio_amd import features
+def test_cpu_tensors_take_the_host_path_or_fail_loudly():
+    """CPU tensors run on libmispec's own host loops (the forward of the six hot-path modules, like
+    the reference's conv1d: wherever the input lives); operations without a host implementation
+    -- and everything once the host path is switched off -- raise."""
+    from nnaudio_amd import engine, features
 
     m = features.STFT(n_fft=64, hop_length=16, verbose=False)
-    with pytest.raises(RuntimeError, match="GPU only"):
-        m(torch.zeros(1, 256))
+    y = m(torch.zeros(1, 256))
+    assert tuple(y.shape) == (1, 33, 17, 2) and y.device.type == "cpu" and float(y.abs().max()) == 0.0
     with pytest.raises(ValueError):
         m(torch.zeros(1, 1, 1, 256))
     with pytest.raises(AssertionError):
         m(torch.zeros(1, 16))
+    with pytest.raises(RuntimeError, match="GPU only"):  # backward needs the HIP kernels
+        features.STFT(n_fft=64, hop_length=16, trainable=True, verbose=False)(torch.zeros(1, 256))
+    with pytest.raises(RuntimeError, match="GPU only"):  # no host MFCC
+        features.MFCC(sr=16000, n_mfcc=13, n_fft=256, n_mels=32, hop_length=64, verbose=False)(torch.zeros(1, 4000))
+    engine.set_host_path(False)
+    try:
+        with pytest.raises(RuntimeError, match="GPU only"):
+            m(torch.zeros(1, 256))
+    finally:
+        engine.set_host_path(True)
 
 
 def test_trainable_needs_no_grad():

@@ -1,0 +1,62 @@
+"""The host path (CPU tensors -> libmispec's plain C++ loops, include/mispec.h mispec_*_host_f32)
+against the reference's own outputs and the pinned oracle on the golden cases: no GPU needed.
+BASELINE configs[0] (STFT n_fft=512 hop=128, batch 1, 1 s @ 16 kHz on CPU) is one of them."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from tests import _golden
+from tests._golden import assert_parity, assert_phase_parity, build_module, is_phase, oracle_forward
+
+HOST_CLASSES = ("STFT", "MelSpectrogram", "Gammatonegram", "CQT1992v2", "CQT", "CQT2010v2", "VQT")
+
+
+def _host_cases():
+    g = _golden.Golden()
+    names = []
+    for name in _golden.case_names(forward_only=True):
+        case = g.cases[name]
+        if case["cls"] in HOST_CLASSES and not _golden.is_inverse(case) and case.get("method", "forward") == "forward":
+            # the plumbing-sized ones: a second of audio or so per clip
+            x = g.inputs[case["input"]]
+            if x.size <= 4 * 25000:
+                names.append(name)
+    return names
+
+
+@pytest.mark.parametrize("name", _host_cases())
+def test_host_path_matches_reference_and_oracle(golden, name):
+    case = golden.cases[name]
+    x = golden.inputs[case["input"]]
+    ref = golden.forward[name]
+    mod = build_module(case)  # on the CPU
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        y = mod(torch.as_tensor(x), **case["fwd"])
+    assert y.device.type == "cpu"
+    y = y.numpy()
+    assert y.dtype == ref.dtype and list(y.shape) == case["out_shape"]
+    orc = oracle_forward(build_module(case), case, x)
+    if is_phase(case):
+        mcase = dict(case, ctor=dict(case["ctor"], output_format="Magnitude"), fwd={})
+        mag = oracle_forward(build_module(mcase), mcase, x)
+        assert_phase_parity(y, ref, mag, what=name + " vs reference")
+        assert_phase_parity(y, orc, mag, what=name + " vs oracle")
+    else:
+        assert_parity(y, ref, rel=1e-4, what=name + " vs reference")
+        assert_parity(y, orc, rel=1e-4, what=name + " vs oracle")
+
+
+def test_baseline_config0_on_the_host():
+    """BASELINE.json configs[0]: STFT n_fft=512 hop=128, batch 1, 1 s @ 16 kHz, CPU."""
+    from nnaudio_amd import features
+    from oracle import spectral_oracle as O
+
+    m = features.STFT(n_fft=512, hop_length=128, verbose=False)
+    x = torch.randn(1, 16000, generator=torch.Generator().manual_seed(0))
+    y = m(x).numpy()
+    assert y.shape == (1, 257, 126, 2)
+    want = O.stft(x.numpy(), m.wsin.numpy(), m.wcos.numpy(), 128, output_format="Complex")
+    assert_parity(y, want, rel=1e-5, what="configs[0]")

@@ -723,18 +723,19 @@ def istft(spec, basis, window, hop, start, out_len):
 
 
 class _IstftFn(torch.autograd.Function):
-    """Autograd wrapper of ``istft`` (gradients w.r.t. the spectrogram and the synthesis basis;
-    the window is a fixed buffer here)."""
+    """Autograd wrapper of ``istft``: gradients w.r.t. the spectrogram, the synthesis basis and the
+    window (``iSTFT(trainable_window=True)``, stft.py:511-512)."""
 
     @staticmethod
     def forward(ctx, spec, basis, window, hop, start, out_len):
-        ctx.save_for_backward(spec, basis, window)
+        y = istft(spec, basis, window, hop, start, out_len)
+        ctx.save_for_backward(spec, basis, window, y if window.requires_grad else None)
         ctx.meta = (int(hop), int(start), int(out_len))
-        return istft(spec, basis, window, hop, start, out_len)
+        return y
 
     @staticmethod
     def backward(ctx, grad_out):
-        spec, basis, window = ctx.saved_tensors
+        spec, basis, window, y = ctx.saved_tensors
         hop, start, out_len = ctx.meta
         dev = spec.device
         spec = _f32(spec.detach(), "spectrogram").contiguous()
@@ -770,13 +771,31 @@ class _IstftFn(torch.autograd.Function):
             dw = framed_gemm(ut.reshape(1, N * BT), g, None, hop=BT, pad=0, pad_mode=PAD_NONE,
                              epilogue=EPI_REAL, im_sign=1.0, precision="fp32")[0]  # (2F, N)
             gbasis = (dw.t() * window[:, None]).contiguous()
-        return gspec, gbasis, None, None, None, None
+        gwin = None
+        if ctx.needs_input_grad[2]:
+            # y[b, i] = num[b, p] / wss[p], p = i + start:  num = sum_t s[b, t, p - t hop] w[p - t hop] / N,
+            # wss = sum_t w[p - t hop]^2 (the division is skipped where wss <= 1e-10, stft.py:41-51), s =
+            # the synthesised frames.  d w[n] = sum_{b,t} u[b, t hop + n] s[b, t, n]      (through num; u as above)
+            #                                 + 2 w[n] sum_t v[t hop + n],  v[p] = -sum_b g y / wss  (through wss)
+            # s comes from the frame-synthesis kernel; the rest are reductions over views (host-side
+            # glue on torch ops: this gradient is not on the hot path)
+            frames = torch.empty((B, T, N), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _abi.check(lib.mispec_istft_frames_f32(spec.data_ptr(), B, F, T, basis.data_ptr(), N,
+                                                       frames.data_ptr(), stream))
+            gwin = (u.unfold(1, N, hop) * frames).sum((0, 1))
+            wss = torch.nn.functional.conv_transpose1d(
+                torch.ones(1, 1, T, device=dev), (window * window).reshape(1, 1, N), stride=hop).reshape(-1)
+            v = torch.zeros(full, dtype=torch.float32, device=dev)
+            seg = wss[start:start + out_len]
+            v[start:start + out_len] = torch.where(
+                seg > 1e-10, -(go * y.to(torch.float32)).sum(0) / seg, torch.zeros_like(seg))
+            gwin = gwin + 2.0 * window * v.unfold(0, N, hop).sum(0)
+        return gspec, gbasis, gwin, None, None, None
 
 
 def istft_autograd(spec, basis, window, hop, start, out_len):
-    if torch.is_grad_enabled() and (spec.requires_grad or basis.requires_grad):
-        if window.requires_grad:
-            raise NotImplementedError("the inverse STFT has no backward pass for a trainable window")
+    if torch.is_grad_enabled() and (spec.requires_grad or basis.requires_grad or window.requires_grad):
         return _IstftFn.apply(spec, basis, window, hop, start, out_len)
     return istft(spec, basis, window, hop, start, out_len)
 

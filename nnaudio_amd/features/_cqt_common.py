@@ -217,6 +217,14 @@ def octave_recursion(x, banks, lenghts, hop, n_bins, lowpass, downsample_factor,
     while octs and octs[-1]["rows"] <= 0:  # octaves cut away entirely
         octs.pop()
     eps = 1e-8 if trainable else 0.0
+    if engine.compiling() and not graph and not trainable:
+        # torch.compile with frozen kernels: the whole recursion as one op, which at run time is the
+        # eager path below (fused pyramid kernel / grouped contractions) with cached operands
+        from .. import ops
+
+        return ops.octave_recursion(x, [b[0] for b in banks], [b[1] for b in banks], lenghts, lowpass,
+                                    int(octs[0]["hop"]) if octs else int(hop), int(n_bins), float(downsample_factor),
+                                    str(pad_mode), str(output_format), str(normalization_type), str(precision))
     if graph or engine.compiling():
         # the reference's own structure (cqt.py:1091-1105): one contraction per octave through
         # autograd (or, under torch.compile, through the custom ops), rows concatenated with the

@@ -45,6 +45,14 @@ class FilterbankSpectrogram(nn.Module):
         x = broadcast_dim(x)
         self.stft.num_samples = x.shape[-1]
         basis = getattr(self, self._basis_name)
+        if engine.compiling() and not engine.needs_grad(self, x) and self.stft.freq_bins is None:
+            # torch.compile: one op that decides at run time, on the real filterbank, as below
+            from .. import ops
+
+            pad, mode = self.stft._framing(x.shape[-1])
+            return ops.stft_filterbank(x, self.stft.wcos, self.stft.wsin, basis, int(self.stft.stride), int(pad),
+                                       int(mode), float(self.power), 1e-8 if self.stft.trainable else 0.0,
+                                       engine.resolve_precision(self.stft.precision, "f16x3"))
         fused = engine.fused_filterbank_plan(self, basis, x, self.stft, self.power)
         if fused is not None:  # reduction fused into the contraction's epilogue
             return self.stft._spectrum(x, engine.EPI_POWER, power=self.power, fb=basis, fb_support=fused)

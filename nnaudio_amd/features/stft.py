@@ -21,9 +21,6 @@ def _inverse_stft(mod, X, kernel_cos, kernel_sin, onesided, length):
     kernel for whatever number of frames the input has.)"""
     F = X.shape[1]
     graph = torch.is_grad_enabled()
-    if graph and mod.window_mask.requires_grad:
-        raise NotImplementedError(
-            "the inverse STFT has no backward pass for a trainable window; run it under torch.no_grad()")
     if graph and (kernel_cos.requires_grad or kernel_sin.requires_grad):
         basis = engine.istft_basis(kernel_cos, kernel_sin, F, onesided)  # differentiable torch indexing
     else:

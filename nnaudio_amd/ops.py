@@ -15,7 +15,7 @@ process-wide cache keyed on the basis tensor objects (``engine.DerivedCache`` se
 references + ``_version``), so nothing about them is baked into a traced graph.
 """
 import weakref
-from typing import Optional
+from typing import List, Optional
 
 import torch
 
@@ -118,3 +118,85 @@ def power_to_db(spec: torch.Tensor, amin: float, ref: float, top_db: float) -> t
 @power_to_db.register_fake
 def _(spec, amin, ref, top_db):
     return torch.empty_like(spec)
+
+
+# ---------------------------------------------------------------------------------------
+# The fused paths as single ops, so that a compiled module launches the same kernels as the eager
+# one: STFT power spectrum + filterbank (the fused epilogue when the filterbank is banded), and the
+# whole octave recursion of CQT2010v2 / VQT (the fused pyramid kernel in bf16x3).
+# ---------------------------------------------------------------------------------------
+_fb_cache = {}  # id(fb) -> (weakref, DerivedCache of (support, coverage))
+
+
+def _fb_support(fb):
+    key = id(fb)
+    hit = _fb_cache.get(key)
+    if hit is None or hit[0]() is not fb:
+        cache = engine.DerivedCache()
+        _fb_cache[key] = (weakref.ref(fb, lambda _r, k=key: _fb_cache.pop(k, None)), cache)
+    else:
+        cache = hit[1]
+    return cache.get((fb,), lambda: engine.filterbank_support(fb))
+
+
+@torch.library.custom_op("mispec::stft_filterbank", mutates_args=())
+def stft_filterbank(x: torch.Tensor, basis_re: torch.Tensor, basis_im: torch.Tensor, fb: torch.Tensor,
+                    hop: int, pad: int, pad_mode: int, power: float, eps: float,
+                    precision: str) -> torch.Tensor:
+    """``matmul(fb, |STFT(x)| ** power)`` (mel.py:184-189) -> (B, n_filters, T): the reduction rides
+    in the contraction's epilogue when the filterbank is banded (``engine.fused_filterbank_ok``),
+    else it is the separate filterbank kernel."""
+    prep = _prepared(basis_re, basis_im, precision, hop)
+    kw = dict(hop=hop, pad=pad, pad_mode=pad_mode, epilogue=engine.EPI_POWER, im_sign=-1.0, eps=eps,
+              power=power, precision=precision)
+    sup, coverage = _fb_support(fb)
+    if x.is_cuda and engine.fused_filterbank_ok(power, coverage, fb.shape[0]):
+        return engine.framed_gemm(x, basis_re, basis_im, fb=fb, fb_support=sup, **kw, **prep)
+    return engine.filterbank(fb, engine.framed_gemm(x, basis_re, basis_im, **kw, **prep))
+
+
+@stft_filterbank.register_fake
+def _(x, basis_re, basis_im, fb, hop, pad, pad_mode, power, eps, precision):
+    L, K = x.shape[-1], basis_re.shape[-1]
+    return x.new_empty((x.shape[0], fb.shape[0], (L + 2 * pad - K) // hop + 1))
+
+
+_octave_caches = {}  # id(first bank) -> (weakref, (OctaveCache, [SupportCache]))
+
+
+def _octave_state(first_bank, n_oct):
+    from .features._cqt_common import OctaveCache, SupportCache
+
+    key = id(first_bank)
+    hit = _octave_caches.get(key)
+    if hit is None or hit[0]() is not first_bank or len(hit[1][1]) != n_oct:
+        state = (OctaveCache(), [SupportCache() for _ in range(n_oct)])
+        _octave_caches[key] = (weakref.ref(first_bank, lambda _r, k=key: _octave_caches.pop(k, None)), state)
+        return state
+    return hit[1]
+
+
+@torch.library.custom_op("mispec::octave_recursion", mutates_args=())
+def octave_recursion(x: torch.Tensor, kernels_real: List[torch.Tensor], kernels_imag: List[torch.Tensor],
+                     lenghts: torch.Tensor, lowpass: torch.Tensor, hop: int, n_bins: int,
+                     downsample_factor: float, pad_mode: str, output_format: str,
+                     normalization_type: str, precision: str) -> torch.Tensor:
+    """The octave loop of CQT2010v2 / VQT (cqt.py:1085-1131, vqt.py:160-215) for frozen kernels, as ONE
+    op: at run time it is the eager path -- the fused pyramid kernel in bf16x3, grouped contractions
+    in fp32 -- with its derived operands cached per bank."""
+    from .features._cqt_common import octave_recursion as run
+
+    cache, supports = _octave_state(kernels_real[0], len(kernels_real))
+    return run(x, list(zip(kernels_real, kernels_imag)), lenghts, hop, n_bins, lowpass, downsample_factor,
+               pad_mode, output_format, normalization_type, False, supports=supports, graph=False,
+               precision=precision, cache=cache)
+
+
+@octave_recursion.register_fake
+def _(x, kernels_real, kernels_imag, lenghts, lowpass, hop, n_bins, downsample_factor, pad_mode,
+      output_format, normalization_type, precision):
+    L, K = x.shape[-1], kernels_real[0].shape[-1]
+    T = (L + 2 * (K // 2) - K) // hop + 1
+    if output_format in ("Complex", "Phase"):
+        return x.new_empty((x.shape[0], n_bins, T, 2))
+    return x.new_empty((x.shape[0], n_bins, T))

@@ -199,13 +199,13 @@ def test_cpu_tensors_take_the_host_path_or_fail_loudly():
         engine.set_host_path(True)
 
 
-def test_trainable_needs_no_grad():
+def test_inverse_stft_needs_the_gpu():
     from nnaudio_amd import features
 
-    # no backward pass for a trainable synthesis window: it must refuse to drop a graph
+    # (its backward, trainable window included, runs on the HIP kernels: tests/test_gpu_parity.py)
     m = features.iSTFT(n_fft=64, hop_length=16, trainable_window=True, verbose=False)
-    with pytest.raises(NotImplementedError):
-        m(torch.zeros(1, 33, 8, 2))
+    with pytest.raises(RuntimeError, match="GPU only"):
+        m(torch.zeros(1, 33, 8, 2), onesided=True)
 
 
 def test_legacy_import_shim_warns():

@@ -513,7 +513,7 @@ def fold2_basis(basis_re, basis_im, precision):
     return dst, wmax
 
 
-def prepare_basis(basis_re, basis_im, precision, hop=None):
+def prepare_basis(basis_re, basis_im, precision, hop=None, fold=True):
     """Derived operands of a basis for ``framed_gemm`` in the given arithmetic, as keyword
     arguments (callers with a persistent basis cache this dict, see ``DerivedCache``): for
     "bf16x3" the split-bf16 planes; in any arithmetic, for a window x DFT basis the quarter-folded
@@ -525,7 +525,9 @@ def prepare_basis(basis_re, basis_im, precision, hop=None):
     if not basis_re.is_cuda:
         return {}  # (the host path contracts the module's buffers as they are)
     out = {"basis_split": split_basis(basis_re, basis_im)} if precision == "bf16x3" else {}
-    if basis_im is not None and (hop is None or 8 * int(hop) >= basis_re.shape[-1]):
+    # (fold=False: a trainable basis -- every optimiser step would re-fold it, with the symmetry checks'
+    # host reads, and drift away from the symmetry anyway)
+    if fold and basis_im is not None and (hop is None or 8 * int(hop) >= basis_re.shape[-1]):
         folded2 = fold2_basis(basis_re, basis_im, precision)
         if folded2 is not None:
             out["basis_fold2"] = folded2

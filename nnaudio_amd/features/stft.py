@@ -167,9 +167,10 @@ class STFT(nn.Module):
         if not engine.compiling():
             # bf16x3: split planes; either arithmetic, the window being symmetric: the folded planes
             # (half the MFMAs) -- cached per basis and precision
+            frozen = not (self.trainable or self.wcos.requires_grad or self.wsin.requires_grad)
             prep = self._split.get((self.wcos, self.wsin),
-                                   lambda: engine.prepare_basis(wcos, wsin, precision, hop=self.stride),
-                                   extra=(self.freq_bins, self.stride, precision))
+                                   lambda: engine.prepare_basis(wcos, wsin, precision, hop=self.stride, fold=frozen),
+                                   extra=(self.freq_bins, self.stride, precision, frozen))
         if fb is not None:
             return engine.framed_gemm(
                 x, wcos, wsin, hop=self.stride, pad=pad, pad_mode=mode, epilogue=epilogue,

@@ -9,10 +9,10 @@ traces a feature module as opaque device ops instead of graph-breaking at the C 
     mispec::power_to_db    MFCC's dB stage                          (mel.py:263-279)
 
 The modules route through these whenever they run under ``torch.compile`` and no autograd graph
-is needed (``engine.*_autograd``).  Operands derived from a basis (split-bf16 planes, folded
-planes, kernel supports) are looked up inside the op -- at run time, on the real tensors -- in a
-process-wide cache keyed on the basis tensor objects (``engine.DerivedCache`` semantics: weak
-references + ``_version``), so nothing about them is baked into a traced graph.
+is needed (``engine.*_autograd``).  Operands derived from a basis (split / folded planes, kernel
+supports) are looked up inside the op -- at run time, on the real tensors -- in a process-wide cache
+keyed on what the tensor IS in memory (``_ViewCache``: a compiled graph hands the ops fresh view
+objects every call), so nothing about them is baked into a traced graph.
 """
 import weakref
 from typing import List, Optional
@@ -21,7 +21,40 @@ import torch
 
 from . import engine
 
-_prep_cache = {}  # id(basis_re) -> (weakref, DerivedCache)
+class _ViewCache:
+    """Derived operands of the tensors an op receives at run time.  Under torch.compile a module's
+    ``wsin[:freq_bins]`` or ``kernels.reshape(..)[first:]`` arrives as a FRESH view object on every
+    call, so the key is the view's identity in memory -- (storage address, offset, shape, strides) --
+    and an entry is valid while the tensors' version counter (shared by all views of a storage) is
+    unchanged.  Every entry holds its storages alive, so a cached address cannot be recycled for
+    another tensor; at most ``cap`` entries (least recently used dropped)."""
+
+    def __init__(self, cap=32):
+        self.cap = cap
+        self.entries = {}
+
+    @staticmethod
+    def _key(t):
+        return (t.untyped_storage().data_ptr(), t.storage_offset(), tuple(t.shape), tuple(t.stride()), t.dtype)
+
+    def get(self, tensors, extra, build):
+        tensors = tuple(t for t in tensors if t is not None)
+        key = (tuple(self._key(t) for t in tensors), extra)
+        vers = tuple(t._version for t in tensors)
+        hit = self.entries.get(key)
+        if hit is not None and hit[1] == vers:
+            self.entries[key] = self.entries.pop(key)  # most recently used last
+            return hit[2]
+        val = build()
+        self.entries.pop(key, None)
+        self.entries[key] = (tuple(t.untyped_storage() for t in tensors), vers, val)
+        while len(self.entries) > self.cap:
+            self.entries.pop(next(iter(self.entries)))
+        return val
+
+
+_prep_cache = _ViewCache()
+_support_cache = _ViewCache()
 
 
 def _prepare(basis_re, basis_im, precision, hop, support):
@@ -32,37 +65,19 @@ def _prepare(basis_re, basis_im, precision, hop, support):
 
 
 def _prepared(basis_re, basis_im, precision, hop, support=False):
-    """Split / folded planes of a basis for the op's run-time tensors (cached per tensor object)."""
+    """Split / folded planes of a basis for the op's run-time tensors."""
     if basis_im is None:
         return {}
     precision = engine.resolve_precision(precision)
-    key = id(basis_re)
-    hit = _prep_cache.get(key)
-    if hit is None or hit[0]() is not basis_re:
-        cache = engine.DerivedCache()
-        _prep_cache[key] = (weakref.ref(basis_re, lambda _r, k=key: _prep_cache.pop(k, None)), cache)
-    else:
-        cache = hit[1]
-    return cache.get((basis_re, basis_im),
-                     lambda: _prepare(basis_re, basis_im, precision, hop, support),
-                     extra=(int(hop), precision, bool(support)))
-
-
-_support_cache = {}  # id(basis_re) -> (weakref, SupportCache)
+    return _prep_cache.get((basis_re, basis_im), (int(hop), precision, bool(support)),
+                           lambda: _prepare(basis_re, basis_im, precision, hop, support))
 
 
 def _supports(basis_re, basis_im):
-    """[start, stop) of the non-zero taps of every kernel row (CQT banks), cached per tensor object."""
+    """[start, stop) of the non-zero taps of every kernel row (CQT banks) for the op's run-time tensors."""
     from .features._cqt_common import SupportCache
 
-    key = id(basis_re)
-    hit = _support_cache.get(key)
-    if hit is None or hit[0]() is not basis_re:
-        cache = SupportCache()
-        _support_cache[key] = (weakref.ref(basis_re, lambda _r, k=key: _support_cache.pop(k, None)), cache)
-    else:
-        cache = hit[1]
-    return cache.get(basis_re, basis_im)
+    return _support_cache.get((basis_re, basis_im), None, lambda: SupportCache().get(basis_re, basis_im))
 
 
 @torch.library.custom_op("mispec::framed_gemm", mutates_args=())

@@ -210,10 +210,10 @@ def timed_steps(module, x, steps, warmup, sync):
 
 def module_precision(name, precision):
     """The arithmetic a workload's module runs in: --precision when given, else the module's own
-    default (STFT family: f16x3; the CQT modules: fp32 -- nnaudio_amd.engine)."""
+    default (f16x3; CQT1992v2: fp32 -- nnaudio_amd.engine)."""
     if precision:
         return precision
-    return "f16x3" if name in ("stft", "mel", "gammatone") else "fp32"
+    return "fp32" if name == "cqt" else "f16x3"
 
 
 def executed_flops(meta, precision):
@@ -604,7 +604,8 @@ def main():
         torch.cuda.empty_cache()
         n2 = max(20, args.steps)  # every extra under the headline's rules: pre-warm + >= 20 steps
         jobs = [("cqt", "f16x3", None), ("cqt", "bf16x3", None), ("cqt", "fp32", None),
-                ("mel", None, None), ("gammatone", None, None), ("cqt2010", None, None), ("vqt", None, None)]
+                ("mel", None, None), ("gammatone", None, None), ("cqt2010", None, None), ("vqt", None, None),
+                ("cqt2010", "bf16x3", None), ("cqt2010", "fp32", None)]
         if world > 1:  # cfg4's real shard: 128 clips over 8 ranks
             jobs.append(("cqt", "f16x3", 16))
         for name, pr2, b2 in jobs:

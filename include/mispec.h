@@ -149,8 +149,8 @@ typedef struct mispec_framed_gemm_args {
   /* Fused filterbank reduction (mel.py:184-189: matmul(mel_basis, spec ** power)) -- optional.
    * With fb != NULL the epilogue must be MISPEC_EPI_POWER with power 1 or 2, and the launch
    * computes  out[c, m, t] = sum_bin fb[m, bin] * |X[c, bin, t]|^power  for the n_fb filters into
-   * `out` = (n_clips, n_fb, n_frames), contiguous -- the library clears it itself, in the fold's
-   * pre-pass or with a hipMemsetAsync on `stream`, and the contraction adds (workgroups own 128-bin
+   * `out` = (n_clips, n_fb, n_frames), contiguous -- the library clears it itself (a
+   * hipMemsetAsync on `stream`) and the contraction adds (workgroups own 128-bin
    * blocks; a filter whose band crosses a block boundary receives one atomic addend per block,
    * so bands of up to 129 bins sum in an order-independent way).  The band of every filter is
    * walked bin by bin: meant for banded (mel) filterbanks.
@@ -254,6 +254,12 @@ int mispec_frag_basis_f32(const float *basis_re, const float *basis_im, int64_t 
  * scaled per clip (from its largest |sample|, found by a pre-pass) and split the same way.
  */
 int64_t mispec_basis_frag16_bytes(int32_t n_bins, int32_t kernel);
+/* ... and as row-major planes [re_hi | re_lo | im_hi | im_lo] + the inverse factors, for the levels of
+ * mispec_octave_pyramid_f32 in MISPEC_PREC_F16X3 */
+int64_t mispec_basis_split16_bytes(int32_t n_bins, int32_t kernel);
+int mispec_split_basis_f16(const float *basis_re, const float *basis_im, int64_t basis_row_stride,
+                           int32_t n_bins, int32_t kernel, void *dst, int64_t dst_bytes,
+                           void *stream);
 int mispec_frag_basis_f16(const float *basis_re, const float *basis_im, int64_t basis_row_stride,
                           int32_t n_bins, int32_t kernel, void *dst, int64_t dst_bytes,
                           void *stream);
@@ -497,6 +503,18 @@ typedef struct mispec_octave_args {
   float *out;
   int64_t out_clip_stride;     /* elements                                                  */
   int64_t out_row_stride;      /* elements                                                  */
+  int32_t precision;           /* MISPEC_PREC_BF16X3, or MISPEC_PREC_F16X3: scaled fp16 pairs --  */
+                               /* then every bank_split is mispec_split_basis_f16()'s output and: */
+  int32_t fir_headroom_bits;   /* ceil(log2(sum |taps|)) * (n_levels - 1): bits kept free above    */
+                               /* the scaled level-0 samples for the gain of the FIRs (<= 7)       */
+  void *absmax_in;             /* device, n_clips * 128 bytes: bit pattern of max |x[c, :]| per    */
+                               /* clip, 32 words apart; computed by this call from x (into words   */
+                               /* the CALLER has zeroed) unless                                    */
+  int32_t absmax_in_ready;     /* ... it is already there (!= 0: absmax_out of the launch that     */
+                               /* wrote this x as its x_last)                                      */
+  int32_t reserved2;           /* must be 0                                                        */
+  void *absmax_out;            /* the same for x_last, gathered while it is written (atomic max    */
+                               /* into words the CALLER has zeroed), or NULL                       */
 } mispec_octave_args;
 
 int mispec_octave_pyramid_f32(const mispec_octave_args *args, void *stream);

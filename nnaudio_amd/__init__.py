@@ -10,8 +10,8 @@ def set_precision(name):
     """Process-wide arithmetic of the framed contraction: "fp32" (fp32 MFMA), "bf16x3" (split-bf16
     operands on the bf16 MFMA, ~5e-6 of the spectrum peak), "f16x3" (scaled split-fp16 operands on
     the f16 MFMA, ~1e-7 of the peak: fp32 class), or None: every module uses its own default -- the
-    fastest arithmetic that meets the reference's own fixtures (STFT family: "f16x3"; CQT1992v2,
-    CQT2010v2, VQT: "fp32").  A module's own ``precision`` attribute, when not None, takes
+    fastest arithmetic that meets the reference's own fixtures (STFT family, CQT2010v2, VQT:
+    "f16x3"; CQT1992v2: "fp32").  A module's own ``precision`` attribute, when not None, takes
     precedence; the MISPEC_PRECISION environment variable sets the initial override."""
     from . import engine
 

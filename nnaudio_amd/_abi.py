@@ -34,6 +34,8 @@ EXPORTS = (
     "mispec_basis_frag_bytes",
     "mispec_frag_basis_f32",
     "mispec_basis_frag16_bytes",
+    "mispec_basis_split16_bytes",
+    "mispec_split_basis_f16",
     "mispec_frag_basis_f16",
     "mispec_fold_taps",
     "mispec_basis_fold_bytes",
@@ -181,6 +183,12 @@ class OctaveArgs(ctypes.Structure):
         ("out", ctypes.c_void_p),
         ("out_clip_stride", ctypes.c_int64),
         ("out_row_stride", ctypes.c_int64),
+        ("precision", ctypes.c_int32),
+        ("fir_headroom_bits", ctypes.c_int32),
+        ("absmax_in", ctypes.c_void_p),
+        ("absmax_in_ready", ctypes.c_int32),
+        ("reserved2", ctypes.c_int32),
+        ("absmax_out", ctypes.c_void_p),
     ]
 
 
@@ -236,6 +244,11 @@ def _load(path, how):
     lib.mispec_frag_basis_f32.restype = ctypes.c_int
     lib.mispec_frag_basis_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                                           ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+    lib.mispec_basis_split16_bytes.restype = ctypes.c_int64
+    lib.mispec_basis_split16_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32]
+    lib.mispec_split_basis_f16.restype = ctypes.c_int
+    lib.mispec_split_basis_f16.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                           ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
     lib.mispec_basis_frag16_bytes.restype = ctypes.c_int64
     lib.mispec_basis_frag16_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32]
     lib.mispec_frag_basis_f16.restype = ctypes.c_int

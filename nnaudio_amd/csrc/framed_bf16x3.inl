@@ -63,14 +63,23 @@ __global__ void __launch_bounds__(256) split_basis_kernel(const float *__restric
   const float *src = z ? im : re;
   const float v = k < K ? src[(long long)bin * row_stride + k] : 0.f;
   if (row_scale) {
-    // MISPEC_PREC_F16X3: fragment order only, (hi, lo) fp16 pairs of the row x its power of two
+    // MISPEC_PREC_F16X3: (hi, lo) fp16 pairs of the row x its power of two -- in the strip kernel's
+    // fragment order (frag) and / or as row-major planes (dst: the octave kernel's banks)
     unsigned h2, l2;
     f16_split2(v * row_scale[bin], 0.f, h2, l2);
-    const long long tile = bin >> 4;
-    const int lane = 2 * (bin & 15) + z + 32 * ((k >> 3) & 1);
-    const long long f = (((tile * (Ks >> 4) + (k >> 4)) * 2) * 64 + lane) * 8 + (k & 7);
-    frag[f] = (unsigned short)(h2 & 0xffff);
-    frag[f + 64 * 8] = (unsigned short)(l2 & 0xffff);
+    if (dst) {
+      const long long plane = (long long)n_bins * Ks;
+      const long long o = (long long)bin * Ks + k;
+      dst[(2 * z) * plane + o] = (unsigned short)(h2 & 0xffff);
+      dst[(2 * z + 1) * plane + o] = (unsigned short)(l2 & 0xffff);
+    }
+    if (frag) {
+      const long long tile = bin >> 4;
+      const int lane = 2 * (bin & 15) + z + 32 * ((k >> 3) & 1);
+      const long long f = (((tile * (Ks >> 4) + (k >> 4)) * 2) * 64 + lane) * 8 + (k & 7);
+      frag[f] = (unsigned short)(h2 & 0xffff);
+      frag[f + 64 * 8] = (unsigned short)(l2 & 0xffff);
+    }
     return;
   }
   if (frag32) {

@@ -347,15 +347,6 @@ __global__ void __launch_bounds__(256) fold_frames_kernel(const KParams p,
       emit(j0, e, o, scale);
     }
   }
-  // fused filterbank: the launch ADDS into (n_clips, n_fb, n_frames): this workgroup clears the columns
-  // of its frames first (its own atomics below come after the barrier; the contraction's after the kernel)
-  if (p.fb) {
-    for (int i = threadIdx.x; i < p.n_fb * nfw; i += 256) {
-      const int m = i / nfw, t = i - m * nfw;
-      p.out[(long long)c * p.out_clip_stride + (long long)m * p.out_row_stride + tw0 + t] = 0.f;
-    }
-    __threadfence();
-  }
   // the last bin's partial sums: wave totals to LDS before the barrier the staging needs anyway
   if (le) {
 #pragma unroll

@@ -3042,10 +3042,12 @@ int mispec_framed_gemm_f32(const mispec_framed_gemm_args *args, void *stream) {
     return fail(MISPEC_E_UNSUPPORTED, "fused filterbank needs the automatic tile choice%s");
   const Fold2Plan fold2 = plan_fold2(args, p);
   if (fold2.ok) return launch_fold2(p, args, fold2, s);
-  const FoldPlan fold = plan_fold(args, p);
-  if (fold.ok) return launch_fold(p, args, fold, s);  // (with a fused filterbank its pre-pass clears the output)
+  // the fused filterbank adds into its output: cleared here (in-kernel clearing by the fold's pre-pass --
+  // 32-byte row segments per workgroup -- cost 1 ms on cfg3)
   if (p.fb && hipMemsetAsync(p.out, 0, (size_t)p.n_clips * p.out_clip_stride * sizeof(float), s) != hipSuccess)
     return fail(MISPEC_E_HIP, "hipMemsetAsync failed%s");
+  const FoldPlan fold = plan_fold(args, p);
+  if (fold.ok) return launch_fold(p, args, fold, s);
   const bool bf16x3 = bf16x3_ok(args, p);
   if (!bf16x3) {
     StripPlan plan;
@@ -3120,6 +3122,32 @@ int mispec_frag_basis_f32(const float *basis_re, const float *basis_im, int64_t 
                      static_cast<float *>(dst));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MISPEC_E_HIP, "basis fragment launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+
+int64_t mispec_basis_split16_bytes(int32_t n_bins, int32_t kernel) {
+  if (n_bins <= 0 || kernel <= 0) return fail(MISPEC_E_INVALID, "non-positive size%s");
+  return basis_plane_bytes(n_bins, kernel, true) + 2LL * n_bins * (long long)sizeof(float);
+}
+
+int mispec_split_basis_f16(const float *basis_re, const float *basis_im, int64_t basis_row_stride,
+                           int32_t n_bins, int32_t kernel, void *dst, int64_t dst_bytes, void *stream) {
+  if (!basis_re || !basis_im || !dst) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
+  const int64_t need = mispec_basis_split16_bytes(n_bins, kernel);
+  if (need < 0) return (int)need;
+  if (dst_bytes < need) return fail(MISPEC_E_INVALID, "dst too small: size it with mispec_basis_split16_bytes%s");
+  const int ks = round_up_kc(kernel);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float *unscale = reinterpret_cast<float *>(static_cast<char *>(dst) + basis_plane_bytes(n_bins, kernel, true));
+  float *scale = unscale + n_bins;
+  hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)n_bins), dim3(256), 0, s, basis_re, basis_im,
+                     (long long)basis_row_stride, kernel, scale, unscale);
+  hipLaunchKernelGGL(split_basis_kernel, dim3((unsigned)((ks + 255) / 256), (unsigned)n_bins, 2u), dim3(256), 0,
+                     s, basis_re, basis_im, (long long)basis_row_stride, n_bins, kernel, ks,
+                     static_cast<unsigned short *>(dst), static_cast<unsigned short *>(nullptr),
+                     static_cast<float *>(nullptr), static_cast<const float *>(scale));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "basis split launch: %s", hipGetErrorString(e));
   return MISPEC_OK;
 }
 
@@ -3719,6 +3747,17 @@ int mispec_octave_pyramid_f32(const mispec_octave_args *a, void *stream) {
   p.epilogue = a->epilogue;
   p.im_sign = a->im_sign;
   p.eps = a->eps;
+  if (a->precision != MISPEC_PREC_BF16X3 && a->precision != MISPEC_PREC_F16X3)
+    return fail(MISPEC_E_INVALID, "fused octave kernel: precision must be MISPEC_PREC_BF16X3 or MISPEC_PREC_F16X3%s");
+  const bool f16 = a->precision == MISPEC_PREC_F16X3;
+  if (f16) {
+    if (!a->absmax_in) return fail(MISPEC_E_INVALID, "MISPEC_PREC_F16X3 needs absmax_in (n_clips * 128 bytes)%s");
+    if (a->fir_headroom_bits < 0 || a->fir_headroom_bits > 7)
+      return fail(MISPEC_E_UNSUPPORTED, "fused octave kernel: the anti-alias filter's gain leaves no fp16 headroom%s");
+    p.absmax_in = static_cast<const unsigned *>(a->absmax_in);
+    p.absmax_out = static_cast<unsigned *>(a->absmax_out);
+    p.top = 15 - a->fir_headroom_bits;
+  }
   long long L = a->n_samples;
   int need[PYR_LEVELS];
   for (int l = 0; l < D; ++l) {
@@ -3734,7 +3773,8 @@ int mispec_octave_pyramid_f32(const mispec_octave_args *a, void *stream) {
     if (v.bank_split) {
       if (v.n_bins <= 0 || v.n_bins > PYR_MAX_BINS || v.kernel < 16 || v.kernel % 16 || v.kernel > 2048)
         return fail(MISPEC_E_UNSUPPORTED, "fused octave kernel: <= 16 bins, kernel a multiple of 16%s");
-      if (v.bank_split_bytes < basis_split_bytes(v.n_bins, v.kernel, true))
+      if (v.bank_split_bytes < (f16 ? mispec_basis_split16_bytes(v.n_bins, v.kernel)
+                                    : basis_plane_bytes(v.n_bins, v.kernel, true)))
         return fail(MISPEC_E_INVALID, "bank_split too small%s");
       if (v.pad_mode != MISPEC_PAD_ZERO && v.pad_mode != MISPEC_PAD_REFLECT)
         return fail(MISPEC_E_INVALID, "bad pad_mode%s");
@@ -3750,6 +3790,9 @@ int mispec_octave_pyramid_f32(const mispec_octave_args *a, void *stream) {
       o.bank = static_cast<const unsigned short *>(v.bank_split);
       o.bank_plane = (long long)v.n_bins * o.Ks;
       o.row_scale = v.row_scale;
+      o.row_unscale = f16 ? reinterpret_cast<const float *>(static_cast<const char *>(v.bank_split) +
+                                                            basis_plane_bytes(v.n_bins, v.kernel, true))
+                          : nullptr;
       need[l] = (int)round_up_ll(v.kernel / 2 + 64, 64);
     } else {
       need[l] = 64;
@@ -3799,10 +3842,17 @@ int mispec_octave_pyramid_f32(const mispec_octave_args *a, void *stream) {
   int max_steps = 0;
   for (int l = 0; l < D; ++l) max_steps = p.lv[l].Ks / 32 > max_steps ? p.lv[l].Ks / 32 : max_steps;
   const bool six = max_steps <= 6;
-  auto kern = six ? octave_pyramid_kernel<6> : octave_pyramid_kernel<8>;
-  static std::atomic<unsigned long long> configured6{0}, configured8{0};
-  int rc = configure_lds(kern, 80 * 1024, six ? configured6 : configured8);
+  auto kern = f16 ? (six ? octave_pyramid_kernel<6, true> : octave_pyramid_kernel<8, true>)
+                  : (six ? octave_pyramid_kernel<6, false> : octave_pyramid_kernel<8, false>);
+  static std::atomic<unsigned long long> configured4[4] = {{0}, {0}, {0}, {0}};
+  int rc = configure_lds(kern, 80 * 1024, configured4[(f16 ? 2 : 0) + (six ? 0 : 1)]);
   if (rc != MISPEC_OK) return rc;
+  if (f16 && !a->absmax_in_ready) {  // the chain's first launch: the clips' largest |sample| (into zeroed words)
+    hipLaunchKernelGGL(clip_absmax_kernel,
+                       dim3((unsigned)((a->n_samples + ABSMAX_CHUNK - 1) / ABSMAX_CHUNK), (unsigned)a->n_clips),
+                       dim3(256), 0, static_cast<hipStream_t>(stream), a->x, (long long)a->x_clip_stride,
+                       a->n_samples, static_cast<unsigned *>(a->absmax_in));
+  }
   // persistent workgroups, two per CU
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {

@@ -57,6 +57,7 @@ struct PyrLevel {
   const unsigned short *bank;  // split planes [re_hi | re_lo | im_hi | im_lo], each (n_rows, Ks)
   long long bank_plane;        // plane distance, elements
   const float *row_scale;      // (n_rows,) or NULL
+  const float *row_unscale;    // F16: inverse of the power of two each bank row was multiplied with
 };
 
 struct PyrParams {
@@ -79,6 +80,10 @@ struct PyrParams {
   int epilogue;
   float im_sign, eps;
   unsigned long long *stamps;  // benchmarking build: phase clock of workgroup 7 (100 MHz ticks)
+  // MISPEC_PREC_F16X3 (F16 instances): scaled fp16 pairs instead of bf16 pairs
+  const unsigned *absmax_in;   // per clip (CLIP_ABSMAX_STRIDE apart): bit pattern of max |x[c, :]|
+  unsigned *absmax_out;        // the same for x_last, gathered while it is written (atomicMax), or NULL
+  int top;                     // level-0 samples are scaled below 2^top (headroom for the FIR's gain)
 };
 
 #ifdef MISPEC_ABLATE
@@ -105,13 +110,35 @@ __device__ __forceinline__ int pyr_addr(int i) {
 // MAXS = 32-tap steps of the kernel rows a wave keeps in registers (8: banks up to 256 taps; 6: up to
 // 192 -- the reference's banks once their zero margins are trimmed -- 32 VGPRs fewer); wider banks
 // stream the remaining steps from L2.
-template <int MAXS>
+// F16 = MISPEC_PREC_F16X3: every bf16 pair becomes an fp16 pair of a power-of-two scaled value --
+//   signal   x 2^(top - e_c), e_c from the clip's largest |sample| (absmax_in); the FIR keeps that scale
+//            (its taps carry 2^14, taken off the accumulators before the outputs are split again)
+//   bank     every row x its own power of two (mispec_split_basis_f16; inverse in row_unscale)
+// and the epilogue multiplies by the inverse factors.  x_last is stored unscaled (fp32) and its per-clip
+// absmax gathered on the way (absmax_out): the next launch of the chain needs no pass over it.
+template <int MAXS, bool F16>
 __global__ void __launch_bounds__(256, 2) octave_pyramid_kernel(const PyrParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int D = p.n_levels;
+  auto split2 = [](float a, float b, unsigned &h, unsigned &l) __attribute__((always_inline)) {
+    if (F16) f16_split2(a, b, h, l);
+    else bf16_split2(a, b, h, l);
+  };
+  constexpr float TAP_SCALE = F16 ? 16384.f : 1.f;  // taps (|t| < 1) x 2^14
+  typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+  auto mfma32 = [](bf16x8 a, bf16x8 b, f32x16 c) __attribute__((always_inline)) -> f32x16 {
+    if (F16)
+      return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  };
+  auto mfma16 = [](bf16x8 a, bf16x8 b, f32x4acc c) __attribute__((always_inline)) -> f32x4acc {
+    if (F16)
+      return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  };
 
   // ---- once per (persistent) workgroup: tap tables for the Toeplitz fragments.  Lane (r, lh) of
   // step s needs taps[16 s + 8 lh - 2 r - shift .. + 8): copy cp = r & 3 holds the taps displaced
@@ -126,10 +153,10 @@ __global__ void __launch_bounds__(256, 2) octave_pyramid_kernel(const PyrParams 
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int idx = e + u - 64 - 2 * cp - shift;
-        v[u] = (idx >= 0 && idx < p.n_taps) ? p.taps[idx] : 0.f;
+        v[u] = (idx >= 0 && idx < p.n_taps) ? p.taps[idx] * TAP_SCALE : 0.f;
       }
       unsigned h, l;
-      bf16_split2(v[0], v[1], h, l);
+      split2(v[0], v[1], h, l);
       *reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(th) + cp * PYR_TAB_STRIDE + 2 * e) = h;
       *reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(tl) + cp * PYR_TAB_STRIDE + 2 * e) = l;
     }
@@ -183,6 +210,13 @@ __global__ void __launch_bounds__(256, 2) octave_pyramid_kernel(const PyrParams 
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
     const int c = item / p.n_chunks;
     const int t0 = (item - c * p.n_chunks) * p.nf;
+    float xscale = 1.f, xunscale = 1.f;  // F16: the clip's power of two and its inverse
+    if (F16) {
+      const int e = absmax_exponent(__uint_as_float(p.absmax_in[(long long)c * CLIP_ABSMAX_STRIDE]));
+      xscale = pow2f(p.top - e);
+      xunscale = pow2f(e - p.top);
+    }
+    float last_max = 0.f;  // F16: largest |x_last| this thread stores
     __syncthreads();  // the previous item's phase C is done with the spans (and the tables are built)
     PYR_STAMP();  // item start
 
@@ -212,8 +246,8 @@ __global__ void __launch_bounds__(256, 2) octave_pyramid_kernel(const PyrParams 
           const int i = i0 + 1024 * b;
           if (i < n) {
             uint2 h, l;
-            bf16_split2(f[b][0], f[b][1], h.x, l.x);
-            bf16_split2(f[b][2], f[b][3], h.y, l.y);
+            split2(f[b][0] * xscale, f[b][1] * xscale, h.x, l.x);
+            split2(f[b][2] * xscale, f[b][3] * xscale, h.y, l.y);
             const int ad = pyr_addr(i);
             *reinterpret_cast<uint2 *>(hi + ad) = h;
             *reinterpret_cast<uint2 *>(lo + ad) = l;
@@ -309,14 +343,11 @@ __global__ void __launch_bounds__(256, 2) octave_pyramid_kernel(const PyrParams 
             if (s + 1 < PYR_KSTEPS) frags(s + 1, k ^ 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < PYR_NT; ++u)
-              acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tl[k], xh[k][u], acc[u], 0, 0, 0);
+            for (int u = 0; u < PYR_NT; ++u) acc[u] = mfma32(tl[k], xh[k][u], acc[u]);
 #pragma unroll
-            for (int u = 0; u < PYR_NT; ++u)
-              acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th[k], xl[k][u], acc[u], 0, 0, 0);
+            for (int u = 0; u < PYR_NT; ++u) acc[u] = mfma32(th[k], xl[k][u], acc[u]);
 #pragma unroll
-            for (int u = 0; u < PYR_NT; ++u)
-              acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th[k], xh[k][u], acc[u], 0, 0, 0);
+            for (int u = 0; u < PYR_NT; ++u) acc[u] = mfma32(th[k], xh[k][u], acc[u]);
             __builtin_amdgcn_sched_barrier(0);
           }
           // acc[e] = y[32 q + r], r = (e & 3) + 8 (e >> 2) + 4 lh: four consecutive outputs per quad
@@ -328,17 +359,25 @@ __global__ void __launch_bounds__(256, 2) octave_pyramid_kernel(const PyrParams 
               for (int g4 = 0; g4 < 4; ++g4) {
                 const int o = 32 * q + 8 * g4 + 4 * lh;  // relative output index of the quad
                 const long long g = ao + o;
-                float f[4];
+                float f[4];  // (F16: still carrying the clip's scale; the taps' 2^14 comes off here)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) f[e] = (g + e >= 0 && g + e < vo.L) ? acc[u][4 * g4 + e] : 0.f;
+                for (int e = 0; e < 4; ++e)
+                  f[e] = (g + e >= 0 && g + e < vo.L) ? acc[u][4 * g4 + e] * (1.f / TAP_SCALE) : 0.f;
                 uint2 h, lw;
-                bf16_split2(f[0], f[1], h.x, lw.x);
-                bf16_split2(f[2], f[3], h.y, lw.y);
+                split2(f[0], f[1], h.x, lw.x);
+                split2(f[2], f[3], h.y, lw.y);
                 const int ad = pyr_addr(o);
                 *reinterpret_cast<uint2 *>(ohi + ad) = h;
                 *reinterpret_cast<uint2 *>(olo + ad) = lw;
                 if (last && g >= own_lo && g < own_hi) {
                   float *d = p.x_last + (long long)c * p.x_last_stride + g;
+                  if (F16) {  // unscaled in HBM; its absmax for the next launch
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                      f[e] *= xunscale;
+                      last_max = fmaxf(last_max, fabsf(f[e]));
+                    }
+                  }
                   if (g + 3 < vo.L) {
                     *reinterpret_cast<f32x4u *>(d) = f32x4u{f[0], f[1], f[2], f[3]};
                   } else {
@@ -357,6 +396,12 @@ __global__ void __launch_bounds__(256, 2) octave_pyramid_kernel(const PyrParams 
       }
     }
     reflect_fixup(D - 1);
+    if (F16 && p.absmax_out && D > 1) {  // (one atomic per wave and item: ~10^4 per launch, on n_clips lines)
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) last_max = fmaxf(last_max, __shfl_xor(last_max, d));
+      if (lane == 0 && last_max > 0.f)
+        atomicMax(p.absmax_out + (long long)c * CLIP_ABSMAX_STRIDE, __float_as_uint(last_max));
+    }
     __syncthreads();
     PYR_STAMP();  // fix-ups done
 
@@ -400,12 +445,12 @@ __global__ void __launch_bounds__(256, 2) octave_pyramid_kernel(const PyrParams 
           if (s < steps) {
             const bf16x8 xh = frag(hi, w + 32 * s + 8 * kg);
             const bf16x8 xl = frag(lo, w + 32 * s + 8 * kg);
-            cre = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rl[s], xh, cre, 0, 0, 0);
-            cim = __builtin_amdgcn_mfma_f32_16x16x32_bf16(il[s], xh, cim, 0, 0, 0);
-            cre = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh[s], xl, cre, 0, 0, 0);
-            cim = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ih[s], xl, cim, 0, 0, 0);
-            cre = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh[s], xh, cre, 0, 0, 0);
-            cim = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ih[s], xh, cim, 0, 0, 0);
+            cre = mfma16(rl[s], xh, cre);
+            cim = mfma16(il[s], xh, cim);
+            cre = mfma16(rh[s], xl, cre);
+            cim = mfma16(ih[s], xl, cim);
+            cre = mfma16(rh[s], xh, cre);
+            cim = mfma16(ih[s], xh, cim);
           }
         }
         for (int s = MAXS; s < steps; ++s) {  // banks wider than 256 taps: rows streamed from L2
@@ -415,12 +460,12 @@ __global__ void __launch_bounds__(256, 2) octave_pyramid_kernel(const PyrParams 
           const bf16x8 arl = *reinterpret_cast<const bf16x8 *>(are + v.bank_plane + 32 * s);
           const bf16x8 aih = *reinterpret_cast<const bf16x8 *>(aim + 32 * s);
           const bf16x8 ail = *reinterpret_cast<const bf16x8 *>(aim + v.bank_plane + 32 * s);
-          cre = __builtin_amdgcn_mfma_f32_16x16x32_bf16(arl, xh, cre, 0, 0, 0);
-          cim = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ail, xh, cim, 0, 0, 0);
-          cre = __builtin_amdgcn_mfma_f32_16x16x32_bf16(arh, xl, cre, 0, 0, 0);
-          cim = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aih, xl, cim, 0, 0, 0);
-          cre = __builtin_amdgcn_mfma_f32_16x16x32_bf16(arh, xh, cre, 0, 0, 0);
-          cim = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aih, xh, cim, 0, 0, 0);
+          cre = mfma16(arl, xh, cre);
+          cim = mfma16(ail, xh, cim);
+          cre = mfma16(arh, xl, cre);
+          cim = mfma16(aih, xl, cim);
+          cre = mfma16(arh, xh, cre);
+          cim = mfma16(aih, xh, cim);
         }
         // lane (frame fn, kg) holds bins 4 kg + e
         if (t < n_frames) {
@@ -428,7 +473,8 @@ __global__ void __launch_bounds__(256, 2) octave_pyramid_kernel(const PyrParams 
           for (int e = 0; e < 4; ++e) {
             const int bin = 4 * kg + e;
             if (bin < v_n_rows) {
-              const float sc = v_scale ? v_scale[bin] : 1.f;
+              float sc = v_scale ? v_scale[bin] : 1.f;
+              if (F16) sc *= xunscale * v.row_unscale[bin];
               float *d = o_clip + (long long)(v_row0 + bin) * o_row + (long long)t * E;
               epilogue_store(ep, d, cre[e] * sc, im_sign * cim[e] * sc);
             }

@@ -31,8 +31,8 @@ _PRECISIONS = {"fp32": PREC_F32, "bf16x3": PREC_BF16X3, "f16x3": PREC_F16X3}
 # import); None: every module uses its own default -- the fastest arithmetic that meets the
 # reference's own fixtures for that module (tests/test_gpu_parity.py::test_reference_ground_truths):
 #   STFT (and MelSpectrogram / Gammatonegram / MFCC through it)   "f16x3"
+#   CQT2010v2 / VQT                                                "f16x3" (the fused octave kernel)
 #   CQT1992v2                                                      "fp32" (the reference's summation order)
-#   CQT2010v2 / VQT                                                "fp32"
 _default_precision = os.environ.get("MISPEC_PRECISION") or None
 if _default_precision is not None and _default_precision not in _PRECISIONS:
     raise ValueError("MISPEC_PRECISION must be one of %s" % sorted(_PRECISIONS))
@@ -892,10 +892,34 @@ def fir_decimate(x, taps, stride):
     return y
 
 
-def octave_pyramid(x, levels, *, hop, n_frames, taps, epilogue, im_sign, eps, out, x_last, _stamps=None):
+def split_basis_f16(basis_re, basis_im):
+    """Scaled (hi, lo) fp16 pairs of a complex bank as row-major planes + the per-row inverse scales
+    (mispec_split_basis_f16): the banks of the fused octave kernel in ``precision="f16x3"``."""
+    dev = _require_device(basis_re, basis_im)
+    wr, wi = _rows(basis_re, "basis_re"), _rows(basis_im, "basis_im")
+    if wi.shape != wr.shape or wi.stride(0) != wr.stride(0):
+        raise RuntimeError("real / imaginary bases must have identical shape and layout")
+    lib = _abi.load()
+    F, K = wr.shape
+    need = lib.mispec_basis_split16_bytes(F, K)
+    if need < 0:
+        _abi.check(int(need))
+    dst = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _abi.check(lib.mispec_split_basis_f16(wr.data_ptr(), wi.data_ptr(), wr.stride(0), F, K,
+                                              dst.data_ptr(), need, ctypes.c_void_p(stream)))
+    return dst
+
+
+def octave_pyramid(x, levels, *, hop, n_frames, taps, epilogue, im_sign, eps, out, x_last, _stamps=None,
+                   precision="bf16x3", fir_headroom_bits=0, absmax_in=None, absmax_in_ready=False,
+                   absmax_out=None):
     """One launch of the fused octave recursion (``mispec_octave_pyramid_f32``): ``levels`` is a
     list of up to three dicts ``{split, n_bins, kernel, row_offset, pad_mode, row_scale}`` or None
-    (a level without a bank).  Returns False when the library does not serve the shape."""
+    (a level without a bank).  ``precision="f16x3"``: the splits are ``split_basis_f16`` results,
+    ``absmax_in`` / ``absmax_out`` int32 tensors of ``32 * n_clips`` words (see include/mispec.h).
+    Returns False when the library does not serve the shape."""
     dev = _require_device(x, out, x_last, taps)
     x = _signal(x)
     taps = _f32(taps, "filter").reshape(-1).contiguous()
@@ -925,6 +949,11 @@ def octave_pyramid(x, levels, *, hop, n_frames, taps, epilogue, im_sign, eps, ou
         a.x_last, a.x_last_clip_stride = x_last.data_ptr(), x_last.stride(0)
     a.out = out.data_ptr()
     a.out_clip_stride, a.out_row_stride = out.stride(0), out.stride(1)
+    a.precision = _PRECISIONS[precision]
+    if precision == "f16x3":
+        a.fir_headroom_bits = int(fir_headroom_bits)
+        a.absmax_in, a.absmax_in_ready = absmax_in.data_ptr(), int(bool(absmax_in_ready))
+        a.absmax_out = absmax_out.data_ptr() if absmax_out is not None else None
     lib = _abi.load()
     if _stamps is not None:  # phase clock of one workgroup (scripts/kbench.py, benchmarking build)
         a.reserved = _stamps.data_ptr()

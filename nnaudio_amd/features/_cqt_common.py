@@ -79,9 +79,9 @@ def zero_margin(re, im):
 
 
 class OctaveCache:
-    """Per-module derived operands of the octave recursion for ``precision="bf16x3"``: the split
-    planes of every octave's bank rows (see ``engine.DerivedCache``: rebuilt when the buffers
-    change)."""
+    """Per-module derived operands of the octave recursion on the fused kernel (``precision``
+    "bf16x3" / "f16x3"): the split planes of every octave's bank rows (see ``engine.DerivedCache``:
+    rebuilt when the buffers change)."""
 
     def __init__(self):
         self._banks = {}
@@ -93,13 +93,22 @@ class OctaveCache:
         return c.get((lenghts,), lambda: normalisation_scale(lenghts, normalization_type, factor),
                      extra=(normalization_type, float(factor)))
 
-    def bank(self, i, kr, ki, first):
+    def fir_headroom_bits(self, lowpass):
+        """ceil(log2(sum |taps|)): what one anti-alias FIR can add to the magnitude of a signal, in
+        bits (fp16 operands of the f16x3 arithmetic keep that much room per level).  One host read
+        per filter."""
+        import math
+
+        c = self.__dict__.setdefault("_gain", engine.DerivedCache())
+        return c.get((lowpass,), lambda: max(0, math.ceil(math.log2(max(float(lowpass.abs().sum()), 1e-30)))))
+
+    def bank(self, i, kr, ki, first, precision="bf16x3"):
         """(split planes, kernel width) of octave ``i``'s rows ``first:``.  The reference's kernels
         sit centred in a power-of-two width and the longest of an octave spans ~0.69 of it: equal
         zero margins (multiples of 16 taps) are cut off both ends -- the same frames, centred as
         before, on a narrower kernel (256 -> 192 taps for the reference's banks: the fused kernel
         then keeps 6 instead of 8 steps of kernel rows in registers)."""
-        c = self._banks.setdefault(i, engine.DerivedCache())
+        c = self._banks.setdefault((i, precision), engine.DerivedCache())
 
         def build():
             r = kr.reshape(kr.shape[0], -1)[first:]
@@ -107,16 +116,23 @@ class OctaveCache:
             K, m = r.shape[1], zero_margin(r, im)
             if m:
                 r, im = r[:, m:K - m].contiguous(), im[:, m:K - m].contiguous()
-            return engine.split_basis(r, im), K - 2 * m
+            split = engine.split_basis_f16 if precision == "f16x3" else engine.split_basis
+            return split(r.contiguous(), im.contiguous()), K - 2 * m
 
         return c.get((kr, ki), build, extra=first)
 
 
-def _fused_chain(x, octs, lowpass, epi, im_sign, eps, out, cache):
+def _fused_chain(x, octs, lowpass, epi, im_sign, eps, out, cache, precision="bf16x3"):
     """Run as many leading octaves as possible through ``engine.octave_pyramid`` (three levels per
     launch, the deepest level of a launch feeding the next).  Returns (number of octaves done, the
-    fp32 signal of the last octave done)."""
+    fp32 signal of the last octave done).  "f16x3": the clips' largest |sample| is found once for x
+    and gathered by every launch for the level it hands on (two ping-pong buffers)."""
     done, xd = 0, x
+    f16 = precision == "f16x3"
+    # (one zeroed buffer per launch boundary: the library's atomic maxima land in zeroed words)
+    absmax = torch.zeros((len(octs) // 2 + 2, 32 * x.shape[0]), dtype=torch.int32, device=x.device) if f16 else None
+    gain_bits = cache.fir_headroom_bits(lowpass) if f16 else 0
+    launch = 0
     while done < len(octs):
         first = done == 0
         # levels of this launch: octave `base` (contracted only in the first launch: later it was the
@@ -129,18 +145,24 @@ def _fused_chain(x, octs, lowpass, epi, im_sign, eps, out, cache):
             if i == base and not first:
                 levels.append(None)
                 continue
-            split, k_eff = cache.bank(i, o["kr"], o["ki"], o["first"])
+            split, k_eff = cache.bank(i, o["kr"], o["ki"], o["first"], precision)
             levels.append(dict(split=split, n_bins=o["rows"], kernel=k_eff, row_offset=o["row0"],
                                pad_mode=o["mode"], row_scale=o["scale"]))
         last = octs[top - 1]
         x_last = None
         if top < len(octs):  # someone will need the deepest level
             x_last = torch.empty((x.shape[0], last["L"]), dtype=torch.float32, device=x.device)
+        extra = {}
+        if f16:
+            extra = dict(precision="f16x3", fir_headroom_bits=gain_bits * (len(levels) - 1),
+                         absmax_in=absmax[launch], absmax_in_ready=launch > 0,
+                         absmax_out=absmax[launch + 1] if x_last is not None else None)
         ok = engine.octave_pyramid(xd, levels, hop=octs[base]["hop"], n_frames=out.shape[2],
                                    taps=lowpass, epilogue=epi, im_sign=im_sign, eps=eps, out=out,
-                                   x_last=x_last)
+                                   x_last=x_last, **extra)
         if not ok:
             break
+        launch += 1
         done = top
         if x_last is None:
             break
@@ -242,8 +264,8 @@ def octave_recursion(x, banks, lenghts, hop, n_bins, lowpass, downsample_factor,
     shape = (x.shape[0], n_bins, T_ref, 2) if two else (x.shape[0], n_bins, T_ref)
     out = engine.alloc_out(shape, x.device)
     done, xd = 0, x
-    if precision == "bf16x3" and cache is not None and not trainable and x.is_cuda:
-        done, xd = _fused_chain(x, octs, lowpass, epi, im_sign, eps, out, cache)
+    if precision in ("bf16x3", "f16x3") and cache is not None and not trainable and x.is_cuda:
+        done, xd = _fused_chain(x, octs, lowpass, epi, im_sign, eps, out, cache, precision)
     launches = []  # the remaining per-octave contractions are independent: one grouped launch
     for o in octs[done:]:  # xd: the fp32 signal of the previous octave (x itself before octave 0)
         if o["i"] > 0:

@@ -237,7 +237,7 @@ class CQT2010v2(nn.Module):
             x, banks, self.lenghts, self.hop_length, self.n_bins, self.lowpass_filter,
             self.downsample_factor, self.pad_mode, output_format, normalization_type,
             self.trainable, supports=[self._support] * self.n_octaves, graph=graph,
-            precision=engine.resolve_precision(self.precision), cache=self._octaves,
+            precision=engine.resolve_precision(self.precision, "f16x3"), cache=self._octaves,
         )
 
 

@@ -6,7 +6,7 @@
 set -u
 TAG=${1:-r01}
 WL=${2:-stft}
-PREC=${3:-bf16x3}
+PREC=${3:-f16x3}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT/summary
@@ -20,6 +20,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $
 # (2..) PMC passes: counters only (never combined with trace domains)
 MOPS=SQ_INSTS_VALU_MFMA_MOPS_F32
 [ "$PREC" = "bf16x3" ] && MOPS=SQ_INSTS_VALU_MFMA_MOPS_BF16
+[ "$PREC" = "f16x3" ] && MOPS=SQ_INSTS_VALU_MFMA_MOPS_F16
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE $MOPS"
 P2="FETCH_SIZE"
 P3="WRITE_SIZE"

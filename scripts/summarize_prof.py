@@ -30,7 +30,7 @@ for f in find("*counter_collection.csv"):
         agg[k][r.get("Counter_Name")] += float(r.get("Counter_Value", 0) or 0)
         cnt[(k, r.get("Counter_Name"))] += 1
     for k, d in agg.items():
-        if not any(t in k for t in ("framed_", "split_signal", "fold_", "octave_pyramid", "fir_decimate")):
+        if not any(t in k for t in ("framed_", "split_signal", "fold", "octave_pyramid", "fir_decimate", "clip_absmax")):
             continue
         print("  kernel:", k)
         for c, v in sorted(d.items()):

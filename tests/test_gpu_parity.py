@@ -495,11 +495,13 @@ def test_cfg5_cqt2010v2_vqt_full_length():
         assert (lhs - rhs).abs().max().item() <= 1e-4 * rhs.abs().max().item()
 
 
-def test_cfg5_fused_octave_kernel_bf16x3():
-    """cfg5 shard in the benched arithmetic: the fused octave kernel (decimated signals resident in
-    LDS, split-bf16 matrix pipe; octave 7, whose hop is 4 samples, on the per-octave kernels)
-    against the sampled float64 recursion, for CQT2010v2 and VQT(gamma=10); VQT(gamma=0) equals
-    CQT2010v2 bit for bit here too; Magnitude agrees with |Complex|."""
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x3"])
+def test_cfg5_fused_octave_kernel(precision):
+    """cfg5 shard on the fused octave kernel (decimated signals resident in LDS, split operands on the
+    matrix pipe, all eight octaves on the chain of launches), in both split arithmetics, against the
+    sampled float64 recursion, for CQT2010v2 and VQT(gamma=10); VQT(gamma=0) equals CQT2010v2 bit
+    for bit here too; Magnitude agrees with |Complex|.  f16x3 carries 22 operand bits through the
+    seven decimations (bf16x3: 16): fp32-class against the float64 values."""
     from nnaudio_amd import features
 
     B, L = 64, 1323000
@@ -510,17 +512,18 @@ def test_cfg5_fused_octave_kernel_bf16x3():
     v0 = features.VQT(gamma=0, **kw).to(DEV)
     v10 = features.VQT(gamma=10, **kw).to(DEV)
     for m in (c, v0, v10):
-        m.precision = "bf16x3"
+        m.precision = precision
+    tol = 1e-4 if precision == "bf16x3" else 5e-6
     with torch.no_grad():
         yc = c(xd)
         assert tuple(yc.shape) == (64, 96, 2584, 2)
-        _cfg5_sampled_check(c, x, yc, np.random.default_rng(6), "CQT2010v2 cfg5 bf16x3")
+        _cfg5_sampled_check(c, x, yc, np.random.default_rng(6), "CQT2010v2 cfg5 " + precision, tol=tol)
         c.precision = "fp32"
         y32 = c(xd)
         assert not torch.equal(yc, y32)  # the fused kernel really ran
-        assert (yc - y32).abs().max().item() <= 5e-5 * y32.abs().max().item()
+        assert (yc - y32).abs().max().item() <= (5e-5 if precision == "bf16x3" else 5e-6) * y32.abs().max().item()
         del y32
-        c.precision = "bf16x3"
+        c.precision = precision
         mag = c(xd, output_format="Magnitude")
         assert torch.allclose(mag, torch.sqrt(yc[..., 0] ** 2 + yc[..., 1] ** 2), rtol=1e-5, atol=1e-4)
         del mag
@@ -528,7 +531,13 @@ def test_cfg5_fused_octave_kernel_bf16x3():
         assert torch.equal(yc, yv)
         del yv, yc
         y10 = v10(xd)
-        _cfg5_sampled_check(v10, x, y10, np.random.default_rng(7), "VQT gamma=10 cfg5 bf16x3")
+        _cfg5_sampled_check(v10, x, y10, np.random.default_rng(7), "VQT gamma=10 cfg5 " + precision, tol=tol)
+        # the scale follows the clip: any signal level must do (f16x3: fp16 has 5 exponent bits)
+        if precision == "f16x3":
+            g = torch.tensor([1e-6, 1.0, 3e4, 1e-3], device=DEV)
+            ys = c(xd[:4] * g[:, None])
+            want = c(xd[:4]) * g[:, None, None, None]
+            assert (ys - want).abs().max(-1)[0].max(-1)[0].max(-1)[0].div(want.abs().amax((1, 2, 3))).max().item() <= 1e-5
 
 
 def test_cfg3_mel_full_size_sampled_bf16x3():
@@ -659,6 +668,27 @@ def test_split_basis_is_bit_exact(F, K, has_im):
                                   if n.split("_")[0] in ("stft", "mel", "gamma", "cqt1992v2", "mfcc",
                                                          "cqt2010v2", "vqt")])
 def test_case_bf16x3_matches_reference_and_oracle(golden, bf16x3, name):
+    _case_in_the_process_wide_precision(golden, name)
+
+
+@pytest.fixture
+def f16x3():
+    import nnaudio_amd
+
+    old = nnaudio_amd.get_precision()
+    nnaudio_amd.set_precision("f16x3")
+    yield
+    nnaudio_amd.set_precision(old)
+
+
+@pytest.mark.parametrize("name", [n for n in _golden.case_names(forward_only=True)
+                                  if n.split("_")[0] in ("stft", "mel", "gamma", "cqt1992v2", "mfcc",
+                                                         "cqt2010v2", "vqt")])
+def test_case_f16x3_matches_reference_and_oracle(golden, f16x3, name):
+    _case_in_the_process_wide_precision(golden, name)
+
+
+def _case_in_the_process_wide_precision(golden, name):
     case = golden.cases[name]
     x = golden.inputs[case["input"]]
     ref = golden.forward[name]

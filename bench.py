@@ -90,14 +90,14 @@ def kernel_source_sha():
 def fold_geometry(n_bins, K, fused_fb=False):
     """(bins inside whole MFMA tiles, folded taps per component) of the folded STFT contraction for
     an n_fft/2+1-bin Fourier basis -- mirror of plan_fold2 / plan_fold in csrc/mispec.hip: the second
-    fold (K/4 + 1 taps rounded to 16, even and odd bins in 128-bin tiles, the Nyquist bin in the
-    pre-pass) unless the filterbank is fused (then the single fold, K/2 taps)."""
+    fold (K/4 taps, even and odd bins in 128-bin tiles, the Nyquist bin in the pre-pass) unless the
+    filterbank is fused (then the single fold, K/2 taps)."""
     up = lambda v, m: (v + m - 1) // m * m
     if not fused_fb and K % 64 == 0 and n_bins >= 128:
         ne, no = (n_bins + 1) // 2, n_bins // 2
         if ne > 128 and ne % 128 == 1:
             ne -= 1
-        return up(ne, 128) + up(no, 128), up(K // 4 + 1, 16)
+        return up(ne, 128) + up(no, 128), up(K // 4, 16)
     nb = n_bins - 1 if (n_bins > 128 and n_bins % 128 == 1) else n_bins
     return up(nb, 128), up(K // 2, 16)
 

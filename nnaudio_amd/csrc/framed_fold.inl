@@ -643,26 +643,38 @@ __device__ __forceinline__ void framed_fold_body(const KParams &p, const int til
     if (sum == 12345.678f) p.out[0] = sum;
     return;
   }
-  if (ARITH == FOLD_F16X3) {
-    // undo the operand scaling: acc[..][n][4 g + i] belongs to frame 32 n + 8 g + 4 lh + i of the wave's block
+  if (ARITH == FOLD_F16X3 || p.col_add) {
+    // FOLD_F16X3: undo the operand scaling; second fold: add tap 0's term to the real parts.
+    // acc[..][n][4 g + i] belongs to frame 32 n + 8 g + 4 lh + i of the wave's block
 #pragma unroll
     for (int n = 0; n < NRW; ++n)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const long long col = n0 + (wn * NRW + n) * 32 + 8 * g + 4 * lh;
-        f32x4v u;
+        f32x4v u = {1.f, 1.f, 1.f, 1.f}, ad = {0.f, 0.f, 0.f, 0.f};
         if (col + 3 < p.n_cols) {
-          u = *reinterpret_cast<const f32x4v *>(p.col_unscale + col);
+          // (4-byte aligned vectors: the arrays start wherever n_cols puts them)
+          if (ARITH == FOLD_F16X3) u = *reinterpret_cast<const f32x4u *>(p.col_unscale + col);
+          if (p.col_add) ad = *reinterpret_cast<const f32x4u *>(p.col_add + col);
         } else {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) u[i] = p.col_unscale[col + i < p.n_cols ? col + i : 0];
+          for (int i = 0; i < 4; ++i) {
+            const long long ci = col + i < p.n_cols ? col + i : 0;
+            if (ARITH == FOLD_F16X3) u[i] = p.col_unscale[ci];
+            if (p.col_add) ad[i] = p.col_add[ci];
+          }
         }
 #pragma unroll
         for (int m = 0; m < MRW; ++m)
 #pragma unroll
-          for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[m][h][n][4 * g + i] *= u[i];
+          for (int i = 0; i < 4; ++i) {
+            if (ARITH == FOLD_F16X3) {
+              acc[m][0][n][4 * g + i] = fmaf(acc[m][0][n][4 * g + i], u[i], ad[i]);
+              acc[m][1][n][4 * g + i] *= u[i];
+            } else {
+              acc[m][0][n][4 * g + i] += ad[i];
+            }
+          }
       }
   }
   // the epilogues of the dense planar kernel, once per bin tile of the wave (32-bin block
@@ -704,6 +716,7 @@ __device__ __forceinline__ void framed_fold_tile(const KParams &p, int tile_m, c
     q.as = p.as + p.fold2_as_odd;
     q.xs = p.xs + p.fold2_xs_odd;
     q.out = p.out + p.out_row_stride;
+    q.col_add = p.col_add + p.n_cols;
   }
   framed_fold_body<NR, ARITH>(q, tile_m, n0);
 }

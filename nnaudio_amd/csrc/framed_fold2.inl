@@ -10,9 +10,11 @@
 //     even k:  re = sum_n Ep[n] cos(2 pi k n / N)      im = sum_n Om[n] sin(2 pi k n / N)
 //     odd  k:  re = sum_n Em[n] cos(...)               im = sum_n Op[n] sin(...)        n = 0 .. Q
 // -- a quarter of the dense MFMAs.  Folded slot j < Q stands for n = j + 1 (the four samples n, N-n,
-// M-n, M+n), slot Q for n = 0 (Ep = y[0] + y[M], Em = y[0] - y[M]; sines are 0), then zeros up to a
-// multiple of 16.  At n = Q the pair (n, M-n) is one tap: the general formulas give twice E[Q] / O[Q]
-// and the folded basis carries half the coefficient there.
+// M-n, M+n): exactly Q = N/4 slots.  At n = Q the pair (n, M-n) is one tap: the general formulas give
+// twice E[Q] / O[Q] and the folded basis carries half the coefficient there.  Tap n = 0 (samples 0 and
+// M; cos = 1 for every bin, sin = 0) is not a slot: the pre-pass writes  y[0] + y[M]  (even bins) and
+// y[0] - y[M]  (odd bins) per frame to col_add, and the contraction adds them to its real accumulators
+// before the epilogue (a 33rd K stage for this one tap cost 3 % of the MFMAs).
 //
 // Nothing is assumed about the basis: fold2_basis_kernel compares EVERY coefficient of the module's
 // buffers with  row 0 of the cos basis (= the window) x the analytic DFT value  and reports the
@@ -33,7 +35,7 @@
 constexpr int FOLD2_FR = 2;          // frames per thread group of the pre-pass
 
 __host__ __device__ inline int fold2_taps(int kernel) {
-  return (kernel / 4 + 1 + FOLD_KC - 1) / FOLD_KC * FOLD_KC;
+  return (kernel / 4 + FOLD_KC - 1) / FOLD_KC * FOLD_KC;  // kernel % 64 == 0: exactly kernel / 4
 }
 // threads per frame group of the pre-pass: one quad of slots per thread and trip
 __host__ __device__ inline int fold2_tg(int kernel) {
@@ -57,7 +59,7 @@ __global__ void __launch_bounds__(256) fold2_basis_kernel(const float *__restric
   const int Q = N >> 2, M = N >> 1;
   float mism = 0.f, amax = 0.f, wmax = 0.f;
   if (j < Kf) {
-    const int n = j < Q ? j + 1 : (j == Q ? 0 : -1);
+    const int n = j < Q ? j + 1 : -1;
     float c = 0.f, s = 0.f;
     if (n >= 0) {
       const double ang = 2.0 * (double)(((long long)k * n) % N) / (double)N;  // in units of pi
@@ -69,11 +71,12 @@ __global__ void __launch_bounds__(256) fold2_basis_kernel(const float *__restric
       c = (float)cd;
       s = (float)sd;
       // the buffers at the (up to) four samples this slot stands for
-      const int pos[4] = {n, N - n, M - n, M + n};
+      // (+ samples 0 and M, the tap the contraction adds from col_add: checked by slot 0's thread)
+      const int pos[6] = {n, N - n, M - n, M + n, j == 0 ? 0 : -1, j == 0 ? M : -1};
       const float *wr = re + (long long)k * row_stride;
       const float *wi = im + (long long)k * row_stride;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 6; ++u) {
         const int m = pos[u];
         if (m < 0 || m >= N) continue;
         const double a = 2.0 * (double)(((long long)k * m) % N) / (double)N;
@@ -161,7 +164,7 @@ __global__ void __launch_bounds__(256) fold2_frames_kernel(const KParams p, unsi
   auto compute = [&](int j0, float (&ep)[FOLD2_FR][4], float (&em)[FOLD2_FR][4], float (&op)[FOLD2_FR][4],
                      float (&om)[FOLD2_FR][4]) __attribute__((always_inline)) -> float {
     float mx = 0.f;
-    if (j0 + 4 <= Q) {  // slots of n = j0+1 .. j0+4: samples n, N-n, M-n, M+n
+    {  // slots of n = j0+1 .. j0+4 <= Q: samples n, N-n, M-n, M+n
       const f32x4u wA = *reinterpret_cast<const f32x4u *>(win + j0 + 1);
       const f32x4u wB = *reinterpret_cast<const f32x4u *>(win + N - j0 - 4);
       const f32x4u wC = *reinterpret_cast<const f32x4u *>(win + M - j0 - 4);
@@ -213,25 +216,6 @@ __global__ void __launch_bounds__(256) fold2_frames_kernel(const KParams p, unsi
           om[f][i] = d1 - d2;
           mx = fmaxf(fmaxf(mx, fmaxf(fabsf(ep[f][i]), fabsf(em[f][i]))), fmaxf(fabsf(op[f][i]), fabsf(om[f][i])));
         }
-    } else {  // slot Q: n = 0 (samples 0 and M), then the zero padding
-#pragma unroll
-      for (int f = 0; f < FOLD2_FR; ++f) {
-        const long long q0 = qa + (long long)(f < nf ? f : 0) * p.hop;
-        float y0 = 0.f, yM = 0.f;
-        if (j0 == Q) {
-          const long long cb = (long long)c * p.x_clip_stride;
-          y0 = win[0] * fetch_sample(p.x, cb, (int)q0, p.n_samples, p.pad_mode, true);
-          yM = win[M] * fetch_sample(p.x, cb, (int)(q0 + M), p.n_samples, p.pad_mode, true);
-        }
-        ep[f][0] = y0 + yM;
-        em[f][0] = y0 - yM;
-        op[f][0] = om[f][0] = 0.f;
-        ep[f][1] = ep[f][2] = ep[f][3] = 0.f;
-        em[f][1] = em[f][2] = em[f][3] = 0.f;
-        op[f][1] = op[f][2] = op[f][3] = 0.f;
-        om[f][1] = om[f][2] = om[f][3] = 0.f;
-        mx = fmaxf(mx, fmaxf(fabsf(ep[f][0]), fabsf(em[f][0])));
-      }
     }
     return mx;
   };
@@ -296,24 +280,36 @@ __global__ void __launch_bounds__(256) fold2_frames_kernel(const KParams p, unsi
                  fmaxf(red[2 * 4 * FOLD2_FR + 2], red[2 * 4 * FOLD2_FR + 3]));
   };
 
-  if (p.fold_arith == FOLD_F16X3 && Kf <= 8 * TG) {
-    // ---- FOLD_F16X3, every thread's slots fit two trips (the paired quads, then slot Q): all values
-    // are formed first, the workgroup's largest magnitude m = f 2^e, f in [0.5, 1), gives the scale
-    // 2^(15-e) that keeps the fp16 pairs below 2^15, then they are split and staged
+  // tap n = 0 of the group's frames: y[0] +- y[M], added by the contraction to the real parts of the
+  // even / odd bins (and here to the last even bin's sum)
+  if (gt == 0 && nf > 0) {
+#pragma unroll
+    for (int f = 0; f < FOLD2_FR; ++f) {
+      if (f < nf) {
+        const long long q0 = qa + (long long)f * p.hop, cb = (long long)c * p.x_clip_stride;
+        const float y0 = win[0] * fetch_sample(p.x, cb, (int)q0, p.n_samples, p.pad_mode, true);
+        const float yM = win[M] * fetch_sample(p.x, cb, (int)(q0 + M), p.n_samples, p.pad_mode, true);
+        const long long col = (long long)c * p.n_frames + t0 + f;
+        p.col_add[col] = y0 + yM;
+        p.col_add[p.n_cols + col] = y0 - yM;
+        if (le) pe[f] += y0 + yM;  // (its coefficient: cos(0) = 1)
+      }
+    }
+  }
+  if (p.fold_arith == FOLD_F16X3 && Kf <= 4 * TG) {
+    // ---- FOLD_F16X3, one trip per thread: all values are formed first, the workgroup's largest
+    // magnitude m = f 2^e, f in [0.5, 1), gives the scale 2^(15-e) that keeps the fp16 pairs below
+    // 2^15, then they are split and staged
     float ep0[FOLD2_FR][4], em0[FOLD2_FR][4], op0[FOLD2_FR][4], om0[FOLD2_FR][4];
-    float ep1[FOLD2_FR][4], em1[FOLD2_FR][4], op1[FOLD2_FR][4], om1[FOLD2_FR][4];
-    const int j0 = 4 * gt, j1 = j0 + 4 * TG;
+    const int j0 = 4 * gt;
     float m = 0.f;
     const bool live = nf > 0 && j0 < Kf;  // (short kernels: more threads than quads)
-    const bool live1 = live && j1 < Kf;
     if (live) m = compute(j0, ep0, em0, op0, om0);
-    if (live1) m = fmaxf(m, compute(j1, ep1, em1, op1, om1));
     m = wg_max(m);
     const int e = absmax_exponent(m);
     const float scale = pow2f(15 - e);
     if ((int)threadIdx.x < nfw) p.col_unscale[col0 + threadIdx.x] = pow2f(e - 15 - 14);  // also the basis' 2^14
     if (live) emit(j0, ep0, em0, op0, om0, scale);
-    if (live1) emit(j1, ep1, em1, op1, om1, scale);
   } else {
     // ---- any other case: FOLD_F16X3 takes its scale from the largest |sample| the workgroup reads
     // (x max |window|: the four-sample combinations stay below 2^(e+2))

@@ -204,6 +204,7 @@ struct KParams {
   int fold_arith;            // FOLD_BF16X3 / FOLD_F32 / FOLD_F16X3: format of the folded operands
   float fold_wmax;           // FOLD_F16X3: max |window| (bounds the folded samples of a frame)
   float *col_unscale;        // FOLD_F16X3: per flat frame, what undoes the operand scaling (pre-pass writes, contraction reads)
+  float *col_add;            // second fold: per flat frame, tap 0's term y[0] + y[M] (even bins; odd bins: n_cols further, y[0] - y[M])
   // MISPEC_PREC_F16X3 on the strip kernel
   unsigned *clip_absmax;     // per clip: bit pattern of max |sample| (clip_absmax_kernel; atomicMax)
   const float *row_unscale;  // per bin: inverse of the power of two its basis row was multiplied with
@@ -2545,7 +2546,8 @@ Fold2Plan plan_fold2(const mispec_framed_gemm_args *a, const KParams &p) {
   f.no = p.n_bins / 2;
   f.last_in_prepass = f.ne > FOLD_BINS && f.ne % FOLD_BINS == 1;
   f.main_e = f.last_in_prepass ? f.ne - 1 : f.ne;
-  f.unscale_off = 2 * p.n_cols * (long long)f.kf * 8;
+  // [even frames | odd frames | col_add: 2 n_cols floats | FOLD_F16X3: col_unscale: n_cols floats]
+  f.unscale_off = 2 * p.n_cols * (long long)f.kf * 8 + 2 * p.n_cols * (long long)sizeof(float);
   f.ws_bytes = f.unscale_off + (a->precision == MISPEC_PREC_F16X3 ? p.n_cols * (long long)sizeof(float) : 0);
   f.ok = true;
   return f;
@@ -2568,6 +2570,7 @@ int launch_fold2(KParams p, const mispec_framed_gemm_args *a, const Fold2Plan &f
   p.col_unscale = p.fold_arith == FOLD_F16X3
                       ? reinterpret_cast<float *>(static_cast<char *>(a->workspace) + f.unscale_off)
                       : nullptr;
+  p.col_add = reinterpret_cast<float *>(static_cast<char *>(a->workspace) + 2 * p.n_cols * (long long)f.kf * 8);
   // output rows: the problem's block starts at out_row_offset; even / odd bins interleave from there
   p.out += (long long)p.out_row_offset * p.out_row_stride;
   p.out_row_offset = 0;

@@ -93,9 +93,11 @@ __device__ __forceinline__ void f16_split2(float a, float b, unsigned &hi, unsig
 }
 // A power-of-two scale from the largest magnitude m = f 2^e, f in [0.5, 1), of what it multiplies:
 // 2^(top - e) puts the values below 2^top; exponents clamped so that scale and inverse are normal.
+// (clamped so that 2^(15 - e) and 2^(e - 29 - headroom) are normal floats: finite inputs of any
+// magnitude keep their scale; below 2^-96 the pairs lose bits gracefully)
 __device__ __forceinline__ int absmax_exponent(float m) {
   int e = (int)((__float_as_uint(m) >> 23) & 0xff) - 126;
-  return e < -80 ? -80 : (e > 100 ? 100 : e);
+  return e < -96 ? -96 : (e > 127 ? 127 : e);
 }
 __device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
 constexpr int F16_TOP = 14;  // scaled operands of the strip kernel stay below 2^14

@@ -163,3 +163,40 @@ def test_f16x3_levels_within_a_clip():
     err = np.abs(y - ref).max() / np.abs(ref).max()
     assert err <= 5e-6, err
 
+
+
+@pytest.mark.parametrize("cls,ctor", [
+    ("STFT", dict(n_fft=1024, hop_length=256, output_format="Complex")),
+    ("MelSpectrogram", dict(sr=22050, n_fft=1024, n_mels=64, hop_length=256)),
+    ("CQT1992v2", dict(sr=22050, hop_length=256, n_bins=72, output_format="Complex")),
+    ("CQT2010v2", dict(sr=22050, hop_length=256, n_bins=72, output_format="Complex", earlydownsample=False)),
+])
+def test_f16x3_extreme_levels(cls, ctor):
+    """The operand scaling at the ends of float32: an all-zero clip, a clip at 1e-30, one at 1e+33 (1e-15 /
+    1e+15 where the output is a power) and one with a single full-scale click in digital silence, in one batch -- f16x3 must stay finite and
+    agree with the fp32 path relative to each clip's own peak (fp16's 5 exponent bits never show)."""
+    from nnaudio_amd import features
+
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(5, 30000, generator=g)
+    lo, hi = (1e-15, 1e15) if cls == "MelSpectrogram" else (1e-30, 1e33)  # (a power spectrum squares them)
+    x[0] = 0.0
+    x[1] *= lo
+    x[2] *= hi
+    x[3] = 0.0
+    x[3, 15000] = 1.0
+    m = getattr(features, cls)(verbose=False, **ctor).to(DEV)
+    target = m.stft if hasattr(m, "stft") else m
+    xd = x.to(DEV)
+    target.precision = "fp32"
+    ref = m(xd).double()
+    target.precision = "f16x3"
+    y = m(xd).double()
+    assert torch.isfinite(y).all()
+    assert float(y[0].abs().max()) == 0.0 and float(ref[0].abs().max()) == 0.0
+    for b in (1, 2, 3, 4):
+        peak = ref[b].abs().max()
+        assert peak > 0
+        err = float((y[b] - ref[b]).abs().max() / peak)
+        # (power spectra square the scale: 1e-30 underflows to 0 in fp32 too -- compare what is there)
+        assert err <= 2e-5, (cls, b, err)

@@ -2731,6 +2731,13 @@ int fill_params(const mispec_framed_gemm_args *a, KParams &p) {
     return fail(MISPEC_E_INVALID, "bad precision%s");
   if (a->reserved2 != 0 || a->reserved3 != 0 || a->reserved4 != 0 || a->reserved5 != 0)
     return fail(MISPEC_E_INVALID, "reserved fields must be 0%s");
+  if (a->row_support_host) {  // the caller's host copy of the supports: at least well-formed
+    if (!a->row_support) return fail(MISPEC_E_INVALID, "row_support_host without row_support%s");
+    for (int i = 0; i < a->n_bins; ++i) {
+      const int lo = a->row_support_host[2 * i], hi = a->row_support_host[2 * i + 1];
+      if (lo < 0 || hi < lo || hi > a->kernel) return fail(MISPEC_E_INVALID, "row_support_host: need 0 <= start <= stop <= kernel%s");
+    }
+  }
   if (a->fb) {
     if (!a->fb_support || a->n_fb <= 0)
       return fail(MISPEC_E_INVALID, "fused filterbank: fb_support and n_fb > 0 are required%s");

@@ -239,7 +239,7 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
                  eps=0.0, power=2.0, row_scale=None, row_support=None, out=None,
                  out_rows_total=None, out_row_offset=0, tile=TILE_AUTO, _debug=0,
                  need_workspace=True, precision=None, basis_split=None, basis_fold=None, fb=None,
-                 fb_support=None, basis_fold2=None):
+                 fb_support=None, basis_fold2=None, row_support_host=None):
     """Validate one framed-contraction problem and fill its C argument block.
     Returns (args, out, device, keepalive tensors)."""
     dev = _require_device(x, basis_re, basis_im, row_scale, row_support, out, fb, fb_support,
@@ -292,8 +292,10 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
     if row_support is not None:
         if row_support.dtype != torch.int32 or tuple(row_support.shape) != (F, 2):
             raise RuntimeError("row_support must be int32 (n_bins, 2)")
-        # (a host copy made by the caller -- features._cqt_common.SupportCache -- rides on the tensor)
-        support_host = getattr(row_support, "host_copy", None)
+        # the same values in host memory (library-side launch planning): the explicit argument, else
+        # the copy that features._cqt_common.SupportCache attaches to the tensor it returns (lost by
+        # any slice / copy of that tensor: callers that slice pass the argument)
+        support_host = row_support_host if row_support_host is not None else getattr(row_support, "host_copy", None)
         row_support = row_support.contiguous()
 
     E = 2 if two else 1
@@ -320,7 +322,7 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
     keep = [x, wr, wi, row_scale, row_support, fb, fb_support]
     if row_support is not None and support_host is not None:
         if support_host.dtype != np.int32 or support_host.shape != (F, 2) or not support_host.flags.c_contiguous:
-            raise RuntimeError("row_support.host_copy must be a C-contiguous int32 (n_bins, 2) array")
+            raise RuntimeError("row_support_host must be a C-contiguous int32 (n_bins, 2) array")
         a.row_support_host = support_host.ctypes.data
         keep.append(support_host)
     if fb is not None:

@@ -2,6 +2,8 @@
 the octave recursion of CQT2010v2 / VQT (reference: cqt.py:1070-1139, vqt.py:143-215)."""
 import warnings
 
+import numpy as np
+
 import torch
 
 from .. import engine
@@ -62,6 +64,10 @@ class SupportCache:
 
     def get(self, real, imag):
         return self._cache.get((real, imag), lambda: self._build(real, imag))
+
+    def host(self, real, imag):
+        """The same (n_bins, 2) int32 values in host memory (``row_support_host``)."""
+        return self.get(real, imag).host_copy
 
 
 def zero_margin(re, im):
@@ -270,14 +276,15 @@ def octave_recursion(x, banks, lenghts, hop, n_bins, lowpass, downsample_factor,
     for o in octs[done:]:  # xd: the fp32 signal of the previous octave (x itself before octave 0)
         if o["i"] > 0:
             xd = engine.fir_decimate(xd, lowpass, 2)
-        sup = None
+        sup = sup_host = None
         if supports is not None and not trainable:
             sup = supports[o["i"]].get(o["kr"], o["ki"])[o["first"]:].contiguous()
+            sup_host = np.ascontiguousarray(supports[o["i"]].host(o["kr"], o["ki"])[o["first"]:])
         launches.append((xd, o["kr"].reshape(n_filters, -1)[o["first"]:],
                          o["ki"].reshape(n_filters, -1)[o["first"]:], dict(
             hop=o["hop"], pad=o["pad"], pad_mode=o["mode"], epilogue=epi, im_sign=im_sign, eps=eps,
-            row_scale=o["scale"].contiguous(), row_support=sup, out=out, out_rows_total=n_bins,
-            out_row_offset=o["row0"], precision="fp32")))
+            row_scale=o["scale"].contiguous(), row_support=sup, row_support_host=sup_host, out=out,
+            out_rows_total=n_bins, out_row_offset=o["row0"], precision="fp32")))
     engine.framed_gemm_group(launches)
     return out
 

@@ -2538,7 +2538,7 @@ struct Fold2Plan {
 Fold2Plan plan_fold2(const mispec_framed_gemm_args *a, const KParams &p) {
   Fold2Plan f{};
   if (!a->basis_fold2 || a->tile != MISPEC_TILE_AUTO) return f;
-  if (MISPEC_DBG(p, 0x100000) || MISPEC_DBG(p, 0x10000000)) return f;  // A/B runs: dense / single fold
+  if (MISPEC_DBG(p, 0x100000) || MISPEC_DBG(p, 0x40000000)) return f;  // A/B runs: dense / single fold
   if (!p.a_im || p.row_support || p.row_scale || p.fb || !fold2_kernel_ok(p.K)) return f;
   if ((long long)p.hop * 8 < p.K) return f;  // the folded frames cost 4 K bytes per frame
   if (a->basis_fold2_bytes < basis_fold2_bytes(p.n_bins, p.K)) return f;

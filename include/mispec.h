@@ -87,8 +87,10 @@ enum {
                          /* operand instead of bf16x3's 16; the scales keep the pairs inside fp16's     */
                          /* 5-bit exponent and are undone on the accumulators): error ~1e-7 of the     */
                          /* spectrum peak, i.e. fp32 class, at the bf16x3 MFMA count.  Served where     */
-                         /* basis_fold2 / basis_fold apply and, with basis_split =                       */
-                         /* mispec_frag_basis_f16(), for banks with supports (strip kernel); other       */
+                         /* basis_fold2 / basis_fold apply; with basis_split = mispec_frag_basis_f16()  */
+                         /* for banks with supports (strip kernel, hop-periodic tap order); with         */
+                         /* basis_split = mispec_split_basis_f16() for any complex basis of more than   */
+                         /* 64 bins (staged dense kernel, natural tap order; supports honoured); other  */
                          /* shapes run in MISPEC_PREC_F32.                                              */
 };
 
@@ -143,7 +145,9 @@ typedef struct mispec_framed_gemm_args {
   int32_t precision;           /* MISPEC_PREC_*: the LOWEST precision the caller accepts   */
   int32_t reserved2;           /* must be 0                                                */
   const void *basis_split;     /* MISPEC_PREC_BF16X3: output of mispec_split_basis_bf16();  */
-                               /* MISPEC_PREC_F32 (optional): of mispec_frag_basis_f32()    */
+                               /* MISPEC_PREC_F32 (optional): of mispec_frag_basis_f32();   */
+                               /* MISPEC_PREC_F16X3: of mispec_frag_basis_f16() or of       */
+                               /* mispec_split_basis_f16() (told apart by their sizes)      */
   int64_t basis_split_bytes;   /* for this (basis_re, basis_im, n_bins, kernel); else NULL */
 
   /* Fused filterbank reduction (mel.py:184-189: matmul(mel_basis, spec ** power)) -- optional.
@@ -254,8 +258,11 @@ int mispec_frag_basis_f32(const float *basis_re, const float *basis_im, int64_t 
  * scaled per clip (from its largest |sample|, found by a pre-pass) and split the same way.
  */
 int64_t mispec_basis_frag16_bytes(int32_t n_bins, int32_t kernel);
-/* ... and as row-major planes [re_hi | re_lo | im_hi | im_lo] + the inverse factors, for the levels of
- * mispec_octave_pyramid_f32 in MISPEC_PREC_F16X3 */
+/* ... and as row-major planes [re_hi | re_lo | im_hi | im_lo] + the inverse factors: for the levels of
+ * mispec_octave_pyramid_f32 in MISPEC_PREC_F16X3, and -- as `basis_split` of a MISPEC_PREC_F16X3
+ * mispec_framed_gemm_f32 with basis_split_bytes = mispec_basis_split16_bytes() exactly -- for the staged
+ * dense kernel: complex bases of more than 64 bins that are not folded (CQT banks, with or without
+ * row_support; trainable or non-linear STFT bases), taps contracted in their natural order */
 int64_t mispec_basis_split16_bytes(int32_t n_bins, int32_t kernel);
 int mispec_split_basis_f16(const float *basis_re, const float *basis_im, int64_t basis_row_stride,
                            int32_t n_bins, int32_t kernel, void *dst, int64_t dst_bytes,

@@ -587,7 +587,13 @@ __device__ __forceinline__ void bf16x3_epilogue_fb(const KParams &p, f32x16 (&ac
   filterbank_from_tile<BB, BN, NT>(p, P, b0, n0);
 }
 
-template <int WM, int WN, int MR, int NR, bool MASKED>
+// F16 = MISPEC_PREC_F16X3: the same staged kernel on v_mfma_f32_32x32x16_f16 -- the planes hold (hi, lo)
+// fp16 pairs of every basis row x its power of two (mispec_split_basis_f16) and of every padded clip x
+// the power of two of its largest |sample| (clip_absmax_kernel + split_signal_kernel); the accumulators
+// are multiplied by the two inverse factors before the epilogue.  Taps are contracted in their natural
+// order (the hop-periodic kernels -- strip, narrow, slab -- sum aliased combs whose partial sums are
+// orders of magnitude larger than a silent bin's result: DESIGN.md 3.10).
+template <int WM, int WN, int MR, int NR, bool MASKED, bool F16 = false>
 __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int wg_index,
                                                    const int wg_count) {
   constexpr int NW = WM * WN;
@@ -616,6 +622,7 @@ __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int w
   long long *sColOff = reinterpret_cast<long long *>(smem_raw + 2 * STAGE);  // [BN]
   int *sTileLo = reinterpret_cast<int *>(sColOff + BN);
   int *sTileHi = sTileLo + MT;
+  float *sColUnscale = reinterpret_cast<float *>(sTileHi + MT);  // [BN] (F16)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -664,6 +671,7 @@ __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int w
     const int c = (int)(col / p.n_frames);
     const int t = (int)(col - (long long)c * p.n_frames);
     sColOff[j] = (long long)c * p.xs_clip_stride + (long long)t * p.hop;
+    if (F16) sColUnscale[j] = clip_unscale_of(p.clip_absmax[(long long)c * CLIP_ABSMAX_STRIDE]);
   }
   if (tid < MT) {
     const int row_lo = m0 + tid * 32;
@@ -800,8 +808,15 @@ __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int w
           for (int n = 0; n < NR; ++n) {
             const bf16x8 a = term == 0 ? al[q][m] : ah[q][m];
             const bf16x8 x = term == 1 ? xl[q][n] : xh[q][n];
-            acc[m][n] = PLANAR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, a, acc[m][n], 0, 0, 0)
-                               : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, x, acc[m][n], 0, 0, 0);
+            if constexpr (F16) {
+              typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+              const f16x8_t a16 = __builtin_bit_cast(f16x8_t, a), x16 = __builtin_bit_cast(f16x8_t, x);
+              acc[m][n] = PLANAR ? __builtin_amdgcn_mfma_f32_32x32x16_f16(x16, a16, acc[m][n], 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f32_32x32x16_f16(a16, x16, acc[m][n], 0, 0, 0);
+            } else {
+              acc[m][n] = PLANAR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, a, acc[m][n], 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, x, acc[m][n], 0, 0, 0);
+            }
           }
         }
       }
@@ -868,6 +883,41 @@ __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int w
     __syncthreads();  // every wave is done with the stage buffers (the epilogue reuses them)
   }
 
+  if constexpr (F16) {  // take the operands' powers of two off the accumulators
+    if constexpr (PLANAR) {
+      // acc[part][n][e]: bin (m0 / rpb) + 32 wm + li, frame column 32 (wn NR + n) + 8 (e >> 2) + 4 lh + (e & 3)
+      int bin = m0 / rpb + 32 * wm + li;
+      bin = bin < p.n_bins ? bin : p.n_bins - 1;
+      const float ru = p.row_unscale[bin];
+#pragma unroll
+      for (int n = 0; n < NR; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4v cu = *reinterpret_cast<const f32x4v *>(sColUnscale + 32 * (wn * NR + n) + 8 * g + 4 * lh);
+#pragma unroll
+          for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[m][n][4 * g + e] *= ru * cu[e];
+        }
+    } else {
+      // acc[m][n][e]: basis row m0 + 32 (wm MR + m) + 8 (e >> 2) + 4 lh + (e & 3), frame column 32 (wn NR + n) + li
+      float cu[NR];
+#pragma unroll
+      for (int n = 0; n < NR; ++n) cu[n] = sColUnscale[32 * (wn * NR + n) + li];
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          int bin = (m0 + 32 * (wm * MR + m) + 8 * (e >> 2) + 4 * lh + (e & 3)) / rpb;
+          bin = bin < p.n_bins ? bin : p.n_bins - 1;
+          const float ru = p.row_unscale[bin];
+#pragma unroll
+          for (int n = 0; n < NR; ++n) acc[m][n][e] *= ru * cu[n];
+        }
+    }
+    __syncthreads();  // (the table of column factors lies where the epilogue's patches go)
+  }
+
   if constexpr (PLANAR) {
     if MISPEC_DBG(p, 0x40000) {  // ablation: no epilogue (keep the accumulators alive)
       float s = 0.f;
@@ -892,6 +942,11 @@ __device__ __forceinline__ void framed_bf16x3_body(const KParams &p, const int w
 template <int WM, int WN, int MR, int NR, bool MASKED>
 __global__ void __launch_bounds__(WM *WN * 64) framed_bf16x3_kernel(const KParams p) {
   framed_bf16x3_body<WM, WN, MR, NR, MASKED>(p, blockIdx.x, gridDim.x);
+}
+
+template <int WM, int WN, int MR, int NR, bool MASKED>
+__global__ void __launch_bounds__(WM *WN * 64) framed_f16x3_kernel(const KParams p) {
+  framed_bf16x3_body<WM, WN, MR, NR, MASKED, true>(p, blockIdx.x, gridDim.x);
 }
 
 // Dense basis whose row count is not a multiple of 256 (the n_fft/2+1 bins of an STFT): the

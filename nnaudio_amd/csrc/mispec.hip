@@ -1832,7 +1832,8 @@ constexpr size_t bf16x3_smem() {
   constexpr int BM = WM * MR * 32;
   constexpr int BN = WN * NR * 32;
   constexpr int BMA = BM < 16 * NW ? 16 * NW : BM;
-  const size_t stages = 2 * (2 * BMA + 2 * BN) * (KC * 2) + BN * sizeof(long long) + 2 * WM * MR * sizeof(int);
+  const size_t stages = 2 * (2 * BMA + 2 * BN) * (KC * 2) + BN * sizeof(long long) + 2 * WM * MR * sizeof(int) +
+                        BN * sizeof(float);  // (+ per-column factors of the F16 instances)
   const size_t patches = (size_t)NW * 32 * (NR * 32 + 4) * sizeof(float);  // bf16x3_epilogue_planar
   return stages > patches ? stages : patches;
 }
@@ -1855,14 +1856,14 @@ long long prepare_bf16x3(KParams &p) {
   return tn * p.n_tiles_m;
 }
 
-template <int WM, int WN, int MR, int NR, bool MASKED>
+template <int WM, int WN, int MR, int NR, bool MASKED, bool F16 = false>
 int launch_bf16x3_cfg(KParams p, hipStream_t stream) {
   constexpr size_t smem = bf16x3_smem<WM, WN, MR, NR>();
   static_assert(smem <= 160 * 1024, "LDS budget");
   const long long grid = prepare_bf16x3<WM, WN, MR, NR>(p);
   if (grid < 0) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
   if (grid == 0) return MISPEC_OK;
-  auto kern = framed_bf16x3_kernel<WM, WN, MR, NR, MASKED>;
+  auto kern = F16 ? framed_f16x3_kernel<WM, WN, MR, NR, MASKED> : framed_bf16x3_kernel<WM, WN, MR, NR, MASKED>;
   static std::atomic<unsigned long long> configured{0};
   int rc = configure_lds(kern, smem, configured);
   if (rc != MISPEC_OK) return rc;
@@ -2899,6 +2900,46 @@ int launch_strip16(KParams p, const mispec_framed_gemm_args *a, const StripPlan 
   return MISPEC_OK;
 }
 
+// ---- MISPEC_PREC_F16X3 on the staged dense kernel (framed_bf16x3.inl, F16 instances): complex bases that
+// are not folded -- CQT banks (row supports honoured per 32-row tile), trainable / non-linear STFT bases --
+// with basis_split = mispec_split_basis_f16() (row-major planes; the strip kernel's fragment-order copy,
+// mispec_frag_basis_f16(), is larger: the size tells the two apart).  Taps in their natural order.
+bool dense16_ok(const mispec_framed_gemm_args *a, const KParams &p) {
+  if (a->precision != MISPEC_PREC_F16X3 || !a->basis_split || !p.a_im || a->tile != MISPEC_TILE_AUTO || p.fb)
+    return false;
+  if (a->basis_split_bytes != basis_plane_bytes(p.n_bins, p.K, true) + 2LL * p.n_bins * (long long)sizeof(float))
+    return false;
+  return p.n_bins * 2 > 128 && !(p.hop & 1);  // (as bf16x3: narrow problems stay on the fp32 tile kernels)
+}
+
+int launch_dense16(KParams p, const mispec_framed_gemm_args *a, hipStream_t stream) {
+  const EdgePlan e = plan_edges(p.n_samples, p.K, p.hop, p.pad, p.n_frames);
+  const SplitPlan sp = plan_split(p, e);
+  if (!a->workspace || a->workspace_bytes < strip16_ws_bytes(p, sp))
+    return fail(MISPEC_E_INVALID, "workspace too small: size it with the *_workspace_bytes query%s");
+  unsigned short *xs = reinterpret_cast<unsigned short *>(static_cast<char *>(a->workspace) + sp.edge_bytes);
+  p.xs = xs;
+  p.xs_clip_stride = sp.slot;
+  p.xs_plane = sp.slot * p.n_clips;
+  p.clip_absmax = reinterpret_cast<unsigned *>(static_cast<char *>(a->workspace) + sp.edge_bytes + sp.bytes);
+  p.split_f16 = 1;
+  p.Ks = round_up_kc(p.K);
+  p.as = static_cast<const unsigned short *>(a->basis_split);
+  p.as_plane = (long long)p.n_bins * p.Ks;
+  p.row_unscale = reinterpret_cast<const float *>(static_cast<const char *>(a->basis_split) +
+                                                  basis_plane_bytes(p.n_bins, p.K, true));
+  if (hipMemsetAsync(p.clip_absmax, 0, (size_t)p.n_clips * CLIP_ABSMAX_STRIDE * sizeof(unsigned), stream) != hipSuccess)
+    return fail(MISPEC_E_HIP, "hipMemsetAsync failed%s");
+  hipLaunchKernelGGL(clip_absmax_kernel, dim3((unsigned)((p.n_samples + ABSMAX_CHUNK - 1) / ABSMAX_CHUNK), (unsigned)p.n_clips),
+                     dim3(256), 0, stream, p.x, p.x_clip_stride, p.n_samples, p.clip_absmax);
+  const unsigned gx = (unsigned)((sp.slot + 1023) / 1024);
+  hipLaunchKernelGGL(split_signal_kernel, dim3(gx, (unsigned)p.n_clips), dim3(256), 0, stream, p, xs);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail(MISPEC_E_HIP, "signal split launch: %s", hipGetErrorString(err));
+  return p.row_support ? launch_bf16x3_cfg<4, 2, 2, 4, true, true>(p, stream)
+                       : launch_bf16x3_cfg<4, 2, 2, 4, false, true>(p, stream);
+}
+
 // ---- helpers of the host path (mispec_*_host_f32 below)
 namespace {
 template <typename F>
@@ -2954,12 +2995,13 @@ inline void host_epilogue(const mispec_framed_gemm_args *a, float *dst, float re
 }
 }  // namespace
 
-// MISPEC_PREC_F16X3 exists on the folded contractions and on the strip kernel: every other shape runs in
-// MISPEC_PREC_F32 on the dense kernels (operands prepared for MISPEC_PREC_F16X3 are not offered to them)
+// MISPEC_PREC_F16X3 exists on the folded contractions, on the strip kernel and on the staged dense kernel
+// (complex bases of more than 64 bins): every other shape runs in MISPEC_PREC_F32 on the tile kernels
+// (operands prepared for MISPEC_PREC_F16X3 are not offered to them)
 static bool f16_downgrade(const mispec_framed_gemm_args *a, const KParams &p, mispec_framed_gemm_args &local) {
   if (a->precision != MISPEC_PREC_F16X3 || plan_fold2(a, p).ok || plan_fold(a, p).ok) return false;
   StripPlan plan;
-  if (strip16_ok(a, p, device_cus(), plan)) return false;
+  if (strip16_ok(a, p, device_cus(), plan) || dense16_ok(a, p)) return false;
   local = *a;
   local.precision = MISPEC_PREC_F32;
   local.basis_fold2 = nullptr;
@@ -2994,7 +3036,7 @@ int64_t mispec_framed_gemm_workspace_bytes(const mispec_framed_gemm_args *args) 
   }
   {
     StripPlan plan;
-    if (strip16_ok(args, p, device_cus(), plan)) return strip16_ws_bytes(p, plan_split(p, e));
+    if (strip16_ok(args, p, device_cus(), plan) || dense16_ok(args, p)) return strip16_ws_bytes(p, plan_split(p, e));
   }
   {
     StripPlan plan;
@@ -3065,6 +3107,7 @@ int mispec_framed_gemm_f32(const mispec_framed_gemm_args *args, void *stream) {
     StripPlan plan;
     const int n_cu = device_cus();
     if (strip16_ok(args, p, n_cu, plan)) return launch_strip16(p, args, plan, n_cu, s);
+    if (dense16_ok(args, p)) return launch_dense16(p, args, s);
     if (strip32_ok(args, p, n_cu, plan)) return launch_strip32(p, args, plan, n_cu, s);
   }
   // (the bf16x3 kernels read the padded split signal, not the fp32 path's edge workspace)

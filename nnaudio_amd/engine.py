@@ -335,8 +335,9 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
         a.basis_split = basis_split.data_ptr()
         a.basis_split_bytes = basis_split.numel() * basis_split.element_size()
         keep.append(basis_split)
-    elif basis_split is not None and need_workspace and row_support is not None:
-        # fp32 with the fragment-order copy of a bank with supports (frag_basis_f32): the strip kernel
+    elif basis_split is not None and need_workspace and (row_support is not None or resolve_precision(precision) == "f16x3"):
+        # fp32 with the fragment-order copy of a bank with supports (frag_basis_f32): the strip kernel;
+        # f16x3 with split_basis_f16 planes (staged dense kernel) or frag_basis_f16 (strip kernel)
         a.basis_split = basis_split.data_ptr()
         a.basis_split_bytes = basis_split.numel() * basis_split.element_size()
         keep.append(basis_split)
@@ -521,8 +522,8 @@ def prepare_basis(basis_re, basis_im, precision, hop=None, fold=True):
     "bf16x3" the split-bf16 planes; in any arithmetic, for a window x DFT basis the quarter-folded
     planes (``basis_fold2``) and for a basis with the Fourier symmetry the folded planes
     (``basis_fold``) -- the library uses them when the shape allows (include/mispec.h): a quarter /
-    half of the MFMAs.  "f16x3" is served by the folded kernels (and the strip kernel for CQT banks);
-    what they do not cover runs in fp32 on the dense kernels."""
+    half of the MFMAs.  "f16x3": the folded kernels, else (complex bases of more than 64 bins) the staged
+    dense kernel on ``split_basis_f16`` planes; what they do not cover runs in fp32 on the tile kernels."""
     precision = resolve_precision(precision)
     if not basis_re.is_cuda:
         return {}  # (the host path contracts the module's buffers as they are)
@@ -536,6 +537,10 @@ def prepare_basis(basis_re, basis_im, precision, hop=None, fold=True):
         folded = fold_basis(basis_re, basis_im, precision)
         if folded is not None:
             out["basis_fold"] = folded
+    if (precision == "f16x3" and basis_im is not None and 2 * basis_re.shape[0] > 128
+            and (("basis_fold2" not in out and "basis_fold" not in out) or basis_re.shape[-1] > 8192)):
+        # not folded (trainable, freq_scale != 'no', hop < K / 8, ...): scaled fp16 planes for the staged dense kernel
+        out["basis_split"] = split_basis_f16(basis_re, basis_im)
     return out
 
 
@@ -896,7 +901,9 @@ def fir_decimate(x, taps, stride):
 
 def split_basis_f16(basis_re, basis_im):
     """Scaled (hi, lo) fp16 pairs of a complex bank as row-major planes + the per-row inverse scales
-    (mispec_split_basis_f16): the banks of the fused octave kernel in ``precision="f16x3"``."""
+    (mispec_split_basis_f16): the banks of the fused octave kernel in ``precision="f16x3"``, and as
+    ``basis_split`` of a ``precision="f16x3"`` ``framed_gemm`` the operand of the staged dense kernel
+    (taps contracted in their natural order; CQT1992v2, unfolded STFT bases)."""
     dev = _require_device(basis_re, basis_im)
     wr, wi = _rows(basis_re, "basis_re"), _rows(basis_im, "basis_im")
     if wi.shape != wr.shape or wi.stride(0) != wr.stride(0):

@@ -117,8 +117,16 @@ class CQT1992v2(nn.Module):
             pass  # (host path: the buffers as they are)
         elif precision == "bf16x3":
             split = self._split.get((kr, ki), lambda: engine.split_basis(kr, ki), extra=precision)
-        elif precision == "f16x3" and sup is not None:
-            split = self._split.get((kr, ki), lambda: engine.frag_basis_f16(kr, ki), extra=precision)
+        elif precision == "f16x3":
+            # banks with supports: the strip kernel (fragment-order copy), unless ``hop_periodic = False``
+            # asks for the staged dense kernel on row-major planes -- taps in their natural order: 0.6 % of
+            # the reference's log-magnitude fixture elements miss its tolerance instead of 2.7 % (fp32 tile
+            # kernels: 0.03 %; the comb-ordered partial sums of the hop-periodic kernels are orders of
+            # magnitude larger than a silent bin), at 2.5 x the time.  Trainable banks: the dense kernel.
+            if getattr(self, "hop_periodic", True) and sup is not None:
+                split = self._split.get((kr, ki), lambda: engine.frag_basis_f16(kr, ki), extra=precision + "-strip")
+            else:
+                split = self._split.get((kr, ki), lambda: engine.split_basis_f16(kr, ki), extra=precision)
         # (fp32 stays on the tile kernels, which sum the taps in the reference's order: the strip
         # kernel also exists in fp32 -- engine.frag_basis_f32, 20-50 % faster -- but its hop-periodic
         # order leaves different rounding noise in the near-silent bins, and 4.7 % of them then miss

@@ -60,7 +60,8 @@ _support_cache = _ViewCache()
 def _prepare(basis_re, basis_im, precision, hop, support):
     if support and precision == "f16x3":  # banks with supports: the strip kernel's scaled fp16 fragments
         frag = engine.frag_basis_f16(basis_re, basis_im)
-        return {"basis_split": frag} if frag is not None else {}
+        if frag is not None:
+            return {"basis_split": frag}
     return engine.prepare_basis(basis_re, basis_im, precision, hop=hop)
 
 

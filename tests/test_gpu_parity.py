@@ -121,6 +121,23 @@ def test_reference_ground_truths(golden, sweep, method, cls, tagc, fmt, tag, pre
         print("ground truth %s %s %s: %.4f of the elements miss log(X + eps)" % (sweep, cls, precision, miss))
 
 
+@pytest.mark.parametrize("sweep,method", [("log", "logarithmic"), ("linear", "linear")])
+def test_reference_ground_truths_f16x3_natural_order(golden, sweep, method):
+    """CQT1992v2 f16x3 with ``hop_periodic = False`` (staged dense kernel, taps in their natural order):
+    0.58 % / 0.21 % of the log-magnitude elements miss the reference's tolerance on the MI355X (strip kernel:
+    2.7 %; fp32 tile kernels 0.03 %) -- pinned with margin."""
+    case = dict(cls="CQT1992v2", ctor=dict(sr=44100, fmin=55, n_bins=207, bins_per_octave=24,
+                                           output_format="Magnitude"), fwd={})
+    mod = build_module(case, DEV)
+    mod.precision, mod.hop_periodic = "f16x3", False
+    y = run(mod, _chirp(method))
+    gt = golden.ground_truth("%s-sweep-cqt-1992-mag-ground-truth.npy" % sweep)
+    gtc = golden.ground_truth("%s-sweep-cqt-1992-complex-ground-truth.npy" % sweep)
+    miss = check_ground_truth(y, gt, "Magnitude", 1e-5, gtc, what="%s CQT1992v2 f16x3 natural order" % sweep,
+                              max_miss=0.009, phase_floor=1e-3)
+    print("ground truth %s CQT1992v2 f16x3 natural order: %.4f miss" % (sweep, miss))
+
+
 def test_vqt_gamma0_is_bit_identical_to_cqt2010v2(golden):
     """reference tests/test_vqt.py:30-41 asserts exact equality."""
     from nnaudio_amd import features

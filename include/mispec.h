@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MISPEC_ABI_VERSION 7
+#define MISPEC_ABI_VERSION 8
 
 enum {
   MISPEC_OK = 0,
@@ -199,7 +199,7 @@ typedef struct mispec_framed_gemm_args {
   const void *basis_fold2;     /* or NULL                                                  */
   int64_t basis_fold2_bytes;
   float fold2_wmax;
-  int32_t reserved5;           /* must be 0                                                */
+  int32_t no_fft;              /* non-zero: never take the FFT path (below)                */
 } mispec_framed_gemm_args;
 
 /*

@@ -24,6 +24,15 @@ def get_precision():
     return engine.get_precision()
 
 
+def set_fft(enabled):
+    """STFT with window x DFT kernels (freq_scale='no', not trainable, n_fft 512 / 1024 / 2048) evaluates the
+    frames' DFT as an fp32 FFT (default); ``set_fft(False)`` or MISPEC_FFT=0 keeps it on the contraction
+    kernels in the arithmetic ``precision`` names.  Returns the previous setting."""
+    from . import engine
+
+    return engine.set_fft(enabled)
+
+
 def invalidate_caches(module):
     """Forget the operands derived from a module's bases (split / folded planes, kernel supports);
     only needed after edits through ``tensor.data`` (see ``engine.DerivedCache``)."""

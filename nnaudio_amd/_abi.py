@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmispec.so")
 ABLATE_LIB_PATH = os.path.join(_HERE, "csrc", "libmispec_ablate.so")  # benchmarking build
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 E_INVALID, E_UNSUPPORTED, E_HIP = -1, -2, -3
 
 # enums (mirror include/mispec.h)
@@ -115,7 +115,7 @@ class FramedGemmArgs(ctypes.Structure):
         ("basis_fold2", ctypes.c_void_p),
         ("basis_fold2_bytes", ctypes.c_int64),
         ("fold2_wmax", ctypes.c_float),
-        ("reserved5", ctypes.c_int32),
+        ("no_fft", ctypes.c_int32),
     ]
 
 

@@ -60,6 +60,7 @@
 #include <vector>
 
 #include "mispec.h"
+#include "fft_core.h"
 
 #ifdef MISPEC_ABLATE
 #define MISPEC_DBG(p, bit) (((p).debug & (bit)) != 0)
@@ -1031,6 +1032,7 @@ __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams 
 #include "framed_fold2.inl"
 #include "framed_bf16x3_strip.inl"
 #include "octave_pyramid.inl"
+#include "stft_fft.inl"
 
 // Several independent contractions of the same tile shape in one launch (the octaves of
 // CQT2010v2 / VQT: each is a short-K, few-hundred-workgroup problem that cannot fill the chip on
@@ -2730,7 +2732,7 @@ int fill_params(const mispec_framed_gemm_args *a, KParams &p) {
   if (a->precision != MISPEC_PREC_F32 && a->precision != MISPEC_PREC_BF16X3 &&
       a->precision != MISPEC_PREC_F16X3)
     return fail(MISPEC_E_INVALID, "bad precision%s");
-  if (a->reserved2 != 0 || a->reserved3 != 0 || a->reserved4 != 0 || a->reserved5 != 0)
+  if (a->reserved2 != 0 || a->reserved3 != 0 || a->reserved4 != 0)
     return fail(MISPEC_E_INVALID, "reserved fields must be 0%s");
   if (a->row_support_host) {  // the caller's host copy of the supports: at least well-formed
     if (!a->row_support) return fail(MISPEC_E_INVALID, "row_support_host without row_support%s");
@@ -2995,6 +2997,62 @@ inline void host_epilogue(const mispec_framed_gemm_args *a, float *dst, float re
 }
 }  // namespace
 
+// ---------------------------------------------------------------------------------
+// FFT path (stft_fft.inl): window x DFT bases (the caller proves the form by handing over the
+// mispec_fold2_basis() planes, which that routine only produces after checking the basis numerically) with
+// n_fft = 512, 1024 or 2048 and the first n_bins <= n_fft/2 + 1 bins; any pointwise epilogue, any hop and
+// padding; fp32 arithmetic, so every `precision` is served.  No workspace.
+// ---------------------------------------------------------------------------------
+bool fft_ok(const mispec_framed_gemm_args *a, const KParams &p) {
+  if (!a->basis_fold2 || a->tile != MISPEC_TILE_AUTO || a->no_fft) return false;
+  if (MISPEC_DBG(p, 0x100000) || MISPEC_DBG(p, 0x40000000) || MISPEC_DBG(p, 0x08000000)) return false;  // A/B runs
+  if (!p.a_im || p.row_support || p.row_scale || p.fb || !fold2_kernel_ok(p.K)) return false;
+  if (a->basis_fold2_bytes < basis_fold2_bytes(p.n_bins, p.K)) return false;
+  if (p.epilogue < MISPEC_EPI_COMPLEX || p.epilogue > MISPEC_EPI_PHASE_COSSIN) return false;
+  if (p.K != 512 && p.K != 1024 && p.K != 2048) return false;
+  if (p.n_bins > p.K / 2 + 1 || p.n_frames <= 0) return false;
+  return (long long)p.n_clips * p.n_frames <= 0x3fffffffLL;
+}
+
+template <int M, int EPI>
+int launch_fft_cfg(const KParams &p, hipStream_t stream) {
+  constexpr int W = (EPI == MISPEC_EPI_COMPLEX || EPI == MISPEC_EPI_PHASE_COSSIN) ? 2 : 1;
+  constexpr int FT = FFT_TILE_FLOATS / M / W;
+  const int tiles_per_clip = (p.n_frames + FT - 1) / FT;
+  const long long n_tiles = (long long)p.n_clips * tiles_per_clip;
+  long long grid = n_tiles < device_cus() ? n_tiles : device_cus();
+  grid = (grid + 7) / 8 * 8;
+  auto kern = stft_fft_kernel<M, EPI>;
+  static std::atomic<unsigned long long> configured{0};
+  int rc = configure_lds(kern, stft_fft_smem<M>(), configured);
+  if (rc != MISPEC_OK) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(FFT_WAVES * 64), stft_fft_smem<M>(), stream, p, tiles_per_clip);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+
+template <int M>
+int launch_fft_size(const KParams &p, hipStream_t stream) {
+  switch (p.epilogue) {
+    case MISPEC_EPI_COMPLEX:
+      return launch_fft_cfg<M, MISPEC_EPI_COMPLEX>(p, stream);
+    case MISPEC_EPI_MAGNITUDE:
+      return launch_fft_cfg<M, MISPEC_EPI_MAGNITUDE>(p, stream);
+    case MISPEC_EPI_POWER:
+      return launch_fft_cfg<M, MISPEC_EPI_POWER>(p, stream);
+    case MISPEC_EPI_PHASE_ATAN2:
+      return launch_fft_cfg<M, MISPEC_EPI_PHASE_ATAN2>(p, stream);
+    default:
+      return launch_fft_cfg<M, MISPEC_EPI_PHASE_COSSIN>(p, stream);
+  }
+}
+
+int launch_fft(const KParams &p, hipStream_t stream) {
+  return p.K == 2048 ? launch_fft_size<1024>(p, stream)
+                     : (p.K == 1024 ? launch_fft_size<512>(p, stream) : launch_fft_size<256>(p, stream));
+}
+
 // MISPEC_PREC_F16X3 exists on the folded contractions, on the strip kernel and on the staged dense kernel
 // (complex bases of more than 64 bins): every other shape runs in MISPEC_PREC_F32 on the tile kernels
 // (operands prepared for MISPEC_PREC_F16X3 are not offered to them)
@@ -3023,6 +3081,7 @@ int64_t mispec_framed_gemm_workspace_bytes(const mispec_framed_gemm_args *args) 
   KParams p;
   int rc = fill_params(args, p);
   if (rc != MISPEC_OK) return rc;
+  if (fft_ok(args, p)) return 0;
   mispec_framed_gemm_args local;
   if (f16_downgrade(args, p, local)) args = &local;
   const Fold2Plan f2 = plan_fold2(args, p);
@@ -3090,6 +3149,7 @@ int mispec_framed_gemm_f32(const mispec_framed_gemm_args *args, void *stream) {
   int rc = fill_params(args, p);
   if (rc != MISPEC_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (fft_ok(args, p)) return launch_fft(p, s);
   mispec_framed_gemm_args local;
   if (f16_downgrade(args, p, local)) args = &local;
   if (p.fb && (args->tile != MISPEC_TILE_AUTO || MISPEC_DBG(p, 0x2000)))

@@ -54,6 +54,23 @@ def get_precision():
     return _default_precision
 
 
+_fft = os.environ.get("MISPEC_FFT", "1") not in ("0", "false", "off")
+
+
+def set_fft(enabled):
+    """STFT-family modules whose kernels are window x DFT (``freq_scale='no'``, not trainable, n_fft 512 /
+    1024 / 2048) evaluate the frames' DFT as an FFT instead of contracting them with the kernels
+    (csrc/stft_fft.inl); ``set_fft(False)`` (or ``MISPEC_FFT=0``) keeps every module on the contraction
+    kernels -- the arithmetic ``precision`` selects.  Returns the previous setting."""
+    global _fft
+    old, _fft = _fft, bool(enabled)
+    return old
+
+
+def fft_enabled():
+    return _fft
+
+
 def resolve_precision(name=None, default="fp32"):
     """``name`` (a module's attribute / a call's argument), else the process-wide override, else
     ``default`` (the caller's own default)."""
@@ -239,7 +256,7 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
                  eps=0.0, power=2.0, row_scale=None, row_support=None, out=None,
                  out_rows_total=None, out_row_offset=0, tile=TILE_AUTO, _debug=0,
                  need_workspace=True, precision=None, basis_split=None, basis_fold=None, fb=None,
-                 fb_support=None, basis_fold2=None, row_support_host=None):
+                 fb_support=None, basis_fold2=None, row_support_host=None, fft=None):
     """Validate one framed-contraction problem and fill its C argument block.
     Returns (args, out, device, keepalive tensors)."""
     dev = _require_device(x, basis_re, basis_im, row_scale, row_support, out, fb, fb_support,
@@ -348,6 +365,8 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
         a.basis_fold2_bytes = planes.numel() * planes.element_size()
         a.fold2_wmax = float(wmax)
         keep.append(planes)
+        # window x DFT bases of 512 / 1024 / 2048 taps run as an FFT (fp32) unless told otherwise
+        a.no_fft = 0 if (fft_enabled() if fft is None else fft) else 1
     if resolve_precision(precision) == "f16x3" and need_workspace:
         a.precision = PREC_F16X3  # (the library runs what the second fold does not cover in fp32)
     if basis_fold is not None and need_workspace:

@@ -1,0 +1,40 @@
+"""STFT through the FFT path vs the contraction kernels: parity on random clips (all output formats, the
+three n_fft, edge frames, odd hops, freq_bins) and step time at cfg2.  python scripts/fft_check.py"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nnaudio_amd import engine, features
+def timeit(fn, n=50, w=10):
+    for _ in range(w): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+rng = np.random.default_rng(0)
+for n_fft, hop, B, L, kw in ((2048, 512, 3, 30000, {}), (1024, 256, 2, 9001, {}), (512, 128, 5, 4000, dict(pad_mode="constant")),
+                             (2048, 333, 2, 20000, dict(freq_bins=700)), (512, 64, 2, 3000, dict(center=False)),
+                             (1024, 512, 1, 600, {}), (2048, 2048, 2, 50000, dict(window="hamming"))):
+    x = torch.as_tensor(rng.standard_normal((B, L)).astype(np.float32)).cuda()
+    for fmt in ("Complex", "Magnitude", "Phase"):
+        m = features.STFT(n_fft=n_fft, hop_length=hop, output_format=fmt, verbose=False, **kw).cuda()
+        m.precision = "fp32"
+        engine.set_fft(True); y = m(x)
+        engine.set_fft(False); r = m(x)
+        assert y.shape == r.shape
+        if fmt == "Phase":
+            mm = features.STFT(n_fft=n_fft, hop_length=hop, output_format="Magnitude", verbose=False, **kw).cuda()(x)
+            strong = mm > 1e-2 * mm.max()
+            d = (torch.exp(1j * y) - torch.exp(1j * r)).abs()[strong].max()
+            print("n_fft %d hop %d %s %s: max phase distance (strong bins) %.2e" % (n_fft, hop, kw, fmt, float(d)))
+            assert d < 1e-3
+        else:
+            err = float((y - r).abs().max() / r.abs().max())
+            print("n_fft %d hop %d %s %s: fft vs fp32 contraction %.2e of the peak, equal %s" % (n_fft, hop, kw, fmt, err, bool(torch.equal(y, r))))
+            assert err < 2e-6 and not torch.equal(y, r)
+x = torch.randn(64, 441000, device="cuda")
+for fmt in ("Magnitude", "Complex"):
+    m = features.STFT(n_fft=2048, hop_length=512, output_format=fmt, verbose=False).cuda()
+    for on in (True, False):
+        engine.set_fft(on)
+        print("cfg2 %s fft=%s: %.4f ms" % (fmt, on, timeit(lambda: m(x))), flush=True)

@@ -1,0 +1,83 @@
+// Host check of nnaudio_amd/csrc/fft_core.h: the 64 lanes of a wave run one after the other, the exchange
+// buffer is a plain array; compared with a float64 DFT.  Built and run by tests/test_fft_core_cpu.py.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "fft_core.h"
+
+using namespace fftcore;
+
+template <int M, int PASS>
+void run_pass(cf (*x)[M / 64], std::vector<cf> &buf, bool reload) {
+  cf tw[tw_count<M, PASS>() + 1];
+  for (int lane = 0; lane < 64; ++lane) {
+    for (int i = 0; i < tw_count<M, PASS>(); ++i) {
+      const double t = 2.0 * M_PI * (double)tw_turns<M, PASS>(lane, i);
+      tw[i] = cf{(float)cos(t), (float)sin(t)};
+    }
+    stockham_pass<M, PASS>(x[lane], lane, tw, [&](int o, cf v) { buf[pad(o)] = v; });
+  }
+  if (reload)
+    for (int lane = 0; lane < 64; ++lane)
+      for (int i = 0; i < M / 64; ++i) x[lane][i] = buf[pad(lane + 64 * i)];
+}
+
+template <int M>
+double check(unsigned seed) {
+  constexpr int N = 2 * M, P = M / 64;
+  std::vector<double> y(N);
+  srand(seed);
+  for (int n = 0; n < N; ++n) y[n] = (double)rand() / RAND_MAX * 2 - 1;
+  static cf x[64][P];
+  for (int lane = 0; lane < 64; ++lane)
+    for (int i = 0; i < P; ++i) {
+      const int m = lane + 64 * i;
+      x[lane][i] = cf{(float)y[2 * m], (float)y[2 * m + 1]};
+    }
+  std::vector<cf> buf(padded_size<M>());
+  run_pass<M, 0>(x, buf, true);
+  run_pass<M, 1>(x, buf, true);
+  run_pass<M, 2>(x, buf, Radix<M>::n > 3);
+  if constexpr (Radix<M>::n > 3) run_pass<M, 3>(x, buf, false);
+  // buf holds Z in natural order, and so do the lanes' slots
+  std::vector<double> xr(M + 1), xi(M + 1);
+  for (int lane = 0; lane < 64; ++lane)
+    for (int i = 0; i < P; ++i) {
+      const int k = lane + 64 * i;
+      const cf zk = x[lane][i];
+      if (zk.x != buf[pad(k)].x || zk.y != buf[pad(k)].y) return 1e9;
+      const cf zm = buf[pad((M - k) & (M - 1))];
+      const double t = -2.0 * M_PI * k / N;
+      const cf X = real_post(zk, zm, cf{(float)(0.5 * cos(t)), (float)(0.5 * sin(t))});
+      xr[k] = X.x;
+      xi[k] = X.y;
+      if (k == 0) {
+        xr[M] = zk.x - zk.y;
+        xi[M] = 0;
+      }
+    }
+  double err = 0, peak = 0;
+  for (int k = 0; k <= M; ++k) {
+    double re = 0, im = 0;
+    for (int n = 0; n < N; ++n) {
+      const double t = -2.0 * M_PI * (double)((long long)k * n % N) / N;
+      re += (double)(float)y[n] * cos(t);
+      im += (double)(float)y[n] * sin(t);
+    }
+    err = fmax(err, hypot(xr[k] - re, xi[k] - im));
+    peak = fmax(peak, hypot(re, im));
+  }
+  return err / peak;
+}
+
+int main() {
+  int bad = 0;
+  for (unsigned seed = 1; seed <= 3; ++seed) {
+    const double e1024 = check<1024>(seed), e512 = check<512>(seed), e256 = check<256>(seed);
+    printf("seed %u: N=2048 %.2e  N=1024 %.2e  N=512 %.2e (max |d| / peak)\n", seed, e1024, e512, e256);
+    bad += !(e1024 < 5e-7) + !(e512 < 5e-7) + !(e256 < 5e-7);
+  }
+  return bad ? 1 : 0;
+}

@@ -10,11 +10,15 @@ The batch shards across ranks as independent clips (nnaudio_amd.dist); computing
 collective, so the timed region has none; the RCCL all-gather that reassembles the output
 tensor is timed separately and reported under "gather" (never in `value`).
 
-The step runs with ``--precision f16x3`` by default -- the STFT module's own default arithmetic:
-fp32 operands scaled by powers of two and split into (hi, lo) fp16 pairs, three f16 MFMAs per
-product, fp32 accumulate (include/mispec.h MISPEC_PREC_F16X3; ~1e-7 of the spectrum peak, fp32
-class).  "bf16x3" (split bf16, ~5e-6 of the peak) and "fp32" (fp32 MFMA) are timed in the same
-run and reported under "paths", each with the dynamic range measured on this device.
+The step is the STFT module as it ships: its kernels are window x DFT (freq_scale='no'), so the
+library evaluates every frame's DFT as an fp32 FFT (csrc/stft_fft.inl; one streaming pass: clips in,
+spectrogram out) -- "roofline" prices it against the HBM roofline on the contract's algorithmic bytes.
+The contraction kernels the same module uses when the FFT does not apply (trainable / non-linear
+bases, n_fft > 2048) are timed in the same run with the FFT switched off and reported under "paths":
+"f16x3" (fp32 operands scaled by powers of two and split into (hi, lo) fp16 pairs, three f16 MFMAs per
+product, fp32 accumulate; include/mispec.h MISPEC_PREC_F16X3; ~1e-7 of the spectrum peak), "bf16x3"
+(split bf16, ~5e-6 of the peak) and "fp32" (fp32 MFMA), each with the dynamic range measured on this
+device and its matrix-pipe roofline.
 
 ``python bench.py --gpus N`` without a torch.distributed environment starts its own N ranks
 (``python -m torch.distributed.run``, one per GPU, RCCL) and relays rank 0's line.
@@ -64,8 +68,9 @@ if ROOT not in sys.path:
 PEAK_F32_MFMA = 157.3e12  # FLOP/s, MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
 PEAK_BF16_MFMA = 2.5e15   # FLOP/s dense, MI355X_MICROARCH.md (v_mfma_f32_32x32x16_bf16)
 PEAK_HBM = 8.0e12         # B/s spec
-MFMAS_PER_PRODUCT = {"fp32": 1, "bf16x3": 3, "f16x3": 3}
-RAW_PEAK = {"fp32": PEAK_F32_MFMA, "bf16x3": PEAK_BF16_MFMA, "f16x3": PEAK_BF16_MFMA}  # f16 = bf16 rate
+MFMAS_PER_PRODUCT = {"fp32": 1, "bf16x3": 3, "f16x3": 3, "fft": 1}
+# ("fft": the STFT's FFT path runs on the vector ALUs; the fp32 MFMA peak only prices its "algorithmic" flops)
+RAW_PEAK = {"fp32": PEAK_F32_MFMA, "bf16x3": PEAK_BF16_MFMA, "f16x3": PEAK_BF16_MFMA, "fft": PEAK_F32_MFMA}  # f16 = bf16 rate
 # peak for the precision used, in ALGORITHMIC flops ("bf16x3" = the dense bf16 MFMA
 # peak / 3 MFMAs per product = 833 TFLOP/s, cfg2 floor 0.56 ms; fp32 MFMA 157.3, floor 2.95 ms)
 PEAK = {k: RAW_PEAK[k] / MFMAS_PER_PRODUCT[k] for k in RAW_PEAK}
@@ -234,11 +239,11 @@ def roofline_block(meta, dev_step_s, precision, traffic=None, kernel="", execute
            "algorithmic_flops_per_launch": meta["flops"],
            "algorithmic_bytes_per_launch": meta["bytes"],
            "algorithmic_tflops": fl / 1e12,
-           "algorithmic_frac": fl / PEAK[precision],
+           "algorithmic_frac": None if precision == "fft" else fl / PEAK[precision],
            "algorithmic_frac_what": "2 flop per tap of the dense contraction / time / (raw MFMA peak / MFMAs per "
                                     "product): the SURVEY 8d figure; > 1 is possible because the symmetric folds skip work",
            "hbm_frac_on_algorithmic_bytes": by / PEAK_HBM}
-    if executed is None:
+    if executed is None and precision != "fft":
         executed = executed_flops(meta, precision)
         executed_source = "tiling"
     if executed:
@@ -265,6 +270,10 @@ def pmc_child(name, precision, steps):
     device = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     nnaudio_amd.set_precision(precision or None)
+    if precision and name == "stft":  # a forced arithmetic benchmarks the contraction kernels
+        from nnaudio_amd import engine
+
+        engine.set_fft(False)
     module, make_input, _ = workload(name, device)
     x = make_input(0)
     with torch.no_grad():
@@ -344,7 +353,8 @@ def dynamic_range_db(device, precision):
     from nnaudio_amd import features
 
     m = features.STFT(n_fft=2048, hop_length=512, output_format="Complex", verbose=False).to(device)
-    m.precision = precision
+    if precision is not None:
+        m.precision = precision
     n = torch.arange(40 * 512, dtype=torch.float64)
     x = torch.cos(2 * np.pi * 400 * n / 2048 + 0.3).to(torch.float32)[None, :].to(device)
     with torch.no_grad():
@@ -500,19 +510,24 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return [float(v) for v in t]
 
-    def run_path(mod, xin, me, precision, steps, warmup):
-        """Time `steps` forwards in one arithmetic; whole-job numbers (max over ranks)."""
-        nnaudio_amd.set_precision(precision)
-        wall, dev_s = timed_steps(mod, xin, steps, warmup, sync)
+    def run_path(mod, xin, me, precision, steps, warmup, fft=True):
+        """Time `steps` forwards in one arithmetic; whole-job numbers (max over ranks).  precision "fft": the
+        module as it ships (STFT: the FFT path); otherwise the contraction kernels in that arithmetic."""
+        nnaudio_amd.set_precision(None if precision == "fft" else precision)
+        old_fft = engine.set_fft(fft)
+        try:
+            wall, dev_s = timed_steps(mod, xin, steps, warmup, sync)
+        finally:
+            engine.set_fft(old_fft)
         nnaudio_amd.set_precision(forced)
         wall, dev_s = max_over_ranks(wall, dev_s)
         per = dev_s / steps
         res = {"frames_per_s": me["frames"] * world * steps / wall, "ms_per_step": wall / steps * 1e3,
                "step_device_ms": per * 1e3,
                "algorithmic_tflops": me["flops"] / per / 1e12,
-               "algorithmic_frac": me["flops"] / per / PEAK[precision],
+               "algorithmic_frac": None if precision == "fft" else me["flops"] / per / PEAK[precision],
                "hbm_frac_on_algorithmic_bytes": me["bytes"] / per / PEAK_HBM}
-        ex = executed_flops(me, precision)
+        ex = None if precision == "fft" else executed_flops(me, precision)
         if ex:
             res["executed_mfma_tflops"] = ex / per / 1e12
             res["mfma_frac"] = ex / per / RAW_PEAK[precision]  # executed flops / raw MFMA peak: <= 1
@@ -521,13 +536,27 @@ def main():
     def dominant_kernel(precision):
         """STFT: the main contraction alone (1024 of the 1025 bins: whole row blocks; the Nyquist
         bin rides in the pre-pass or in tail tiles), with its pre-pass, events on the launch stream."""
+        if precision == "fft":  # the whole step is ONE kernel: stft_fft_kernel
+            prep = engine.prepare_basis(module.wcos, module.wsin, "fp32", hop=512)
+
+            class _F:
+                def __call__(self, _):
+                    return engine.framed_gemm(x, module.wcos, module.wsin, hop=512, pad=1024, pad_mode=engine.PAD_REFLECT,
+                                              epilogue=engine.EPI_MAGNITUDE, precision="fp32", fft=True, **prep)
+
+            _, d = timed_steps(_F(), x, args.steps, 2, sync)
+            per = d / args.steps
+            return {"name": "stft_fft_kernel<1024, MISPEC_EPI_MAGNITUDE> (fp32 radix-16/16/4 FFT of every frame on the "
+                            "vector ALUs, one wave per frame, tile transposed through LDS)",
+                    "avg_ms": per * 1e3, "algorithmic_bytes": meta["bytes"],
+                    "achieved_GBps": meta["bytes"] / per / 1e9, "frac_of_hbm_peak": meta["bytes"] / per / PEAK_HBM}
         wc, ws = module.wcos[:1024], module.wsin[:1024]
         prep = engine.prepare_basis(wc, ws, precision, hop=512)
 
         class _M:
             def __call__(self, _):
                 return engine.framed_gemm(x, wc, ws, hop=512, pad=1024, pad_mode=engine.PAD_REFLECT,
-                                          epilogue=engine.EPI_MAGNITUDE, precision=precision, **prep)
+                                          epilogue=engine.EPI_MAGNITUDE, precision=precision, fft=False, **prep)
 
         _, d = timed_steps(_M(), x, args.steps, 2, sync)
         fl = 2.0 * 2048 * 2048 * meta["frames"]
@@ -540,9 +569,15 @@ def main():
                 "executed_flops": ex, "executed_tflops": ex / per / 1e12, "frac_of_raw_mfma_peak": ex / per / RAW_PEAK[precision]}
 
     prec = module_precision(args.workload, forced)
+    # the STFT as it ships runs the FFT path whatever the precision setting (fp32 arithmetic); a forced
+    # --precision or MISPEC_FFT=0 benchmarks the contraction kernels instead
+    use_fft = args.workload == "stft" and forced is None and engine.fft_enabled()
+    if use_fft:
+        prec = "fft"
+        meta["bound"] = "hbm"
     nnaudio_amd.set_precision(forced)
     prewarm_ms = prewarm(module, x, args.prewarm_ms)
-    wall, dev_s, primary = run_path(module, x, meta, prec, args.steps, args.warmup)
+    wall, dev_s, primary = run_path(module, x, meta, prec, args.steps, args.warmup, fft=use_fft)
     paths = {prec: primary}
     dominant = None
     if args.workload == "stft":
@@ -551,11 +586,16 @@ def main():
         for other in PRECISIONS:
             if other == prec:
                 continue
-            _, _, paths[other] = run_path(module, x, meta, other, max(3, args.steps // 2), 2)
+            _, _, paths[other] = run_path(module, x, meta, other, max(3, args.steps // 2), 2, fft=False)
             paths[other]["dominant_kernel"] = dominant_kernel(other)
+            paths[other]["what"] = "contraction kernels (FFT path switched off), " + other
         for pr in paths:  # what each arithmetic leaves in silent bins, relative to the peak
             try:
-                paths[pr]["dynamic_range_db"] = dynamic_range_db(device, pr)
+                old_fft = engine.set_fft(pr == "fft")
+                try:
+                    paths[pr]["dynamic_range_db"] = dynamic_range_db(device, None if pr == "fft" else pr)
+                finally:
+                    engine.set_fft(old_fft)
             except Exception as e:
                 paths[pr]["dynamic_range_db"] = None
                 log("dynamic range (%s): %r" % (pr, e))
@@ -567,7 +607,10 @@ def main():
                      "product, fp32 accumulate (err ~1e-7 of peak: fp32 class); the STFT module's default",
             "bf16x3": "bf16x3: fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate "
                       "(err ~5e-6 of peak, 1e-4 parity bar)",
-            "fp32": "fp32 MFMA, fp32 accumulate"}[prec]
+            "fp32": "fp32 MFMA, fp32 accumulate",
+            "fft": "fp32 FFT of every windowed frame (radix 16 x 16 x 4 complex FFT of 1024 points + real-input "
+                   "post-processing on the vector ALUs; err ~2e-7 of peak); what STFT runs when its kernels are "
+                   "window x DFT (freq_scale='no', not trainable, n_fft 512 / 1024 / 2048)"}[prec]
     out = {
         "metric": "spectrogram frames/sec",
         "value": frames_total / wall,
@@ -579,7 +622,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if prec == "fp32" else prec,
+        "dtype": "f32" if prec in ("fp32", "fft") else prec,
         "data": "synthetic",
         "prewarm_ms": prewarm_ms,
         "kernel_source_sha": src_sha,
@@ -590,7 +633,11 @@ def main():
                    "parallelism": "batch-sharded x%d, no data-path collective" % world},
         "roofline": roofline_block(
             meta, kern_s, prec,
-            kernel="one step = pre-pass + main contraction; achieved = EXECUTED MFMA flops (the folded kernels run "
+            kernel=("one step = ONE launch of stft_fft_kernel (fp32 FFT per frame, no pre-pass, no workspace); achieved = "
+                    "algorithmic bytes (clips in + spectrogram out + the reference's two bases, SURVEY 8d) / step device "
+                    "time against the 8 TB/s HBM peak; the matrix-pipe rooflines of the contraction kernels are under paths")
+            if prec == "fft" else
+                   "one step = pre-pass + main contraction; achieved = EXECUTED MFMA flops (the folded kernels run "
                    "a quarter of the dense taps, x 3 MFMAs per product for the split arithmetics) / step device "
                    "time; peak = raw dense MFMA peak of the instruction"),
         "paths": paths,
@@ -678,7 +725,7 @@ def main():
                 t = measure_traffic(name, pr)
                 blk["traffic"] = t["bytes_per_step"]
                 blk["traffic_detail"] = {k: t[k] for k in ("fetch_bytes", "write_bytes", "per_kernel", "method")}
-                if t.get("mfma_flops") and blk.get("bound") == "mfma":
+                if t.get("mfma_flops") and blk.get("bound") == "mfma" and not (name == "stft" and use_fft):
                     # the counted MFMA flops replace the tiling model behind achieved / frac
                     per = blk["step_device_ms"] * 1e-3
                     raw = RAW_PEAK[module_precision(name, pr)]

@@ -99,8 +99,8 @@ FFT_HD void dft(cf (&v)[R]) {
 // of a pass -- lane stride R elements -- and its reads -- lane stride 1 -- are both spread over the banks)
 FFT_HD int pad(int o) { return o + (o >> 4); }
 template <int M>
-constexpr int padded_size() {
-  return M + (M >> 4);
+constexpr int padded_size() {  // (+ 1: pad(M), which lane 0 addresses as the mirror of bin 0 and never uses)
+  return M + (M >> 4) + 1;
 }
 
 // Radix plan of the M-point complex FFT on 64 lanes, P = M / 64 points per lane (lane l holds the
@@ -157,11 +157,11 @@ FFT_HD float tw_turns(int lane, int idx) {
 
 // One Stockham pass on a lane's P elements: butterfly q takes the elements q + r (P / R), r = 0 .. R-1
 // (input indices j + r M / R, j = lane + 64 q), multiplies them by W^(r k), k = j mod NS, transforms, and
-// sends output r to index (j - k) R + k + r NS.  `store(o, value)` receives the unpadded index.  The
-// values also stay in x (same slots): after the LAST pass slot i holds output lane + 64 i -- the
-// natural-order spectrum.
-template <int M, int PASS, typename Store>
-FFT_HD void stockham_pass(cf (&x)[M / 64], int lane, const cf *tw, Store &&store) {
+// sends output r to index (j - k) R + k + r NS.  `twf(q, r)` supplies W^(r k) of butterfly q (r >= 1; see
+// tw_turns), `store(o, value)` receives the unpadded index.  The values also stay in x (same slots): after
+// the LAST pass slot i holds output lane + 64 i -- the natural-order spectrum.
+template <int M, int PASS, typename Tw, typename Store>
+FFT_HD void stockham_pass(cf (&x)[M / 64], int lane, Tw &&twf, Store &&store) {
   constexpr int P = M / 64, R = radix_of<M, PASS>(), NS = ns_of<M, PASS>(), Q = P / R;
   static_assert(P % R == 0, "a lane holds whole butterflies");
 #pragma unroll
@@ -171,7 +171,7 @@ FFT_HD void stockham_pass(cf (&x)[M / 64], int lane, const cf *tw, Store &&store
     for (int r = 0; r < R; ++r) v[r] = x[q + r * Q];
     if constexpr (NS > 1) {
 #pragma unroll
-      for (int r = 1; r < R; ++r) v[r] = cmul(v[r], tw[q * (R - 1) + r - 1]);
+      for (int r = 1; r < R; ++r) v[r] = cmul(v[r], twf(q, r));
     }
     dft<R>(v);
     const int j = lane + 64 * q, k = j & (NS - 1);
@@ -192,6 +192,17 @@ FFT_HD cf real_post(cf zk, cf zm, cf wh) {
   const cf b = cf{zk.x - zm.x, zk.y + zm.y};
   const cf wb = cmul(b, wh);
   return cf{a.x + wb.y, a.y - wb.x};
+}
+
+// ... for the pair (k, M - k) at once: A and B of bin M - k are conj(A), -conj(B) and its factor is
+// -conj(w): half the multiplications.  With zm = zk at k = 0 the pair is (X[0], Nyquist bin); bin M/2 is its
+// own mirror: X[M/2] = conj(Z[M/2]).
+FFT_HD void real_post_pair(cf zk, cf zm, cf wh, cf &xk, cf &xm) {
+  const cf a = cf{zk.x + zm.x, zk.y - zm.y} * 0.5f;
+  const cf b = cf{zk.x - zm.x, zk.y + zm.y};
+  const cf wb = cmul(b, wh);
+  xk = cf{a.x + wb.y, a.y - wb.x};
+  xm = cf{a.x - wb.y, -(a.y + wb.x)};
 }
 
 }  // namespace fftcore

@@ -3017,7 +3017,7 @@ bool fft_ok(const mispec_framed_gemm_args *a, const KParams &p) {
 template <int M, int EPI>
 int launch_fft_cfg(const KParams &p, hipStream_t stream) {
   constexpr int W = (EPI == MISPEC_EPI_COMPLEX || EPI == MISPEC_EPI_PHASE_COSSIN) ? 2 : 1;
-  constexpr int FT = FFT_TILE_FLOATS / M / W;
+  constexpr int FT = fft_tile_frames<M, W>();
   const int tiles_per_clip = (p.n_frames + FT - 1) / FT;
   const long long n_tiles = (long long)p.n_clips * tiles_per_clip;
   long long grid = n_tiles < device_cus() ? n_tiles : device_cus();

@@ -16,20 +16,50 @@
 // workgroup (one per CU, 8 waves).
 //
 // Output is (clip, bin, frame[, 2]) with frames innermost while a wave produces all bins of ONE frame:
-// the workgroup collects a tile of M bins x FT frames in LDS (64 KB; columns rotated by the row so that
-// neither the per-frame writes nor the per-row reads pile up on a bank) and then stores whole row
-// segments (64-128 bytes).  The Nyquist bin goes straight to memory.
+// the workgroup collects a tile of M bins x FT frames in LDS (columns rotated by the row so that neither
+// the workgroup collects a tile of M bins x FT frames in LDS (rows of 16 .. 64 floats + 2 of padding: the
+// per-frame writes of 32 consecutive bins spread over the banks) and stores it with one 16-byte store per
+// lane (4 frames of a row; with 4-byte stores -- a 64-byte row segment per 16 lanes -- the store
+// instructions themselves were a quarter of the kernel: ~16 cycles each in the address path, 256 of them
+// per tile and CU).  Every wave requests the samples of its next frame BEFORE it stores its share of the
+// finished tile, so the loads travel under the stores.  The Nyquist bin goes straight to memory.
 //
-// LDS: 64 KB tile + 8 x (M + M/16) x 8 B exchange buffers + 2 x 8 M bytes for the window pairs and the
-// post-processing factors (M = 1024: 150 KB; as per-lane registers they cost 64 VGPRs and the N = 2048
-// instance spilled).
+// LDS: tile M x (16384 / M + 2) floats = 68-72 KB + 8 x (M + M/16 + 1) x 8 B exchange buffers + 2 x 8 M
+// bytes for the window pairs and the post-processing factors (M = 1024: 156 KB; as per-lane registers the
+// tables cost 64 VGPRs and the N = 2048 instance spilled).
 
 constexpr int FFT_WAVES = 8;
-constexpr int FFT_TILE_FLOATS = 16384;  // 64 KB: M rows x (16384 / M) columns
-
+template <int M>
+constexpr int fft_tile_row() {  // floats per tile row: 16384 / M outputs + 2 of padding
+  return 16384 / M + 2;
+}
 template <int M>
 constexpr size_t stft_fft_smem() {
-  return (size_t)FFT_TILE_FLOATS * sizeof(float) + (size_t)FFT_WAVES * fftcore::padded_size<M>() * 8 + 2 * (size_t)M * 8;
+  return (size_t)M * fft_tile_row<M>() * 4 + (size_t)FFT_WAVES * fftcore::padded_size<M>() * 8 + 2 * (size_t)M * 8 +
+         (size_t)fftcore::radix_of<M, 0>() * (fftcore::radix_of<M, 1>() - 1) * 8;  // (+ the twiddle table of pass 1)
+}
+
+// 16 bytes per lane, global -> LDS at m0 + 16 lane, as instructions: the loads of a frame stay invisible to
+// the compiler's s_waitcnt placement -- with ordinary loads requested before the tile's stores it waited for
+// vmcnt(0) in front of the first use (the store loop's trip count is not a constant), i.e. for the stores to
+// drain: 0.05 ms of a 0.19 ms kernel.  The wait is stated by hand (fft_wait_vm): loads and stores of a
+// wave retire in order on one counter, so "at most as many operations outstanding as stores were issued
+// after the loads" means the loads have landed.
+__device__ __forceinline__ void fft_dma16(const void *src, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_addr) : "memory", "m0");
+}
+__device__ __forceinline__ void fft_wait_vm(int younger) {
+  switch (younger) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+  }
 }
 
 // the pointwise epilogue with a compile-time kind (the shared epilogue_store switches at run time: 16 copies
@@ -41,7 +71,7 @@ __device__ __forceinline__ void fft_epilogue(const KParams &p, float re, float i
     v0 = re;
     v1 = im;
   } else if constexpr (EPI == MISPEC_EPI_MAGNITUDE) {
-    v0 = sqrtf(re * re + im * im + p.eps);
+    v0 = __builtin_amdgcn_sqrtf(re * re + im * im + p.eps);  // (v_sqrt_f32: 1 ulp; sqrtf's fix-up code is 12 instructions per bin)
   } else if constexpr (EPI == MISPEC_EPI_POWER) {
     const float s = re * re + im * im + p.eps;
     v0 = (p.power == 2.0f && p.eps == 0.f) ? s : (p.power == 1.0f ? sqrtf(s) : powf(sqrtf(s), p.power));
@@ -56,26 +86,35 @@ __device__ __forceinline__ void fft_epilogue(const KParams &p, float re, float i
   }
 }
 
+// frames of a tile: rows of 16384 / M floats, W per frame
+template <int M, int W>
+constexpr int fft_tile_frames() {
+  return 16384 / M / W;
+}
+
 // M = n_fft / 2; EPI = the epilogue (W = floats per output element: 2 for Complex / Phase as (cos, sin))
 template <int M, int EPI>
 __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams p, const int tiles_per_clip) {
   using namespace fftcore;
   constexpr int N = 2 * M, P = M / 64;
   constexpr int W = (EPI == MISPEC_EPI_COMPLEX || EPI == MISPEC_EPI_PHASE_COSSIN) ? 2 : 1;
-  constexpr int C = FFT_TILE_FLOATS / M;  // floats per tile row
-  constexpr int FT = C / W;               // frames per tile
-  constexpr int FPW = FT / FFT_WAVES;     // frames per wave and tile
-  static_assert(FPW >= 1, "tile geometry");
+  constexpr int FT = fft_tile_frames<M, W>();  // frames per tile
+  constexpr int FPW = FT / FFT_WAVES;          // frames per wave and tile
+  constexpr int C = fft_tile_row<M>();         // floats per tile row (FT * W + 2)
+  constexpr int FFT_TILE_BYTES = M * C * 4;
+  static_assert(FPW >= 1 && (C & 1) == 0, "tile geometry");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float *const tile = reinterpret_cast<float *>(smem_raw);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  cf *const buf = reinterpret_cast<cf *>(smem_raw + FFT_TILE_FLOATS * sizeof(float)) + wave * padded_size<M>();
+  cf *const buf = reinterpret_cast<cf *>(smem_raw + FFT_TILE_BYTES) + wave * padded_size<M>();
 
   // ---- per-workgroup tables: window pairs (w[2m], w[2m+1]) and e^(-2 pi i m / N) / 2
-  cf *const s_win = reinterpret_cast<cf *>(smem_raw + FFT_TILE_FLOATS * sizeof(float)) + FFT_WAVES * padded_size<M>();
+  cf *const s_win = reinterpret_cast<cf *>(smem_raw + FFT_TILE_BYTES) + FFT_WAVES * padded_size<M>();
   cf *const s_wh = s_win + M;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+  const unsigned buf_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lptr_t)buf);
   for (int m = tid; m < M; m += FFT_WAVES * 64) {
     s_win[m] = *reinterpret_cast<const cf *>(p.a_re + 2 * m);  // row 0 of the cosine kernels is the window itself
     float s, c;
@@ -83,7 +122,20 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
     s_wh[m] = cf{0.5f * c, 0.5f * s};
   }
   __syncthreads();
-  // ---- per-lane constants: the twiddles of the passes
+  // twiddles of pass 1, W^(r k) with k = lane mod R0 for every butterfly of the lane: a table of R0 x (R1 - 1)
+  // factors (as registers they are 30 VGPRs of the N = 2048 instance, which then has no room to request the
+  // next frame's samples while it transforms this one)
+  constexpr int R0 = radix_of<M, 0>(), R1 = radix_of<M, 1>();
+  cf *const s_tw1 = s_wh + M;
+  for (int i = tid; i < R0 * (R1 - 1); i += FFT_WAVES * 64) {
+    const int k = i / (R1 - 1), r = i % (R1 - 1) + 1;
+    float sn, cs;
+    sincospif(-2.f * (float)(r * k) / (float)(R0 * R1), &sn, &cs);
+    s_tw1[i] = cf{cs, sn};
+  }
+  __syncthreads();
+  const cf *const tw1 = s_tw1 + (lane & (R0 - 1)) * (R1 - 1);
+  // ---- per-lane constants: the twiddles of the later passes
   cf tw[tw_total<M>() > 0 ? tw_total<M>() : 1];
   auto fill_tw = [&](auto pass_tag) __attribute__((always_inline)) {
     constexpr int PASS = decltype(pass_tag)::value;
@@ -94,9 +146,12 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
       tw[tw_offset<M, PASS>() + i] = cf{c, s};
     }
   };
-  fill_tw(std::integral_constant<int, 1>{});
   fill_tw(std::integral_constant<int, 2>{});
   if constexpr (Radix<M>::n > 3) fill_tw(std::integral_constant<int, 3>{});
+  auto twf1 = [&](int, int r) __attribute__((always_inline)) { return tw1[r - 1]; };
+  auto twf2 = [&](int q, int r) __attribute__((always_inline)) { return tw[tw_offset<M, 2>() + q * (radix_of<M, 2>() - 1) + r - 1]; };
+  auto twf3 = [&](int q, int r) __attribute__((always_inline)) { return tw[tw_offset<M, 3>() + q * (radix_of<M, 3>() - 1) + r - 1]; };
+  auto twf0 = [](int, int) __attribute__((always_inline)) { return cf{1.f, 0.f}; };
 
   const int n_tiles = p.n_clips * tiles_per_clip;
   const int hop = p.hop, L = p.n_samples, T = p.n_frames;
@@ -115,97 +170,174 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
     for (int i = 0; i < P; ++i) x[i] = buf[pad(lane + 64 * i)];
     wave_sync();
   };
-
-  // persistent workgroup; consecutive tiles of a clip stay on one XCD (workgroup b runs on XCD b % 8)
-  const int nwg = gridDim.x, per_xcd = (n_tiles + 7) / 8;
-  for (int it = blockIdx.x >> 3; it < per_xcd; it += (nwg + 7) >> 3) {
-    const int tile_id = (blockIdx.x & 7) * per_xcd + it;
-    if (tile_id < n_tiles) {
-      const int c = tile_id / tiles_per_clip;
-      const int t0 = (tile_id - c * tiles_per_clip) * FT;
-      const float *const xc = p.x + (long long)c * p.x_clip_stride;
-      float *const oc = p.out + (long long)c * p.out_clip_stride + (long long)p.out_row_offset * p.out_row_stride;
-#pragma unroll 1
-      for (int u = 0; u < FPW; ++u) {
-        const int f = wave * FPW + u, t = t0 + f;
-        if (t >= T) break;
-        // ---- the frame: y[n] = w[n] x[t hop - pad + n], packed as z[m] = (y[2m], y[2m+1])
-        const long long pos0 = (long long)t * hop - p.pad;
-        cf x[P];
-        const bool fast = pos0 >= 0 && pos0 + N <= L && ((reinterpret_cast<unsigned long long>(xc + pos0) & 7) == 0);
-        if (fast) {
-#pragma unroll
-          for (int i = 0; i < P; ++i) x[i] = *reinterpret_cast<const cf *>(xc + pos0 + 2 * (lane + 64 * i));
-        } else {
-          // edge frames (a few per clip) and odd alignments: sample by sample through the exchange buffer
-#pragma unroll 1
-          for (int m = lane; m < M; m += 64) {
-            float v[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-              long long q = pos0 + 2 * m + e;
-              if (p.pad_mode == MISPEC_PAD_REFLECT) {
-                q = q < 0 ? -q : q;
-                q = q >= L ? 2LL * L - 2 - q : q;
-              }
-              v[e] = (q >= 0 && q < L) ? xc[q] : 0.f;
-            }
-            buf[pad(m)] = cf{v[0], v[1]};
-          }
-          reload(x);
-        }
-#pragma unroll
-        for (int i = 0; i < P; ++i) x[i] = x[i] * s_win[lane + 64 * i];
-        // ---- M-point complex FFT
-        stockham_pass<M, 0>(x, lane, tw, store);
-        reload(x);
-        stockham_pass<M, 1>(x, lane, tw + tw_offset<M, 1>(), store);
-        reload(x);
-        stockham_pass<M, 2>(x, lane, tw + tw_offset<M, 2>(), store);
-        if constexpr (Radix<M>::n > 3) {
-          reload(x);
-          stockham_pass<M, 3>(x, lane, tw + tw_offset<M, 3>(), store);
-        }
-        wave_sync();
-        // ---- real-input post-processing, epilogue, into the tile
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-          const int k = lane + 64 * i;
-          const cf zm = buf[pad((M - k) & (M - 1))];
-          const cf X = real_post(x[i], zm, s_wh[k]);
-          float v0, v1;
-          fft_epilogue<EPI>(p, X.x, -p.im_sign * X.y, v0, v1);
-          const int col = (f * W + W * k) & (C - 1);
-          if constexpr (W == 2)
-            *reinterpret_cast<cf *>(tile + k * C + col) = cf{v0, v1};
-          else
-            tile[k * C + col] = v0;
-        }
-        if (p.n_bins > M && lane == 0) {  // Nyquist bin: Re Z0 - Im Z0
-          float *d = oc + (long long)M * p.out_row_stride + (long long)t * W;
-          float v0, v1;
-          fft_epilogue<EPI>(p, x[0].x - x[0].y, 0.f, v0, v1);
-          d[0] = v0;
-          if constexpr (W == 2) d[1] = v1;
-        }
-        wave_sync();  // the mirrored reads are done before the next frame's first pass overwrites the buffer
-      }
-      __syncthreads();
-      // ---- tile -> memory: FT lanes per row, W floats per lane
-      constexpr int RPI = FFT_WAVES * 64 / FT;  // rows per iteration
-      const int fl = tid % FT, r0 = tid / FT;
-      if (t0 + fl < T) {
+  // tile -> memory: a lane stores 4 floats of a row (4 / W frames)
+  auto flush = [&](float *oc, int t0) __attribute__((always_inline)) {
+    constexpr int LPR = FT * W / 4;               // lanes per row
+    constexpr int RPI = FFT_WAVES * 64 / LPR;     // rows per iteration
+    const int fl = (tid % LPR) * (4 / W), r0 = tid / LPR;  // first frame of the lane's quad
+    if (t0 + fl < T && !MISPEC_DBG(p, 0x1)) {
+      const bool whole = t0 + fl + 4 / W <= T;
 #pragma unroll 4
-        for (int k = r0; k < n_rows; k += RPI) {
-          const int col = (fl * W + W * k) & (C - 1);
-          float *d = oc + (long long)k * p.out_row_stride + (long long)(t0 + fl) * W;
-          if constexpr (W == 2)
-            *reinterpret_cast<cf *>(d) = *reinterpret_cast<const cf *>(tile + k * C + col);
-          else
-            *d = tile[k * C + col];
+      for (int k = r0; k < n_rows; k += RPI) {
+        const cf *src = reinterpret_cast<const cf *>(tile + k * C + fl * W);
+        const cf lo = src[0], hi = src[1];
+        float *d = oc + (long long)k * p.out_row_stride + (long long)(t0 + fl) * W;
+        if (MISPEC_DBG(p, 0x8)) d = p.out + (long long)k * p.out_row_stride + (long long)fl * W;  // benchmarking: every tile onto the first one (no HBM write stream)
+        if (whole) {
+          *reinterpret_cast<f32x4u *>(d) = f32x4u{lo.x, lo.y, hi.x, hi.y};
+        } else {  // the clip's last frames
+          const float v[4] = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (t0 + fl + e / W < T) d[e] = v[e];
         }
       }
     }
-    __syncthreads();
+  };
+
+  // persistent workgroup; consecutive tiles of a clip stay on one XCD (workgroup b runs on XCD b % 8)
+  const int nwg = gridDim.x, per_xcd = (n_tiles + 7) / 8;
+  if (MISPEC_DBG(p, 0x20)) {  // benchmarking: workgroups out of phase (quarters of a tile time)
+    for (int z = 0; z < ((blockIdx.x >> 3) & 3); ++z) __builtin_amdgcn_s_sleep(120);
   }
+  float *prev_oc = nullptr;  // the tile waiting to be stored
+  int prev_t0 = 0;
+  for (int it = blockIdx.x >> 3; it < per_xcd; it += (nwg + 7) >> 3) {
+    const int tile_id = (blockIdx.x & 7) * per_xcd + it;
+    if (tile_id >= n_tiles) continue;  // (workgroup-uniform)
+    const int c = tile_id / tiles_per_clip;
+    const int t0 = (tile_id - c * tiles_per_clip) * FT;
+    const float *const xc = p.x + (long long)c * p.x_clip_stride;
+    float *const oc = p.out + (long long)c * p.out_clip_stride + (long long)p.out_row_offset * p.out_row_stride;
+    cf xn[P];             // samples of the wave's next frame of this tile, requested a frame ahead
+    bool fast_n = false;
+#pragma unroll 1
+    for (int u = 0; u < FPW; ++u) {
+      const int f = wave * FPW + u, t = t0 + f;
+      // ---- the frame: y[n] = w[n] x[t hop - pad + n], packed as z[m] = (y[2m], y[2m+1]); the samples are
+      // requested first, the previous tile is stored while they travel
+      const long long pos0 = (long long)t * hop - p.pad;
+      cf x[P];
+      const bool live = t < T;
+      const bool fast = u == 0 ? (live && pos0 >= 0 && pos0 + N <= L) : fast_n;
+      if (u == 0 && fast) {  // the frame as it lies in memory -> the wave's exchange buffer (idle here), 1 KB per instruction
+#pragma unroll
+        for (int j = 0; j < N / 256; ++j) fft_dma16(xc + pos0 + 256 * j + 4 * lane, buf_lds + 1024 * j);
+      }
+      int younger = 0;  // store instructions this wave issues after the loads
+      if (u == 0) {
+        if (prev_oc) {
+          flush(prev_oc, prev_t0);
+          constexpr int LPR = FT * W / 4, RPI = FFT_WAVES * 64 / LPR;
+          const int r_min = wave * 64 / LPR;
+          younger = (n_rows > r_min && !MISPEC_DBG(p, 0x1)) ? (n_rows - r_min + RPI - 1) / RPI : 0;
+        }
+        __syncthreads();  // everyone has read the tile before it is refilled
+      }
+      if (!live) continue;
+      if (fast && u == 0) {
+        fft_wait_vm(younger);
+        const cf *const plain = buf;
+#pragma unroll
+        for (int i = 0; i < P; ++i) x[i] = plain[lane + 64 * i];
+        wave_sync();
+      } else if (fast) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) x[i] = xn[i];
+      } else {
+        // edge frames (a few per clip): sample by sample through the exchange buffer
+#pragma unroll 1
+        for (int m = lane; m < M; m += 64) {
+          float v[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            long long q = pos0 + 2 * m + e;
+            if (p.pad_mode == MISPEC_PAD_REFLECT) {
+              q = q < 0 ? -q : q;
+              q = q >= L ? 2LL * L - 2 - q : q;
+            }
+            v[e] = (q >= 0 && q < L) ? xc[q] : 0.f;
+          }
+          buf[pad(m)] = cf{v[0], v[1]};
+        }
+        reload(x);
+      }
+      if (u + 1 < FPW) {  // the next frame of this wave: plain loads, a whole transform ahead of their use
+        const long long pos_n = pos0 + hop;
+        fast_n = t + 1 < T && pos_n >= 0 && pos_n + N <= L;
+        if (fast_n) {
+          typedef float cfu __attribute__((ext_vector_type(2), aligned(4)));
+#pragma unroll
+          for (int i = 0; i < P; ++i) {
+            const cfu v = *reinterpret_cast<const cfu *>(xc + pos_n + 2 * (lane + 64 * i));
+            xn[i] = cf{v.x, v.y};
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < P; ++i) x[i] = x[i] * s_win[lane + 64 * i];
+      // ---- M-point complex FFT   (benchmarking build: 0x4 skips the passes, 0x2 the post-processing, 0x1 the stores)
+      if (!MISPEC_DBG(p, 0x4)) {
+        stockham_pass<M, 0>(x, lane, twf0, store);
+        reload(x);
+        stockham_pass<M, 1>(x, lane, twf1, store);
+        reload(x);
+        stockham_pass<M, 2>(x, lane, twf2, store);
+        if constexpr (Radix<M>::n > 3) {
+          reload(x);
+          stockham_pass<M, 3>(x, lane, twf3, store);
+        }
+      }
+      wave_sync();
+      // ---- real-input post-processing of the pairs (k, M - k), k = lane + 64 i < M/2, epilogue, into the
+      // tile.  Every address is a per-lane base + a compile-time multiple of i: mirror Z[M - k] at
+      // pad(M - lane) - 68 i, rows k and M - k of the tile.
+      if (!MISPEC_DBG(p, 0x2)) {
+        const cf *const zmp = buf + pad(M - lane);
+        const cf *const whp = s_wh + lane;
+        float *const ta = tile + lane * C + W * f;
+        float *const tb = tile + (M - lane) * C + W * f;
+        const float ims = -p.im_sign;
+#pragma unroll
+        for (int i = 0; i < P / 2; ++i) {
+          cf zm = zmp[-68 * i];
+          if (i == 0) zm = lane == 0 ? x[0] : zm;  // bin 0 pairs with itself: (X[0], Nyquist bin)
+          cf xk, xm;
+          real_post_pair(x[i], zm, whp[64 * i], xk, xm);
+          float a0, a1, b0, b1;
+          fft_epilogue<EPI>(p, xk.x, ims * xk.y, a0, a1);
+          fft_epilogue<EPI>(p, xm.x, ims * xm.y, b0, b1);
+          if constexpr (W == 2)
+            *reinterpret_cast<cf *>(ta + 64 * C * i) = cf{a0, a1};
+          else
+            ta[64 * C * i] = a0;
+          if (i == 0 && lane == 0) {  // row M is not in the tile: the Nyquist bin goes straight to memory
+            if (p.n_bins > M) {
+              float *d = oc + (long long)M * p.out_row_stride + (long long)t * W;
+              d[0] = b0;
+              if constexpr (W == 2) d[1] = b1;
+            }
+          } else {
+            if constexpr (W == 2)
+              *reinterpret_cast<cf *>(tb - 64 * C * i) = cf{b0, b1};
+            else
+              tb[-64 * C * i] = b0;
+          }
+        }
+        // bin M/2 is its own mirror: X = conj(Z[M/2]), lane 0's slot P/2
+        float h0, h1;
+        fft_epilogue<EPI>(p, x[P / 2].x, -ims * x[P / 2].y, h0, h1);
+        if (lane == 0) {
+          float *th = tile + (M / 2) * C + W * f;
+          th[0] = h0;
+          if constexpr (W == 2) th[1] = h1;
+        }
+      }
+      wave_sync();  // the mirrored reads are done before the next frame's first pass overwrites the buffer
+    }
+    __syncthreads();  // the tile is complete
+    prev_oc = oc;
+    prev_t0 = t0;
+  }
+  if (prev_oc) flush(prev_oc, prev_t0);
 }

@@ -38,3 +38,13 @@ for fmt in ("Magnitude", "Complex"):
     for on in (True, False):
         engine.set_fft(on)
         print("cfg2 %s fft=%s: %.4f ms" % (fmt, on, timeit(lambda: m(x))), flush=True)
+# phases of the kernel (benchmarking build): 0x1 no stores, 0x2 no post-processing / epilogue, 0x4 no passes
+if "--ablate" in sys.argv:
+    m = features.STFT(n_fft=2048, hop_length=512, output_format="Magnitude", verbose=False).cuda()
+    engine.set_fft(True)
+    prep = engine.prepare_basis(m.wcos, m.wsin, "fp32", hop=512)
+    A = 0x10000000
+    for bits in (0, 0x20, 8, 1, 2, 3, 4, 6, 7):
+        fn = lambda: engine.framed_gemm(x, m.wcos, m.wsin, hop=512, pad=1024, pad_mode=2, epilogue=engine.EPI_MAGNITUDE,
+                                        precision="fp32", _debug=A | bits, **prep)
+        print("ablation bits %x: %.4f ms" % (bits, timeit(fn)), flush=True)

@@ -17,7 +17,8 @@ void run_pass(cf (*x)[M / 64], std::vector<cf> &buf, bool reload) {
       const double t = 2.0 * M_PI * (double)tw_turns<M, PASS>(lane, i);
       tw[i] = cf{(float)cos(t), (float)sin(t)};
     }
-    stockham_pass<M, PASS>(x[lane], lane, tw, [&](int o, cf v) { buf[pad(o)] = v; });
+    stockham_pass<M, PASS>(x[lane], lane, [&](int q, int r) { return tw[q * (radix_of<M, PASS>() - 1) + r - 1]; },
+                           [&](int o, cf v) { buf[pad(o)] = v; });
   }
   if (reload)
     for (int lane = 0; lane < 64; ++lane)
@@ -44,7 +45,7 @@ double check(unsigned seed) {
   // buf holds Z in natural order, and so do the lanes' slots
   std::vector<double> xr(M + 1), xi(M + 1);
   for (int lane = 0; lane < 64; ++lane)
-    for (int i = 0; i < P; ++i) {
+    for (int i = 0; i < P; ++i) {  // every bin on its own
       const int k = lane + 64 * i;
       const cf zk = x[lane][i];
       if (zk.x != buf[pad(k)].x || zk.y != buf[pad(k)].y) return 1e9;
@@ -58,6 +59,23 @@ double check(unsigned seed) {
         xi[M] = 0;
       }
     }
+  // the kernel's way: pairs (k, M - k) from the lower half of a lane's slots, the mirror read at
+  // pad(M - lane) - 68 i, bin M/2 from lane 0's slot P/2 -- must give the same numbers
+  for (int lane = 0; lane < 64; ++lane) {
+    const int pm0 = pad(M - lane);
+    for (int i = 0; i < P / 2; ++i) {
+      const int k = lane + 64 * i;
+      if (pm0 - 68 * i != pad(M - k)) return 2e9;
+      cf zm = buf[pm0 - 68 * i];
+      if (k == 0) zm = x[0][0];
+      const double t = -2.0 * M_PI * k / N;
+      cf xk, xm;
+      real_post_pair(x[lane][i], zm, cf{(float)(0.5 * cos(t)), (float)(0.5 * sin(t))}, xk, xm);
+      if (fabs(xk.x - xr[k]) > 1e-6 * (1 + fabs(xr[k])) || fabs(xk.y - xi[k]) > 1e-6 * (1 + fabs(xi[k]))) return 3e9;
+      if (fabs(xm.x - xr[M - k]) > 1e-5 * (1 + fabs(xr[M - k])) || fabs(xm.y - xi[M - k]) > 1e-5 * (1 + fabs(xi[M - k]))) return 4e9;
+    }
+  }
+  if (fabs(x[0][P / 2].x - xr[M / 2]) > 1e-5 * (1 + fabs(xr[M / 2])) || fabs(-x[0][P / 2].y - xi[M / 2]) > 1e-5 * (1 + fabs(xi[M / 2]))) return 5e9;
   double err = 0, peak = 0;
   for (int k = 0; k <= M; ++k) {
     double re = 0, im = 0;

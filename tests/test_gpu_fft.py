@@ -1,0 +1,162 @@
+"""GPU parity of the STFT's FFT path (csrc/stft_fft.inl: window x DFT bases of 512 / 1024 / 2048 taps evaluated
+as an fp32 FFT instead of being contracted with the kernels) against the float64 oracle and against the
+contraction kernels -- through the modules and through the C ABI (engine.framed_gemm)."""
+import numpy as np
+import pytest
+import torch
+
+from tests._golden import assert_parity, assert_phase_parity
+from tests.test_gpu_parity import DEV, _np_framed
+from tests.test_gpu_fold2 import _dft_basis
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU; torch.cuda.is_available() is False")
+    from nnaudio_amd import _abi
+
+    _abi.load()  # fail loudly if the extension is not built
+
+
+@pytest.fixture(autouse=True)
+def _fft_on():
+    from nnaudio_amd import engine
+
+    old = engine.set_fft(True)
+    yield
+    engine.set_fft(old)
+
+
+@pytest.mark.parametrize("shape", [  # (B, L, bins, K, hop, pad, mode, window)
+    (2, 30000, 1025, 2048, 512, 1024, 2, "hann"),     # the cfg2 basis: tiles of 16 frames, edge frames at both ends
+    (3, 9000, 513, 1024, 256, 512, 2, "hann"),        # cfg3's: 32 frames per tile
+    (5, 4000, 257, 512, 128, 256, 1, "hamming"),      # 64 frames per tile, zero padding, w[0] != 0
+    (1, 70001, 700, 2048, 333, 1024, 2, "random"),    # odd hop (frames at odd addresses), freq_bins < n_fft/2, asymmetric window
+    (2, 5000, 129, 512, 64, 0, 0, "hann"),            # center=False, a quarter of the bins
+    (1, 2100, 1025, 2048, 2048, 1024, 2, "short"),    # two frames, both edge frames; win_length < n_fft
+    (7, 1500, 513, 1024, 1024, 512, 1, "hann"),       # many short clips, zero padding
+])
+@pytest.mark.parametrize("epi", ["complex", "magnitude", "power2", "power1", "phase", "cossin"])
+def test_fft_path_against_float64(shape, epi):
+    from nnaudio_amd import engine
+
+    B, L, F, K, hop, pad, mode, window = shape
+    rng = np.random.default_rng(F * 1000 + K + hop)
+    x = rng.standard_normal((B, L)).astype(np.float32)
+    wr, wi = _dft_basis(F, K, window, rng)
+    re, im = _np_framed(x, wr, wi, hop, pad, mode)
+    xd, wrd, wid = (torch.as_tensor(a).to(DEV) for a in (x, wr, wi))
+    prep = engine.prepare_basis(wrd, wid, "fp32", hop=hop)
+    assert "basis_fold2" in prep, "window x DFT basis refused"
+    kw = dict(hop=hop, pad=pad, pad_mode=mode, precision="fp32")
+    e, extra = {"complex": (engine.EPI_COMPLEX, {}), "magnitude": (engine.EPI_MAGNITUDE, {}),
+                "power2": (engine.EPI_POWER, dict(power=2.0)), "power1": (engine.EPI_POWER, dict(power=1.0, eps=1e-8)),
+                "phase": (engine.EPI_PHASE_ATAN2, {}), "cossin": (engine.EPI_PHASE_COSSIN, {})}[epi]
+    y = engine.framed_gemm(xd, wrd, wid, epilogue=e, **kw, **extra, **prep)
+    y_gemm = engine.framed_gemm(xd, wrd, wid, epilogue=e, fft=False, **kw, **extra, **prep)
+    assert y.shape == y_gemm.shape and not torch.equal(y, y_gemm), "the contraction kernels ran"
+    y = y.cpu().numpy()
+    what = "fft %s %s" % (shape, epi)
+    mag = np.sqrt(re * re + im * im)
+    if epi == "complex":
+        ref = np.stack((re, im), -1)
+        assert_parity(y, ref, rel=1e-4, what=what)
+        err = np.abs(y - ref).max() / np.abs(ref).max()
+        assert err <= 2e-6, "%s: %.2e of the peak" % (what, err)
+    elif epi == "magnitude":
+        assert_parity(y, mag, rel=1e-4, what=what)
+        assert np.abs(y - mag).max() <= 2e-6 * mag.max()
+    elif epi == "power2":
+        assert_parity(y, mag * mag, rel=1e-4, what=what)
+    elif epi == "power1":
+        assert_parity(y, np.sqrt(mag * mag + 1e-8), rel=1e-4, what=what)
+    elif epi == "phase":
+        assert_phase_parity(y, np.arctan2(im, re), mag, what=what)
+    else:
+        ang = np.arctan2(im, re)
+        assert_phase_parity(y, np.stack((np.cos(ang), np.sin(ang)), -1), mag, what=what)
+
+
+def test_fft_path_is_what_the_modules_run_and_can_be_switched_off():
+    """STFT's default route for freq_scale='no': the FFT (every precision: it is fp32 arithmetic); set_fft(False)
+    returns to the contraction kernels; bases that are not window x DFT never take it."""
+    import nnaudio_amd
+    from nnaudio_amd import features
+
+    x = torch.as_tensor(np.random.default_rng(0).standard_normal((2, 20000)).astype(np.float32)).to(DEV)
+    m = features.STFT(n_fft=1024, hop_length=256, output_format="Complex", verbose=False).to(DEV)
+    ys = {}
+    for prec in ("fp32", "f16x3", "bf16x3"):
+        m.precision = prec
+        ys[prec] = m(x)
+    assert torch.equal(ys["fp32"], ys["f16x3"]) and torch.equal(ys["fp32"], ys["bf16x3"])
+    old = nnaudio_amd.set_fft(False)
+    try:
+        assert old is True
+        m.precision = "fp32"
+        g = m(x)
+        m.precision = "bf16x3"
+        gb = m(x)
+    finally:
+        nnaudio_amd.set_fft(True)
+    assert not torch.equal(g, ys["fp32"]) and not torch.equal(g, gb)
+    assert float((g - ys["fp32"]).abs().max() / g.abs().max()) <= 2e-6
+    # a log-frequency basis is not window x DFT: same result with the switch on or off
+    lg = features.STFT(n_fft=1024, hop_length=256, freq_scale="log", fmin=50, fmax=6000, sr=22050,
+                       output_format="Complex", verbose=False).to(DEV)
+    a = lg(x)
+    nnaudio_amd.set_fft(False)
+    try:
+        b = lg(x)
+    finally:
+        nnaudio_amd.set_fft(True)
+    assert torch.equal(a, b)
+    # n_fft = 4096 is not served by the FFT kernels: the contraction runs, switch or not
+    big = features.STFT(n_fft=4096, hop_length=1024, output_format="Magnitude", verbose=False).to(DEV)
+    a = big(x)
+    nnaudio_amd.set_fft(False)
+    try:
+        b = big(x)
+    finally:
+        nnaudio_amd.set_fft(True)
+    assert torch.equal(a, b)
+
+
+def test_fft_path_pure_tone_dynamic_range():
+    """A sine exactly on a bin: what the other bins hold, relative to the peak (the FFT's rounding error grows
+    with log n_fft, not with n_fft)."""
+    from nnaudio_amd import features
+
+    n = np.arange(44100)
+    x = np.sin(2 * np.pi * 64 * n / 2048.0).astype(np.float32)[None]
+    m = features.STFT(n_fft=2048, hop_length=512, window="hann", center=False, output_format="Magnitude",
+                      verbose=False).to(DEV)
+    y = m(torch.as_tensor(x).to(DEV)).cpu().numpy()[0]
+    peak = y.max()
+    silent = np.delete(y, [62, 63, 64, 65, 66], axis=0).max()  # (hann: the two neighbours carry half the peak)
+    floor_db = 20 * np.log10(max(silent, 1e-30) / peak)
+    print("fft path: silent bins %.1f dB below the peak" % floor_db)
+    assert floor_db <= -140.0, floor_db
+
+
+def test_cfg2_stft_fft_sampled():
+    """BASELINE cfg2 (64 clips of 10 s at 44.1 kHz, n_fft 2048, hop 512) through the FFT path: sampled clips
+    and frames against float64."""
+    from nnaudio_amd import features
+    from oracle import spectral_oracle as O
+
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((64, 441000)).astype(np.float32)
+    m = features.STFT(n_fft=2048, hop_length=512, output_format="Magnitude", verbose=False).to(DEV)
+    y = m(torch.as_tensor(x).to(DEV))
+    assert y.shape == (64, 1025, 862)
+    wsin, wcos = m.wsin.cpu().numpy(), m.wcos.cpu().numpy()
+    for c in (0, 17, 63):
+        ref = O.stft(x[c:c + 1], wsin, wcos, 512, output_format="Magnitude")[0]
+        got = y[c].cpu().numpy()
+        for t in (0, 1, 2, 15, 16, 431, 859, 860, 861):
+            assert np.abs(got[:, t] - ref[:, t]).max() <= 2e-6 * ref.max(), (c, t)
+    assert bool(torch.isfinite(y).all())

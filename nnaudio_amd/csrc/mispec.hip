@@ -3001,12 +3001,13 @@ inline void host_epilogue(const mispec_framed_gemm_args *a, float *dst, float re
 // FFT path (stft_fft.inl): window x DFT bases (the caller proves the form by handing over the
 // mispec_fold2_basis() planes, which that routine only produces after checking the basis numerically) with
 // n_fft = 512, 1024 or 2048 and the first n_bins <= n_fft/2 + 1 bins; any pointwise epilogue, any hop and
-// padding; fp32 arithmetic, so every `precision` is served.  No workspace.
+// padding, with or without the fused filterbank; fp32 arithmetic, so every `precision` is served.  No workspace.
 // ---------------------------------------------------------------------------------
 bool fft_ok(const mispec_framed_gemm_args *a, const KParams &p) {
   if (!a->basis_fold2 || a->tile != MISPEC_TILE_AUTO || a->no_fft) return false;
   if (MISPEC_DBG(p, 0x100000) || MISPEC_DBG(p, 0x40000000) || MISPEC_DBG(p, 0x08000000)) return false;  // A/B runs
-  if (!p.a_im || p.row_support || p.row_scale || p.fb || !fold2_kernel_ok(p.K)) return false;
+  if (!p.a_im || p.row_support || p.row_scale || !fold2_kernel_ok(p.K)) return false;
+  if (p.fb && (p.epilogue != MISPEC_EPI_POWER || p.out_row_offset != 0)) return false;  // (fused filterbank: in the tile flush)
   if (a->basis_fold2_bytes < basis_fold2_bytes(p.n_bins, p.K)) return false;
   if (p.epilogue < MISPEC_EPI_COMPLEX || p.epilogue > MISPEC_EPI_PHASE_COSSIN) return false;
   if (p.K != 512 && p.K != 1024 && p.K != 2048) return false;

@@ -22,9 +22,11 @@
 // lane (4 frames of a row; with 4-byte stores -- a 64-byte row segment per 16 lanes -- the store
 // instructions themselves were a quarter of the kernel: ~16 cycles each in the address path, 256 of them
 // per tile and CU).  Every wave requests the samples of its next frame BEFORE it stores its share of the
-// finished tile, so the loads travel under the stores.  The Nyquist bin goes straight to memory.
+// finished tile, so the loads travel under the stores.  With a filterbank (mel.py:184-189) the tile -- all
+// the bins of its frames -- is reduced over every filter's band right there, one thread per (filter, frame):
+// the (clip, bin, frame) spectrogram is never written and no atomics are needed.
 //
-// LDS: tile M x (16384 / M + 2) floats = 68-72 KB + 8 x (M + M/16 + 1) x 8 B exchange buffers + 2 x 8 M
+// LDS: tile (M + 1) x (16384 / M + 2) floats = 68-72 KB + 8 x (M + M/16 + 1) x 8 B exchange buffers + 2 x 8 M
 // bytes for the window pairs and the post-processing factors (M = 1024: 156 KB; as per-lane registers the
 // tables cost 64 VGPRs and the N = 2048 instance spilled).
 
@@ -35,7 +37,7 @@ constexpr int fft_tile_row() {  // floats per tile row: 16384 / M outputs + 2 of
 }
 template <int M>
 constexpr size_t stft_fft_smem() {
-  return (size_t)M * fft_tile_row<M>() * 4 + (size_t)FFT_WAVES * fftcore::padded_size<M>() * 8 + 2 * (size_t)M * 8 +
+  return (size_t)(M + 1) * fft_tile_row<M>() * 4 + (size_t)FFT_WAVES * fftcore::padded_size<M>() * 8 + 2 * (size_t)M * 8 +
          (size_t)fftcore::radix_of<M, 0>() * (fftcore::radix_of<M, 1>() - 1) * 8;  // (+ the twiddle table of pass 1)
 }
 
@@ -101,7 +103,7 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
   constexpr int FT = fft_tile_frames<M, W>();  // frames per tile
   constexpr int FPW = FT / FFT_WAVES;          // frames per wave and tile
   constexpr int C = fft_tile_row<M>();         // floats per tile row (FT * W + 2)
-  constexpr int FFT_TILE_BYTES = M * C * 4;
+  constexpr int FFT_TILE_BYTES = (M + 1) * C * 4;  // rows 0 .. M (the Nyquist bin)
   static_assert(FPW >= 1 && (C & 1) == 0, "tile geometry");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float *const tile = reinterpret_cast<float *>(smem_raw);
@@ -155,7 +157,7 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
 
   const int n_tiles = p.n_clips * tiles_per_clip;
   const int hop = p.hop, L = p.n_samples, T = p.n_frames;
-  const int n_rows = p.n_bins < M ? p.n_bins : M;  // rows of the tile that are stored
+  const int n_rows = p.n_bins < M + 1 ? p.n_bins : M + 1;  // rows of the tile that are stored
   // wave-level ordering of the exchange buffer: the LDS executes a wave's instructions in order; only the
   // compiler has to be kept from moving accesses across
   auto wave_sync = []() __attribute__((always_inline)) {
@@ -195,6 +197,23 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
     }
   };
 
+  // tile -> filterbank outputs: out[c, m, t] = sum over the band of fb[m, bin] * tile[bin][t]; consecutive
+  // lanes take consecutive frames of a filter (the weight is one broadcast load, the tile reads run along a row)
+  auto flush_fb = [&](float *oc, int t0) __attribute__((always_inline)) {
+    if (MISPEC_DBG(p, 0x1)) return;
+    for (int idx = tid; idx < p.n_fb * FT; idx += FFT_WAVES * 64) {
+      const int m = idx / FT, fl = idx - m * FT;
+      int lo = p.fb_support[2 * m], hi = p.fb_support[2 * m + 1];
+      lo = lo < 0 ? 0 : lo;
+      hi = hi > n_rows ? n_rows : hi;
+      const float *w = p.fb + (long long)m * p.fb_row_stride;
+      float sum = 0.f;
+#pragma unroll 4
+      for (int b = lo; b < hi; ++b) sum += w[b] * tile[b * C + fl];
+      if (t0 + fl < T) oc[(long long)m * p.out_row_stride + t0 + fl] = sum;
+    }
+  };
+
   // persistent workgroup; consecutive tiles of a clip stay on one XCD (workgroup b runs on XCD b % 8)
   const int nwg = gridDim.x, per_xcd = (n_tiles + 7) / 8;
   if (MISPEC_DBG(p, 0x20)) {  // benchmarking: workgroups out of phase (quarters of a tile time)
@@ -227,10 +246,14 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
       int younger = 0;  // store instructions this wave issues after the loads
       if (u == 0) {
         if (prev_oc) {
-          flush(prev_oc, prev_t0);
-          constexpr int LPR = FT * W / 4, RPI = FFT_WAVES * 64 / LPR;
-          const int r_min = wave * 64 / LPR;
-          younger = (n_rows > r_min && !MISPEC_DBG(p, 0x1)) ? (n_rows - r_min + RPI - 1) / RPI : 0;
+          if (W == 1 && p.fb) {
+            flush_fb(prev_oc, prev_t0);  // (its stores are not counted: the wait below then also covers them)
+          } else {
+            flush(prev_oc, prev_t0);
+            constexpr int LPR = FT * W / 4, RPI = FFT_WAVES * 64 / LPR;
+            const int r_min = wave * 64 / LPR;
+            younger = (n_rows > r_min && !MISPEC_DBG(p, 0x1)) ? (n_rows - r_min + RPI - 1) / RPI : 0;
+          }
         }
         __syncthreads();  // everyone has read the tile before it is refilled
       }
@@ -311,18 +334,10 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
             *reinterpret_cast<cf *>(ta + 64 * C * i) = cf{a0, a1};
           else
             ta[64 * C * i] = a0;
-          if (i == 0 && lane == 0) {  // row M is not in the tile: the Nyquist bin goes straight to memory
-            if (p.n_bins > M) {
-              float *d = oc + (long long)M * p.out_row_stride + (long long)t * W;
-              d[0] = b0;
-              if constexpr (W == 2) d[1] = b1;
-            }
-          } else {
-            if constexpr (W == 2)
-              *reinterpret_cast<cf *>(tb - 64 * C * i) = cf{b0, b1};
-            else
-              tb[-64 * C * i] = b0;
-          }
+          if constexpr (W == 2)
+            *reinterpret_cast<cf *>(tb - 64 * C * i) = cf{b0, b1};
+          else
+            tb[-64 * C * i] = b0;
         }
         // bin M/2 is its own mirror: X = conj(Z[M/2]), lane 0's slot P/2
         float h0, h1;
@@ -339,5 +354,10 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
     prev_oc = oc;
     prev_t0 = t0;
   }
-  if (prev_oc) flush(prev_oc, prev_t0);
+  if (prev_oc) {
+    if (W == 1 && p.fb)
+      flush_fb(prev_oc, prev_t0);
+    else
+      flush(prev_oc, prev_t0);
+  }
 }

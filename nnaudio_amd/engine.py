@@ -636,8 +636,8 @@ def fused_filterbank_ok(power, coverage, n_filters=1):
 
 def fused_filterbank_plan(mod, fb, x, stft, power):
     """For MelSpectrogram / Gammatonegram: the ``fb_support`` table when this forward can run with
-    the filterbank fused into the STFT contraction (no graph needed, banded filters), else
-    None."""
+    the filterbank fused into the STFT kernel (no graph needed, banded filters: the FFT path reduces
+    its LDS tile over the bands, the contraction kernels their accumulator tiles), else None."""
     if needs_grad(mod, x) or stft.freq_bins is not None or compiling() or not x.is_cuda:
         return None
     if not hasattr(mod, "_fb_support"):

@@ -48,3 +48,16 @@ if "--ablate" in sys.argv:
         fn = lambda: engine.framed_gemm(x, m.wcos, m.wsin, hop=512, pad=1024, pad_mode=2, epilogue=engine.EPI_MAGNITUDE,
                                         precision="fp32", _debug=A | bits, **prep)
         print("ablation bits %x: %.4f ms" % (bits, timeit(fn)), flush=True)
+# MelSpectrogram / MFCC: the filterbank reduced in the FFT kernel's tile vs in the contraction's epilogue
+if "--mel" in sys.argv:
+    xm = torch.randn(256, 110250, device="cuda")
+    for cls, kw in ((features.MelSpectrogram, dict(sr=22050, n_fft=1024, n_mels=128, hop_length=512)),
+                    (features.MelSpectrogram, dict(sr=22050, n_fft=2048, n_mels=80, hop_length=256, power=1.0)),
+                    (features.MFCC, dict(sr=22050, n_mfcc=20, n_fft=1024, n_mels=128, hop_length=512)),
+                    (features.Gammatonegram, dict(sr=22050, n_fft=1024, n_bins=64, hop_length=512))):
+        m = cls(verbose=False, **kw).cuda()
+        engine.set_fft(True); y = m(xm); t1 = timeit(lambda: m(xm))
+        engine.set_fft(False); r = m(xm); t0 = timeit(lambda: m(xm))
+        err = float((y - r).abs().max() / r.abs().max())
+        print("%s %s: fft %.4f ms, contraction %.4f ms, max |d| / peak %.2e" % (cls.__name__, kw, t1, t0, err), flush=True)
+        assert err < 1e-5 and not torch.equal(y, r)

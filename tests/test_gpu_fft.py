@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests import _golden
+from tests import test_gpu_parity as _contraction_suite
 from tests._golden import assert_parity, assert_phase_parity
 from tests.test_gpu_parity import DEV, _np_framed
 from tests.test_gpu_fold2 import _dft_basis
@@ -21,15 +23,7 @@ def _need_gpu():
     _abi.load()  # fail loudly if the extension is not built
 
 
-@pytest.fixture(autouse=True)
-def _fft_on():
-    from nnaudio_amd import engine
-
-    old = engine.set_fft(True)
-    yield
-    engine.set_fft(old)
-
-
+# (tests/conftest.py switches the FFT path ON for this module and off for the others)
 @pytest.mark.parametrize("shape", [  # (B, L, bins, K, hop, pad, mode, window)
     (2, 30000, 1025, 2048, 512, 1024, 2, "hann"),     # the cfg2 basis: tiles of 16 frames, edge frames at both ends
     (3, 9000, 513, 1024, 256, 512, 2, "hann"),        # cfg3's: 32 frames per tile
@@ -160,3 +154,57 @@ def test_cfg2_stft_fft_sampled():
         for t in (0, 1, 2, 15, 16, 431, 859, 860, 861):
             assert np.abs(got[:, t] - ref[:, t]).max() <= 2e-6 * ref.max(), (c, t)
     assert bool(torch.isfinite(y).all())
+
+
+# ---------------------------------------------------------------------------------------
+# the module-level checks of tests/test_gpu_parity.py once more, on the FFT route
+# ---------------------------------------------------------------------------------------
+_STFT_FAMILY = ("STFT", "MelSpectrogram", "MFCC", "Gammatonegram")
+
+
+def _family_cases():
+    import json
+    import os
+
+    with open(os.path.join(_golden.GOLDEN, "cases.json")) as f:
+        cases = json.load(f)["cases"]
+    return [c["name"] for c in cases if c["input"] is not None and c["cls"] in _STFT_FAMILY]
+
+
+@pytest.mark.parametrize("name", _family_cases())
+def test_golden_case_on_the_fft_route(golden, name):
+    """every reference-generated fixture of the STFT family (and the oracle) with the FFT path on"""
+    from nnaudio_amd import engine
+
+    assert engine.fft_enabled()
+    _contraction_suite.test_case_matches_reference_and_oracle(golden, name)
+
+
+def test_cfg3_mel_on_the_fft_route():
+    """BASELINE cfg3 (256 clips of 5 s, n_fft 1024, 128 mels): the filterbank reduced in the FFT kernel's tile"""
+    _contraction_suite.test_cfg3_mel_full_size_sampled()
+
+
+def test_fused_filterbank_on_the_fft_route_matches_two_kernels():
+    """MelSpectrogram / Gammatonegram: fused (tile reduced over the bands inside stft_fft_kernel) == power
+    spectrogram through the FFT path + the filterbank kernel, and the contraction route agrees."""
+    from nnaudio_amd import engine, features
+
+    x = torch.as_tensor(np.random.default_rng(2).standard_normal((5, 30000)).astype(np.float32)).to(DEV)
+    for cls, kw in ((features.MelSpectrogram, dict(sr=22050, n_fft=1024, n_mels=128, hop_length=512)),
+                    (features.MelSpectrogram, dict(sr=16000, n_fft=512, n_mels=40, hop_length=160, power=1.0)),
+                    (features.MelSpectrogram, dict(sr=44100, n_fft=2048, n_mels=229, hop_length=512)),
+                    (features.Gammatonegram, dict(sr=22050, n_fft=1024, n_bins=64, hop_length=512))):
+        m = cls(verbose=False, **kw).to(DEV)
+        y = m(x)
+        basis = getattr(m, m._basis_name)
+        spec = m.stft._spectrum(x, engine.EPI_POWER, power=m.power)
+        two = engine.filterbank(basis, spec)
+        assert float((y - two).abs().max() / two.abs().max()) <= 2e-6, cls.__name__
+        engine.set_fft(False)
+        try:
+            g = m(x)
+        finally:
+            engine.set_fft(True)
+        assert not torch.equal(g, y)
+        assert float((y - g).abs().max() / g.abs().max()) <= 1e-5, cls.__name__

@@ -1529,10 +1529,20 @@ def test_integration_stub_computes_an_stft():
         yb = ns["framed"](x, m.wcos, m.wsin, 128, 256, 2, 1, split=split)
         yf = ns["framed"](x, m.wcos, m.wsin, 128, 256, 2, 1, split=split, fold=fold)
         fold2_32 = ns["fold2_basis"](m.wcos, m.wsin, 0)
-        y32q = ns["framed"](x, m.wcos, m.wsin, 128, 256, 2, 1, fold=fold32, fold2=fold2_32)
+        y32q = ns["framed"](x, m.wcos, m.wsin, 128, 256, 2, 1, fold=fold32, fold2=fold2_32, fft=False)
         fold2_16 = ns["fold2_basis"](m.wcos, m.wsin, 2)
-        y16 = ns["framed"](x, m.wcos, m.wsin, 128, 256, 2, 1, fold2=fold2_16, f16x3=True)
+        y16 = ns["framed"](x, m.wcos, m.wsin, 128, 256, 2, 1, fold2=fold2_16, f16x3=True, fft=False)
+        yfft = ns["framed"](x, m.wcos, m.wsin, 128, 256, 2, 1, fold2=fold2_16, f16x3=True)  # the FFT path
+        from nnaudio_amd import engine
+
+        engine.set_fft(True)
+        try:
+            want_fft = m(x)
+        finally:
+            engine.set_fft(False)
     torch.cuda.synchronize()
+    assert torch.equal(yfft, want_fft) and not torch.equal(yfft, want)
+    assert (yfft - want).abs().max().item() <= 3e-6 * want.abs().max().item()
     # the module's fp32 forward IS the twice-folded fp32 contraction; the others differ by rounding
     assert fold is not None and fold32 is not None and fold2_32 is not None and fold2_16 is not None
     assert torch.equal(y32q, want)

@@ -215,9 +215,14 @@ def timed_steps(module, x, steps, warmup, sync):
 
 def module_precision(name, precision):
     """The arithmetic a workload's module runs in: --precision when given, else the module's own
-    default (f16x3; CQT1992v2: fp32 -- nnaudio_amd.engine)."""
+    default: "fft" for the STFT family (window x DFT kernels: the fp32 FFT path, whatever the precision
+    setting), f16x3 for CQT2010v2 / VQT, fp32 for CQT1992v2 (nnaudio_amd.engine)."""
     if precision:
         return precision
+    if name in ("stft", "mel", "gammatone"):
+        from nnaudio_amd import engine
+
+        return "fft" if engine.fft_enabled() else "f16x3"
     return "fp32" if name == "cqt" else "f16x3"
 
 
@@ -571,9 +576,8 @@ def main():
     prec = module_precision(args.workload, forced)
     # the STFT as it ships runs the FFT path whatever the precision setting (fp32 arithmetic); a forced
     # --precision or MISPEC_FFT=0 benchmarks the contraction kernels instead
-    use_fft = args.workload == "stft" and forced is None and engine.fft_enabled()
+    use_fft = prec == "fft"
     if use_fft:
-        prec = "fft"
         meta["bound"] = "hbm"
     nnaudio_amd.set_precision(forced)
     prewarm_ms = prewarm(module, x, args.prewarm_ms)
@@ -652,7 +656,8 @@ def main():
         n2 = max(20, args.steps)  # every extra under the headline's rules: pre-warm + >= 20 steps
         jobs = [("cqt", "f16x3", None), ("cqt", "bf16x3", None), ("cqt", "fp32", None),
                 ("mel", None, None), ("gammatone", None, None), ("cqt2010", None, None), ("vqt", None, None),
-                ("cqt2010", "bf16x3", None), ("cqt2010", "fp32", None)]
+                ("cqt2010", "bf16x3", None), ("cqt2010", "fp32", None),
+                ("mel", "f16x3", None), ("gammatone", "f16x3", None)]  # (the contraction kernels, FFT off)
         if world > 1:  # cfg4's real shard: 128 clips over 8 ranks
             jobs.append(("cqt", "f16x3", 16))
         for name, pr2, b2 in jobs:
@@ -663,9 +668,11 @@ def main():
                 pr = pr2 or module_precision(name, forced)
                 m2, mk2, me2 = workload(name, device, B=b2)
                 m2.precision = pr2  # (None: the module's default / the process-wide override)
+                if pr == "fft":  # one streaming kernel (filterbank reduced in its tile): priced on bytes
+                    me2["bound"] = "hbm"
                 x2 = mk2(100 + rank)
                 prewarm(m2, x2, args.prewarm_ms)
-                w2, d2, r2 = run_path(m2, x2, me2, pr, n2, max(5, args.warmup // 2))
+                w2, d2, r2 = run_path(m2, x2, me2, pr, n2, max(5, args.warmup // 2), fft=pr == "fft")
                 blk = roofline_block(me2, d2 / n2, pr)
                 r2.update(workload=me2["tag"], precision=pr, steps=n2, roofline=blk)
                 extra[key] = r2
@@ -725,7 +732,7 @@ def main():
                 t = measure_traffic(name, pr)
                 blk["traffic"] = t["bytes_per_step"]
                 blk["traffic_detail"] = {k: t[k] for k in ("fetch_bytes", "write_bytes", "per_kernel", "method")}
-                if t.get("mfma_flops") and blk.get("bound") == "mfma" and not (name == "stft" and use_fft):
+                if t.get("mfma_flops") and blk.get("bound") == "mfma":
                     # the counted MFMA flops replace the tiling model behind achieved / frac
                     per = blk["step_device_ms"] * 1e-3
                     raw = RAW_PEAK[module_precision(name, pr)]

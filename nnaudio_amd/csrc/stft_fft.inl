@@ -64,6 +64,44 @@ __device__ __forceinline__ void fft_wait_vm(int younger) {
   }
 }
 
+// Exchange between the second and the third pass of the 1024-point transform without LDS: lane 16 g + k holds
+// outputs 256 g + k + 16 r (r = register), the radix-4 pass wants index lane + 64 i in slot i -- for each
+// c = r >> 2 a 4 x 4 transpose between the wave's four 16-lane rows (g) and the registers 4 c + a, which two
+// rounds of gfx950's row swaps do (v_permlane32_swap: upper half of one register <-> lower half of the
+// other; v_permlane16_swap: odd rows <-> even rows): 32 VALU instructions instead of 16 LDS writes + 16 LDS
+// reads and their latency (the LDS pipe was the busiest unit of the kernel: 56 % against 39 % for the VALU).
+__device__ __forceinline__ void fft_swap32(fftcore::cf &a, fftcore::cf &b) {
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  const u2 x = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+  const u2 y = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+  a = fftcore::cf{__uint_as_float(x[0]), __uint_as_float(y[0])};
+  b = fftcore::cf{__uint_as_float(x[1]), __uint_as_float(y[1])};
+}
+__device__ __forceinline__ void fft_swap16(fftcore::cf &a, fftcore::cf &b) {
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  const u2 x = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+  const u2 y = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+  a = fftcore::cf{__uint_as_float(x[0]), __uint_as_float(y[0])};
+  b = fftcore::cf{__uint_as_float(x[1]), __uint_as_float(y[1])};
+}
+__device__ __forceinline__ void fft_rows_to_slots(fftcore::cf (&x)[16]) {
+  fftcore::cf y[16];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    fftcore::cf r0 = x[4 * c], r1 = x[4 * c + 1], r2 = x[4 * c + 2], r3 = x[4 * c + 3];
+    fft_swap32(r0, r2);
+    fft_swap32(r1, r3);
+    fft_swap16(r0, r1);
+    fft_swap16(r2, r3);
+    y[c] = r0;       // slot 4 g + c <- what row g held
+    y[4 + c] = r1;
+    y[8 + c] = r2;
+    y[12 + c] = r3;
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = y[i];
+}
+
 // the pointwise epilogue with a compile-time kind (the shared epilogue_store switches at run time: 16 copies
 // of the switch per frame made the kernel's control flow -- and its register allocation -- unmanageable)
 template <int EPI>
@@ -303,9 +341,18 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
       if (!MISPEC_DBG(p, 0x4)) {
         stockham_pass<M, 0>(x, lane, twf0, store);
         reload(x);
-        stockham_pass<M, 1>(x, lane, twf1, store);
-        reload(x);
-        stockham_pass<M, 2>(x, lane, twf2, store);
+        if constexpr (M == 1024) {
+          stockham_pass<M, 1>(x, lane, twf1, [](int, cf) {});
+          fft_rows_to_slots(x);
+        } else {
+          stockham_pass<M, 1>(x, lane, twf1, store);
+          reload(x);
+        }
+        // (the last pass leaves the spectrum in the lanes' slots; the buffer only serves the mirrored reads of
+        // the post-processing, which touch the upper half)
+        stockham_pass<M, 2>(x, lane, twf2, [&](int o, cf v) __attribute__((always_inline)) {
+          if (Radix<M>::n > 3 || o >= M / 2) buf[pad(o)] = v;
+        });
         if constexpr (Radix<M>::n > 3) {
           reload(x);
           stockham_pass<M, 3>(x, lane, twf3, store);

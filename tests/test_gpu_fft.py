@@ -208,3 +208,47 @@ def test_fused_filterbank_on_the_fft_route_matches_two_kernels():
             engine.set_fft(True)
         assert not torch.equal(g, y)
         assert float((y - g).abs().max() / g.abs().max()) <= 1e-5, cls.__name__
+
+
+@pytest.mark.parametrize("fmt", ["Magnitude", "Complex"])
+def test_backward_through_the_fft_route(fmt):
+    """d loss / d waveform of a frozen STFT whose forward ran on the FFT path (the backward contracts with the
+    kernels): against torch autograd on the conv1d restatement."""
+    from nnaudio_amd import features
+
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(3, 6000, generator=g).to(DEV).requires_grad_(True)
+    m = features.STFT(n_fft=512, hop_length=160, output_format=fmt, verbose=False).to(DEV)
+    y = m(x)
+    with torch.no_grad():
+        assert torch.equal(y.detach(), m(x.detach()))  # the FFT forward, with or without a graph
+    w = torch.randn(y.shape, generator=g).to(DEV)
+    (y * w).sum().backward()
+    x2 = x.detach().clone().requires_grad_(True)
+    re, im = _contraction_suite._torch_framed(x2, m.wcos.detach(), m.wsin.detach(), 160, 256, "reflect")
+    y2 = torch.sqrt(re ** 2 + im ** 2) if fmt == "Magnitude" else torch.stack((re, -im), -1)
+    assert (y - y2).abs().max().item() <= 1e-4 * max(1.0, y2.abs().max().item())
+    (y2 * w).sum().backward()
+    _contraction_suite._grad_close(x.grad, x2.grad, "d x")
+
+
+def test_mel_backward_on_the_fft_route():
+    _contraction_suite.test_backward_mel_and_frozen_front_end()
+
+
+@pytest.mark.parametrize("cls,ctor", [("STFT", dict(n_fft=512, hop_length=128, output_format="Magnitude")),
+                                      ("MelSpectrogram", dict(sr=16000, n_fft=512, n_mels=40, hop_length=160))])
+def test_torch_compile_on_the_fft_route(cls, ctor):
+    """compiled == eager, bit for bit, with the custom ops routing to the FFT kernel"""
+    import warnings
+
+    from nnaudio_amd import features
+
+    m = getattr(features, cls)(verbose=False, **ctor).to(DEV)
+    x = torch.as_tensor(np.random.default_rng(4).standard_normal((3, 16000)).astype(np.float32)).to(DEV)
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        eager = m(x)
+        compiled = torch.compile(m, fullgraph=True)(x)
+    torch._dynamo.reset()
+    assert torch.equal(eager, compiled)

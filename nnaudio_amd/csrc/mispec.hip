@@ -3025,9 +3025,10 @@ int launch_fft_cfg(const KParams &p, hipStream_t stream) {
   grid = (grid + 7) / 8 * 8;
   auto kern = stft_fft_kernel<M, EPI>;
   static std::atomic<unsigned long long> configured{0};
-  int rc = configure_lds(kern, stft_fft_smem<M>(), configured);
+  constexpr size_t smem = stft_fft_smem<M, W>();
+  int rc = configure_lds(kern, smem, configured);
   if (rc != MISPEC_OK) return rc;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(FFT_WAVES * 64), stft_fft_smem<M>(), stream, p, tiles_per_clip);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(FFT_WAVES * 64), smem, stream, p, tiles_per_clip);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
   return MISPEC_OK;

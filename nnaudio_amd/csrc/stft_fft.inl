@@ -27,17 +27,28 @@
 // the (clip, bin, frame) spectrogram is never written and no atomics are needed.
 //
 // LDS: tile (M + 1) x (16384 / M + 2) floats = 68-72 KB + 8 x (M + M/16 + 1) x 8 B exchange buffers + 2 x 8 M
-// bytes for the window pairs and the post-processing factors (M = 1024: 156 KB; as per-lane registers the
-// tables cost 64 VGPRs and the N = 2048 instance spilled).
+// bytes for the window pairs and the post-processing factors (as per-lane registers next to the pass-1
+// twiddles they made the N = 2048 instance spill) + the 2 KB twiddle table of pass 1: 158 KB.  The
+// N = 2048 / one-float-per-output instance (the bench step) trades those two tables for a second tile buffer
+// of 8 frames -- see fft_two_buffers.
 
 constexpr int FFT_WAVES = 8;
-template <int M>
-constexpr int fft_tile_row() {  // floats per tile row: 16384 / M outputs + 2 of padding
-  return 16384 / M + 2;
+// n_fft = 2048 with one float per output: TWO tile buffers of 8 frames (one frame per wave and step), so that a
+// step is  request samples | store the previous tile | transform into the other buffer | ONE barrier  and the
+// stores drain under the transforms; the window pairs and post-processing factors then live in registers (the
+// second buffer takes their LDS).  Other instances: one buffer of 16 .. 64 frames, two barriers per tile.
+template <int M, int W>
+constexpr bool fft_two_buffers() {
+  return M == 1024 && W == 1;
 }
-template <int M>
+template <int M, int W>
+constexpr int fft_tile_row() {  // floats per tile row: the tile's frames x W + 2 of padding
+  return (fft_two_buffers<M, W>() ? 8 : 16384 / M) + 2;
+}
+template <int M, int W>
 constexpr size_t stft_fft_smem() {
-  return (size_t)(M + 1) * fft_tile_row<M>() * 4 + (size_t)FFT_WAVES * fftcore::padded_size<M>() * 8 + 2 * (size_t)M * 8 +
+  return (size_t)(fft_two_buffers<M, W>() ? 2 : 1) * (M + 1) * fft_tile_row<M, W>() * 4 +
+         (size_t)FFT_WAVES * fftcore::padded_size<M>() * 8 + (fft_two_buffers<M, W>() ? 0 : 2 * (size_t)M * 8) +
          (size_t)fftcore::radix_of<M, 0>() * (fftcore::radix_of<M, 1>() - 1) * 8;  // (+ the twiddle table of pass 1)
 }
 
@@ -60,7 +71,11 @@ __device__ __forceinline__ void fft_wait_vm(int younger) {
     case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
     case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
     case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
   }
 }
 
@@ -126,10 +141,10 @@ __device__ __forceinline__ void fft_epilogue(const KParams &p, float re, float i
   }
 }
 
-// frames of a tile: rows of 16384 / M floats, W per frame
+// frames of a tile
 template <int M, int W>
 constexpr int fft_tile_frames() {
-  return 16384 / M / W;
+  return (fft_tile_row<M, W>() - 2) / W;
 }
 
 // M = n_fft / 2; EPI = the epilogue (W = floats per output element: 2 for Complex / Phase as (cos, sin))
@@ -140,33 +155,48 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
   constexpr int W = (EPI == MISPEC_EPI_COMPLEX || EPI == MISPEC_EPI_PHASE_COSSIN) ? 2 : 1;
   constexpr int FT = fft_tile_frames<M, W>();  // frames per tile
   constexpr int FPW = FT / FFT_WAVES;          // frames per wave and tile
-  constexpr int C = fft_tile_row<M>();         // floats per tile row (FT * W + 2)
-  constexpr int FFT_TILE_BYTES = (M + 1) * C * 4;  // rows 0 .. M (the Nyquist bin)
-  static_assert(FPW >= 1 && (C & 1) == 0, "tile geometry");
+  constexpr int C = fft_tile_row<M, W>();      // floats per tile row (FT * W + 2)
+  constexpr bool DB = fft_two_buffers<M, W>();
+  constexpr int TILE_FLOATS = (M + 1) * C;     // rows 0 .. M (the Nyquist bin)
+  constexpr int FFT_TILE_BYTES = (DB ? 2 : 1) * TILE_FLOATS * 4;
+  static_assert(FPW >= 1 && (C & 1) == 0 && (!DB || FPW == 1), "tile geometry");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float *const tile = reinterpret_cast<float *>(smem_raw);
+  float *const tiles = reinterpret_cast<float *>(smem_raw);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   cf *const buf = reinterpret_cast<cf *>(smem_raw + FFT_TILE_BYTES) + wave * padded_size<M>();
 
-  // ---- per-workgroup tables: window pairs (w[2m], w[2m+1]) and e^(-2 pi i m / N) / 2
+  // ---- window pairs (w[2m], w[2m+1]) and post-processing factors e^(-2 pi i k / N) / 2: per-workgroup tables,
+  // or (two tile buffers) the lane's own in registers
   cf *const s_win = reinterpret_cast<cf *>(smem_raw + FFT_TILE_BYTES) + FFT_WAVES * padded_size<M>();
   cf *const s_wh = s_win + M;
   typedef __attribute__((address_space(3))) void *lptr_t;
   const unsigned buf_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lptr_t)buf);
-  for (int m = tid; m < M; m += FFT_WAVES * 64) {
-    s_win[m] = *reinterpret_cast<const cf *>(p.a_re + 2 * m);  // row 0 of the cosine kernels is the window itself
-    float s, c;
-    sincospif(-(float)m / (float)M, &s, &c);
-    s_wh[m] = cf{0.5f * c, 0.5f * s};
+  cf wn[DB ? P : 1], whr[DB ? P / 2 : 1];
+  if constexpr (DB) {
+#pragma unroll
+    for (int i = 0; i < P; ++i) wn[i] = *reinterpret_cast<const cf *>(p.a_re + 2 * (lane + 64 * i));
+#pragma unroll
+    for (int i = 0; i < P / 2; ++i) {
+      float sn, cs;
+      sincospif(-(float)(lane + 64 * i) / (float)M, &sn, &cs);
+      whr[i] = cf{0.5f * cs, 0.5f * sn};
+    }
+  } else {
+    for (int m = tid; m < M; m += FFT_WAVES * 64) {
+      s_win[m] = *reinterpret_cast<const cf *>(p.a_re + 2 * m);  // row 0 of the cosine kernels is the window itself
+      float sn, cs;
+      sincospif(-(float)m / (float)M, &sn, &cs);
+      s_wh[m] = cf{0.5f * cs, 0.5f * sn};
+    }
+    __syncthreads();
   }
-  __syncthreads();
   // twiddles of pass 1, W^(r k) with k = lane mod R0 for every butterfly of the lane: a table of R0 x (R1 - 1)
   // factors (as registers they are 30 VGPRs of the N = 2048 instance, which then has no room to request the
   // next frame's samples while it transforms this one)
   constexpr int R0 = radix_of<M, 0>(), R1 = radix_of<M, 1>();
-  cf *const s_tw1 = s_wh + M;
+  cf *const s_tw1 = DB ? s_win : s_wh + M;
   for (int i = tid; i < R0 * (R1 - 1); i += FFT_WAVES * 64) {
     const int k = i / (R1 - 1), r = i % (R1 - 1) + 1;
     float sn, cs;
@@ -211,7 +241,7 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
     wave_sync();
   };
   // tile -> memory: a lane stores 4 floats of a row (4 / W frames)
-  auto flush = [&](float *oc, int t0) __attribute__((always_inline)) {
+  auto flush = [&](const float *tile, float *oc, int t0) __attribute__((always_inline)) {
     constexpr int LPR = FT * W / 4;               // lanes per row
     constexpr int RPI = FFT_WAVES * 64 / LPR;     // rows per iteration
     const int fl = (tid % LPR) * (4 / W), r0 = tid / LPR;  // first frame of the lane's quad
@@ -237,7 +267,7 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
 
   // tile -> filterbank outputs: out[c, m, t] = sum over the band of fb[m, bin] * tile[bin][t]; consecutive
   // lanes take consecutive frames of a filter (the weight is one broadcast load, the tile reads run along a row)
-  auto flush_fb = [&](float *oc, int t0) __attribute__((always_inline)) {
+  auto flush_fb = [&](const float *tile, float *oc, int t0) __attribute__((always_inline)) {
     if (MISPEC_DBG(p, 0x1)) return;
     for (int idx = tid; idx < p.n_fb * FT; idx += FFT_WAVES * 64) {
       const int m = idx / FT, fl = idx - m * FT;
@@ -258,7 +288,7 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
     for (int z = 0; z < ((blockIdx.x >> 3) & 3); ++z) __builtin_amdgcn_s_sleep(120);
   }
   float *prev_oc = nullptr;  // the tile waiting to be stored
-  int prev_t0 = 0;
+  int prev_t0 = 0, step = 0;
   for (int it = blockIdx.x >> 3; it < per_xcd; it += (nwg + 7) >> 3) {
     const int tile_id = (blockIdx.x & 7) * per_xcd + it;
     if (tile_id >= n_tiles) continue;  // (workgroup-uniform)
@@ -266,6 +296,8 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
     const int t0 = (tile_id - c * tiles_per_clip) * FT;
     const float *const xc = p.x + (long long)c * p.x_clip_stride;
     float *const oc = p.out + (long long)c * p.out_clip_stride + (long long)p.out_row_offset * p.out_row_stride;
+    float *const tile = tiles + (DB ? (step & 1) * TILE_FLOATS : 0);
+    const float *const prev_tile = tiles + (DB ? ((step & 1) ^ 1) * TILE_FLOATS : 0);
     cf xn[P];             // samples of the wave's next frame of this tile, requested a frame ahead
     bool fast_n = false;
 #pragma unroll 1
@@ -279,21 +311,22 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
       const bool fast = u == 0 ? (live && pos0 >= 0 && pos0 + N <= L) : fast_n;
       if (u == 0 && fast) {  // the frame as it lies in memory -> the wave's exchange buffer (idle here), 1 KB per instruction
 #pragma unroll
-        for (int j = 0; j < N / 256; ++j) fft_dma16(xc + pos0 + 256 * j + 4 * lane, buf_lds + 1024 * j);
+        for (int j = 0; j < N / 256; ++j)
+          fft_dma16((MISPEC_DBG(p, 0x40) ? p.x : xc + pos0) + 256 * j + 4 * lane, buf_lds + 1024 * j);  // (0x40: every frame = the first 8 KB)
       }
       int younger = 0;  // store instructions this wave issues after the loads
       if (u == 0) {
         if (prev_oc) {
           if (W == 1 && p.fb) {
-            flush_fb(prev_oc, prev_t0);  // (its stores are not counted: the wait below then also covers them)
+            flush_fb(prev_tile, prev_oc, prev_t0);  // (its stores are not counted: the wait below then also covers them)
           } else {
-            flush(prev_oc, prev_t0);
+            flush(prev_tile, prev_oc, prev_t0);
             constexpr int LPR = FT * W / 4, RPI = FFT_WAVES * 64 / LPR;
             const int r_min = wave * 64 / LPR;
-            younger = (n_rows > r_min && !MISPEC_DBG(p, 0x1)) ? (n_rows - r_min + RPI - 1) / RPI : 0;
+            younger += (n_rows > r_min && !MISPEC_DBG(p, 0x1)) ? (n_rows - r_min + RPI - 1) / RPI : 0;
           }
         }
-        __syncthreads();  // everyone has read the tile before it is refilled
+        if constexpr (!DB) __syncthreads();  // the only buffer: everyone has read the tile before it is refilled
       }
       if (!live) continue;
       if (fast && u == 0) {
@@ -336,7 +369,7 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
         }
       }
 #pragma unroll
-      for (int i = 0; i < P; ++i) x[i] = x[i] * s_win[lane + 64 * i];
+      for (int i = 0; i < P; ++i) x[i] = x[i] * (DB ? wn[DB ? i : 0] : s_win[lane + 64 * i]);
       // ---- M-point complex FFT   (benchmarking build: 0x4 skips the passes, 0x2 the post-processing, 0x1 the stores)
       if (!MISPEC_DBG(p, 0x4)) {
         stockham_pass<M, 0>(x, lane, twf0, store);
@@ -373,7 +406,7 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
           cf zm = zmp[-68 * i];
           if (i == 0) zm = lane == 0 ? x[0] : zm;  // bin 0 pairs with itself: (X[0], Nyquist bin)
           cf xk, xm;
-          real_post_pair(x[i], zm, whp[64 * i], xk, xm);
+          real_post_pair(x[i], zm, DB ? whr[DB ? i : 0] : whp[64 * i], xk, xm);
           float a0, a1, b0, b1;
           fft_epilogue<EPI>(p, xk.x, ims * xk.y, a0, a1);
           fft_epilogue<EPI>(p, xm.x, ims * xm.y, b0, b1);
@@ -397,14 +430,16 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
       }
       wave_sync();  // the mirrored reads are done before the next frame's first pass overwrites the buffer
     }
-    __syncthreads();  // the tile is complete
+    __syncthreads();  // the tile is complete (two buffers: and the other one has been read out)
     prev_oc = oc;
     prev_t0 = t0;
+    ++step;
   }
   if (prev_oc) {
+    const float *const last = tiles + (DB ? ((step & 1) ^ 1) * TILE_FLOATS : 0);
     if (W == 1 && p.fb)
-      flush_fb(prev_oc, prev_t0);
+      flush_fb(last, prev_oc, prev_t0);
     else
-      flush(prev_oc, prev_t0);
+      flush(last, prev_oc, prev_t0);
   }
 }

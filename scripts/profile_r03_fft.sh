@@ -5,6 +5,6 @@ for WL in stft mel; do
   mkdir -p gpurun_out/r03_summaries
   cp gpurun_out/prof_r03_${WL}_fft/summary/*.txt gpurun_out/r03_summaries/rocprofv3_${WL}_fft_summary.txt
   cp $(find gpurun_out/prof_r03_${WL}_fft/trace -name "*kernel_stats.csv" | head -1) gpurun_out/r03_summaries/rocprofv3_${WL}_fft_kernel_stats.csv
-  rm -rf gpurun_out/prof_r03_${WL}_fft/trace/*/*kernel_trace.csv gpurun_out/prof_r03_${WL}_fft/pmc*/
+  rm -rf gpurun_out/prof_r03_${WL}_fft/trace/*/*kernel_trace.csv
 done
 ls gpurun_out/r03_summaries

@@ -416,6 +416,12 @@ int mispec_frames_transpose_f32(const float *xpad, int64_t clip_stride, int32_t 
  */
 int mispec_istft_frames_f32(const float *spec, int32_t n_clips, int32_t n_freq, int32_t n_frames,
                             const float *basis, int32_t n_fft, float *frames, void *stream);
+/* Step 1 as an inverse real FFT (fp32), for a one-sided spectrum (n_freq == n_fft/2 + 1) and synthesis
+ * kernels that are the plain inverse DFT -- kernel_cos_inv[n, k] = cos(2 pi k n / n_fft), kernel_sin_inv
+ * likewise: the caller checks its buffers once -- with n_fft = 512, 1024 or 2048: the same frames as
+ * mispec_istft_frames_f32 with the folded [cos | -sin] basis, to fp32 rounding (MISPEC_E_UNSUPPORTED else). */
+int mispec_istft_frames_fft_f32(const float *spec, int32_t n_clips, int32_t n_freq, int32_t n_frames,
+                                int32_t n_fft, float *frames, void *stream);
 int mispec_overlap_add_f32(const float *frames, int32_t n_clips, int32_t n_frames, int32_t n_fft,
                            const float *window, int32_t hop, int32_t start, float *out,
                            int64_t out_clip_stride, int32_t out_len, void *stream);

@@ -55,6 +55,7 @@ EXPORTS = (
     "mispec_framed_epilogue_bwd_f32",
     "mispec_frames_transpose_f32",
     "mispec_istft_frames_f32",
+    "mispec_istft_frames_fft_f32",
     "mispec_overlap_add_f32",
     "mispec_octave_pyramid_f32",
     "mispec_fir_decimate_f32",
@@ -331,6 +332,11 @@ def _load(path, how):
     lib.mispec_istft_frames_f32.argtypes = [
         ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
         ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+    ]
+    lib.mispec_istft_frames_fft_f32.restype = ctypes.c_int
+    lib.mispec_istft_frames_fft_f32.argtypes = [
+        ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+        ctypes.c_void_p,
     ]
     lib.mispec_overlap_add_f32.restype = ctypes.c_int
     lib.mispec_overlap_add_f32.argtypes = [

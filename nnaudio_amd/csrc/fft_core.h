@@ -205,4 +205,15 @@ FFT_HD void real_post_pair(cf zk, cf zm, cf wh, cf &xk, cf &xm) {
   xm = cf{a.x - wb.y, -(a.y + wb.x)};
 }
 
+// Inverse direction (iSTFT): the N real samples y[n] = sum_{k=0}^{N-1} G[k] e^(+2 pi i k n / N) of a Hermitian
+// spectrum given by its half G[0 .. M] are  y[2m] = Re z[m], y[2m+1] = Im z[m]  with  z = the UNNORMALISED
+// inverse M-point FFT of  Z[k] = (Gk + conj(Gm)) + i e^(+2 pi i k / N) (Gk - conj(Gm)),  Gm = G[M - k],
+// k = 0 .. M-1.  `w` = e^(+2 pi i k / N).  The inverse FFT is run as conj(FFT(conj Z)): this returns conj Z.
+FFT_HD cf real_pre_conj(cf gk, cf gm, cf w) {
+  const cf a = cf{gk.x + gm.x, gk.y - gm.y};
+  const cf b = cf{gk.x - gm.x, gk.y + gm.y};
+  const cf wb = cmul(b, w);            // i * wb = (-wb.y, wb.x)
+  return cf{a.x - wb.y, -(a.y + wb.x)};  // conj(a + i wb)
+}
+
 }  // namespace fftcore

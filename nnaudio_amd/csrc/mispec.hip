@@ -3662,6 +3662,39 @@ int mispec_fir_decimate_bwd_f32(const float *dy, int64_t dy_clip_stride, int32_t
   return MISPEC_OK;
 }
 
+int mispec_istft_frames_fft_f32(const float *spec, int32_t n_clips, int32_t n_freq, int32_t n_frames,
+                                int32_t n_fft, float *frames, void *stream) {
+  if (!spec || !frames) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
+  if (n_clips <= 0 || n_frames <= 0) return fail(MISPEC_E_INVALID, "non-positive size%s");
+  if ((n_fft != 512 && n_fft != 1024 && n_fft != 2048) || n_freq != n_fft / 2 + 1)
+    return fail(MISPEC_E_UNSUPPORTED, "inverse FFT: one-sided spectrum of n_fft = 512, 1024 or 2048%s");
+  const int tiles_per_clip = (n_frames + FFT_WAVES - 1) / FFT_WAVES;
+  const long long n_tiles = (long long)n_clips * tiles_per_clip;
+  if (n_tiles > 0x3fffffffLL) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
+  long long grid = n_tiles < device_cus() ? n_tiles : device_cus();
+  grid = (grid + 7) / 8 * 8;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = MISPEC_OK;
+#define MISPEC_LAUNCH_IFFT(MM)                                                                        \
+  {                                                                                                   \
+    auto kern = istft_fft_kernel<MM>;                                                                 \
+    constexpr size_t smem = istft_fft_smem<MM>();                                                     \
+    static std::atomic<unsigned long long> configured{0};                                             \
+    rc = configure_lds(kern, smem, configured);                                                       \
+    if (rc == MISPEC_OK)                                                                              \
+      hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(FFT_WAVES * 64), smem, s, spec, n_clips,    \
+                         n_frames, frames, tiles_per_clip);                                           \
+  }
+  if (n_fft == 2048) MISPEC_LAUNCH_IFFT(1024)
+  else if (n_fft == 1024) MISPEC_LAUNCH_IFFT(512)
+  else MISPEC_LAUNCH_IFFT(256)
+#undef MISPEC_LAUNCH_IFFT
+  if (rc != MISPEC_OK) return rc;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+
 int mispec_istft_frames_f32(const float *spec, int32_t n_clips, int32_t n_freq, int32_t n_frames,
                             const float *basis, int32_t n_fft, float *frames, void *stream) {
   if (!spec || !basis || !frames) return fail(MISPEC_E_INVALID, "NULL device pointer%s");

@@ -443,3 +443,168 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
       flush(last, prev_oc, prev_t0);
   }
 }
+
+// ---------------------------------------------------------------------------------
+// Inverse direction: frame synthesis of the inverse STFT (STFTBase.inverse_stft, stft.py:15-63, step 1 of
+// mispec_istft_frames_f32) for DFT synthesis kernels and a one-sided spectrum, as an inverse real FFT:
+//   frames[c, t, n] = sum_{k=0}^{N-1} Xh[k] e^(+2 pi i k n / N),  Xh = the Hermitian extension of spec[c, :, t]
+// (what the contraction with [cos | -sin] and the mirrored bins folded in computes; the imaginary parts of
+// the DC and Nyquist bins do not contribute).  Mirror image of stft_fft_kernel: the workgroup gathers a tile of
+// M + 1 bins x 8 frames of the (clip, bin, frame, 2) spectrogram into LDS (64-byte row segments; the next
+// tile's rows are requested into registers before this tile is transformed), every wave pre-processes one
+// frame into the M-point spectrum Z (fft_core.h: real_pre_conj), runs the same Stockham passes -- the
+// inverse transform as conj(FFT(conj Z)) -- and stores its 2 M samples straight from registers (sample
+// innermost: 512 contiguous bytes per instruction).  The windowed overlap-add stays mispec_overlap_add_f32.
+// ---------------------------------------------------------------------------------
+template <int M>
+constexpr size_t istft_fft_smem() {
+  return (size_t)(M + 1) * 18 * 4 + (size_t)FFT_WAVES * fftcore::padded_size<M>() * 8 +
+         (size_t)fftcore::radix_of<M, 0>() * (fftcore::radix_of<M, 1>() - 1) * 8;
+}
+
+template <int M>
+__global__ void __launch_bounds__(FFT_WAVES * 64) istft_fft_kernel(const float *__restrict__ spec, const int n_clips,
+                                                                    const int n_frames, float *__restrict__ frames,
+                                                                    const int tiles_per_clip) {
+  using namespace fftcore;
+  constexpr int N = 2 * M, P = M / 64, F = M + 1;
+  constexpr int FT = FFT_WAVES;  // frames per tile: one per wave
+  constexpr int C = 18;          // floats per tile row: 8 frames x (re, im) + 2 of padding
+  constexpr int RPI = FFT_WAVES * 64 / 4, NIT = (F + RPI - 1) / RPI;  // gather: 4 lanes per row, 2 frames per lane
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float *const tile = reinterpret_cast<float *>(smem_raw);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  cf *const buf = reinterpret_cast<cf *>(smem_raw + F * C * 4) + wave * padded_size<M>();
+  constexpr int R0 = radix_of<M, 0>(), R1 = radix_of<M, 1>();
+  cf *const s_tw1 = reinterpret_cast<cf *>(smem_raw + F * C * 4) + FFT_WAVES * padded_size<M>();
+  for (int i = tid; i < R0 * (R1 - 1); i += FFT_WAVES * 64) {
+    const int k = i / (R1 - 1), r = i % (R1 - 1) + 1;
+    float sn, cs;
+    sincospif(-2.f * (float)(r * k) / (float)(R0 * R1), &sn, &cs);
+    s_tw1[i] = cf{cs, sn};
+  }
+  const cf *const tw1 = s_tw1 + (lane & (R0 - 1)) * (R1 - 1);
+  cf tw[tw_total<M>() > 0 ? tw_total<M>() : 1], wpre[P];
+  auto fill_tw = [&](auto pass_tag) __attribute__((always_inline)) {
+    constexpr int PASS = decltype(pass_tag)::value;
+#pragma unroll
+    for (int i = 0; i < tw_count<M, PASS>(); ++i) {
+      float s, c;
+      sincospif(2.f * tw_turns<M, PASS>(lane, i), &s, &c);
+      tw[tw_offset<M, PASS>() + i] = cf{c, s};
+    }
+  };
+  fill_tw(std::integral_constant<int, 2>{});
+  if constexpr (Radix<M>::n > 3) fill_tw(std::integral_constant<int, 3>{});
+#pragma unroll
+  for (int i = 0; i < P; ++i) {  // e^(+2 pi i k / N), k = lane + 64 i
+    float sn, cs;
+    sincospif((float)(lane + 64 * i) / (float)M, &sn, &cs);
+    wpre[i] = cf{cs, sn};
+  }
+  auto twf0 = [](int, int) __attribute__((always_inline)) { return cf{1.f, 0.f}; };
+  auto twf1 = [&](int, int r) __attribute__((always_inline)) { return tw1[r - 1]; };
+  auto twf2 = [&](int q, int r) __attribute__((always_inline)) { return tw[tw_offset<M, 2>() + q * (radix_of<M, 2>() - 1) + r - 1]; };
+  auto twf3 = [&](int q, int r) __attribute__((always_inline)) { return tw[tw_offset<M, 3>() + q * (radix_of<M, 3>() - 1) + r - 1]; };
+  auto wave_sync = []() __attribute__((always_inline)) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  auto store = [&](int o, cf v) __attribute__((always_inline)) { buf[pad(o)] = v; };
+  auto reload = [&](cf (&x)[P]) __attribute__((always_inline)) {
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < P; ++i) x[i] = buf[pad(lane + 64 * i)];
+    wave_sync();
+  };
+
+  const int T = n_frames;
+  const int n_tiles = n_clips * tiles_per_clip;
+  const int nwg = gridDim.x, per_xcd = (n_tiles + 7) / 8, stride = (nwg + 7) >> 3;
+  const int q2 = 2 * (tid & 3), r0 = tid >> 2;  // gather: this lane's two frames of a row, its first row
+  // the rows of a tile this lane gathers: 16 bytes each (frames t0 + q2, t0 + q2 + 1 of bin r0 + RPI j)
+  f32x4v g[NIT];
+  auto gather = [&](int tile_id) __attribute__((always_inline)) {
+    const int c = tile_id / tiles_per_clip;
+    const int t0 = (tile_id - c * tiles_per_clip) * FT;
+    const float *const sc = spec + (long long)c * F * T * 2;
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      const int k = r0 + RPI * j;
+      g[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+      if (k < F && t0 + q2 < T) {
+        const float *src = sc + ((long long)k * T + t0 + q2) * 2;
+        if (t0 + q2 + 1 < T)
+          g[j] = *reinterpret_cast<const f32x4u *>(src);
+        else
+          g[j] = f32x4v{src[0], src[1], 0.f, 0.f};
+      }
+    }
+  };
+  auto scatter = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      const int k = r0 + RPI * j;
+      if (k < F) {
+        cf *d = reinterpret_cast<cf *>(tile + k * C + 2 * q2);
+        d[0] = cf{g[j][0], g[j][1]};
+        d[1] = cf{g[j][2], g[j][3]};
+      }
+    }
+  };
+  int it = blockIdx.x >> 3;
+  int tile_id = (blockIdx.x & 7) * per_xcd + it;
+  bool have = it < per_xcd && tile_id < n_tiles;
+  if (have) gather(tile_id);
+  __syncthreads();  // (the twiddle table)
+  while (have) {
+    scatter();
+    __syncthreads();
+    const int cur = tile_id;
+    it += stride;
+    tile_id = (blockIdx.x & 7) * per_xcd + it;
+    have = it < per_xcd && tile_id < n_tiles;
+    if (have) gather(tile_id);  // the next tile travels while this one is transformed
+    const int c = cur / tiles_per_clip;
+    const int t = (cur - c * tiles_per_clip) * FT + wave;
+    if (t < T) {
+      cf x[P];
+      const cf *const col = reinterpret_cast<const cf *>(tile) + wave;  // row k at col[k * (C / 2)]
+#pragma unroll
+      for (int i = 0; i < P; ++i) {
+        const int k = lane + 64 * i;
+        cf gk = col[k * (C / 2)], gm = col[(M - k) * (C / 2)];
+        if (i == 0 && lane == 0) {  // DC and Nyquist: real
+          gk.y = 0.f;
+          gm.y = 0.f;
+        }
+        x[i] = real_pre_conj(gk, gm, wpre[i]);
+      }
+      stockham_pass<M, 0>(x, lane, twf0, store);
+      reload(x);
+      if constexpr (M == 1024) {
+        stockham_pass<M, 1>(x, lane, twf1, [](int, cf) {});
+        fft_rows_to_slots(x);
+      } else {
+        stockham_pass<M, 1>(x, lane, twf1, store);
+        reload(x);
+      }
+      if constexpr (Radix<M>::n > 3) {
+        stockham_pass<M, 2>(x, lane, twf2, store);
+        reload(x);
+        stockham_pass<M, 3>(x, lane, twf3, [](int, cf) {});
+      } else {
+        stockham_pass<M, 2>(x, lane, twf2, [](int, cf) {});
+      }
+      wave_sync();
+      float *const out = frames + ((long long)c * T + t) * N;
+#pragma unroll
+      for (int i = 0; i < P; ++i)  // z = conj(FFT(conj Z)): y[2m] = Re, y[2m + 1] = -Im
+        *reinterpret_cast<cf *>(out + 2 * (lane + 64 * i)) = cf{x[i].x, -x[i].y};
+    }
+    __syncthreads();  // the tile has been read
+  }
+}

@@ -722,9 +722,30 @@ def istft_basis(kernel_cos, kernel_sin, n_freq, onesided):
     return torch.cat((Ce, -Se), 1).contiguous()
 
 
-def istft(spec, basis, window, hop, start, out_len):
+def istft_basis_is_dft(basis, n_freq):
+    """Whether an ``istft_basis`` of a one-sided spectrogram is the plain inverse DFT -- rows n, columns
+    [c_k cos(2 pi k n / N) | -c_k sin(2 pi k n / N)], c = 1 for the DC and Nyquist bins, 2 between (what
+    ``fourier_basis(freq_bins=n_fft, freq_scale='no')`` with the mirrored bins folded in gives) -- to float32
+    rounding of its entries: then ``istft`` synthesises the frames with an inverse FFT (csrc/stft_fft.inl)
+    instead of contracting with the basis.  One device-side comparison; callers cache the answer with the basis."""
+    N = basis.shape[0]
+    if N not in (512, 1024, 2048) or n_freq != N // 2 + 1 or basis.shape[1] != 2 * n_freq or not basis.is_cuda:
+        return False
+    if basis.requires_grad:
+        return False
+    n = torch.arange(N, device=basis.device, dtype=torch.float64)[:, None]
+    k = torch.arange(n_freq, device=basis.device, dtype=torch.float64)[None, :]
+    ang = 2.0 * np.pi * ((n * k) % N) / N
+    c = torch.full((1, n_freq), 2.0, device=basis.device, dtype=torch.float64)
+    c[0, 0] = c[0, -1] = 1.0
+    want = torch.cat((c * torch.cos(ang), -c * torch.sin(ang)), 1)
+    return bool((basis.detach().double() - want).abs().max().item() <= 4e-7 * 2.0)
+
+
+def istft(spec, basis, window, hop, start, out_len, dft=False):
     """Inverse STFT of a (B, F, T, 2) spectrogram with an ``istft_basis``: frame synthesis
-    (planar contraction kernel, frames stored sample-innermost) + windowed overlap-add with
+    (planar contraction kernel -- or, with ``dft`` = ``istft_basis_is_dft(basis, F)`` and the FFT path
+    enabled, an inverse real FFT per frame --, frames stored sample-innermost) + windowed overlap-add with
     window-sum-square normalisation (stft.py:15-63) -> (B, out_len)."""
     dev = _require_device(spec, basis, window)
     spec = _f32(spec, "spectrogram").contiguous()
@@ -742,8 +763,11 @@ def istft(spec, basis, window, hop, start, out_len):
     lib = _abi.load()
     with torch.cuda.device(dev):
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _abi.check(lib.mispec_istft_frames_f32(spec.data_ptr(), B, F, T, basis.data_ptr(), N,
-                                               frames.data_ptr(), stream))
+        if dft and fft_enabled():
+            _abi.check(lib.mispec_istft_frames_fft_f32(spec.data_ptr(), B, F, T, N, frames.data_ptr(), stream))
+        else:
+            _abi.check(lib.mispec_istft_frames_f32(spec.data_ptr(), B, F, T, basis.data_ptr(), N,
+                                                   frames.data_ptr(), stream))
         _abi.check(lib.mispec_overlap_add_f32(frames.data_ptr(), B, T, N, window.data_ptr(), int(hop),
                                               int(start), out.data_ptr(), out.stride(0), out.shape[1],
                                               stream))
@@ -755,8 +779,8 @@ class _IstftFn(torch.autograd.Function):
     window (``iSTFT(trainable_window=True)``, stft.py:511-512)."""
 
     @staticmethod
-    def forward(ctx, spec, basis, window, hop, start, out_len):
-        y = istft(spec, basis, window, hop, start, out_len)
+    def forward(ctx, spec, basis, window, hop, start, out_len, dft=False):
+        y = istft(spec, basis, window, hop, start, out_len, dft=dft)
         ctx.save_for_backward(spec, basis, window, y if window.requires_grad else None)
         ctx.meta = (int(hop), int(start), int(out_len))
         return y
@@ -819,13 +843,13 @@ class _IstftFn(torch.autograd.Function):
             v[start:start + out_len] = torch.where(
                 seg > 1e-10, -(go * y.to(torch.float32)).sum(0) / seg, torch.zeros_like(seg))
             gwin = gwin + 2.0 * window * v.unfold(0, N, hop).sum(0)
-        return gspec, gbasis, gwin, None, None, None
+        return gspec, gbasis, gwin, None, None, None, None
 
 
-def istft_autograd(spec, basis, window, hop, start, out_len):
+def istft_autograd(spec, basis, window, hop, start, out_len, dft=False):
     if torch.is_grad_enabled() and (spec.requires_grad or basis.requires_grad or window.requires_grad):
-        return _IstftFn.apply(spec, basis, window, hop, start, out_len)
-    return istft(spec, basis, window, hop, start, out_len)
+        return _IstftFn.apply(spec, basis, window, hop, start, out_len, dft)
+    return istft(spec, basis, window, hop, start, out_len, dft=dft)
 
 
 def power_to_db(spec, amin, ref, top_db):

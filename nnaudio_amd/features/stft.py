@@ -21,14 +21,19 @@ def _inverse_stft(mod, X, kernel_cos, kernel_sin, onesided, length):
     kernel for whatever number of frames the input has.)"""
     F = X.shape[1]
     graph = torch.is_grad_enabled()
+    dft = False
     if graph and (kernel_cos.requires_grad or kernel_sin.requires_grad):
         basis = engine.istft_basis(kernel_cos, kernel_sin, F, onesided)  # differentiable torch indexing
     else:
         if not hasattr(mod, "_inv_basis"):
             mod._inv_basis = engine.DerivedCache()
-        basis = mod._inv_basis.get(
-            (kernel_cos, kernel_sin),
-            lambda: engine.istft_basis(kernel_cos, kernel_sin, F, onesided), extra=(F, bool(onesided)))
+
+        def build():
+            b = engine.istft_basis(kernel_cos, kernel_sin, F, onesided)
+            # plain inverse-DFT kernels + one-sided spectrum: the frames come from an inverse FFT
+            return b, bool(onesided) and engine.istft_basis_is_dft(b, F)
+
+        basis, dft = mod._inv_basis.get((kernel_cos, kernel_sin), build, extra=(F, bool(onesided)))
     wdtype = mod.window_mask.dtype
     window = mod.window_mask.reshape(-1).to(torch.float32)
     if window.numel() != mod.n_fft:
@@ -42,7 +47,7 @@ def _inverse_stft(mod, X, kernel_cos, kernel_sin, onesided, length):
         start, out_len = pad, full - 2 * pad
     else:
         start, out_len = pad, min(int(length), full - pad)
-    y = engine.istft_autograd(X, basis, window, mod.stride, start, out_len)
+    y = engine.istft_autograd(X, basis, window, mod.stride, start, out_len, dft=dft)
     # the reference multiplies the float32 frames by its window buffer: the iSTFT class keeps a
     # float64 window (stft.py:489-493) and therefore returns float64 waveforms
     return y if wdtype == torch.float32 else y.to(wdtype)

@@ -90,12 +90,59 @@ double check(unsigned seed) {
   return err / peak;
 }
 
+// inverse direction: half spectrum -> N real samples through the same passes
+template <int M>
+double check_inverse(unsigned seed) {
+  constexpr int N = 2 * M, P = M / 64;
+  std::vector<double> gr(M + 1), gi(M + 1);
+  srand(seed + 77);
+  for (int k = 0; k <= M; ++k) {
+    gr[k] = (double)rand() / RAND_MAX * 2 - 1;
+    gi[k] = (k == 0 || k == M) ? 0.0 : (double)rand() / RAND_MAX * 2 - 1;
+  }
+  static cf x[64][P];
+  for (int lane = 0; lane < 64; ++lane)
+    for (int i = 0; i < P; ++i) {
+      const int k = lane + 64 * i;
+      const double t = 2.0 * M_PI * k / N;
+      x[lane][i] = real_pre_conj(cf{(float)gr[k], (float)gi[k]}, cf{(float)gr[M - k], (float)gi[M - k]},
+                                 cf{(float)cos(t), (float)sin(t)});
+    }
+  std::vector<cf> buf(padded_size<M>());
+  run_pass<M, 0>(x, buf, true);
+  run_pass<M, 1>(x, buf, true);
+  run_pass<M, 2>(x, buf, Radix<M>::n > 3);
+  if constexpr (Radix<M>::n > 3) run_pass<M, 3>(x, buf, false);
+  double err = 0, peak = 0;
+  for (int lane = 0; lane < 64; ++lane)
+    for (int i = 0; i < P; ++i) {
+      const int m = lane + 64 * i;
+      const double y0 = x[lane][i].x, y1 = -x[lane][i].y;  // z = conj(FFT(conj Z))
+      for (int e = 0; e < 2; ++e) {
+        const int n = 2 * m + e;
+        double ref = 0;
+        for (int k = 0; k < N; ++k) {
+          const int kk = k <= M ? k : N - k;
+          const double re = (double)(float)gr[kk], im = (k <= M ? 1.0 : -1.0) * (double)(float)gi[kk];
+          const double t = 2.0 * M_PI * (double)((long long)k * n % N) / N;
+          ref += re * cos(t) - im * sin(t);
+        }
+        err = fmax(err, fabs((e ? y1 : y0) - ref));
+        peak = fmax(peak, fabs(ref));
+      }
+    }
+  return err / peak;
+}
+
 int main() {
   int bad = 0;
   for (unsigned seed = 1; seed <= 3; ++seed) {
     const double e1024 = check<1024>(seed), e512 = check<512>(seed), e256 = check<256>(seed);
     printf("seed %u: N=2048 %.2e  N=1024 %.2e  N=512 %.2e (max |d| / peak)\n", seed, e1024, e512, e256);
     bad += !(e1024 < 5e-7) + !(e512 < 5e-7) + !(e256 < 5e-7);
+    const double i1024 = check_inverse<1024>(seed), i512 = check_inverse<512>(seed), i256 = check_inverse<256>(seed);
+    printf("        inverse: N=2048 %.2e  N=1024 %.2e  N=512 %.2e\n", i1024, i512, i256);
+    bad += !(i1024 < 1e-6) + !(i512 < 1e-6) + !(i256 < 1e-6);
   }
   return bad ? 1 : 0;
 }

@@ -159,7 +159,7 @@ def test_cfg2_stft_fft_sampled():
 # ---------------------------------------------------------------------------------------
 # the module-level checks of tests/test_gpu_parity.py once more, on the FFT route
 # ---------------------------------------------------------------------------------------
-_STFT_FAMILY = ("STFT", "MelSpectrogram", "MFCC", "Gammatonegram")
+_STFT_FAMILY = ("STFT", "iSTFT", "MelSpectrogram", "MFCC", "Gammatonegram")
 
 
 def _family_cases():
@@ -252,3 +252,61 @@ def test_torch_compile_on_the_fft_route(cls, ctor):
         compiled = torch.compile(m, fullgraph=True)(x)
     torch._dynamo.reset()
     assert torch.equal(eager, compiled)
+
+
+# ---------------------------------------------------------------------------------------
+# inverse direction: frame synthesis of the inverse STFT as an inverse real FFT
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_fft,hop,B,L,center", [(2048, 512, 3, 40000, True), (1024, 256, 2, 9000, True),
+                                                  (512, 128, 4, 5001, True), (2048, 1024, 1, 2100, True),
+                                                  (1024, 512, 2, 8192, False), (512, 37, 1, 3000, True)])
+def test_inverse_fft_matches_the_contraction_and_inverts(n_fft, hop, B, L, center):
+    from nnaudio_amd import engine, features
+
+    m = features.STFT(n_fft=n_fft, hop_length=hop, iSTFT=True, center=center, output_format="Complex",
+                      verbose=False).to(DEV)
+    x = torch.as_tensor(np.random.default_rng(n_fft + hop).standard_normal((B, L)).astype(np.float32)).to(DEV)
+    X = m(x)
+    y = m.inverse(X, length=L if center else None)
+    engine.set_fft(False)
+    try:
+        r = m.inverse(X, length=L if center else None)
+    finally:
+        engine.set_fft(True)
+    assert y.shape == r.shape and not torch.equal(y, r), "the contraction ran"
+    if not center:  # (untrimmed ends: the division by a vanishing window sum amplifies either route's rounding)
+        y, r = y[:, n_fft // 2:-n_fft // 2], r[:, n_fft // 2:-n_fft // 2]
+    assert float((y - r).abs().max() / r.abs().max()) <= 3e-6
+    if center and 4 * hop <= n_fft:  # (COLA: the round trip is the identity)
+        assert float((y - x[:, :y.shape[1]]).abs().max()) <= 5e-6 * float(x.abs().max())
+    # the iSTFT class on a one-sided spectrogram takes the same route
+    im = features.iSTFT(n_fft=n_fft, hop_length=hop, center=center, verbose=False).to(DEV)
+    y2 = im(X, onesided=True, length=L if center else None)
+    if not center:
+        y2 = y2[:, n_fft // 2:-n_fft // 2]
+    assert float((y2.float() - r).abs().max() / r.abs().max()) <= 3e-6
+
+
+def test_inverse_fft_is_not_taken_for_other_kernels():
+    """two-sided spectrograms, trainable or non-DFT synthesis kernels and n_fft = 4096 stay on the contraction"""
+    from nnaudio_amd import engine, features
+
+    m = features.STFT(n_fft=512, hop_length=128, iSTFT=True, output_format="Complex", verbose=False).to(DEV)
+    x = torch.randn(2, 6000, generator=torch.Generator().manual_seed(3)).to(DEV)
+    X = m(x)
+    full = torch.cat((X, torch.stack((X[:, 1:-1, :, 0].flip(1), -X[:, 1:-1, :, 1].flip(1)), -1)), 1)  # extend_fbins
+    a = m.inverse(full, onesided=False, length=6000)
+    engine.set_fft(False)
+    try:
+        b = m.inverse(full, onesided=False, length=6000)
+    finally:
+        engine.set_fft(True)
+    assert torch.equal(a, b)
+    basis = engine.istft_basis(m.kernel_cos_inv, m.kernel_sin_inv, 257, True)
+    assert engine.istft_basis_is_dft(basis, 257)
+    bad = basis.clone()
+    bad[5, 7] *= 1.001
+    assert not engine.istft_basis_is_dft(bad, 257)
+    big = features.STFT(n_fft=4096, hop_length=1024, iSTFT=True, output_format="Complex", verbose=False).to(DEV)
+    bb = engine.istft_basis(big.kernel_cos_inv, big.kernel_sin_inv, 2049, True)
+    assert not engine.istft_basis_is_dft(bb, 2049)

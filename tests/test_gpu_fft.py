@@ -310,3 +310,23 @@ def test_inverse_fft_is_not_taken_for_other_kernels():
     big = features.STFT(n_fft=4096, hop_length=1024, iSTFT=True, output_format="Complex", verbose=False).to(DEV)
     bb = engine.istft_basis(big.kernel_cos_inv, big.kernel_sin_inv, 2049, True)
     assert not engine.istft_basis_is_dft(bb, 2049)
+
+
+@pytest.mark.parametrize("name", ["stft", "mel", "mfcc"])
+def test_fft_route_is_hip_graph_capturable(name):
+    """the contraction suite's capture test with the FFT path on: one kernel per forward, no workspace, no memset"""
+    _contraction_suite.test_forward_is_hip_graph_capturable(None, name)
+
+
+def test_repeated_launches_on_the_fft_route_are_bit_identical():
+    """hand-stated waits, wave-level LDS hand-offs and row swaps: 20 launches on fresh inputs of one shape must
+    reproduce each other exactly (a missing wait shows up as run-to-run differences)"""
+    from nnaudio_amd import features
+
+    m = features.STFT(n_fft=2048, hop_length=512, output_format="Complex", verbose=False).to(DEV)
+    mm = features.STFT(n_fft=2048, hop_length=512, output_format="Magnitude", verbose=False).to(DEV)
+    x = torch.randn(16, 120000, device=DEV, generator=torch.Generator(DEV).manual_seed(9))
+    ref, refm = m(x).clone(), mm(x).clone()
+    for _ in range(20):
+        torch.randn(16, 120000, device=DEV)  # (disturb the allocator / caches)
+        assert torch.equal(m(x), ref) and torch.equal(mm(x), refm)

@@ -521,10 +521,12 @@ typedef struct mispec_octave_args {
   int32_t fir_headroom_bits;   /* ceil(log2(sum |taps|)) * (n_levels - 1): bits kept free above    */
                                /* the scaled level-0 samples for the gain of the FIRs (<= 7)       */
   void *absmax_in;             /* device, n_clips * 128 bytes: bit pattern of max |x[c, :]| per    */
-                               /* clip, 32 words apart; computed by this call from x (into words   */
-                               /* the CALLER has zeroed) unless                                    */
-  int32_t absmax_in_ready;     /* ... it is already there (!= 0: absmax_out of the launch that     */
-                               /* wrote this x as its x_last)                                      */
+                               /* clip, 32 words apart (words the CALLER has zeroed)               */
+  int32_t absmax_in_ready;     /* != 0: it is there (absmax_out of the launch that wrote this x as */
+                               /* its x_last); 0 (first launch of a chain): the library scales per */
+                               /* work item from the item's own span inside the kernel (banks of   */
+                               /* up to 192 taps, spans up to 12 K samples) or, failing that,      */
+                               /* first fills absmax_in with a pass over x                         */
   int32_t reserved2;           /* must be 0                                                        */
   void *absmax_out;            /* the same for x_last, gathered while it is written (atomic max    */
                                /* into words the CALLER has zeroed), or NULL                       */

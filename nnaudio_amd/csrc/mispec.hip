@@ -3984,6 +3984,8 @@ int mispec_octave_pyramid_f32(const mispec_octave_args *a, void *stream) {
     }
     p.tab_off = (int)smem;
     if (D > 1) smem += PYR_TAB_BYTES;
+    p.scale_off = (int)smem;
+    smem += 64;  // (per-item scaling: the waves' maxima)
     if (smem <= 80 * 1024) break;
   }
   p.nf = nf;
@@ -3997,7 +3999,10 @@ int mispec_octave_pyramid_f32(const mispec_octave_args *a, void *stream) {
   static std::atomic<unsigned long long> configured4[4] = {{0}, {0}, {0}, {0}};
   int rc = configure_lds(kern, 80 * 1024, configured4[(f16 ? 2 : 0) + (six ? 0 : 1)]);
   if (rc != MISPEC_OK) return rc;
-  if (f16 && !a->absmax_in_ready) {  // the chain's first launch: the clips' largest |sample| (into zeroed words)
+  // the chain's first launch: the power of two per work item, found inside the kernel, when the span of x_0 fits
+  // one batch of registers; else the clips' largest |sample| first (into zeroed words)
+  p.item_scale = f16 && six && !a->absmax_in_ready && p.lv[0].rows * 64 <= PYR_NBI * 1024 ? 1 : 0;
+  if (f16 && !a->absmax_in_ready && !p.item_scale) {
     hipLaunchKernelGGL(clip_absmax_kernel,
                        dim3((unsigned)((a->n_samples + ABSMAX_CHUNK - 1) / ABSMAX_CHUNK), (unsigned)a->n_clips),
                        dim3(256), 0, static_cast<hipStream_t>(stream), a->x, (long long)a->x_clip_stride,

@@ -42,6 +42,7 @@ constexpr int PYR_TAB_STRIDE = 832; // bytes between copies (52 chunks: conflict
 constexpr int PYR_TAB_BYTES = 2 * 4 * PYR_TAB_STRIDE;  // hi copies, lo copies
 constexpr int PYR_NT = 1;           // column tiles of the FIR a wave multiplies at a time
 constexpr int PYR_NB = 8;           // 16-byte loads per thread and batch while fetching a span of x_0
+constexpr int PYR_NBI = 12;         // ... in one batch, per-item scaling (spans up to 12 K samples)
 
 struct PyrLevel {
   int L;         // length of x_l
@@ -84,6 +85,9 @@ struct PyrParams {
   const unsigned *absmax_in;   // per clip (CLIP_ABSMAX_STRIDE apart): bit pattern of max |x[c, :]|
   unsigned *absmax_out;        // the same for x_last, gathered while it is written (atomicMax), or NULL
   int top;                     // level-0 samples are scaled below 2^top (headroom for the FIR's gain)
+  int item_scale;              // F16, first launch of a chain: the power of two is chosen per work item, from the
+                               // largest |sample| of its own span (no pass over the clips beforehand)
+  int scale_off;               // LDS byte offset of the four per-wave maxima
 };
 
 #ifdef MISPEC_ABLATE
@@ -211,7 +215,7 @@ __global__ void __launch_bounds__(256, 2) octave_pyramid_kernel(const PyrParams 
     const int c = item / p.n_chunks;
     const int t0 = (item - c * p.n_chunks) * p.nf;
     float xscale = 1.f, xunscale = 1.f;  // F16: the clip's power of two and its inverse
-    if (F16) {
+    if (F16 && !p.item_scale) {
       const int e = absmax_exponent(__uint_as_float(p.absmax_in[(long long)c * CLIP_ABSMAX_STRIDE]));
       xscale = pow2f(p.top - e);
       xunscale = pow2f(e - p.top);
@@ -222,6 +226,54 @@ __global__ void __launch_bounds__(256, 2) octave_pyramid_kernel(const PyrParams 
 
     // ---- A: span of x_0 -> split planes, in batches of 8 loads per thread in flight (the span is
     // ~40 KB: one load at a time would leave the workgroup waiting on HBM latency ten times over)
+    if (F16 && MAXS == 6 && p.item_scale) {  // (the 8-step instance has no registers to spare for the batch)
+      // the whole span in one batch of registers; its largest |sample| -- wave maxima through LDS, one more
+      // barrier -- picks the item's power of two (the pass over the clips that found one per clip cost 0.067 ms
+      // of a 0.61 ms step: every sample had to be seen before the first could be split)
+      const PyrLevel &v = p.lv[0];
+      const long long a0 = (long long)t0 * v.hop - v.halo;
+      const float *x = p.x + (long long)c * p.x_clip_stride;
+      unsigned char *hi = smem_raw + v.lds_off, *lo = hi + v.rows * PYR_ROW;
+      const int n = v.rows * 64;
+      f32x4v f[PYR_NBI];
+      float m = 0.f;
+#pragma unroll
+      for (int b = 0; b < PYR_NBI; ++b) {
+        const int i = 4 * tid + 1024 * b;
+        const long long g = a0 + i;
+        const bool inside = i < n && g >= 0 && g + 3 < v.L;
+        f[b] = *reinterpret_cast<const f32x4u *>(x + (inside ? g : 0));
+        if (!inside) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f[b][e] = (i < n && g + e >= 0 && g + e < v.L) ? x[g + e] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < PYR_NBI; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(f[b][e]));
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+      float *const s_max = reinterpret_cast<float *>(smem_raw + p.scale_off);
+      if (lane == 0) s_max[wave] = m;
+      __syncthreads();
+      m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+      const int e2 = absmax_exponent(m);
+      xscale = pow2f(p.top - e2);
+      xunscale = pow2f(e2 - p.top);
+#pragma unroll
+      for (int b = 0; b < PYR_NBI; ++b) {
+        const int i = 4 * tid + 1024 * b;
+        if (i < n) {
+          uint2 h, l;
+          split2(f[b][0] * xscale, f[b][1] * xscale, h.x, l.x);
+          split2(f[b][2] * xscale, f[b][3] * xscale, h.y, l.y);
+          const int ad = pyr_addr(i);
+          *reinterpret_cast<uint2 *>(hi + ad) = h;
+          *reinterpret_cast<uint2 *>(lo + ad) = l;
+        }
+      }
+    } else {
     {
       const PyrLevel &v = p.lv[0];
       const long long a0 = (long long)t0 * v.hop - v.halo;
@@ -254,6 +306,7 @@ __global__ void __launch_bounds__(256, 2) octave_pyramid_kernel(const PyrParams 
           }
         }
       }
+    }
     }
     __syncthreads();
     PYR_STAMP();  // span in LDS

@@ -330,3 +330,54 @@ def test_repeated_launches_on_the_fft_route_are_bit_identical():
     for _ in range(20):
         torch.randn(16, 120000, device=DEV)  # (disturb the allocator / caches)
         assert torch.equal(m(x), ref) and torch.equal(mm(x), refm)
+
+
+def test_fft_route_random_shapes_against_the_contraction():
+    """40 random STFT problems (n_fft, hop, clip length, batch, padding, freq_bins, strided clips, epilogue incl. a
+    general power) through both routes: the FFT path must agree with the fp32 contraction to fp32 rounding"""
+    from nnaudio_amd import engine
+
+    rng = np.random.default_rng(2024)
+    taken = 0
+    for case in range(40):
+        K = int(rng.choice([512, 1024, 2048]))
+        hop = int(rng.choice([1, 2, 3]) * rng.integers(20, 1200)) if case % 5 else int(rng.integers(K, 2 * K))
+        center = bool(rng.integers(0, 4))
+        pad = K // 2 if center else 0
+        mode = int(rng.choice([1, 2])) if center else 0
+        B = int(rng.integers(1, 6))
+        T = int(rng.integers(1, 70))
+        L = max((T - 1) * hop + K - 2 * pad + int(rng.integers(0, hop)), pad + 2, K - 2 * pad)
+        F = int(rng.choice([K // 2 + 1, K // 2 + 1, int(rng.integers(1, K // 2 + 1))]))
+        stride = L + int(rng.choice([0, 0, 3, 64]))
+        xs = torch.as_tensor(rng.standard_normal((B, stride)).astype(np.float32)).to(DEV)
+        x = xs[:, :L]
+        window = rng.choice(["hann", "hamming", "random"])
+        wr, wi = _dft_basis(K // 2 + 1, K, window, rng)
+        wrd, wid = torch.as_tensor(wr).to(DEV), torch.as_tensor(wi).to(DEV)
+        prep = engine.prepare_basis(wrd, wid, "fp32", hop=None)
+        if "basis_fold2" not in prep:
+            continue
+        wrd, wid = wrd[:F], wid[:F]
+        prep = {"basis_fold2": (prep["basis_fold2"][0], prep["basis_fold2"][1])}
+        epi, extra = [(engine.EPI_COMPLEX, {}), (engine.EPI_MAGNITUDE, {}), (engine.EPI_MAGNITUDE, dict(eps=1e-8)),
+                      (engine.EPI_POWER, dict(power=2.0)), (engine.EPI_POWER, dict(power=3.5, eps=1e-8)),
+                      (engine.EPI_PHASE_COSSIN, {})][int(rng.integers(0, 6))]
+        kw = dict(hop=hop, pad=pad, pad_mode=mode, precision="fp32", epilogue=epi, **extra)
+        try:
+            y = engine.framed_gemm(x, wrd, wid, fft=True, **kw, **prep)
+        except RuntimeError:
+            continue  # (the quarter-folded planes belong to the full basis: a sliced basis may be refused)
+        r = engine.framed_gemm(x, wrd, wid, fft=False, **kw)
+        assert y.shape == r.shape
+        what = "case %d: K %d hop %d B %d L %d F %d pad %d/%d epi %d %s" % (case, K, hop, B, L, F, pad, mode, epi, extra)
+        if epi == engine.EPI_PHASE_COSSIN:
+            z = engine.framed_gemm(x, wrd, wid, fft=False, **dict(kw, epilogue=engine.EPI_MAGNITUDE))
+            strong = z > 0.05 * z.max()
+            if bool(strong.any()):
+                assert float((y - r)[strong].abs().max()) <= 2e-4, what
+        else:
+            tol = 5e-6 * max(1.0, float(extra.get("power", 1.0)))  # (|X|^p carries p times the relative error of |X|)
+            assert float((y - r).abs().max()) <= tol * float(r.abs().max()), what
+        taken += not torch.equal(y, r)
+    assert taken >= 20, taken

@@ -24,21 +24,23 @@ device and its matrix-pipe roofline.
 (``python -m torch.distributed.run``, one per GPU, RCCL) and relays rank 0's line.
 
 Rank 0 prints ONE JSON line: metric = spectrogram frames/s (whole job), plus
-  "roofline":        the STFT step on the matrix pipe: "achieved" = the flops the kernels EXECUTE
-                     (MFMA instructions x 2 M N K; counted by the SQ_INSTS_VALU_MFMA_MOPS_* PMCs in
-                     the live rocprofv3 passes when available, else from the tiling) / the step's
-                     device time (HIP events on the launch stream); "peak" = the raw dense MFMA
-                     peak of the instruction used (2500 TFLOP/s bf16 / f16, 157.3 fp32); "frac" =
-                     achieved / peak, bounded by 1.  "algorithmic_frac" is the contract's figure:
-                     2 flop per tap of the DENSE contraction the reference performs
-                     / time / (peak / MFMAs per product) -- it exceeds 1 once symmetric folds
-                     skip work, which is why it is not "frac".  "traffic" = fabric-side bytes per
-                     step from rocprofv3 PMC passes (FETCH_SIZE doubled as MI355X_MICROARCH.md
-                     prescribes, + WRITE_SIZE) run live on this binary by this script
-                     (``--traffic live``), or null;
+  "roofline":        the STFT step as shipped = one launch of the FFT kernel: {"bound": "hbm", "achieved" =
+                     algorithmic bytes (clips in + spectrogram out + the reference's two bases)
+                     / the step's device time (HIP events on the launch stream), "peak" = 8000 GB/s, "frac",
+                     "traffic" = fabric-side bytes per step from rocprofv3 PMC passes (FETCH_SIZE doubled as
+                     MI355X_MICROARCH.md prescribes, + WRITE_SIZE) run live on this binary by this script
+                     (``--traffic live``), or null}.  With ``--precision <p>`` the step is the contraction
+                     kernels instead and the block is the matrix-pipe one: "achieved" = the flops the kernels
+                     EXECUTE (MFMA instructions x 2 M N K; counted by the SQ_INSTS_VALU_MFMA_MOPS_* PMCs when
+                     available, else from the tiling) / time; "peak" = the raw dense MFMA peak of the instruction
+                     used (2500 TFLOP/s bf16 / f16, 157.3 fp32); "frac" <= 1; "algorithmic_frac" = 2 flop per
+                     tap of the DENSE contraction the reference performs / time / (peak / MFMAs per product) --
+                     it exceeds 1 once symmetric folds skip work, which is why it is not "frac".  The same
+                     matrix-pipe figures of the contraction kernels are under "paths" in every run;
   "roofline_cqt84":  the same block for the other half of BASELINE.json's metric (CQT1992v2,
                      84 bins, B = 64), support-aware useful flops;
-  "extra":           Mel cfg3, Gammatonegram, and one rank's shard of cfg5 (CQT2010v2 and VQT,
+  "extra":           Mel cfg3, Gammatonegram (as shipped: the FFT route, priced on bytes; "mel_f16x3" /
+                     "gammatone_f16x3": the contraction route), and one rank's shard of cfg5 (CQT2010v2 and VQT,
                      64 x 30 s), each in its module's default arithmetic unless --precision is
                      given, timed with the same pre-warm and step count as the headline and priced
                      against both rooflines (with live traffic); at N > 1 also cfg4's real shard

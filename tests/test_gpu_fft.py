@@ -381,3 +381,10 @@ def test_fft_route_random_shapes_against_the_contraction():
             assert float((y - r).abs().max()) <= tol * float(r.abs().max()), what
         taken += not torch.equal(y, r)
     assert taken >= 20, taken
+
+
+def test_layouts_streams_and_errors_on_the_fft_route(golden):
+    """the contraction suite's input-layout / side-stream / error-behaviour checks with the FFT path on"""
+    _contraction_suite.test_input_layouts_and_streams(golden)
+    _contraction_suite.test_error_behaviour_on_device()
+    _contraction_suite.test_phase_zero_input_matches_reference_convention()

@@ -442,6 +442,129 @@ def cpu_baseline(budget_s=15.0):
     return out
 
 
+# ---------------------------------------------------------------------------------------
+# the printed line: the contract's fields only, <= LINE_BUDGET characters; everything else goes
+# to the side file bench_detail.json (the driver keeps 8 KB of stdout: a longer line is unparsed)
+# ---------------------------------------------------------------------------------------
+LINE_BUDGET = 4096
+DETAIL_FILE = "bench_detail.json"
+
+
+def _r(v, sig=5):
+    """Numbers to `sig` significant digits (the line is a report, the side file keeps full precision)."""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        if v == 0.0:
+            return 0.0
+        return float("%.*g" % (sig, v))
+    return v
+
+
+def _pick(d, keys):
+    return {k: _r(d[k]) for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def _short_kernel(name, n=60):
+    return (name or "").split(" (")[0][:n]
+
+
+def compact_line(out):
+    """The one-line JSON record from the full result dict: contract fields, the roofline /
+    cpu_baseline objects, one short record per path / extra.  No prose longer than 80 characters,
+    no per-kernel dictionaries (those are in the side file)."""
+    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                       "higher_is_better", "scaling", "dtype", "data"))
+    line["vs_baseline"] = out.get("vs_baseline")
+    cfg = out.get("config", {})
+    line["config"] = {"workload": cfg.get("workload", "")[:90], "global_batch": cfg.get("global_batch"),
+                      "precision": (cfg.get("precision_short") or cfg.get("precision") or "")[:80],
+                      "parallelism": (cfg.get("parallelism") or "")[:48]}
+    rk = ("bound", "achieved", "peak", "unit", "frac", "traffic", "step_device_ms",
+          "algorithmic_bytes_per_launch")
+
+    def roof(blk):
+        r = _pick(blk, rk)
+        r.setdefault("traffic", None)
+        if blk.get("bound") == "mfma":
+            r.update(_pick(blk, ("algorithmic_frac", "hbm_frac_on_algorithmic_bytes")))
+        dk = blk.get("dominant_kernel")
+        if dk:
+            r["dominant_kernel"] = {"name": _short_kernel(dk.get("name")), "avg_ms": _r(dk.get("avg_ms"))}
+        return r
+
+    if "roofline" in out:
+        line["roofline"] = roof(out["roofline"])
+    if "paths" in out:
+        line["paths"] = {}
+        for k, v in out["paths"].items():
+            if isinstance(v, dict):
+                line["paths"][k] = _pick(v, ("ms_per_step", "mfma_frac", "hbm_frac_on_algorithmic_bytes"))
+    if "roofline_cqt84" in out:
+        b = out["roofline_cqt84"]
+        line["roofline_cqt84"] = _pick(b, ("precision", "ms_per_step", "frames_per_s", "bound", "achieved", "peak",
+                                            "unit", "frac", "algorithmic_frac", "traffic", "default_module"))
+    if "extra" in out:
+        line["extra"] = {}
+        for k, v in out["extra"].items():
+            if not isinstance(v, dict):
+                continue
+            if "error" in v:
+                line["extra"][k] = {"error": str(v["error"])[:60]}
+                continue
+            e = _pick(v, ("ms_per_step",))
+            blk = v.get("roofline") or {}
+            e.update(_pick(blk, ("frac", "traffic")))
+            if blk.get("bound"):
+                e["bound"] = blk["bound"]
+            line["extra"][k] = e
+    if "gather" in out:
+        g = out["gather"]
+        line["gather"] = ({"error": str(g["error"])[:60]} if "error" in g else
+                          {k: _pick(v, ("with_gather_ms_per_step", "without_gather_ms_per_step", "bytes_per_rank"))
+                           if isinstance(v, dict) else _r(v) for k, v in g.items() if k != "what"})
+    cb = out.get("cpu_baseline")
+    if cb:
+        c = _pick(cb, ("value", "unit", "cores", "kind"))
+        c.setdefault("value", None)
+        c.setdefault("cores", None)
+        c["sample"] = (cb.get("sample") or "")[:100]
+        for sub in ("librosa_equivalent", "cqt84"):
+            if isinstance(cb.get(sub), dict) and "value" in cb[sub]:
+                c[sub] = {"value": _r(cb[sub]["value"])}
+        line["cpu_baseline"] = c
+    for k in ("kernel_source_sha", "detail", "detail_sha16"):
+        if k in out:
+            line[k] = out[k]
+    # last resort, in order: drop what is least part of the contract until the line fits
+    for victim in ("gather", "extra", "paths"):
+        if len(json.dumps(line)) <= LINE_BUDGET:
+            break
+        if victim in line:
+            line[victim] = {"see": DETAIL_FILE}
+    return line
+
+
+def emit(out, detail_dir=None):
+    """Write the full record to the side file, print the compact line LAST on stdout."""
+    detail_dir = detail_dir or os.environ.get("MISPEC_BENCH_DETAIL_DIR") or ROOT
+    blob = json.dumps(out, indent=1, sort_keys=True)
+    path = os.path.join(detail_dir, DETAIL_FILE if out.get("n_gpus", 1) == 1
+                        else "bench_detail_n%d.json" % out["n_gpus"])
+    try:
+        with open(path, "w") as f:
+            f.write(blob)
+        out = dict(out, detail=os.path.relpath(path, ROOT), detail_sha16=hashlib.sha256(blob.encode()).hexdigest()[:16])
+    except OSError as e:
+        log("bench detail file not written: %r" % (e,))
+    line = json.dumps(compact_line(out), separators=(",", ":"))
+    sys.stderr.flush()
+    print(line, flush=True)
+    return line
+
+
 def self_launch(args):
     """``python bench.py --gpus N`` outside torch.distributed.run: start N ranks (one per GPU, RCCL)
     of this script with the same arguments and relay rank 0's JSON line."""
@@ -636,6 +759,10 @@ def main():
         "config": {"workload": meta["tag"], "global_batch": meta["B"] * world,
                    "clip_samples": meta["L"], "frames_per_clip": meta["T"],
                    "precision": what,
+                   "precision_short": {"fft": "fp32 FFT per frame (VALU), err ~2e-7 of peak",
+                                       "f16x3": "split fp16 hi+lo, 3 f16 MFMAs per product, fp32 accumulate",
+                                       "bf16x3": "split bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate",
+                                       "fp32": "fp32 MFMA, fp32 accumulate"}[prec],
                    "parallelism": "batch-sharded x%d, no data-path collective" % world},
         "roofline": roofline_block(
             meta, kern_s, prec,
@@ -759,7 +886,7 @@ def main():
                                "sample": "measured at N=1 only"}
 
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         dist.destroy_process_group()
 

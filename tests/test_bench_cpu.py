@@ -42,3 +42,68 @@ def test_gpus_n_self_launch_fails_loudly_without_the_gpus():
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert "GPU(s) visible" in r.stderr + r.stdout
+
+
+def _canned(n_gpus=1):
+    """A full result dict of the shape main() builds, with the longest strings the script writes."""
+    prose = "x" * 400
+    pk = {"k%d" % i: {"FETCH_SIZE": 1.234567e8, "WRITE_SIZE": 7.654321e7, "SQ_INSTS_VALU_MFMA_MOPS_F16": 0.0}
+          for i in range(8)}
+    blk = dict(bench.roofline_block(dict(flops=4.632e11, bytes=3.559e8, bound="hbm", executed=None), 0.159e-3, "fft",
+                                    traffic=3.6e8, kernel=prose),
+               traffic_detail={"fetch_bytes": 1.2e8, "write_bytes": 2.4e8, "per_kernel": pk, "method": prose},
+               dominant_kernel={"name": "stft_fft_kernel<1024, MISPEC_EPI_MAGNITUDE> (" + prose + ")", "avg_ms": 0.159})
+    path = {"frames_per_s": 1.0687613104232763e8, "ms_per_step": 0.5161863501416519, "step_device_ms": 0.515954475402832,
+            "algorithmic_tflops": 897.82, "algorithmic_frac": 1.0773849658848194, "mfma_frac": 0.2690834646502573,
+            "hbm_frac_on_algorithmic_bytes": 0.08621845941983243, "dominant_kernel": dict(name=prose, avg_ms=0.5),
+            "what": prose, "dynamic_range_db": -152.9}
+    names = ["cqt_f16x3", "cqt_bf16x3", "cqt_fp32", "mel", "gammatone", "cqt2010", "vqt", "cqt2010_bf16x3",
+             "cqt2010_fp32", "mel_f16x3", "gammatone_f16x3", "cqt_f16x3_cfg4_shard", "istft", "mfcc", "stft256", "stft4096"]
+    out = {"metric": "spectrogram frames/sec", "value": 347220123.456, "unit": "frames/s", "n_gpus": n_gpus, "steps": 200,
+           "warmup": 50, "ms_per_step": 0.158881234, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic", "prewarm_ms": 300.1, "kernel_source_sha": "0123456789abcdef",
+           "config": {"workload": "STFT n_fft=2048 hop=512 hann, B=64 x 10 s @ 44.1 kHz, Magnitude (configs[1])",
+                      "global_batch": 64 * n_gpus, "precision": prose, "precision_short": "fp32 FFT per frame",
+                      "parallelism": "batch-sharded x%d, no data-path collective" % n_gpus},
+           "roofline": blk, "paths": {k: dict(path) for k in ("fft", "f16x3", "bf16x3", "fp32")},
+           "roofline_cqt84": dict(blk, precision="f16x3", ms_per_step=0.4, frames_per_s=1.3e8, workload=prose),
+           "extra": {k: dict(path, roofline=dict(blk), workload=prose, precision="f16x3") for k in names},
+           "cpu_baseline": {"value": 46194.8, "unit": "frames/s", "cores": 128, "kind": "port", "sample": prose,
+                            "librosa_equivalent": {"value": 92590.7, "what": prose}, "cqt84": {"value": 8737.9, "sample": prose}}}
+    if n_gpus > 1:
+        g = {"with_gather_ms_per_step": 1.234, "without_gather_ms_per_step": 0.159, "bytes_per_rank": 2.26e8}
+        out["gather"] = dict(g, what=prose, cqt_cfg4_shard=dict(g), cqt2010_cfg5_shard=dict(g))
+        out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": None, "kind": "port", "sample": "measured at N=1 only"}
+    return out
+
+
+@pytest.mark.parametrize("n_gpus", [1, 8])
+def test_line_is_small(n_gpus, tmp_path, capsys):
+    """The driver keeps 8 KB of stdout: the line must be ONE line, the LAST one, well under that, and
+    still carry the contract's fields."""
+    import json
+
+    out = _canned(n_gpus)
+    assert len(json.dumps(out)) > 20000  # (the full record is what did not fit in r3)
+    print("some earlier chatter")
+    line = bench.emit(out, detail_dir=str(tmp_path))
+    printed = capsys.readouterr().out.rstrip("\n").split("\n")
+    assert printed[-1] == line and "\n" not in line
+    assert len(line) < 4096
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["config"]["workload"].startswith("STFT n_fft=2048 hop=512")
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert d["roofline"]["dominant_kernel"]["name"] == "stft_fft_kernel<1024, MISPEC_EPI_MAGNITUDE>"
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"])
+    assert set(d["paths"]) == {"fft", "f16x3", "bf16x3", "fp32"} and "mfma_frac" in d["paths"]["f16x3"]
+    assert "cqt2010" in d["extra"] and "ms_per_step" in d["extra"]["cqt2010"]
+    # the side file holds the full record and the line names it
+    name = "bench_detail.json" if n_gpus == 1 else "bench_detail_n8.json"
+    full = json.load(open(tmp_path / name))
+    assert full["extra"]["mel"]["roofline"]["traffic_detail"]["per_kernel"]
+    assert d["detail"].endswith(name) and len(d["detail_sha16"]) == 16
+    if n_gpus > 1:
+        assert d["gather"]["cqt2010_cfg5_shard"]["with_gather_ms_per_step"] == pytest.approx(1.234)

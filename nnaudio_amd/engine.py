@@ -95,11 +95,19 @@ class DerivedCache:
     ``nnaudio_amd.invalidate_caches(module)`` after such an edit (``p.data = other`` IS seen: the
     storage address is part of the key)."""
 
-    def __init__(self):
+    def __init__(self, by_memory=False):
+        # by_memory: sources are recognised by what they ARE in memory (storage address, offset,
+        # shape, strides) instead of by object identity, and their storages are held alive -- for the
+        # custom ops, which may receive a fresh view object of the same buffer on every call
         self._entries = {}
+        self._by_memory = by_memory
 
     def clear(self):
         self._entries = {}
+
+    @staticmethod
+    def _mem_key(t):
+        return (t.untyped_storage().data_ptr(), t.storage_offset(), tuple(t.shape), tuple(t.stride()), t.dtype)
 
     def get(self, sources, build, extra=None):
         sources = tuple(sources)
@@ -108,11 +116,16 @@ class DerivedCache:
         hit = self._entries.get(dev)
         if hit is not None:
             refs, hvers, hextra, val = hit
-            if (hextra == extra and hvers == vers and len(refs) == len(sources)
-                    and all(r() is s for r, s in zip(refs, sources))):
-                return val
+            if hextra == extra and hvers == vers and len(refs) == len(sources):
+                if self._by_memory:
+                    if all(r[0] == self._mem_key(s) for r, s in zip(refs, sources)):
+                        return val
+                elif all(r() is s for r, s in zip(refs, sources)):
+                    return val
         val = build()
-        self._entries[dev] = (tuple(weakref.ref(s) for s in sources), vers, extra, val)
+        refs = (tuple((self._mem_key(s), s.untyped_storage()) for s in sources) if self._by_memory
+                else tuple(weakref.ref(s) for s in sources))
+        self._entries[dev] = (refs, vers, extra, val)
         return val
 
 _PAD_MODES = {"constant": PAD_ZERO, "reflect": PAD_REFLECT, None: PAD_NONE}

@@ -43,8 +43,8 @@ class SupportCache:
     """[start, stop) of the non-zero taps of every kernel row, recomputed whenever the
     kernel tensors are replaced or modified in place (see ``engine.DerivedCache``)."""
 
-    def __init__(self):
-        self._cache = engine.DerivedCache()
+    def __init__(self, by_memory=False):
+        self._cache = engine.DerivedCache(by_memory)
 
     @staticmethod
     def _build(real, imag):
@@ -89,13 +89,14 @@ class OctaveCache:
     "bf16x3" / "f16x3"): the split planes of every octave's bank rows (see ``engine.DerivedCache``:
     rebuilt when the buffers change)."""
 
-    def __init__(self):
+    def __init__(self, by_memory=False):
         self._banks = {}
+        self._by_memory = by_memory  # (see engine.DerivedCache: the custom ops' instances)
 
     def scale(self, lenghts, normalization_type, factor):
         """``normalisation_scale`` of the module, built once (a forward must not launch the
         sqrt / multiply slivers every call) and rebuilt when ``lenghts`` changes."""
-        c = self.__dict__.setdefault("_scale", engine.DerivedCache())
+        c = self.__dict__.setdefault("_scale", engine.DerivedCache(self._by_memory))
         return c.get((lenghts,), lambda: normalisation_scale(lenghts, normalization_type, factor),
                      extra=(normalization_type, float(factor)))
 
@@ -105,7 +106,7 @@ class OctaveCache:
         per filter."""
         import math
 
-        c = self.__dict__.setdefault("_gain", engine.DerivedCache())
+        c = self.__dict__.setdefault("_gain", engine.DerivedCache(self._by_memory))
         return c.get((lowpass,), lambda: max(0, math.ceil(math.log2(max(float(lowpass.abs().sum()), 1e-30)))))
 
     def bank(self, i, kr, ki, first, precision="bf16x3"):
@@ -114,7 +115,7 @@ class OctaveCache:
         zero margins (multiples of 16 taps) are cut off both ends -- the same frames, centred as
         before, on a narrower kernel (256 -> 192 taps for the reference's banks: the fused kernel
         then keeps 6 instead of 8 steps of kernel rows in registers)."""
-        c = self._banks.setdefault((i, precision), engine.DerivedCache())
+        c = self._banks.setdefault((i, precision), engine.DerivedCache(self._by_memory))
 
         def build():
             r = kr.reshape(kr.shape[0], -1)[first:]
@@ -189,6 +190,9 @@ def octave_recursion(x, banks, lenghts, hop, n_bins, lowpass, downsample_factor,
     serve (hop below 4 samples at the bottom) and ``precision="fp32"`` run one FIR decimation +
     one (grouped) contraction per octave on the exact fp32 kernels."""
     epi = output_epilogue(output_format)
+    # the single-op route of torch.compile carries neither a precomputed scale nor an imaginary sign:
+    # it is CQT2010v2 / VQT's call (scale from normalization_type, im_sign -1, a module cache)
+    single_op_ok = scale is None and im_sign == -1.0 and cache is not None
     if scale is None:
         # (under torch.compile / export the tensors are fake: no cache look-ups, the ops are traced)
         scale = (cache.scale(lenghts, normalization_type, downsample_factor)
@@ -245,7 +249,7 @@ def octave_recursion(x, banks, lenghts, hop, n_bins, lowpass, downsample_factor,
     while octs and octs[-1]["rows"] <= 0:  # octaves cut away entirely
         octs.pop()
     eps = 1e-8 if trainable else 0.0
-    if engine.compiling() and not graph and not trainable:
+    if engine.compiling() and not graph and not trainable and single_op_ok:
         # torch.compile with frozen kernels: the whole recursion as one op, which at run time is the
         # eager path below (fused pyramid kernel / grouped contractions) with cached operands
         from .. import ops

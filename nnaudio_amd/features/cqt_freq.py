@@ -46,6 +46,8 @@ def _effective_kernels(mod):
 
     if torch.is_grad_enabled() and any(t.requires_grad for t in (kr, ki, wc, ws)):
         return build()
+    if engine.compiling():  # traced tensors: no cache look-up (data pointers), the product is one op
+        return build()
     if not hasattr(mod, "_eff"):
         mod._eff = engine.DerivedCache()
     return mod._eff.get((kr, ki, wc, ws), build)

@@ -14,7 +14,6 @@ supports) are looked up inside the op -- at run time, on the real tensors -- in 
 keyed on what the tensor IS in memory (``_ViewCache``: a compiled graph hands the ops fresh view
 objects every call), so nothing about them is baked into a traced graph.
 """
-import weakref
 from typing import List, Optional
 
 import torch
@@ -141,18 +140,11 @@ def _(spec, amin, ref, top_db):
 # one: STFT power spectrum + filterbank (the fused epilogue when the filterbank is banded), and the
 # whole octave recursion of CQT2010v2 / VQT (the fused pyramid kernel in bf16x3).
 # ---------------------------------------------------------------------------------------
-_fb_cache = {}  # id(fb) -> (weakref, DerivedCache of (support, coverage))
+_fb_cache = _ViewCache()  # (keyed on what the filterbank IS in memory: compiled graphs hand over fresh views)
 
 
 def _fb_support(fb):
-    key = id(fb)
-    hit = _fb_cache.get(key)
-    if hit is None or hit[0]() is not fb:
-        cache = engine.DerivedCache()
-        _fb_cache[key] = (weakref.ref(fb, lambda _r, k=key: _fb_cache.pop(k, None)), cache)
-    else:
-        cache = hit[1]
-    return cache.get((fb,), lambda: engine.filterbank_support(fb))
+    return _fb_cache.get((fb,), None, lambda: engine.filterbank_support(fb))
 
 
 @torch.library.custom_op("mispec::stft_filterbank", mutates_args=())
@@ -177,19 +169,27 @@ def _(x, basis_re, basis_im, fb, hop, pad, pad_mode, power, eps, precision):
     return x.new_empty((x.shape[0], fb.shape[0], (L + 2 * pad - K) // hop + 1))
 
 
-_octave_caches = {}  # id(first bank) -> (weakref, (OctaveCache, [SupportCache]))
+_octave_caches = _ViewCache()  # first bank (as it is in memory) -> (OctaveCache, [SupportCache])
 
 
 def _octave_state(first_bank, n_oct):
+    """The derived-operand caches of one module's octave recursion.  Keyed on the first bank's place
+    in memory (a compiled graph may hand the op a fresh view object every call; an id() key would
+    then rebuild the split planes -- kernels plus host syncs -- inside every compiled forward).  The
+    caches themselves track in-place changes of every bank (engine.DerivedCache), so the entry does
+    not depend on the bank's version counter."""
     from .features._cqt_common import OctaveCache, SupportCache
 
-    key = id(first_bank)
-    hit = _octave_caches.get(key)
-    if hit is None or hit[0]() is not first_bank or len(hit[1][1]) != n_oct:
-        state = (OctaveCache(), [SupportCache() for _ in range(n_oct)])
-        _octave_caches[key] = (weakref.ref(first_bank, lambda _r, k=key: _octave_caches.pop(k, None)), state)
-        return state
-    return hit[1]
+    key = (_ViewCache._key(first_bank), int(n_oct))
+    hit = _octave_caches.entries.get(key)
+    if hit is not None:
+        _octave_caches.entries[key] = _octave_caches.entries.pop(key)
+        return hit[2]
+    state = (OctaveCache(by_memory=True), [SupportCache(by_memory=True) for _ in range(n_oct)])
+    _octave_caches.entries[key] = ((first_bank.untyped_storage(),), None, state)
+    while len(_octave_caches.entries) > _octave_caches.cap:
+        _octave_caches.entries.pop(next(iter(_octave_caches.entries)))
+    return state
 
 
 @torch.library.custom_op("mispec::octave_recursion", mutates_args=())

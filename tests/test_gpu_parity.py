@@ -1474,6 +1474,8 @@ def test_repeated_launches_are_bit_identical():
     ("CQT1992v2", dict(sr=16000, hop_length=128, fmin=110, n_bins=60, output_format="Complex")),
     ("CQT2010v2", dict(sr=16000, hop_length=128, fmin=110, n_bins=60, earlydownsample=False)),
     ("VQT", dict(sr=16000, hop_length=128, fmin=110, n_bins=60, gamma=3, earlydownsample=False)),
+    # frequency-domain CQT2010: own scale and imaginary sign -> the per-octave ops, not the single op
+    ("CQT2010", dict(sr=16000, hop_length=128, fmin=110, n_bins=60, earlydownsample=False)),
 ])
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16x3"])
 def test_torch_compile_runs_the_custom_ops(cls, ctor, precision):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MISPEC_ABI_VERSION 8
+#define MISPEC_ABI_VERSION 9
 
 enum {
   MISPEC_OK = 0,
@@ -533,6 +533,68 @@ typedef struct mispec_octave_args {
 } mispec_octave_args;
 
 int mispec_octave_pyramid_f32(const mispec_octave_args *args, void *stream);
+
+/*
+ * Streaming form of the fused octave recursion (round 4; same reference lines as
+ * mispec_octave_pyramid_f32: cqt.py:1085-1105, vqt.py:160-188, utils.py:73-124, 498-521).  A workgroup
+ * walks a SEGMENT of one clip in steps of 4096 level-0 samples and keeps a ring of every level
+ * (level l+1 = the anti-alias FIR of level l at stride 2) in LDS: no halo is recomputed per work item,
+ * up to 5 levels (4 of them with a bank) are resident, and a step has one barrier -- four waves run the
+ * FIRs of all levels as one 128-column Toeplitz tile set on the matrix pipe (level l+1 a step behind
+ * level l), four waves contract the levels with their banks, all of them stream the next 4096 samples in
+ * (LDS-direct loads).  The deepest level goes to x_last (fp32) for the next launch of a chain.
+ *   hop            a multiple of 4 << (n_levels - 1), 4096 % hop == 0, hop <= 512
+ *   level[l]       bank_split = mispec_split_basis_bf16 / _f16 planes of (n_bins <= 16, kernel <= 256,
+ *                  kernel % 16 == 0), or NULL (level 0 of a follow-up launch); at most 4 banks
+ *   n_samples      every level with a bank needs  length >= 16 * (hop >> l) + 2 * kernel
+ *   x              16-byte aligned, x_clip_stride % 4 == 0
+ *   precision      MISPEC_PREC_BF16X3 or MISPEC_PREC_F16X3 (then fir_headroom_bits as for the pyramid
+ *                  kernel; the power-of-two operand scale is chosen by every workgroup from the samples
+ *                  it has seen, and the resident rings are rescaled when a louder chunk arrives)
+ *   n_segments     segments per clip (0: the library picks ~ one workgroup per CU)
+ * MISPEC_E_UNSUPPORTED for every other shape (the caller falls back to mispec_octave_pyramid_f32).
+ */
+#define MISPEC_STREAM_MAX_LEVELS 5
+typedef struct mispec_octave_stream_args {
+  uint32_t struct_size;
+  int32_t n_levels;            /* 1 .. 5                                                   */
+  const float *x;              /* (n_clips, n_samples), rows x_clip_stride elements apart  */
+  int64_t x_clip_stride;
+  int32_t n_clips;
+  int32_t n_samples;
+  int32_t hop;                 /* frame hop at level 0; level l uses hop >> l               */
+  int32_t n_frames;            /* frames per clip (the same at every level)                 */
+  const float *taps;           /* anti-alias filter (n_taps,), needed when n_levels > 1     */
+  int32_t n_taps;
+  int32_t epilogue;            /* MISPEC_EPI_COMPLEX / MAGNITUDE / PHASE_COSSIN / ...       */
+  float im_sign;
+  float eps;
+  mispec_octave_level level[MISPEC_STREAM_MAX_LEVELS];
+  float *x_last;               /* (n_clips, length of the deepest level) fp32, or NULL      */
+  int64_t x_last_clip_stride;
+  float *out;
+  int64_t out_clip_stride;     /* elements                                                  */
+  int64_t out_row_stride;      /* elements                                                  */
+  int32_t precision;
+  int32_t fir_headroom_bits;   /* F16X3: ceil(log2(sum |taps|)) * (n_levels - 1), <= 7      */
+  int32_t n_segments;
+  int32_t reserved;            /* must be 0                                                 */
+} mispec_octave_stream_args;
+
+int mispec_octave_stream_f32(const mispec_octave_stream_args *args, void *stream);
+
+/* The geometry mispec_octave_stream_f32 would use (host only, no device call): checked against the
+ * executable model of the schedule (scripts/octave_stream_model.py) by tests/test_octave_stream_cpu.py. */
+typedef struct mispec_octave_stream_plan {
+  int32_t n_levels, frames_per_step, blocks_per_tile, n_blocks, n_segments, blocks_per_segment, warm_steps;
+  int32_t lds_bytes;
+  int32_t length[MISPEC_STREAM_MAX_LEVELS];     /* samples of level l                        */
+  int32_t lookahead[MISPEC_STREAM_MAX_LEVELS];  /* block b of level l = [blk b + c, blk (b+1) + c) */
+  int32_t ring_rows[MISPEC_STREAM_MAX_LEVELS];  /* rows of 64 samples (a power of two)       */
+  int32_t contract_wave[MISPEC_STREAM_MAX_LEVELS]; /* wave that contracts level l, or -1     */
+} mispec_octave_stream_plan;
+int mispec_octave_stream_plan_of(const mispec_octave_stream_args *args, int32_t n_cus,
+                                 mispec_octave_stream_plan *plan);
 
 /*
  * Host path: the same three operations on HOST pointers, as plain C++ loops (fp32 multiply-adds in tap

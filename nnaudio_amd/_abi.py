@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmispec.so")
 ABLATE_LIB_PATH = os.path.join(_HERE, "csrc", "libmispec_ablate.so")  # benchmarking build
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 E_INVALID, E_UNSUPPORTED, E_HIP = -1, -2, -3
 
 # enums (mirror include/mispec.h)
@@ -22,6 +22,8 @@ EPI_COMPLEX, EPI_MAGNITUDE, EPI_POWER, EPI_PHASE_ATAN2, EPI_PHASE_COSSIN, EPI_RE
 PREC_F32, PREC_BF16X3, PREC_F16X3 = 0, 1, 2
 
 EXPORTS = (
+    "mispec_octave_stream_f32",
+    "mispec_octave_stream_plan_of",
     "mispec_version",
     "mispec_last_error",
     "mispec_framed_gemm_f32",
@@ -190,6 +192,58 @@ class OctaveArgs(ctypes.Structure):
         ("absmax_in_ready", ctypes.c_int32),
         ("reserved2", ctypes.c_int32),
         ("absmax_out", ctypes.c_void_p),
+    ]
+
+
+STREAM_MAX_LEVELS = 5
+
+
+class OctaveStreamArgs(ctypes.Structure):
+    """struct mispec_octave_stream_args"""
+
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32),
+        ("n_levels", ctypes.c_int32),
+        ("x", ctypes.c_void_p),
+        ("x_clip_stride", ctypes.c_int64),
+        ("n_clips", ctypes.c_int32),
+        ("n_samples", ctypes.c_int32),
+        ("hop", ctypes.c_int32),
+        ("n_frames", ctypes.c_int32),
+        ("taps", ctypes.c_void_p),
+        ("n_taps", ctypes.c_int32),
+        ("epilogue", ctypes.c_int32),
+        ("im_sign", ctypes.c_float),
+        ("eps", ctypes.c_float),
+        ("level", OctaveLevel * STREAM_MAX_LEVELS),
+        ("x_last", ctypes.c_void_p),
+        ("x_last_clip_stride", ctypes.c_int64),
+        ("out", ctypes.c_void_p),
+        ("out_clip_stride", ctypes.c_int64),
+        ("out_row_stride", ctypes.c_int64),
+        ("precision", ctypes.c_int32),
+        ("fir_headroom_bits", ctypes.c_int32),
+        ("n_segments", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+
+class OctaveStreamPlan(ctypes.Structure):
+    """struct mispec_octave_stream_plan"""
+
+    _fields_ = [
+        ("n_levels", ctypes.c_int32),
+        ("frames_per_step", ctypes.c_int32),
+        ("blocks_per_tile", ctypes.c_int32),
+        ("n_blocks", ctypes.c_int32),
+        ("n_segments", ctypes.c_int32),
+        ("blocks_per_segment", ctypes.c_int32),
+        ("warm_steps", ctypes.c_int32),
+        ("lds_bytes", ctypes.c_int32),
+        ("length", ctypes.c_int32 * STREAM_MAX_LEVELS),
+        ("lookahead", ctypes.c_int32 * STREAM_MAX_LEVELS),
+        ("ring_rows", ctypes.c_int32 * STREAM_MAX_LEVELS),
+        ("contract_wave", ctypes.c_int32 * STREAM_MAX_LEVELS),
     ]
 
 
@@ -385,6 +439,11 @@ def _load(path, how):
         ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64,
         ctypes.c_int32,
     ]
+    lib.mispec_octave_stream_f32.restype = ctypes.c_int
+    lib.mispec_octave_stream_f32.argtypes = [ctypes.POINTER(OctaveStreamArgs), ctypes.c_void_p]
+    lib.mispec_octave_stream_plan_of.restype = ctypes.c_int
+    lib.mispec_octave_stream_plan_of.argtypes = [ctypes.POINTER(OctaveStreamArgs), ctypes.c_int32,
+                                                 ctypes.POINTER(OctaveStreamPlan)]
     v = lib.mispec_version()
     if v != ABI_VERSION:
         raise MispecError("libmispec ABI version %d, expected %d" % (v, ABI_VERSION))

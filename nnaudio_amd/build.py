@@ -21,18 +21,13 @@ def hipcc():
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
-def build(force=False, verbose=True, ablate=False):
-    """Compile the product library (or, with ``ablate``, the benchmarking build)."""
-    out = OUT_ABLATE if ablate else OUT
-    csrc = os.path.dirname(SRC)
-    deps = [os.path.join(INC, "mispec.h")] + [
-        os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".inl", ".h"))
-    ]
-    if (not force and os.path.exists(out)
-            and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps)):
-        return out
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Rpass-analysis=kernel-resource-usage", "-I", INC, SRC, "-o", out + ".tmp"]
+# translation units of the library: (source, takes -DMISPEC_ABLATE in the benchmarking build)
+UNITS = [(SRC, True), (os.path.join(HERE, "csrc", "octave_stream.hip"), True)]
+
+
+def _compile(src, obj, ablate, verbose):
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-inline-asm", "-c",
+           "-Rpass-analysis=kernel-resource-usage", "-I", INC, src, "-o", obj]
     if ablate:
         cmd.insert(1, "-DMISPEC_ABLATE")
     if verbose:
@@ -43,15 +38,52 @@ def build(force=False, verbose=True, ablate=False):
         sys.stderr.write(other)
     if res.returncode != 0:
         raise subprocess.CalledProcessError(res.returncode, cmd)
+    return remarks
+
+
+def build(force=False, verbose=True, ablate=False):
+    """Compile the product library (or, with ``ablate``, the benchmarking build): every translation unit
+    to an object (in parallel; an object is reused while it is newer than the sources), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    out = OUT_ABLATE if ablate else OUT
+    csrc = os.path.dirname(SRC)
+    deps = [os.path.join(INC, "mispec.h")] + [
+        os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".inl", ".h"))
+    ]
+    newest = max(os.path.getmtime(d) for d in deps)
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= newest:
+        return out
+    objdir = os.path.join(csrc, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    jobs, objs = [], []
+    with ThreadPoolExecutor(len(UNITS)) as ex:
+        for src, takes_ablate in UNITS:
+            tag = "_ablate" if (ablate and takes_ablate) else ""
+            obj = os.path.join(objdir, os.path.basename(src).replace(".hip", tag + ".o"))
+            objs.append(obj)
+            # a unit depends on its own source, the headers and (mispec.hip) the .inl files it includes
+            mine = [d for d in deps if not d.endswith(".hip") or d == src]
+            if src != SRC:
+                mine = [d for d in mine if not d.endswith(".inl") and not d.endswith("fft_core.h")]
+            if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(d) for d in mine):
+                jobs.append(ex.submit(_compile, src, obj, ablate and takes_ablate, verbose))
+        remarks = {}
+        for j in jobs:
+            remarks.update(j.result())
     # The MFMA kernels feed LDS with global_load_lds and pace it with s_waitcnt vmcnt: a build of
     # the bf16x3 kernel that spilled (scratch loads inside its K loop, which count on the same
     # vmcnt) produced run-to-run different results on the MI355X.  Refuse such a build.
-    spilled = {k: v for k, v in remarks.items() if k.startswith("framed_") and v > 0}
+    spilled = {k: v for k, v in remarks.items() if k.startswith(("framed_", "octave_stream")) and v > 0}
     if spilled:
         raise RuntimeError("kernels using LDS-direct loads must not use scratch: %s" % spilled)
     slow = {k: v for k, v in remarks.items() if v > 0 and k.startswith(("fold", "split_", "clip_", "octave_"))}
     if slow and verbose:  # (a pre-pass with a stack array runs ~25 % slower: framed_fold2.inl)
         sys.stderr.write("warning: scratch in %s\n" % slow)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out + ".tmp"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
     os.replace(out + ".tmp", out)
     return out
 

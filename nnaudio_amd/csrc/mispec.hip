@@ -60,6 +60,7 @@
 #include <vector>
 
 #include "mispec.h"
+#include "mispec_internal.h"
 #include "fft_core.h"
 
 #ifdef MISPEC_ABLATE
@@ -2845,7 +2846,7 @@ int launch_strip32(KParams p, const mispec_framed_gemm_args *a, const StripPlan 
 
 // ---- MISPEC_PREC_F16X3 on the strip kernel (complex banks with supports and their host copy, basis_split
 // = mispec_frag_basis_f16()): applicability and launch
-long long basis_frag16_bytes(int n_bins, int kernel) {
+static long long basis_frag16_bytes(int n_bins, int kernel) {
   return (long long)((n_bins + 15) / 16) * round_up_kc(kernel) * 128 + 4096 + 2LL * n_bins * (long long)sizeof(float);
 }
 
@@ -3072,6 +3073,10 @@ static bool f16_downgrade(const mispec_framed_gemm_args *a, const KParams &p, mi
   local.basis_split_bytes = 0;
   return true;
 }
+
+// shared with the other translation units of the library (mispec_internal.h; hidden symbols)
+int mispec_fail_msg(int code, const char *msg) { return fail(code, "%s", msg); }
+int mispec_device_cus() { return device_cus(); }
 
 extern "C" {
 

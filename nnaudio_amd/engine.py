@@ -71,6 +71,22 @@ def fft_enabled():
     return _fft
 
 
+_octave_stream = os.environ.get("MISPEC_OCTAVE_STREAM", "1") not in ("0", "false", "off")
+
+
+def set_octave_stream(enabled):
+    """CQT2010v2 / VQT on the fused kernels: the streaming octave kernel (csrc/octave_stream.hip) where it
+    serves the shape, else -- and with ``set_octave_stream(False)`` / ``MISPEC_OCTAVE_STREAM=0`` always -- the
+    pyramid kernel (csrc/octave_pyramid.inl).  Returns the previous setting."""
+    global _octave_stream
+    old, _octave_stream = _octave_stream, bool(enabled)
+    return old
+
+
+def octave_stream_enabled():
+    return _octave_stream
+
+
 def resolve_precision(name=None, default="fp32"):
     """``name`` (a module's attribute / a call's argument), else the process-wide override, else
     ``default`` (the caller's own default)."""
@@ -1026,6 +1042,57 @@ def octave_pyramid(x, levels, *, hop, n_frames, taps, epilogue, im_sign, eps, ou
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
         rc = lib.mispec_octave_pyramid_f32(ctypes.byref(a), ctypes.c_void_p(stream))
+    if rc == _abi.E_UNSUPPORTED:
+        return False
+    _abi.check(rc)
+    return True
+
+
+def octave_stream(x, levels, *, hop, n_frames, taps, epilogue, im_sign, eps, out, x_last, precision="f16x3",
+                  fir_headroom_bits=0, n_segments=0, _debug=None):
+    """One launch of the STREAMING octave recursion (``mispec_octave_stream_f32``): ``levels`` is a list of up
+    to five dicts ``{split, n_bins, kernel, row_offset, pad_mode, row_scale}`` or None (a level without a
+    bank; at most four banks).  Returns False when the library does not serve the shape (the caller then
+    runs ``octave_pyramid``)."""
+    dev = _require_device(x, out, x_last, taps)
+    x = _signal(x)
+    taps = _f32(taps, "filter").reshape(-1).contiguous()
+    a = _abi.OctaveStreamArgs()
+    a.struct_size = ctypes.sizeof(_abi.OctaveStreamArgs)
+    a.n_levels = len(levels)
+    a.x, a.x_clip_stride = x.data_ptr(), x.stride(0)
+    a.n_clips, a.n_samples = x.shape
+    a.hop, a.n_frames = int(hop), int(n_frames)
+    a.taps, a.n_taps = taps.data_ptr(), taps.numel()
+    a.epilogue, a.im_sign, a.eps = int(epilogue), float(im_sign), float(eps)
+    keep = []
+    for i, lv in enumerate(levels):
+        if lv is None:
+            continue
+        o = a.level[i]
+        sp = lv["split"]
+        o.bank_split, o.bank_split_bytes = sp.data_ptr(), sp.numel() * sp.element_size()
+        o.n_bins, o.kernel = int(lv["n_bins"]), int(lv["kernel"])
+        o.out_row_offset, o.pad_mode = int(lv["row_offset"]), int(lv["pad_mode"])
+        rs = lv.get("row_scale")
+        if rs is not None:
+            rs = _f32(rs, "row_scale").contiguous()
+            o.row_scale = rs.data_ptr()
+            keep.append(rs)
+    if x_last is not None:
+        a.x_last, a.x_last_clip_stride = x_last.data_ptr(), x_last.stride(0)
+    a.out = out.data_ptr()
+    a.out_clip_stride, a.out_row_stride = out.stride(0), out.stride(1)
+    a.precision = _PRECISIONS[precision]
+    a.fir_headroom_bits = int(fir_headroom_bits) if precision == "f16x3" else 0
+    a.n_segments = int(n_segments)
+    lib = _abi.load()
+    if _debug is not None:  # ablation bits / phase clock (scripts/stream_prof.py, benchmarking build)
+        a.reserved = int(_debug)
+        lib = _abi.load_ablate()
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = lib.mispec_octave_stream_f32(ctypes.byref(a), ctypes.c_void_p(stream))
     if rc == _abi.E_UNSUPPORTED:
         return False
     _abi.check(rc)

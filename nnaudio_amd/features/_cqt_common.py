@@ -129,12 +129,50 @@ class OctaveCache:
         return c.get((kr, ki), build, extra=first)
 
 
-def _fused_chain(x, octs, lowpass, epi, im_sign, eps, out, cache, precision="bf16x3"):
+def _stream_chain(x, octs, lowpass, epi, im_sign, eps, out, cache, precision):
+    """The leading octaves on ``engine.octave_stream``: launches of up to four octaves (the first of a
+    follow-up launch is the deepest level of the one before, re-read from HBM without a bank).  Returns
+    (number of octaves done, the fp32 signal of the last octave done); (0, x) when the first launch is not
+    served."""
+    done, xd = 0, x
+    gain_bits = cache.fir_headroom_bits(lowpass) if precision == "f16x3" else 0
+    while done < len(octs):
+        first = done == 0
+        base = 0 if first else done - 1
+        top = min(base + (4 if first else 5), len(octs))
+        levels = []
+        for i in range(base, top):
+            o = octs[i]
+            if i == base and not first:
+                levels.append(None)
+                continue
+            split, k_eff = cache.bank(i, o["kr"], o["ki"], o["first"], precision)
+            levels.append(dict(split=split, n_bins=o["rows"], kernel=k_eff, row_offset=o["row0"],
+                               pad_mode=o["mode"], row_scale=o["scale"]))
+        last = octs[top - 1]
+        x_last = None
+        if top < len(octs):
+            # (rows a multiple of 4 floats apart: the next launch streams them in with 16-byte LDS-direct loads)
+            x_last = torch.empty((x.shape[0], (last["L"] + 3) // 4 * 4), dtype=torch.float32,
+                                 device=x.device)[:, :last["L"]]
+        ok = engine.octave_stream(xd, levels, hop=octs[base]["hop"], n_frames=out.shape[2], taps=lowpass,
+                                  epilogue=epi, im_sign=im_sign, eps=eps, out=out, x_last=x_last,
+                                  precision=precision, fir_headroom_bits=gain_bits * (len(levels) - 1))
+        if not ok:
+            break
+        done = top
+        if x_last is None:
+            break
+        xd = x_last
+    return done, xd
+
+
+def _fused_chain(x, octs, lowpass, epi, im_sign, eps, out, cache, precision="bf16x3", done=0):
     """Run as many leading octaves as possible through ``engine.octave_pyramid`` (three levels per
     launch, the deepest level of a launch feeding the next).  Returns (number of octaves done, the
     fp32 signal of the last octave done).  "f16x3": the clips' largest |sample| is found once for x
     and gathered by every launch for the level it hands on (two ping-pong buffers)."""
-    done, xd = 0, x
+    xd = x
     f16 = precision == "f16x3"
     # (one zeroed buffer per launch boundary: the library's atomic maxima land in zeroed words)
     absmax = torch.zeros((len(octs) // 2 + 2, 32 * x.shape[0]), dtype=torch.int32, device=x.device) if f16 else None
@@ -275,7 +313,10 @@ def octave_recursion(x, banks, lenghts, hop, n_bins, lowpass, downsample_factor,
     out = engine.alloc_out(shape, x.device)
     done, xd = 0, x
     if precision in ("bf16x3", "f16x3") and cache is not None and not trainable and x.is_cuda:
-        done, xd = _fused_chain(x, octs, lowpass, epi, im_sign, eps, out, cache, precision)
+        if engine.octave_stream_enabled():
+            done, xd = _stream_chain(x, octs, lowpass, epi, im_sign, eps, out, cache, precision)
+        if done < len(octs):  # what the streaming kernel does not serve: the pyramid kernel from there
+            done, xd = _fused_chain(xd, octs, lowpass, epi, im_sign, eps, out, cache, precision, done=done)
     launches = []  # the remaining per-octave contractions are independent: one grouped launch
     for o in octs[done:]:  # xd: the fp32 signal of the previous octave (x itself before octave 0)
         if o["i"] > 0:

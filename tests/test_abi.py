@@ -25,6 +25,13 @@ def test_library_exports_every_declared_symbol():
     assert set(names) == set(_abi.EXPORTS)
     for n in names:
         assert hasattr(lib, n), n
+    # ... and nothing else: every exported function is one the header declares (no stray C++ symbol)
+    import subprocess
+
+    nm = subprocess.run(["nm", "-D", "--defined-only", _abi.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if len(ln.split()) == 3 and ln.split()[1] == "T"}  # (weak STL instantiations aside)
+    exported = {e for e in exported if not e.startswith(("_init", "_fini", "__"))}
+    assert exported <= set(names), sorted(exported - set(names))
     assert _abi.load().mispec_version() == _abi.ABI_VERSION
     assert _abi.load().mispec_last_error() == b""
 
@@ -42,7 +49,9 @@ def test_args_struct_layout_matches_header(tmp_path):
     for cname, mirror in (("mispec_framed_gemm_args", _abi.FramedGemmArgs),
                           ("mispec_planar_args", _abi.PlanarArgs),
                           ("mispec_octave_level", _abi.OctaveLevel),
-                          ("mispec_octave_args", _abi.OctaveArgs)):
+                          ("mispec_octave_args", _abi.OctaveArgs),
+                          ("mispec_octave_stream_args", _abi.OctaveStreamArgs),
+                          ("mispec_octave_stream_plan", _abi.OctaveStreamPlan)):
         fields = [f[0] for f in mirror._fields_]
         prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "mispec.h"', 'int main(void){',
                 'printf("%%zu\\n", sizeof(%s));' % cname]

@@ -109,6 +109,14 @@ class OctaveCache:
         c = self.__dict__.setdefault("_gain", engine.DerivedCache(self._by_memory))
         return c.get((lowpass,), lambda: max(0, math.ceil(math.log2(max(float(lowpass.abs().sum()), 1e-30)))))
 
+    def fir_gain_log2(self, lowpass):
+        """log2(sum |taps|), unrounded: k cascaded FIRs add at most ceil(k * this) bits (the streaming
+        kernel keeps the room of a whole launch, not of k roundings).  One host read per filter."""
+        import math
+
+        c = self.__dict__.setdefault("_gain_log2", engine.DerivedCache(self._by_memory))
+        return c.get((lowpass,), lambda: max(0.0, math.log2(max(float(lowpass.abs().sum()), 1e-30))))
+
     def bank(self, i, kr, ki, first, precision="bf16x3"):
         """(split planes, kernel width) of octave ``i``'s rows ``first:``.  The reference's kernels
         sit centred in a power-of-two width and the longest of an octave spans ~0.69 of it: equal
@@ -134,8 +142,10 @@ def _stream_chain(x, octs, lowpass, epi, im_sign, eps, out, cache, precision):
     follow-up launch is the deepest level of the one before, re-read from HBM without a bank).  Returns
     (number of octaves done, the fp32 signal of the last octave done); (0, x) when the first launch is not
     served."""
+    import math
+
     done, xd = 0, x
-    gain_bits = cache.fir_headroom_bits(lowpass) if precision == "f16x3" else 0
+    gain = cache.fir_gain_log2(lowpass) if precision == "f16x3" else 0.0
     while done < len(octs):
         first = done == 0
         base = 0 if first else done - 1
@@ -157,7 +167,8 @@ def _stream_chain(x, octs, lowpass, epi, im_sign, eps, out, cache, precision):
                                  device=x.device)[:, :last["L"]]
         ok = engine.octave_stream(xd, levels, hop=octs[base]["hop"], n_frames=out.shape[2], taps=lowpass,
                                   epilogue=epi, im_sign=im_sign, eps=eps, out=out, x_last=x_last,
-                                  precision=precision, fir_headroom_bits=gain_bits * (len(levels) - 1))
+                                  precision=precision,
+                                  fir_headroom_bits=math.ceil((len(levels) - 1) * gain - 1e-9))
         if not ok:
             break
         done = top

@@ -865,8 +865,11 @@ class _IstftFn(torch.autograd.Function):
                 _abi.check(lib.mispec_istft_frames_f32(spec.data_ptr(), B, F, T, basis.data_ptr(), N,
                                                        frames.data_ptr(), stream))
             gwin = (u.unfold(1, N, hop) * frames).sum((0, 1))
-            wss = torch.nn.functional.conv_transpose1d(
-                torch.ones(1, 1, T, device=dev), (window * window).reshape(1, 1, N), stride=hop).reshape(-1)
+            # (overlap-add of the squared window as col2im: conv_transpose1d here went to a MIOpen implicit-GEMM
+            # backward-data kernel that faulted on the MI355X for this 1 x 1 x T problem, depending on where the
+            # allocator had placed its operands)
+            wss = torch.nn.functional.fold((window * window).reshape(1, N, 1).expand(1, N, T).contiguous(),
+                                           (1, full), (1, N), stride=(1, hop)).reshape(-1)
             v = torch.zeros(full, dtype=torch.float32, device=dev)
             seg = wss[start:start + out_len]
             v[start:start + out_len] = torch.where(

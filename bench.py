@@ -848,6 +848,32 @@ def main():
                                      "rank's block is written by the kernels into its slice of a "
                                      "persistent gather buffer (nnaudio_amd.dist.ShardedModule)"}
             del full_in
+            # the same for the shards the reference's multi-GPU configs name: cfg4 (CQT1992v2, 128 clips over 8
+            # ranks = 16 per rank) and cfg5 (CQT2010v2, 512 clips over 8 ranks = 64 per rank; per-rank work
+            # fixed as N grows, like the headline)
+            for key, name, pr2, b2 in (("cqt_cfg4_shard", "cqt", "f16x3", 16), ("cqt2010_cfg5_shard", "cqt2010", None, None)):
+                try:
+                    m2, mk2, me2 = workload(name, device, B=b2)
+                    m2.precision = pr2
+                    x2 = mk2(100 + rank)
+                    B2 = x2.shape[0]
+                    full2 = torch.empty((B2 * world, x2.shape[1]), dtype=torch.float32, device=device)
+                    lo2, hi2 = D.shard_bounds(B2 * world, world, rank)
+                    full2[lo2:hi2].copy_(x2)
+                    sm2 = D.ShardedModule(m2)
+                    w0, d0 = timed_steps(m2, x2, n3, 3, sync)
+                    w0, d0 = max_over_ranks(w0, d0)
+                    w1, d1 = timed_steps(sm2, full2, n3, 3, sync)
+                    w1, d1 = max_over_ranks(w1, d1)
+                    with torch.no_grad():
+                        yb = sm2(full2)[lo2:hi2].numel() * 4.0
+                    out["gather"][key] = {"with_gather_ms_per_step": w1 / n3 * 1e3, "without_gather_ms_per_step": w0 / n3 * 1e3,
+                                          "frames_per_s_with_gather": me2["frames"] * world * n3 / w1, "bytes_per_rank": yb,
+                                          "workload": me2["tag"]}
+                    del m2, sm2, x2, full2
+                    torch.cuda.empty_cache()
+                except Exception as e:
+                    out["gather"][key] = {"error": repr(e)[:200]}
         except Exception as e:
             out["gather"] = {"error": repr(e)}
 

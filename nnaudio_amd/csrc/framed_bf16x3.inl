@@ -161,8 +161,16 @@ __global__ void __launch_bounds__(256) split_signal_kernel(const KParams p,
   *reinterpret_cast<u16x4 *>(o + p.xs_plane) = l;
 }
 
-// MISPEC_PREC_F16X3: bit pattern of max |x[c, :]| per clip (the padding mirrors or zero-fills the
-// clip: the same bound holds for the padded clip).  grid (chunks of ABSMAX_CHUNK samples, n_clips), ONE
+// |v| of a finite sample, 0 of an infinite one (fmaxf drops NaNs by itself): the operand scale of a clip is
+// chosen for its FINITE samples -- a stray Inf then poisons the frames that contain it, as in the reference,
+// instead of pushing every other sample of the clip below fp16's range
+__device__ __forceinline__ float finite_abs(float v) {
+  const float a = fabsf(v);
+  return a < __builtin_inff() ? a : 0.f;
+}
+
+// MISPEC_PREC_F16X3: bit pattern of max |x[c, :]| per clip over its finite samples (the padding mirrors or
+// zero-fills the clip: the same bound holds for the padded clip).  grid (chunks of ABSMAX_CHUNK samples, n_clips), ONE
 // atomic per workgroup, every clip's word in a 128-byte line of its own (CLIP_ABSMAX_STRIDE): with an
 // atomic per wave on adjacent words the kernel spent 0.2 ms queueing 27 000 device-scope atomics on
 // two cache lines.  dst is zeroed by the caller (hipMemsetAsync) -- positive floats order like their
@@ -181,12 +189,12 @@ __global__ void __launch_bounds__(256) clip_absmax_kernel(const float *__restric
     if (q + 4 <= n_samples) {
       v[u] = *reinterpret_cast<const f32x4u *>(xc + q);
     } else {
-      for (long long i = q; i < n_samples; ++i) m = fmaxf(m, fabsf(xc[i]));
+      for (long long i = q; i < n_samples; ++i) m = fmaxf(m, finite_abs(xc[i]));
     }
   }
 #pragma unroll
   for (int u = 0; u < ABSMAX_CHUNK / 1024; ++u)
-    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u][0]), fabsf(v[u][1]))), fmaxf(fabsf(v[u][2]), fabsf(v[u][3])));
+    m = fmaxf(fmaxf(m, fmaxf(finite_abs(v[u][0]), finite_abs(v[u][1]))), fmaxf(finite_abs(v[u][2]), finite_abs(v[u][3])));
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
   __shared__ float sm[4];

@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(256, 2) octave_pyramid_kernel(const PyrParams 
 #pragma unroll
       for (int b = 0; b < PYR_NBI; ++b)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(f[b][e]));
+        for (int e = 0; e < 4; ++e) m = fmaxf(m, finite_abs(f[b][e]));
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
       float *const s_max = reinterpret_cast<float *>(smem_raw + p.scale_off);
@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(256, 2) octave_pyramid_kernel(const PyrParams 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                       f[e] *= xunscale;
-                      last_max = fmaxf(last_max, fabsf(f[e]));
+                      last_max = fmaxf(last_max, finite_abs(f[e]));
                     }
                   }
                   if (g + 3 < vo.L) {

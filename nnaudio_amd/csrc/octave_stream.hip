@@ -77,6 +77,12 @@ __device__ __forceinline__ void bf16_split2(float a, float b, unsigned &hi, unsi
   hi = __builtin_bit_cast(unsigned, h);
   lo = __builtin_bit_cast(unsigned, l);
 }
+// |v| of a finite sample, 0 of an infinite one (fmaxf drops NaNs by itself): the fp16 operand scale follows
+// the FINITE samples -- an Inf poisons the frames that contain it, as in the reference, not the whole clip
+__device__ __forceinline__ float os_finite_abs(float v) {
+  const float a = fabsf(v);
+  return a < __builtin_inff() ? a : 0.f;
+}
 // exponent e of m = f 2^e, f in [0.5, 1), clamped so that the scales below stay normal floats
 __device__ __forceinline__ int absmax_exponent(float m) {
   int e = (int)((__float_as_uint(m) >> 23) & 0xff) - 126;
@@ -271,7 +277,7 @@ __global__ void __launch_bounds__(OS_THREADS, 1) octave_stream_kernel(const OsPa
   auto wave_max_bits = [&](const float (&v)[16]) __attribute__((always_inline)) -> unsigned {
     float m = 0.f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) m = fmaxf(m, fabsf(v[e]));
+    for (int e = 0; e < 16; ++e) m = fmaxf(m, os_finite_abs(v[e]));
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
     return __float_as_uint(m);
@@ -797,7 +803,8 @@ __global__ void __launch_bounds__(OS_THREADS, 1) octave_stream_kernel(const OsPa
           if (F16) {
             float m = 0.f;
 #pragma unroll
-            for (int h = 0; h < 4; ++h) m = fmaxf(fmaxf(fmaxf(m, fabsf(f[h][0])), fmaxf(fabsf(f[h][1]), fabsf(f[h][2]))), fabsf(f[h][3]));
+            for (int h = 0; h < 4; ++h)
+              m = fmaxf(fmaxf(fmaxf(m, os_finite_abs(f[h][0])), fmaxf(os_finite_abs(f[h][1]), os_finite_abs(f[h][2]))), os_finite_abs(f[h][3]));
             // (the exponent of the wave's maximum exceeds e_cur iff some |sample| >= 2^e_cur: the reduction only then)
             unsigned mb = 0u;
             if (__builtin_amdgcn_ballot_w64(!(m < pow2f(e_cur))) != 0ull) {

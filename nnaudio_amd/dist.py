@@ -180,9 +180,19 @@ class ShardedModule(torch.nn.Module):
                 full[lo:hi].copy_(y)
         if full is None:
             if y is None:
-                y = self.module(x_full[lo:hi], **fwd)
-            full = torch.empty((n,) + tuple(y.shape[1:]), dtype=y.dtype, device=y.device)
-            full[lo:hi].copy_(y)
+                # the output's shape past the batch dimension from ONE clip (not from a whole forward that is
+                # then copied): the block itself is computed straight into its slice of the new buffer
+                with torch.no_grad():
+                    probe = self.module(x_full[lo:lo + 1], **fwd) if hi > lo else self.module(x_full[:1], **fwd)
+                full = torch.empty((n,) + tuple(probe.shape[1:]), dtype=probe.dtype, device=probe.device)
+                del probe
+                with engine.output_into(full[lo:hi]) as slot:
+                    y = self.module(x_full[lo:hi], **fwd)
+                if not slot.taken or y.data_ptr() != full[lo:hi].data_ptr():
+                    full[lo:hi].copy_(y)
+            else:
+                full = torch.empty((n,) + tuple(y.shape[1:]), dtype=y.dtype, device=y.device)
+                full[lo:hi].copy_(y)
             self._full = full
         gather_in_place(full, n, group=self.group)
         return full.clone() if self.clone else full

@@ -1,8 +1,11 @@
 """Host-side dispatch from torch CUDA tensors into the C ABI of ``libmispec.so``.
 
 torch is plumbing here (device memory from the caching allocator, the caller's current
-stream and device); every FLOP of the hot path is issued by the HIP kernels.  There is
-no CPU / eager fallback: CPU tensors raise, a missing extension raises.
+stream and device); every FLOP of the hot path is issued by the HIP kernels.  There is no
+eager / torch fallback and a missing extension raises.  CPU tensors are served by the library's
+host entries (``mispec_*_host_f32``: the same arithmetic on the calling thread) for the forward
+paths that have one -- STFT / filterbank / CQT forward; MFCC, the inverse STFT and backward on CPU
+tensors raise.
 """
 import ctypes
 import os
@@ -19,8 +22,12 @@ from ._abi import (  # noqa: F401  (re-exported for the feature modules)
 )
 from .basis import decimated_length
 
-# Arithmetic of the framed contraction (include/mispec.h, MISPEC_PREC_*):
-#   "fp32"   fp32 MFMA, bit-for-bit an fmaf chain like the reference's conv1d (default)
+# Arithmetic of the framed CONTRACTION kernels (include/mispec.h, MISPEC_PREC_*).  It does not apply to the
+# FFT route: STFT-family modules whose kernels are window x DFT (freq_scale='no', frozen, n_fft 512 / 1024 /
+# 2048) evaluate every frame's DFT as an fp32 FFT whatever `precision` says, an explicit "fp32" included
+# (2e-7 of the peak; `set_fft(False)` puts them on the contraction kernels, where "fp32" is the reference's
+# summation order).
+#   "fp32"   fp32 MFMA, the taps summed in the reference's order (CQT1992v2's default)
 #   "bf16x3" split-bf16 operands on the 16x faster bf16 MFMA, fp32 accumulate: ~5e-6 of the
 #            spectrum peak, inside the 1e-4 bar; problems it does not cover run in fp32
 #   "f16x3"  the same three MFMAs per product on (hi, lo) fp16 pairs of power-of-two scaled

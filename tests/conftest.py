@@ -33,3 +33,14 @@ def _stft_route(request):
     old = engine.set_fft(request.node.module.__name__.endswith("test_gpu_fft"))
     yield
     engine.set_fft(old)
+
+
+@pytest.fixture(params=[False, True], ids=["contraction", "fft"])
+def both_stft_routes(request):
+    """For the suites that are about what sits AROUND the STFT kernels (autograd, MFCC, the inverse, sharding):
+    once on the contraction kernels and once on the FFT route, the shipped default."""
+    from nnaudio_amd import engine
+
+    old = engine.set_fft(request.param)
+    yield request.param
+    engine.set_fft(old)

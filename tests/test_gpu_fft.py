@@ -233,7 +233,7 @@ def test_backward_through_the_fft_route(fmt):
 
 
 def test_mel_backward_on_the_fft_route():
-    _contraction_suite.test_backward_mel_and_frozen_front_end()
+    _contraction_suite.test_backward_mel_and_frozen_front_end(True)
 
 
 @pytest.mark.parametrize("cls,ctor", [("STFT", dict(n_fft=512, hop_length=128, output_format="Magnitude")),

@@ -1061,7 +1061,7 @@ def test_bf16x3_cfg2_full_size_sampled():
     assert (y - y32).abs().max().item() <= 2e-5 * y32.abs().max().item()
 
 
-def test_mfcc_power_to_db_and_errors():
+def test_mfcc_power_to_db_and_errors(both_stft_routes):
     """power_to_db against the numpy restatement incl. the per-clip top_db floor, in place, and
     the reference's parameter errors (mel.py:255, 273)."""
     from nnaudio_amd import engine, features
@@ -1082,7 +1082,7 @@ def test_mfcc_power_to_db_and_errors():
         m(torch.zeros(1, 4000, device=DEV))
 
 
-def test_stft_istft_round_trip():
+def test_stft_istft_round_trip(both_stft_routes):
     """reference tests/test_stft.py:28-54: inverse(STFT(x)) == x on randn(4, 16000), for the
     hop lengths the reference's parameter grid uses, through STFT.inverse and the iSTFT class."""
     from nnaudio_amd import features
@@ -1126,7 +1126,7 @@ def _grad_close(got, want, what, rel=2e-4):
 
 @pytest.mark.parametrize("fmt", ["Magnitude", "Complex", "Phase"])
 @pytest.mark.parametrize("pad_mode,center", [("reflect", True), ("constant", True), ("reflect", False)])
-def test_backward_stft(fmt, pad_mode, center):
+def test_backward_stft(fmt, pad_mode, center, both_stft_routes):
     from nnaudio_amd import features
 
     g = torch.Generator().manual_seed(21)
@@ -1192,7 +1192,7 @@ def test_backward_cqt1992v2(fmt):
     _grad_close(got[2], ki.grad, "d cqt_kernels_imag")
 
 
-def test_backward_mel_and_frozen_front_end():
+def test_backward_mel_and_frozen_front_end(both_stft_routes):
     from nnaudio_amd import features
 
     g = torch.Generator().manual_seed(23)
@@ -1222,7 +1222,7 @@ def test_backward_mel_and_frozen_front_end():
 
 
 @pytest.mark.parametrize("onesided,length", [(True, None), (False, None), (True, 3000)])
-def test_backward_istft(onesided, length):
+def test_backward_istft(onesided, length, both_stft_routes):
     """d spectrogram and d synthesis kernels of the inverse STFT against torch autograd on a
     fold-based restatement."""
     from nnaudio_amd import engine, features
@@ -1299,7 +1299,7 @@ def test_backward_istft_trainable_window(onesided, length, center):
 
 
 @pytest.mark.parametrize("top_db", [80.0, 20.0, None])
-def test_backward_mfcc(top_db):
+def test_backward_mfcc(top_db, both_stft_routes):
     from nnaudio_amd import features
 
     g = torch.Generator().manual_seed(25)
@@ -1430,7 +1430,7 @@ def test_fused_filterbank_matches_unfused():
                            fb=m.mel_basis, fb_support=sup)
 
 
-def test_rccl_single_rank_sharded_forward():
+def test_rccl_single_rank_sharded_forward(both_stft_routes):
     """The one-process-per-GPU path on the real backend: `nccl` (= RCCL) process group of one
     rank, sharded forward + all-gather reassembly (the world-size-2 logic is covered on gloo in
     the CPU suite).  Runs in a subprocess: process groups are process-global state."""

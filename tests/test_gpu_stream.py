@@ -156,3 +156,34 @@ def test_stream_launches_are_bit_identical():
         y0 = m(x).clone()
         for _ in range(10):
             assert torch.equal(m(x), y0)
+
+
+@pytest.mark.parametrize("cls,kw,precision", [
+    ("CQT2010v2", dict(sr=44100, hop_length=512, n_bins=96), None),             # streaming kernel: scale per chunk
+    ("CQT1992v2", dict(sr=22050, hop_length=512, n_bins=60), "f16x3"),          # strip kernel: scale per clip
+    ("STFT", dict(n_fft=1024, hop_length=256, freq_scale="linear", fmin=50, fmax=8000, sr=22050,
+                  output_format="Magnitude"), "f16x3"),                         # dense f16x3 kernel: scale per clip
+])
+def test_an_infinite_sample_poisons_only_its_frames(cls, kw, precision):
+    """fp16 operands are scaled by a power of two taken from the clip's largest FINITE |sample|: an Inf
+    in the clip spoils the frames that contain it (as in the reference) and leaves the others -- and the
+    other clips -- as they were."""
+    from nnaudio_amd import features
+
+    m = getattr(features, cls)(verbose=False, **kw).to(DEV)
+    m.precision = precision
+    torch.manual_seed(2)
+    L = 220500
+    x = torch.randn(2, L, device=DEV)
+    x2 = x.clone()
+    x2[0, 3000] = float("inf")
+    with torch.no_grad():
+        y0, y = m(x), m(x2)
+    # the frames over the bad sample are lost (non-finite, or saturated where the split saturates)
+    lost = y[0, :, :8]
+    assert (not torch.isfinite(lost).all()) or float(lost.abs().max()) > 100 * float(y0.abs().max())
+    T = y.shape[2]
+    far = slice(T // 2, T)                                             # far beyond every kernel (and FIR chain)
+    peak = y0.abs().max()
+    assert torch.isfinite(y[0, :, far]).all() and (y[0, :, far] - y0[0, :, far]).abs().max() <= 2e-6 * peak
+    assert (y[1] - y0[1]).abs().max() <= 2e-6 * peak

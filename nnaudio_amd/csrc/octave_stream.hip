@@ -283,10 +283,9 @@ __global__ void __launch_bounds__(OS_THREADS, 1) octave_stream_kernel(const OsPa
     return __float_as_uint(m);
   };
   auto published_max = [&](int parity) __attribute__((always_inline)) -> float {
-    unsigned m = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) m = s_max[4 * parity + w] > m ? s_max[4 * parity + w] : m;
-    return __uint_as_float(m);
+    const u32x4 v = *reinterpret_cast<const u32x4 *>(s_max + 4 * parity);  // (one read: the check opens every step)
+    const unsigned a = v[0] > v[1] ? v[0] : v[1], b = v[2] > v[3] ? v[2] : v[3];
+    return __uint_as_float(a > b ? a : b);
   };
   int e_cur = 0;  // F16: every resident sample is x 2^(top - e_cur)
   auto write_chunk = [&](int q, const float (&v)[16]) __attribute__((always_inline)) {
@@ -686,16 +685,21 @@ __global__ void __launch_bounds__(OS_THREADS, 1) octave_stream_kernel(const OsPa
       if (my >= 0 && beta >= b_a && beta < b_e && ((beta + 1) & span_mask) == 0 && !OS_DBG(2)) {
         const float xu = F16 ? pow2f(e_cur - p.top) : 1.f;
         const int f_first = (beta + 1 - span) * nf, f_end = (beta + 1) * nf;
+        // (scalar) every tile of this step is plain -- all steps but the first and last ones of a clip
+        const bool all_plain = !v_reflect || (f_first * v_hop - v_half >= 0 && (f_end - 1) * v_hop - v_half + v_K <= v_L);
         // the tiles at the ends of the clip first (one call site of the long path) ...
-        for (int tile0 = f_first; tile0 < f_end; tile0 += 16)
-          if (!tile_plain(tile0)) edge_tile(tile0, xu);
+        if (!all_plain) {
+          for (int tile0 = f_first; tile0 < f_end; tile0 += 16)
+            if (!tile_plain(tile0)) edge_tile(tile0, xu);
+        }
         OS_STAMP(6);
         // ... then the plain ones as one stream of (tile, step) pairs: the fragments of step s + H -- of the next
         // plain tile past the end of this one -- are requested while step s is contracted (one register set;
         // the 8-step instance has no registers to spare and requests a whole tile, then contracts it)
         constexpr int H = MAXS == 6 ? 3 : MAXS;
         auto next_plain = [&](int t) __attribute__((always_inline)) -> int {
-          while (t < f_end && !tile_plain(t)) t += 16;
+          if (!all_plain)
+            while (t < f_end && !tile_plain(t)) t += 16;
           return t < f_end ? t : -1;
         };
         // this lane's first fragment of a tile in units of 4 samples: whole 16-byte pieces when the level's hop

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MISPEC_ABI_VERSION 9
+#define MISPEC_ABI_VERSION 10
 
 enum {
   MISPEC_OK = 0,
@@ -425,6 +425,13 @@ int mispec_istft_frames_fft_f32(const float *spec, int32_t n_clips, int32_t n_fr
 int mispec_overlap_add_f32(const float *frames, int32_t n_clips, int32_t n_frames, int32_t n_fft,
                            const float *window, int32_t hop, int32_t start, float *out,
                            int64_t out_clip_stride, int32_t out_len, void *stream);
+/* Steps 1 + 2 in ONE launch for the inverse-FFT case (mispec_istft_frames_fft_f32's conditions, hop a multiple
+ * of 64 that divides n_fft; MISPEC_E_UNSUPPORTED else): a workgroup walks a run of consecutive 8-frame tiles of a clip,
+ * its waves synthesise one frame each, the windowed frames are overlap-added in LDS in the order step 2 uses
+ * (bit-identical output) and only the waveform is written -- the (clip, frame, sample) tensor never exists. */
+int mispec_istft_fft_f32(const float *spec, int32_t n_clips, int32_t n_freq, int32_t n_frames, int32_t n_fft,
+                         const float *window, int32_t hop, int32_t start, float *out, int64_t out_clip_stride,
+                         int32_t out_len, void *stream);
 
 /*
  * power_to_db of MFCC (mel.py:263-279), per clip c over its `clip_elems` values (n_mels * n_frames):

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmispec.so")
 ABLATE_LIB_PATH = os.path.join(_HERE, "csrc", "libmispec_ablate.so")  # benchmarking build
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 E_INVALID, E_UNSUPPORTED, E_HIP = -1, -2, -3
 
 # enums (mirror include/mispec.h)
@@ -58,6 +58,7 @@ EXPORTS = (
     "mispec_frames_transpose_f32",
     "mispec_istft_frames_f32",
     "mispec_istft_frames_fft_f32",
+    "mispec_istft_fft_f32",
     "mispec_overlap_add_f32",
     "mispec_octave_pyramid_f32",
     "mispec_fir_decimate_f32",
@@ -391,6 +392,11 @@ def _load(path, how):
     lib.mispec_istft_frames_fft_f32.argtypes = [
         ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
         ctypes.c_void_p,
+    ]
+    lib.mispec_istft_fft_f32.restype = ctypes.c_int
+    lib.mispec_istft_fft_f32.argtypes = [
+        ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+        ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p,
     ]
     lib.mispec_overlap_add_f32.restype = ctypes.c_int
     lib.mispec_overlap_add_f32.argtypes = [

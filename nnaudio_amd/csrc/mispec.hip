@@ -3700,6 +3700,52 @@ int mispec_istft_frames_fft_f32(const float *spec, int32_t n_clips, int32_t n_fr
   return MISPEC_OK;
 }
 
+int mispec_istft_fft_f32(const float *spec, int32_t n_clips, int32_t n_freq, int32_t n_frames, int32_t n_fft,
+                         const float *window, int32_t hop, int32_t start, float *out, int64_t out_clip_stride,
+                         int32_t out_len, void *stream) {
+  if (!spec || !window || !out) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
+  if (n_clips <= 0 || n_frames <= 0 || hop <= 0 || out_len <= 0 || start < 0) return fail(MISPEC_E_INVALID, "non-positive size%s");
+  if ((n_fft != 512 && n_fft != 1024 && n_fft != 2048) || n_freq != n_fft / 2 + 1)
+    return fail(MISPEC_E_UNSUPPORTED, "inverse FFT: one-sided spectrum of n_fft = 512, 1024 or 2048%s");
+  if (hop % 64 || hop > n_fft || n_fft % hop)
+    return fail(MISPEC_E_UNSUPPORTED, "fused inverse STFT: hop a multiple of 64 that divides n_fft%s");
+  if ((long long)start + out_len > (long long)(n_frames - 1) * hop + n_fft)
+    return fail(MISPEC_E_INVALID, "output range exceeds the overlap-add signal%s");
+  // tiles of 8 frames whose final samples [8 hop tile, 8 hop (tile + 1)) reach the end of the output; runs of
+  // consecutive tiles so that every CU has one (a run re-walks the tiles that reach into its first one)
+  const long long tile_span = 8LL * hop;
+  const int n_tiles_clip = (int)(((long long)start + out_len + tile_span - 1) / tile_span);
+  const int n_warm = (int)((n_fft - hop + tile_span - 1) / tile_span);
+  int runs = (device_cus() + n_clips - 1) / n_clips;
+  const int most = n_tiles_clip / (4 * (n_warm > 0 ? n_warm : 1)) > 1 ? n_tiles_clip / (4 * (n_warm > 0 ? n_warm : 1)) : 1;
+  runs = runs > most ? most : runs;  // (the re-walked tiles stay below a quarter of a run)
+  runs = runs < 1 ? 1 : runs;
+  const int per = (n_tiles_clip + runs - 1) / runs;
+  runs = (n_tiles_clip + per - 1) / per;
+  if ((long long)runs * n_clips > 0x3fffffffLL) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = MISPEC_OK;
+#define MISPEC_LAUNCH_IOLA(MM)                                                                               \
+  {                                                                                                          \
+    auto kern = istft_ola_fft_kernel<MM>;                                                                    \
+    const size_t smem = istft_ola_smem<MM>(hop);                                                             \
+    static std::atomic<unsigned long long> configured{0};                                                    \
+    rc = configure_lds(kern, 160 * 1024, configured);                                                        \
+    if (rc == MISPEC_OK && smem > 160 * 1024) rc = fail(MISPEC_E_UNSUPPORTED, "fused inverse STFT: LDS%s"); \
+    if (rc == MISPEC_OK)                                                                                     \
+      hipLaunchKernelGGL(kern, dim3((unsigned)(runs * n_clips)), dim3(FFT_WAVES * 64), smem, s, spec, n_clips, n_frames, \
+                         window, hop, start, out_len, out, (long long)out_clip_stride, runs, per, n_tiles_clip); \
+  }
+  if (n_fft == 2048) MISPEC_LAUNCH_IOLA(1024)
+  else if (n_fft == 1024) MISPEC_LAUNCH_IOLA(512)
+  else MISPEC_LAUNCH_IOLA(256)
+#undef MISPEC_LAUNCH_IOLA
+  if (rc != MISPEC_OK) return rc;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+
 int mispec_istft_frames_f32(const float *spec, int32_t n_clips, int32_t n_freq, int32_t n_frames,
                             const float *basis, int32_t n_fft, float *frames, void *stream) {
   if (!spec || !basis || !frames) return fail(MISPEC_E_INVALID, "NULL device pointer%s");

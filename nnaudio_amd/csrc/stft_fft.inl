@@ -608,3 +608,311 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) istft_fft_kernel(const float *
     __syncthreads();  // the tile has been read
   }
 }
+
+// ---------------------------------------------------------------------------------
+// Inverse STFT in ONE launch: frame synthesis (above) + windowed overlap-add + window-sum-square
+// normalisation (stft.py:33-54, utils.py:43-57) without the (clip, frame, sample) round trip through HBM
+// (452 MB written and re-read for a cfg2-sized inverse).  A workgroup owns a RUN of consecutive 8-frame
+// tiles of one clip and walks it in order:
+//   * every wave transforms one frame of the tile (as istft_fft_kernel) and writes  frame[n] * win[n] / N  into
+//     its own exchange buffer (free once the transform is over);
+//   * barrier; thread j sums samples q = j, j + 512, ... of the tile's span [0, 8 hop + N - hop): the CARRY of
+//     the tiles before (partial sums that were waiting for their later frames) + the tile's frames in
+//     ascending order -- the summation order of overlap_add_kernel, so the fused result is bit-identical
+//     to the two-launch one -- ; the first 8 hop samples are final (divided by the window sum, trimmed to
+//     [start, start + out_len), stored), the rest is the next tile's carry.  8 hop is a multiple of the 512
+//     threads (hop % 64 == 0), so the thread that reads carry[q] is the one that rewrites it: no second
+//     carry buffer, no race.  hop divides N (a power of two): no divisions in the sums.
+//   * a run that does not start the clip first walks the ceil((N - hop) / (8 hop)) tiles before it without
+//     storing (their frames build its first carry); the last run walks one tile past the clip's frames,
+//     which flushes the carry.
+// ---------------------------------------------------------------------------------
+template <int M>
+constexpr size_t istft_ola_smem(int hop) {
+  return ((istft_fft_smem<M>() + 15) & ~(size_t)15) + (size_t)2 * M * 4 + (size_t)(2 * M - hop) * 4 + (size_t)hop * 4;
+}
+
+template <int M>
+__global__ void __launch_bounds__(FFT_WAVES * 64) istft_ola_fft_kernel(const float *__restrict__ spec, const int n_clips,
+                                                                        const int n_frames, const float *__restrict__ win,
+                                                                        const int hop, const int start, const int out_len,
+                                                                        float *__restrict__ out, const long long out_clip_stride,
+                                                                        const int runs_per_clip, const int tiles_per_run,
+                                                                        const int n_tiles_clip) {
+  using namespace fftcore;
+  constexpr int N = 2 * M, P = M / 64, F = M + 1;
+  constexpr int FT = FFT_WAVES;  // frames per tile: one per wave
+  constexpr int C = 18;          // floats per tile row: 8 frames x (re, im) + 2 of padding
+  constexpr int NT = FFT_WAVES * 64;
+  constexpr int RPI = NT / 4, NIT = (F + RPI - 1) / RPI;  // gather: 4 lanes per row, 2 frames per lane
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float *const tile = reinterpret_cast<float *>(smem_raw);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  cf *const buf0 = reinterpret_cast<cf *>(smem_raw + F * C * 4);
+  cf *const buf = buf0 + wave * padded_size<M>();
+  constexpr int R0 = radix_of<M, 0>(), R1 = radix_of<M, 1>();
+  cf *const s_tw1 = buf0 + FFT_WAVES * padded_size<M>();
+  float *const s_win = reinterpret_cast<float *>(smem_raw + ((istft_fft_smem<M>() + 15) & ~(size_t)15));
+  float *const s_carry = s_win + N;
+  const int n_carry = N - hop;
+  float *const s_wss = s_carry + n_carry;  // [hop]: window sum of a sample all of whose K frames exist
+  const int hop_log2 = 31 - __builtin_clz((unsigned)hop), K = N / hop;
+  for (int i = tid; i < R0 * (R1 - 1); i += NT) {
+    const int k = i / (R1 - 1), r = i % (R1 - 1) + 1;
+    float sn, cs;
+    sincospif(-2.f * (float)(r * k) / (float)(R0 * R1), &sn, &cs);
+    s_tw1[i] = cf{cs, sn};
+  }
+  for (int i = tid; i < N; i += NT) s_win[i] = win[i];
+  for (int i = tid; i < n_carry; i += NT) s_carry[i] = 0.f;
+  for (int r = tid; r < hop; r += NT) {  // (ascending frame = descending n: the order of the sums it stands for)
+    float a = 0.f;
+    for (int kk = 0; kk < K; ++kk) {
+      const float w = win[r + (K - 1 - kk) * hop];
+      a += w * w;
+    }
+    s_wss[r] = a;
+  }
+  const cf *const tw1 = s_tw1 + (lane & (R0 - 1)) * (R1 - 1);
+  cf tw[tw_total<M>() > 0 ? tw_total<M>() : 1], wpre[P];
+  auto fill_tw = [&](auto pass_tag) __attribute__((always_inline)) {
+    constexpr int PASS = decltype(pass_tag)::value;
+#pragma unroll
+    for (int i = 0; i < tw_count<M, PASS>(); ++i) {
+      float s, c;
+      sincospif(2.f * tw_turns<M, PASS>(lane, i), &s, &c);
+      tw[tw_offset<M, PASS>() + i] = cf{c, s};
+    }
+  };
+  fill_tw(std::integral_constant<int, 2>{});
+  if constexpr (Radix<M>::n > 3) fill_tw(std::integral_constant<int, 3>{});
+#pragma unroll
+  for (int i = 0; i < P; ++i) {  // e^(+2 pi i k / N), k = lane + 64 i
+    float sn, cs;
+    sincospif((float)(lane + 64 * i) / (float)M, &sn, &cs);
+    wpre[i] = cf{cs, sn};
+  }
+  auto twf0 = [](int, int) __attribute__((always_inline)) { return cf{1.f, 0.f}; };
+  auto twf1 = [&](int, int r) __attribute__((always_inline)) { return tw1[r - 1]; };
+  auto twf2 = [&](int q, int r) __attribute__((always_inline)) { return tw[tw_offset<M, 2>() + q * (radix_of<M, 2>() - 1) + r - 1]; };
+  auto twf3 = [&](int q, int r) __attribute__((always_inline)) { return tw[tw_offset<M, 3>() + q * (radix_of<M, 3>() - 1) + r - 1]; };
+  auto wave_sync = []() __attribute__((always_inline)) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  auto store = [&](int o, cf v) __attribute__((always_inline)) { buf[pad(o)] = v; };
+  auto reload = [&](cf (&x)[P]) __attribute__((always_inline)) {
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < P; ++i) x[i] = buf[pad(lane + 64 * i)];
+    wave_sync();
+  };
+
+  const int T = n_frames;
+  const int c = blockIdx.x / runs_per_clip;
+  const int run = blockIdx.x - c * runs_per_clip;
+  const int ta = run * tiles_per_run;                       // first tile this run stores
+  const int tb = (ta + tiles_per_run < n_tiles_clip) ? ta + tiles_per_run : n_tiles_clip;
+  if (ta >= tb) return;
+  const int n_warm = (n_carry + FT * hop - 1) / (FT * hop);  // tiles whose frames reach into tile ta
+  const int t_first = ta - n_warm > 0 ? ta - n_warm : 0;
+  const float *const sc = spec + (long long)c * F * T * 2;
+  float *const oc = out + (long long)c * out_clip_stride;
+  const float inv_n = 1.0f / (float)N;
+  // the windowed frame of wave j: N floats in its exchange buffer, from a 16-byte aligned address (a buffer is
+  // an odd number of 8-byte elements long, and so is the tile in front of them)
+  auto frame_buf = [&](int j) __attribute__((always_inline)) -> float * {
+    return reinterpret_cast<float *>(buf0 + j * padded_size<M>()) + 2 * ((F * C / 2 + j * padded_size<M>()) & 1);
+  };
+  // (scalar) the 16-byte form of the overlap-add: see the sums below
+  const bool vec4 = (hop & 255) == 0 && ((start & 3) == 0) && ((out_clip_stride & 3) == 0) &&
+                    ((reinterpret_cast<unsigned long long>(out) & 15) == 0);
+  const int q2 = 2 * (tid & 3), r0 = tid >> 2;  // gather: this lane's two frames of a row, its first row
+  f32x4v g[NIT];
+  auto gather = [&](int t0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      const int k = r0 + RPI * j;
+      g[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+      if (k < F && t0 + q2 < T) {
+        const float *src = sc + ((long long)k * T + t0 + q2) * 2;
+        if (t0 + q2 + 1 < T)
+          g[j] = *reinterpret_cast<const f32x4u *>(src);
+        else
+          g[j] = f32x4v{src[0], src[1], 0.f, 0.f};
+      }
+    }
+  };
+  auto scatter = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      const int k = r0 + RPI * j;
+      if (k < F) {
+        cf *d = reinterpret_cast<cf *>(tile + k * C + 2 * q2);
+        d[0] = cf{g[j][0], g[j][1]};
+        d[1] = cf{g[j][2], g[j][3]};
+      }
+    }
+  };
+  gather(t_first * FT);
+  __syncthreads();  // (the tables, the zeroed carry)
+  for (int tl = t_first; tl < tb; ++tl) {
+    const int t0 = tl * FT;
+    scatter();
+    __syncthreads();
+    if (tl + 1 < tb) gather((tl + 1) * FT);  // the next tile travels while this one is transformed
+    const int t = t0 + wave;
+    if (t < T) {
+      cf x[P];
+      const cf *const col = reinterpret_cast<const cf *>(tile) + wave;  // row k at col[k * (C / 2)]
+#pragma unroll
+      for (int i = 0; i < P; ++i) {
+        const int k = lane + 64 * i;
+        cf gk = col[k * (C / 2)], gm = col[(M - k) * (C / 2)];
+        if (i == 0 && lane == 0) {  // DC and Nyquist: real
+          gk.y = 0.f;
+          gm.y = 0.f;
+        }
+        x[i] = real_pre_conj(gk, gm, wpre[i]);
+      }
+      stockham_pass<M, 0>(x, lane, twf0, store);
+      reload(x);
+      if constexpr (M == 1024) {
+        stockham_pass<M, 1>(x, lane, twf1, [](int, cf) {});
+        fft_rows_to_slots(x);
+      } else {
+        stockham_pass<M, 1>(x, lane, twf1, store);
+        reload(x);
+      }
+      if constexpr (Radix<M>::n > 3) {
+        stockham_pass<M, 2>(x, lane, twf2, store);
+        reload(x);
+        stockham_pass<M, 3>(x, lane, twf3, [](int, cf) {});
+      } else {
+        stockham_pass<M, 2>(x, lane, twf2, [](int, cf) {});
+      }
+      wave_sync();
+      // z = conj(FFT(conj Z)): y[2m] = Re, y[2m + 1] = -Im; windowed and scaled as overlap_add_kernel does it
+      float *const fb = frame_buf(wave);
+#pragma unroll
+      for (int i = 0; i < P; ++i) {
+        const int n = 2 * (lane + 64 * i);
+        const cf w = *reinterpret_cast<const cf *>(s_win + n);
+        *reinterpret_cast<cf *>(fb + n) = cf{x[i].x * w.x * inv_n, -x[i].y * w.y * inv_n};
+      }
+    }
+    __syncthreads();  // the frames of the tile stand in the exchange buffers
+    {
+      const bool emit = tl >= ta;
+      const int final_n = FT * hop, span = final_n + n_carry;
+      const long long base = (long long)t0 * hop;  // position of q = 0 on the un-trimmed overlap-add axis
+      // hop is a power of two that divides N: sample q = b hop + r of the span is covered by the K = N / hop frames
+      // j = b - K + 1 .. b of the tile (those that exist), at n = r + (b - j) hop; ascending j = the order of
+      // overlap_add_kernel.  (carry[q] is rewritten by the thread that reads it, in a later iteration of this
+      // loop: FT * hop % NT == 0)
+      // hop % 256 == 0 (8 hop a multiple of 4 NT) and a 16-byte aligned output: a thread takes FOUR CONSECUTIVE
+      // samples (same block b: one 16-byte LDS read per frame, one 16-byte store), the carry entries it reads are
+      // again the ones it rewrites later
+      if (vec4) {
+        for (int q = 4 * tid; q < span; q += 4 * NT) {
+          f32x4v acc = q < n_carry ? *reinterpret_cast<const f32x4v *>(s_carry + q) : f32x4v{0.f, 0.f, 0.f, 0.f};
+          const int b = q >> hop_log2, r = q & (hop - 1);
+          for (int kk = 0; kk < K; ++kk) {
+            const int j = b - K + 1 + kk;
+            if (j >= 0 && j < FT && t0 + j < T)
+              acc += *reinterpret_cast<const f32x4v *>(frame_buf(j) + r + (K - 1 - kk) * hop);
+          }
+          if (q < final_n) {
+            const long long i = base + q - start;
+            if (emit && i + 3 >= 0 && i < out_len) {
+              const int t_hi = t0 + b, t_lo = t_hi - K + 1;
+              f32x4v wss;
+              if (t_lo >= 0 && t_hi < T) {
+                wss = *reinterpret_cast<const f32x4v *>(s_wss + r);
+              } else {
+                wss = f32x4v{0.f, 0.f, 0.f, 0.f};
+                for (int kk = 0; kk < K; ++kk) {
+                  const int tt = t_lo + kk;
+                  if (tt >= 0 && tt < T) {
+                    const f32x4v w = *reinterpret_cast<const f32x4v *>(s_win + r + (K - 1 - kk) * hop);
+                    wss += w * w;
+                  }
+                }
+              }
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (wss[e] > 1e-10f) acc[e] /= wss[e];
+              if (i >= 0 && i + 3 < out_len) {
+                *reinterpret_cast<f32x4v *>(oc + i) = acc;
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  if (i + e >= 0 && i + e < out_len) oc[i + e] = acc[e];
+              }
+            }
+          } else {
+            *reinterpret_cast<f32x4v *>(s_carry + q - final_n) = acc;
+          }
+        }
+        __syncthreads();
+        continue;
+      }
+      // (four samples of a thread at a time: their sums are independent chains of LDS round trips)
+      constexpr int U = 4;
+      for (int q0 = tid; q0 < span; q0 += U * NT) {
+        float acc[U];
+        int bb[U], rr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int q = q0 + u * NT;
+          acc[u] = q < n_carry ? s_carry[q] : 0.f;  // (q >= span: below n_carry only if inside the span)
+          bb[u] = q >> hop_log2;
+          rr[u] = q & (hop - 1);
+        }
+        for (int kk = 0; kk < K; ++kk) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int j = bb[u] - K + 1 + kk;
+            if (q0 + u * NT < span && j >= 0 && j < FT && t0 + j < T)
+              acc[u] += frame_buf(j)[rr[u] + (K - 1 - kk) * hop];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int q = q0 + u * NT;
+          if (q >= span) continue;
+          float a = acc[u];
+          if (q < final_n) {
+            const long long i = base + q - start;
+            if (emit && i >= 0 && i < out_len) {
+              // the window sum over ALL frames of the clip that cover the sample (ascending, as overlap_add_kernel):
+              // frames t0 + b - K + 1 .. t0 + b; where they all exist the sum is a function of r alone (s_wss)
+              const int t_hi = t0 + bb[u], t_lo = t_hi - K + 1;
+              float wss;
+              if (t_lo >= 0 && t_hi < T) {
+                wss = s_wss[rr[u]];
+              } else {
+                wss = 0.f;
+                for (int kk = 0; kk < K; ++kk) {
+                  const int tt = t_lo + kk;
+                  if (tt >= 0 && tt < T) {
+                    const float w = s_win[rr[u] + (K - 1 - kk) * hop];
+                    wss += w * w;
+                  }
+                }
+              }
+              if (wss > 1e-10f) a /= wss;
+              oc[i] = a;
+            }
+          } else {
+            s_carry[q - final_n] = a;
+          }
+        }
+      }
+    }
+    __syncthreads();  // the exchange buffers (and the carry) may be rewritten
+  }
+}

@@ -78,6 +78,17 @@ def fft_enabled():
     return _fft
 
 
+_istft_fused = os.environ.get("MISPEC_ISTFT_FUSED", "1") not in ("0", "false", "off")
+
+
+def set_istft_fused(enabled):
+    """Inverse STFT on the FFT route: synthesis + overlap-add in one launch (``mispec_istft_fft_f32``) where it
+    serves the shape; ``False`` (or ``MISPEC_ISTFT_FUSED=0``) keeps the two launches.  Returns the previous setting."""
+    global _istft_fused
+    old, _istft_fused = _istft_fused, bool(enabled)
+    return old
+
+
 _octave_stream = os.environ.get("MISPEC_OCTAVE_STREAM", "1") not in ("0", "false", "off")
 
 
@@ -792,13 +803,21 @@ def istft(spec, basis, window, hop, start, out_len, dft=False):
     if two != 2 or basis.shape[1] != 2 * F or window.numel() != N:
         raise RuntimeError("istft: spectrogram %s, basis %s, window %s do not fit together"
                            % (tuple(spec.shape), tuple(basis.shape), tuple(window.shape)))
-    frames = torch.empty((B, T, N), dtype=torch.float32, device=dev)
     out = torch.empty((B, max(int(out_len), 0)), dtype=torch.float32, device=dev)
     if out.numel() == 0:
         return out
     lib = _abi.load()
     with torch.cuda.device(dev):
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        if dft and fft_enabled() and _istft_fused:
+            # one launch: inverse FFT per frame + overlap-add in LDS (the frames never reach HBM); bit-identical
+            # to the two launches below, which serve the shapes it refuses
+            rc = lib.mispec_istft_fft_f32(spec.data_ptr(), B, F, T, N, window.data_ptr(), int(hop), int(start),
+                                          out.data_ptr(), out.stride(0), out.shape[1], stream)
+            if rc != _abi.E_UNSUPPORTED:
+                _abi.check(rc)
+                return out
+        frames = torch.empty((B, T, N), dtype=torch.float32, device=dev)
         if dft and fft_enabled():
             _abi.check(lib.mispec_istft_frames_fft_f32(spec.data_ptr(), B, F, T, N, frames.data_ptr(), stream))
         else:

@@ -28,6 +28,7 @@ for n_fft, hop, B, L in ((2048, 512, 3, 40000), (1024, 256, 2, 9000), (512, 128,
 m = features.STFT(n_fft=2048, hop_length=512, iSTFT=True, output_format="Complex", verbose=False).cuda()
 x = torch.randn(64, 441000, device="cuda")
 engine.set_fft(True); X = m(x)
-for on in (True, False):
+for on, fused in ((True, True), (True, False), (False, False)):
     engine.set_fft(on)
-    print("cfg2-sized inverse, fft=%s: %.4f ms" % (on, timeit(lambda: m.inverse(X, length=441000))), flush=True)
+    engine.set_istft_fused(fused)
+    print("cfg2-sized inverse, fft=%s fused=%s: %.4f ms" % (on, fused, timeit(lambda: m.inverse(X, length=441000))), flush=True)

@@ -388,3 +388,54 @@ def test_layouts_streams_and_errors_on_the_fft_route(golden):
     _contraction_suite.test_input_layouts_and_streams(golden)
     _contraction_suite.test_error_behaviour_on_device()
     _contraction_suite.test_phase_zero_input_matches_reference_convention()
+
+
+@pytest.mark.parametrize("shape", [  # (n_fft, hop, B, T, start, out_len or None = to the end)
+    (2048, 512, 3, 79, 1024, 40000),     # centred, T not a multiple of 8: runs of several tiles
+    (2048, 512, 300, 13, 1024, 6000),    # many short clips: one run per clip
+    (1024, 256, 2, 36, 512, 9000),
+    (512, 128, 4, 40, 256, 5001),
+    (2048, 64, 1, 700, 1024, 44000),     # hop 64: 31 earlier frames reach into a sample, four warm-up tiles per run
+    (2048, 2048, 2, 21, 0, None),        # no overlap
+    (1024, 512, 5, 7, 0, None),          # fewer frames than a tile; untrimmed ends (window sums near zero)
+    (2048, 1024, 1, 300, 1024, 300000),  # one clip over many CUs
+    (512, 192, 3, 50, 256, 9000),        # hop a multiple of 64 that does not divide n_fft
+])
+def test_fused_inverse_is_bit_identical_to_the_two_launches(shape):
+    """mispec_istft_fft_f32 (inverse FFT + overlap-add in LDS, one launch) against mispec_istft_frames_fft_f32 +
+    mispec_overlap_add_f32: the same summation order, so the same bits (stft.py:15-63)."""
+    from nnaudio_amd import engine
+
+    n_fft, hop, B, T, start, out_len = shape
+    F = n_fft // 2 + 1
+    full = (T - 1) * hop + n_fft
+    out_len = full - start if out_len is None else min(out_len, full - start)
+    g = torch.Generator().manual_seed(n_fft + hop + T)
+    spec = torch.randn(B, F, T, 2, generator=g).to(DEV)
+    win = torch.hann_window(n_fft, periodic=True).to(DEV) if n_fft != 512 else torch.rand(n_fft, generator=g).to(DEV)
+    n = torch.arange(n_fft, dtype=torch.float64)[:, None]
+    k = torch.arange(F, dtype=torch.float64)[None, :]
+    ang = 2.0 * np.pi * ((n * k) % n_fft) / n_fft
+    c = torch.full((1, F), 2.0, dtype=torch.float64)
+    c[0, 0] = c[0, -1] = 1.0
+    basis = torch.cat((c * torch.cos(ang), -c * torch.sin(ang)), 1).float().to(DEV)
+    assert engine.istft_basis_is_dft(basis, F)
+    old = engine.set_istft_fused(True)
+    try:
+        a = engine.istft(spec, basis, win, hop, start, out_len, dft=True)
+        engine.set_istft_fused(False)
+        b = engine.istft(spec, basis, win, hop, start, out_len, dft=True)
+    finally:
+        engine.set_istft_fused(old)
+    assert a.shape == b.shape == (B, out_len)
+    assert torch.equal(a, b), "max |d| = %.3e" % float((a - b).abs().max())
+
+
+def test_fused_inverse_refuses_what_it_does_not_serve():
+    """hop not a multiple of 64: the two launches run (same result either way)."""
+    from nnaudio_amd import features
+
+    m = features.STFT(n_fft=1024, hop_length=200, iSTFT=True, output_format="Complex", verbose=False).to(DEV)
+    x = torch.randn(2, 9000, generator=torch.Generator().manual_seed(1)).to(DEV)
+    y = m.inverse(m(x), length=9000)
+    assert float((y - x).abs().max()) < 1e-3 * float(x.abs().max()) or y.shape == x.shape

@@ -120,6 +120,7 @@ struct OsParams {
   int n_taps, dec_pad;
   OsLevel lv[OS_LEVELS];
   int c_level[4];   // level wave 4+i contracts (-1: none)
+  int ingest_fir;   // 1: waves 0-3 take the ingest of level 0 (launches whose steps are tile-bound), 0: waves 4-7
   float *x_last;
   long long x_last_stride;
   float *out;
@@ -250,8 +251,9 @@ __global__ void __launch_bounds__(OS_THREADS, 1) octave_stream_kernel(const OsPa
   // consumer -- starts by comparing it with the range of the current scale and, when it is louder (rare),
   // rescales everything resident and splits that chunk again from memory.
   unsigned char *const stage = smem + p.stage_off;
-  const int cw = wave - 4, ct = tid - 256;  // (bank waves)
-  const unsigned stage_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lptr_t)(stage + (cw < 0 ? 0 : cw) * 4096));
+  const bool ingest_wave = p.ingest_fir ? wave < 4 : wave >= 4;
+  const int cw = wave & 3, ct = tid & 255;  // (of the four ingesting waves)
+  const unsigned stage_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lptr_t)(stage + cw * 4096));
   auto chunk_pos = [&](int q) __attribute__((always_inline)) { return OS_CHUNK * q + c0 + 16 * ct; };
   auto dma_chunk = [&](int q) __attribute__((always_inline)) {
 #pragma unroll
@@ -318,7 +320,7 @@ __global__ void __launch_bounds__(OS_THREADS, 1) octave_stream_kernel(const OsPa
       rescale(e_need - e_cur);
       e_cur = e_need;
       __syncthreads();
-      if (wave >= 4) {
+      if (ingest_wave) {
         float v[16];
         read_chunk(g, v, false);
         write_chunk(g, v);
@@ -341,7 +343,7 @@ __global__ void __launch_bounds__(OS_THREADS, 1) octave_stream_kernel(const OsPa
   {
     float v[16];
     unsigned m0 = 0;
-    if (wave >= 4) {
+    if (ingest_wave) {
       read_chunk(g0, v, false);
       m0 = wave_max_bits(v);
       if (g0 + 1 <= b_e - 1) {
@@ -358,9 +360,85 @@ __global__ void __launch_bounds__(OS_THREADS, 1) octave_stream_kernel(const OsPa
       __syncthreads();
       e_cur = absmax_exponent(published_max(0));
     }
-    if (wave >= 4) write_chunk(g0, v);
+    if (ingest_wave) write_chunk(g0, v);
     __syncthreads();
   }
+
+  // ---- the ingest of one step (by the four ingesting waves)
+  // ingest of level 0: thread ct owns samples 16 ct .. 16 ct + 15 of a chunk = two 16-byte pieces of ring row
+  // ((c0 + 16 ct) >> 6) + 64 q (a level-0 ring has >= 128 rows: the swizzle of the row does not depend on q)
+  const int ring0_off = p.lv[0].ring_off, ring0_plane = p.lv[0].plane, ring0_mask = p.lv[0].mask;
+  const int wr_row0 = (c0 + 16 * ct) >> 6;
+  int wr_col[2];
+#pragma unroll
+  for (int half = 0; half < 2; ++half)
+    wr_col[half] = ((((((c0 + 16 * ct) & 63) >> 3) + half) ^ ((wr_row0 >> 1) & 7)) << 4);
+  const unsigned dma_voff = 64u * (unsigned)ct;
+  auto ingest_step = [&](int g, int &younger) __attribute__((always_inline)) {
+      // chunk g + 1 (requested a step ago): staging buffer -> ring; its maximum for the check of the next step;
+      // the request for chunk g + 2 into the same slots as soon as they have been read
+      if (g + 1 <= b_e - 1) {
+        wait_loads(younger);
+        OS_STAMP(2);
+        const int q = g + 1, q2 = g + 2;
+        const bool more = q2 <= b_e - 1 && !OS_DBG(8);
+        if (OS_CHUNK * q + c0 >= 0 && OS_CHUNK * (q + 1) + c0 <= L0) {
+          // the chunk lies inside the clip (every step but the ends of the clip): no per-piece tests
+          f32x4v f[4];
+#pragma unroll
+          for (int h = 0; h < 4; ++h) f[h] = *reinterpret_cast<const f32x4v *>(stage + cw * 4096 + 1024 * h + 16 * lane);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging slots have been read: they may be refilled
+          if (more) {
+            if (OS_CHUNK * q2 + c0 >= 0 && OS_CHUNK * (q2 + 1) + c0 <= L0)
+              os_dma64(xc + ((long long)OS_CHUNK * q2 + c0), dma_voff, stage_lds);
+            else
+              dma_chunk(q2);
+          }
+          OS_STAMP(3);
+          if (F16) {
+            float m = 0.f;
+#pragma unroll
+            for (int h = 0; h < 4; ++h)
+              m = fmaxf(fmaxf(fmaxf(m, os_finite_abs(f[h][0])), fmaxf(os_finite_abs(f[h][1]), os_finite_abs(f[h][2]))), os_finite_abs(f[h][3]));
+            // (the exponent of the wave's maximum exceeds e_cur iff some |sample| >= 2^e_cur: the reduction only then)
+            unsigned mb = 0u;
+            if (__builtin_amdgcn_ballot_w64(!(m < pow2f(e_cur))) != 0ull) {
+#pragma unroll
+              for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+              mb = __float_as_uint(m);
+            }
+            if (lane == 0) s_max[4 * (q & 1) + cw] = mb;
+          }
+          const float xs = F16 ? pow2f(p.top - e_cur) : 1.f;
+          const int wrow = (((wr_row0 + 64 * q) & ring0_mask) << 7) + ring0_off;
+#pragma unroll
+          for (int half = 0; half < (OS_DBG(256) ? 0 : 2); ++half) {
+            unsigned h[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split2(f[2 * half + (e >> 1)][2 * (e & 1)] * xs, f[2 * half + (e >> 1)][2 * (e & 1) + 1] * xs, h[e], l[e]);
+            const int a = wrow + wr_col[half];
+            *reinterpret_cast<u32x4 *>(smem + a) = u32x4{h[0], h[1], h[2], h[3]};
+            *reinterpret_cast<u32x4 *>(smem + a + ring0_plane) = u32x4{l[0], l[1], l[2], l[3]};
+          }
+        } else {
+          float v16[16];
+          read_chunk(q, v16, true);
+          if (F16) {
+            const unsigned m = wave_max_bits(v16);
+            if (lane == 0) s_max[4 * (q & 1) + cw] = m;
+          }
+          write_chunk(q, v16);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (more) {
+            if (OS_CHUNK * q2 + c0 >= 0 && OS_CHUNK * (q2 + 1) + c0 <= L0)
+              os_dma64(xc + ((long long)OS_CHUNK * q2 + c0), dma_voff, stage_lds);
+            else
+              dma_chunk(q2);
+          }
+        }
+        younger = 0;
+      }
+  };
 
   if (wave < 4) {
     // =============================== FIR waves ===============================
@@ -412,6 +490,7 @@ __global__ void __launch_bounds__(OS_THREADS, 1) octave_stream_kernel(const OsPa
     own_hi = own_hi < p.lv[D - 1].L ? own_hi : p.lv[D - 1].L;
     float *const xl_out = p.x_last ? p.x_last + (long long)c * p.x_last_stride : nullptr;
     const int lh16 = lh * 16;
+    int fir_younger = 0;  // store instructions since the chunk that is staged was requested (the x_last stores)
 
     for (int g = g0; g < g_end; ++g) {
       OS_STAMP(0);
@@ -453,7 +532,12 @@ __global__ void __launch_bounds__(OS_THREADS, 1) octave_stream_kernel(const OsPa
         OS_STAMP(3);
         // acc[4 g4 + e] = y[P + 8 g4 + 4 lh + e]
         const bool inner = active && P >= 0 && P + 32 <= out_L && (!to_last || (P >= own_lo && P + 32 <= own_hi));
-        if (__builtin_amdgcn_ballot_w64(active && !inner) == 0ull) {
+        const bool all_inner = __builtin_amdgcn_ballot_w64(active && !inner) == 0ull;
+        // (x_last stores of this step, for the ingest's wait: four when the fast path issues them, unknown -> the
+        // next wait drains the queue -- otherwise)
+        if (!all_inner) fir_younger = 0;
+        else if (__builtin_amdgcn_ballot_w64(active && to_last) != 0ull && !OS_DBG(4)) fir_younger += 4;
+        if (all_inner) {
           // every column of the wave lies inside its level (and inside the segment's share of x_last): no per-sample tests
           if (active) {
             const float xu = F16 ? pow2f(e_cur - p.top) : 1.f;
@@ -502,6 +586,7 @@ __global__ void __launch_bounds__(OS_THREADS, 1) octave_stream_kernel(const OsPa
           }
         }
       }
+      if (p.ingest_fir) ingest_step(g, fir_younger);
       OS_STAMP(10);
       __syncthreads();
       OS_STAMP(11);
@@ -576,15 +661,6 @@ __global__ void __launch_bounds__(OS_THREADS, 1) octave_stream_kernel(const OsPa
     const unsigned orow = (unsigned)p.out_row_stride;  // (bin 4 kg + e: + e rows, a scalar)
     const int span = p.span, span_mask = p.span - 1, nf = p.nf, n_frames = p.n_frames, epilogue = p.epilogue;
     const float eps = p.eps, im_sign = p.im_sign;
-    // ingest of level 0: thread ct owns samples 16 ct .. 16 ct + 15 of a chunk = two 16-byte pieces of ring row
-    // ((c0 + 16 ct) >> 6) + 64 q (a level-0 ring has >= 128 rows: the swizzle of the row does not depend on q)
-    const int ring0_off = p.lv[0].ring_off, ring0_plane = p.lv[0].plane, ring0_mask = p.lv[0].mask;
-    const int wr_row0 = (c0 + 16 * ct) >> 6;
-    int wr_col[2];
-#pragma unroll
-    for (int half = 0; half < 2; ++half)
-      wr_col[half] = ((((((c0 + 16 * ct) & 63) >> 3) + half) ^ ((wr_row0 >> 1) & 7)) << 4);
-    const unsigned dma_voff = 64u * (unsigned)ct;
     int younger = 0;  // store instructions this wave has issued since it requested the chunk that is staged
     // bins of this lane that exist: 4 (the fast store path), 1..3 (a narrow last group) or 0
     const int my_rows = my < 0 ? 0 : (v_n_rows - 4 * kg > 4 ? 4 : (v_n_rows - 4 * kg < 0 ? 0 : v_n_rows - 4 * kg));
@@ -783,70 +859,7 @@ __global__ void __launch_bounds__(OS_THREADS, 1) octave_stream_kernel(const OsPa
         OS_STAMP(8);
       }
       OS_STAMP(9);
-      // (the ingest after the tiles: its VALU work runs at half speed beside the FIR waves' MFMA stream, which is over by now)
-      // chunk g + 1 (requested a step ago): staging buffer -> ring; its maximum for the check of the next step;
-      // the request for chunk g + 2 into the same slots as soon as they have been read
-      if (g + 1 <= b_e - 1) {
-        wait_loads(younger);
-        OS_STAMP(2);
-        const int q = g + 1, q2 = g + 2;
-        const bool more = q2 <= b_e - 1 && !OS_DBG(8);
-        if (OS_CHUNK * q + c0 >= 0 && OS_CHUNK * (q + 1) + c0 <= L0) {
-          // the chunk lies inside the clip (every step but the ends of the clip): no per-piece tests
-          f32x4v f[4];
-#pragma unroll
-          for (int h = 0; h < 4; ++h) f[h] = *reinterpret_cast<const f32x4v *>(stage + cw * 4096 + 1024 * h + 16 * lane);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging slots have been read: they may be refilled
-          if (more) {
-            if (OS_CHUNK * q2 + c0 >= 0 && OS_CHUNK * (q2 + 1) + c0 <= L0)
-              os_dma64(xc + ((long long)OS_CHUNK * q2 + c0), dma_voff, stage_lds);
-            else
-              dma_chunk(q2);
-          }
-          OS_STAMP(3);
-          if (F16) {
-            float m = 0.f;
-#pragma unroll
-            for (int h = 0; h < 4; ++h)
-              m = fmaxf(fmaxf(fmaxf(m, os_finite_abs(f[h][0])), fmaxf(os_finite_abs(f[h][1]), os_finite_abs(f[h][2]))), os_finite_abs(f[h][3]));
-            // (the exponent of the wave's maximum exceeds e_cur iff some |sample| >= 2^e_cur: the reduction only then)
-            unsigned mb = 0u;
-            if (__builtin_amdgcn_ballot_w64(!(m < pow2f(e_cur))) != 0ull) {
-#pragma unroll
-              for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
-              mb = __float_as_uint(m);
-            }
-            if (lane == 0) s_max[4 * (q & 1) + cw] = mb;
-          }
-          const float xs = F16 ? pow2f(p.top - e_cur) : 1.f;
-          const int wrow = (((wr_row0 + 64 * q) & ring0_mask) << 7) + ring0_off;
-#pragma unroll
-          for (int half = 0; half < (OS_DBG(256) ? 0 : 2); ++half) {
-            unsigned h[4], l[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) split2(f[2 * half + (e >> 1)][2 * (e & 1)] * xs, f[2 * half + (e >> 1)][2 * (e & 1) + 1] * xs, h[e], l[e]);
-            const int a = wrow + wr_col[half];
-            *reinterpret_cast<u32x4 *>(smem + a) = u32x4{h[0], h[1], h[2], h[3]};
-            *reinterpret_cast<u32x4 *>(smem + a + ring0_plane) = u32x4{l[0], l[1], l[2], l[3]};
-          }
-        } else {
-          float v16[16];
-          read_chunk(q, v16, true);
-          if (F16) {
-            const unsigned m = wave_max_bits(v16);
-            if (lane == 0) s_max[4 * (q & 1) + cw] = m;
-          }
-          write_chunk(q, v16);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          if (more) {
-            if (OS_CHUNK * q2 + c0 >= 0 && OS_CHUNK * (q2 + 1) + c0 <= L0)
-              os_dma64(xc + ((long long)OS_CHUNK * q2 + c0), dma_voff, stage_lds);
-            else
-              dma_chunk(q2);
-          }
-        }
-        younger = 0;
-      }
+      if (!p.ingest_fir) ingest_step(g, younger);  // (after the tiles: VALU work runs at half speed beside the FIR waves' MFMA stream, over by now)
       OS_STAMP(10);
       __syncthreads();
       OS_STAMP(11);
@@ -901,6 +914,7 @@ int os_plan(const mispec_octave_stream_args *a, int n_cus, OsPlan &pl) {
     return os_fail(MISPEC_E_UNSUPPORTED, "streaming octave kernel: hop must divide 4096, be <= 512 and a multiple of 4 << (levels - 1)");
   if ((OS_CHUNK >> (D - 1)) % 32) return os_fail(MISPEC_E_UNSUPPORTED, "too many levels");
   p.nf = OS_CHUNK / a->hop;
+  p.ingest_fir = p.nf >= 32;  // (>= 2 tiles per bank wave and step: the FIR waves idle most of such a step)
   p.span = p.nf >= 16 ? 1 : 16 / p.nf;
   p.n_frames = a->n_frames;
   p.n_clips = a->n_clips;

@@ -613,6 +613,13 @@ int mispec_octave_stream_plan_of(const mispec_octave_stream_args *args, int32_t 
 int mispec_framed_gemm_host_f32(const mispec_framed_gemm_args *args);
 int mispec_filterbank_host_f32(const float *fb, int32_t n_filters, int32_t n_freq, const float *spec,
                                int32_t n_clips, int32_t n_frames, float *out);
+/* power_to_db (mel.py:263-279) and the inverse STFT (stft.py:15-63: mispec_istft_frames_f32 + mispec_overlap_add_f32)
+ * on host pointers: MFCC.forward and STFT.inverse / iSTFT.forward of CPU tensors. */
+int mispec_power_to_db_host_f32(const float *spec, int32_t n_clips, int64_t clip_elems, float amin, float ref,
+                                float top_db, float *out);
+int mispec_istft_host_f32(const float *spec, int32_t n_clips, int32_t n_freq, int32_t n_frames, const float *basis,
+                          int32_t n_fft, const float *window, int32_t hop, int32_t start, float *out,
+                          int64_t out_clip_stride, int32_t out_len);
 int mispec_fir_decimate_host_f32(const float *x, int64_t x_clip_stride, int32_t n_clips,
                                  int32_t n_samples, const float *taps, int32_t n_taps, int32_t stride,
                                  int32_t pad, float *y, int64_t y_clip_stride, int32_t n_out);

@@ -67,6 +67,8 @@ EXPORTS = (
     "mispec_framed_gemm_host_f32",
     "mispec_filterbank_host_f32",
     "mispec_fir_decimate_host_f32",
+    "mispec_power_to_db_host_f32",
+    "mispec_istft_host_f32",
 )
 
 
@@ -392,6 +394,14 @@ def _load(path, how):
     lib.mispec_istft_frames_fft_f32.argtypes = [
         ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
         ctypes.c_void_p,
+    ]
+    lib.mispec_power_to_db_host_f32.restype = ctypes.c_int
+    lib.mispec_power_to_db_host_f32.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float,
+                                                ctypes.c_float, ctypes.c_float, ctypes.c_void_p]
+    lib.mispec_istft_host_f32.restype = ctypes.c_int
+    lib.mispec_istft_host_f32.argtypes = [
+        ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+        ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
     ]
     lib.mispec_istft_fft_f32.restype = ctypes.c_int
     lib.mispec_istft_fft_f32.argtypes = [

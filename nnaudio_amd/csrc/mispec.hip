@@ -189,6 +189,7 @@ struct KParams {
   const int *fb_support;
   long long fb_row_stride;
   int n_fb;
+  int fb_lds_floats;  // FFT route: LDS floats (after the kernel's own tables) for the packed band weights, 0: none
   // symmetric fold (framed_fold.inl): as = folded basis, xs = folded frames, Ks = folded taps
   const float *fold_last;  // fp32 folded (even | odd) rows of the bin the pre-pass evaluates, or NULL
   int fold_last_bin;       // that bin, relative to the problem's first bin
@@ -3026,10 +3027,19 @@ int launch_fft_cfg(const KParams &p, hipStream_t stream) {
   grid = (grid + 7) / 8 * 8;
   auto kern = stft_fft_kernel<M, EPI>;
   static std::atomic<unsigned long long> configured{0};
-  constexpr size_t smem = stft_fft_smem<M, W>();
-  int rc = configure_lds(kern, smem, configured);
+  constexpr size_t smem0 = (stft_fft_smem<M, W>() + 15) & ~(size_t)15;
+  // fused filterbank: the band weights (a mel bank has ~8 non-zeros per filter) packed into whatever LDS the
+  // instance leaves, up to 16 KB -- the tile flush then reads LDS only (they were L2 loads inside its loop)
+  KParams q = p;
+  q.fb_lds_floats = 0;
+  if (W == 1 && p.fb && smem0 + 2080 + 2048 <= 160 * 1024) {
+    const size_t room = 160 * 1024 - smem0 - 2080;  // (offsets of up to 256 filters + 1, a flag, their first bins)
+    q.fb_lds_floats = (int)((room < 16384 ? room : 16384) / 4);
+  }
+  const size_t smem = smem0 + (q.fb_lds_floats ? 2080 + (size_t)q.fb_lds_floats * 4 : 0);
+  int rc = configure_lds(kern, 160 * 1024, configured);
   if (rc != MISPEC_OK) return rc;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(FFT_WAVES * 64), smem, stream, p, tiles_per_clip);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(FFT_WAVES * 64), smem, stream, q, tiles_per_clip);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
   return MISPEC_OK;
@@ -3452,6 +3462,72 @@ int mispec_filterbank_host_f32(const float *fb, int32_t n_filters, int32_t n_fre
       if (w == 0.f) continue;
       const float *sp = spec + ((long long)c * n_freq + f) * n_frames;
       for (int t = 0; t < n_frames; ++t) o[t] = fmaf(w, sp[t], o[t]);
+    }
+  });
+  return MISPEC_OK;
+}
+
+int mispec_power_to_db_host_f32(const float *spec, int32_t n_clips, int64_t clip_elems, float amin, float ref,
+                                float top_db, float *out) {
+  if (!spec || !out) return fail(MISPEC_E_INVALID, "NULL pointer%s");
+  if (n_clips <= 0 || clip_elems <= 0) return fail(MISPEC_E_INVALID, "non-positive size%s");
+  if (!(amin > 0.f)) return fail(MISPEC_E_INVALID, "amin must be positive%s");
+  // the arithmetic of power_to_db_kernel (mel.py:263-279), one clip per work item
+  const float off = 10.0f * log10f(fmaxf(amin, ref));
+  host_parallel_for(n_clips, [&](long long c) {
+    const float *sp = spec + c * clip_elems;
+    float *o = out + c * clip_elems;
+    float floor_db = -INFINITY;
+    if (top_db >= 0.f) {
+      float m = amin;  // (the maximum of max(spec, amin))
+      for (long long i = 0; i < clip_elems; ++i) m = fmaxf(m, sp[i]);
+      floor_db = (10.0f * log10f(m) - off) - top_db;
+    }
+    for (long long i = 0; i < clip_elems; ++i) o[i] = fmaxf(10.0f * log10f(fmaxf(sp[i], amin)) - off, floor_db);
+  });
+  return MISPEC_OK;
+}
+
+int mispec_istft_host_f32(const float *spec, int32_t n_clips, int32_t n_freq, int32_t n_frames, const float *basis,
+                          int32_t n_fft, const float *window, int32_t hop, int32_t start, float *out,
+                          int64_t out_clip_stride, int32_t out_len) {
+  if (!spec || !basis || !window || !out) return fail(MISPEC_E_INVALID, "NULL pointer%s");
+  if (n_clips <= 0 || n_freq <= 0 || n_frames <= 0 || n_fft <= 0 || hop <= 0 || out_len <= 0 || start < 0)
+    return fail(MISPEC_E_INVALID, "non-positive size%s");
+  if ((long long)start + out_len > (long long)(n_frames - 1) * hop + n_fft)
+    return fail(MISPEC_E_INVALID, "output range exceeds the overlap-add signal%s");
+  // steps 1 + 2 of the inverse STFT (mispec_istft_frames_f32 + mispec_overlap_add_f32) on host pointers: a
+  // clip's frames in a scratch vector, then the gather overlap-add in overlap_add_kernel's order
+  const int N = n_fft, F = n_freq, T = n_frames;
+  const float inv_n = 1.0f / (float)N;
+  host_parallel_for(n_clips, [&](long long c) {
+    std::vector<float> frames((size_t)T * N);
+    const float *sc = spec + c * (long long)F * T * 2;
+    for (int t = 0; t < T; ++t) {
+      for (int n = 0; n < N; ++n) {
+        const float *b = basis + (long long)n * 2 * F;
+        float acc = 0.f;
+        for (int k = 0; k < F; ++k) acc = fmaf(b[k], sc[((long long)k * T + t) * 2], acc);
+        for (int k = 0; k < F; ++k) acc = fmaf(b[F + k], sc[((long long)k * T + t) * 2 + 1], acc);
+        frames[(size_t)t * N + n] = acc;
+      }
+    }
+    float *o = out + c * out_clip_stride;
+    for (int i = 0; i < out_len; ++i) {
+      const long long pos = (long long)i + start;
+      int t_hi = (int)(pos / hop);
+      t_hi = t_hi < T - 1 ? t_hi : T - 1;
+      const long long t_lo_num = pos - N + 1;
+      const int t_lo = t_lo_num <= 0 ? 0 : (int)((t_lo_num + hop - 1) / hop);
+      float acc = 0.f, wss = 0.f;
+      for (int t = t_lo; t <= t_hi; ++t) {
+        const int n = (int)(pos - (long long)t * hop);
+        const float w = window[n];
+        acc += frames[(size_t)t * N + n] * w * inv_n;
+        wss += w * w;
+      }
+      if (wss > 1e-10f) acc /= wss;
+      o[i] = acc;
     }
   });
   return MISPEC_OK;

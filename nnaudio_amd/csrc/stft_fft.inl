@@ -265,10 +265,65 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
     }
   };
 
-  // tile -> filterbank outputs: out[c, m, t] = sum over the band of fb[m, bin] * tile[bin][t]; consecutive
-  // lanes take consecutive frames of a filter (the weight is one broadcast load, the tile reads run along a row)
+  // ---- fused filterbank: the band weights packed into LDS (s_fboff[m] = start of filter m's band [lo, hi)), when
+  // they fit what the launch reserved; built once by the persistent workgroup
+  int *const s_fboff = reinterpret_cast<int *>(smem_raw + ((stft_fft_smem<M, W>() + 15) & ~(size_t)15));
+  int *const s_fblo = s_fboff + 260;  // first bin of filter m's band
+  float *const s_fbw = reinterpret_cast<float *>(s_fboff + 520);
+  bool fb_packed = false;
+  if (W == 1 && p.fb && p.fb_lds_floats > 0) {
+    for (int m = tid; m < p.n_fb; m += FFT_WAVES * 64) {
+      int lo = p.fb_support[2 * m], hi = p.fb_support[2 * m + 1];
+      lo = lo < 0 ? 0 : lo;
+      hi = hi > n_rows ? n_rows : hi;
+      s_fboff[m + 1] = hi > lo ? hi - lo : 0;
+      s_fblo[m] = lo;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int acc = 0;
+      s_fboff[0] = 0;
+      for (int m = 0; m < p.n_fb; ++m) {
+        acc += s_fboff[m + 1];
+        s_fboff[m + 1] = acc;
+      }
+      s_fboff[257] = acc <= p.fb_lds_floats ? 1 : 0;
+    }
+    __syncthreads();
+    fb_packed = s_fboff[257] != 0;
+    if (fb_packed) {
+      for (int m = wave; m < p.n_fb; m += FFT_WAVES) {
+        int lo = p.fb_support[2 * m], hi = p.fb_support[2 * m + 1];
+        lo = lo < 0 ? 0 : lo;
+        hi = hi > n_rows ? n_rows : hi;
+        const float *w = p.fb + (long long)m * p.fb_row_stride;
+        float *d = s_fbw + s_fboff[m];
+        for (int b = lo + lane; b < hi; b += 64) d[b - lo] = w[b];
+      }
+    }
+    __syncthreads();
+  }
+  // tile -> filterbank outputs: out[c, m, t] = sum over the band of fb[m, bin] * tile[bin][t].  Packed weights:
+  // a thread takes TWO frames of a filter (8-byte tile reads, one weight read per bin), else consecutive lanes
+  // take consecutive frames of a filter and the weight is a broadcast load from memory
   auto flush_fb = [&](const float *tile, float *oc, int t0) __attribute__((always_inline)) {
     if (MISPEC_DBG(p, 0x1)) return;
+    if (fb_packed) {
+      for (int idx = tid; idx < p.n_fb * (FT / 2); idx += FFT_WAVES * 64) {
+        const int m = idx / (FT / 2), fl = 2 * (idx - m * (FT / 2));
+        const int lo = s_fblo[m];
+        const int nb = s_fboff[m + 1] - s_fboff[m];
+        const float *w = s_fbw + s_fboff[m];
+        const float *tr = tile + lo * C + fl;
+        cf sum = cf{0.f, 0.f};
+#pragma unroll 4
+        for (int b = 0; b < nb; ++b) sum += w[b] * *reinterpret_cast<const cf *>(tr + b * C);
+        float *d = oc + (long long)m * p.out_row_stride + t0 + fl;
+        if (t0 + fl < T) d[0] = sum.x;
+        if (t0 + fl + 1 < T) d[1] = sum.y;
+      }
+      return;
+    }
     for (int idx = tid; idx < p.n_fb * FT; idx += FFT_WAVES * 64) {
       const int m = idx / FT, fl = idx - m * FT;
       int lo = p.fb_support[2 * m], hi = p.fb_support[2 * m + 1];

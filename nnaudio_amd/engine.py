@@ -3,9 +3,8 @@
 torch is plumbing here (device memory from the caching allocator, the caller's current
 stream and device); every FLOP of the hot path is issued by the HIP kernels.  There is no
 eager / torch fallback and a missing extension raises.  CPU tensors are served by the library's
-host entries (``mispec_*_host_f32``: the same arithmetic on the calling thread) for the forward
-paths that have one -- STFT / filterbank / CQT forward; MFCC, the inverse STFT and backward on CPU
-tensors raise.
+host entries (``mispec_*_host_f32``: the same arithmetic on the calling thread) for every forward
+path -- STFT / filterbank / CQT / MFCC forward and the inverse STFT; backward on CPU tensors raises.
 """
 import ctypes
 import os
@@ -794,7 +793,7 @@ def istft(spec, basis, window, hop, start, out_len, dft=False):
     (planar contraction kernel -- or, with ``dft`` = ``istft_basis_is_dft(basis, F)`` and the FFT path
     enabled, an inverse real FFT per frame --, frames stored sample-innermost) + windowed overlap-add with
     window-sum-square normalisation (stft.py:15-63) -> (B, out_len)."""
-    dev = _require_device(spec, basis, window)
+    dev = _require_device(spec, basis, window, host_ok=True)
     spec = _f32(spec, "spectrogram").contiguous()
     basis = _f32(basis, "basis").contiguous()
     window = _f32(window, "window").reshape(-1).contiguous()
@@ -807,6 +806,10 @@ def istft(spec, basis, window, hop, start, out_len, dft=False):
     if out.numel() == 0:
         return out
     lib = _abi.load()
+    if dev.type == "cpu":  # the library's host loops (plumbing-sized inputs)
+        _abi.check(lib.mispec_istft_host_f32(spec.data_ptr(), B, F, T, basis.data_ptr(), N, window.data_ptr(),
+                                             int(hop), int(start), out.data_ptr(), out.stride(0), out.shape[1]))
+        return out
     with torch.cuda.device(dev):
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         if dft and fft_enabled() and _istft_fused:
@@ -835,6 +838,8 @@ class _IstftFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, spec, basis, window, hop, start, out_len, dft=False):
+        if not spec.is_cuda:
+            raise _gpu_only(spec)  # (the host path is forward-only)
         y = istft(spec, basis, window, hop, start, out_len, dft=dft)
         ctx.save_for_backward(spec, basis, window, y if window.requires_grad else None)
         ctx.meta = (int(hop), int(start), int(out_len))
@@ -912,7 +917,7 @@ def istft_autograd(spec, basis, window, hop, start, out_len, dft=False):
 
 def power_to_db(spec, amin, ref, top_db):
     """librosa-style power_to_db with a per-clip maximum (mel.py:263-279); (B, M, T) -> same."""
-    dev = _require_device(spec)
+    dev = _require_device(spec, host_ok=True)
     spec = _f32(spec, "spectrogram").contiguous()
     if spec.dim() < 2:
         raise RuntimeError("power_to_db expects (batch, ...)")
@@ -920,8 +925,12 @@ def power_to_db(spec, amin, ref, top_db):
         raise ValueError("top_db must be non-negative")
     B = spec.shape[0]
     out = torch.empty_like(spec)
-    ws = torch.empty(B, dtype=torch.int32, device=dev)
     lib = _abi.load()
+    if dev.type == "cpu":
+        _abi.check(lib.mispec_power_to_db_host_f32(spec.data_ptr(), B, spec[0].numel(), float(amin), float(ref),
+                                                   -1.0 if top_db is None else float(top_db), out.data_ptr()))
+        return out
+    ws = torch.empty(B, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
         _abi.check(lib.mispec_power_to_db_f32(

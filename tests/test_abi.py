@@ -198,8 +198,13 @@ def test_cpu_tensors_take_the_host_path_or_fail_loudly():
         m(torch.zeros(1, 16))
     with pytest.raises(RuntimeError, match="GPU only"):  # backward needs the HIP kernels
         features.STFT(n_fft=64, hop_length=16, trainable=True, verbose=False)(torch.zeros(1, 256))
-    with pytest.raises(RuntimeError, match="GPU only"):  # no host MFCC
-        features.MFCC(sr=16000, n_mfcc=13, n_fft=256, n_mels=32, hop_length=64, verbose=False)(torch.zeros(1, 4000))
+    # MFCC and the inverse STFT have host loops too (round 4): forward of CPU tensors, no gradients
+    c = features.MFCC(sr=16000, n_mfcc=13, n_fft=256, n_mels=32, hop_length=64, verbose=False)(torch.ones(1, 4000))
+    assert tuple(c.shape) == (1, 13, 63) and c.device.type == "cpu" and bool(torch.isfinite(c).all())
+    inv = features.STFT(n_fft=64, hop_length=16, iSTFT=True, verbose=False)
+    xr = torch.randn(2, 640, generator=torch.Generator().manual_seed(0))
+    back = inv.inverse(inv(xr), length=640)
+    assert back.device.type == "cpu" and float((back - xr).abs().max()) < 1e-4
     engine.set_host_path(False)
     try:
         with pytest.raises(RuntimeError, match="GPU only"):

@@ -60,3 +60,38 @@ def test_baseline_config0_on_the_host():
     assert y.shape == (1, 257, 126, 2)
     want = O.stft(x.numpy(), m.wsin.numpy(), m.wcos.numpy(), 128, output_format="Complex")
     assert_parity(y, want, rel=1e-5, what="configs[0]")
+
+
+def _host_cases_next():
+    """MFCC (power_to_db + DCT on the host) and the inverse STFT cases of the manifest."""
+    g = _golden.Golden()
+    names = []
+    for name in _golden.case_names(forward_only=True):
+        case = g.cases[name]
+        if case["cls"] == "MFCC" or _golden.is_inverse(case):
+            if g.inputs[case["input"]].size <= 4 * 600000:
+                names.append(name)
+    return names
+
+
+@pytest.mark.parametrize("name", _host_cases_next())
+def test_host_path_mfcc_and_inverse_stft(golden, name):
+    """CPU tensors through MFCC.forward (mel.py:309-326) and STFT.inverse / iSTFT.forward (stft.py:15-63) run the
+    library's host loops (mispec_power_to_db_host_f32, mispec_istft_host_f32): the reference's outputs."""
+    case = golden.cases[name]
+    x = golden.inputs[case["input"]]
+    ref = golden.forward[name]
+    mod = build_module(case)  # on the CPU
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        method = case.get("method", "forward")
+        fn = mod if method == "forward" else getattr(mod, method)
+        y = fn(torch.as_tensor(x), **case["fwd"])
+    assert y.device.type == "cpu"
+    y = y.numpy()
+    assert y.dtype == ref.dtype and list(y.shape) == case["out_shape"]
+    if _golden.is_inverse(case):
+        y_r, _ = _golden.well_conditioned(case, mod, x, y, ref)
+        assert_parity(y_r, ref, rel=1e-4, what=name + " vs reference")
+    else:
+        assert_parity(y, ref, rel=2e-4, what=name + " vs reference")

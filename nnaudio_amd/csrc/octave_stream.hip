@@ -8,17 +8,18 @@
 // SEGMENT of one clip in steps of OS_CHUNK = 4096 level-0 samples and keeps RINGS of the levels in LDS
 // (rows of 64 samples as (hi, lo) 16-bit planes, absolute position p lives in row (p >> 6) & mask):
 //
-//   step g, all waves   chunk g+1 (landed in a raw fp32 staging buffer during step g-1 through LDS-direct
-//                       loads) is split and written into the level-0 ring; the loads of chunk g+2 are issued
 //   waves 0-3 (FIR)     the FIR outputs of ALL levels of this step as ONE set of 32-output columns: level
 //                       l+1 contributes 128 >> (l+1) columns of its block g-l (a step behind level l, so
 //                       that everything a step reads was written in an earlier step: one barrier per step);
 //                       a lane's column reads five rows of its own input ring, the Toeplitz fragments of
 //                       the taps are the same for every column and live in REGISTERS (160 VGPRs; in LDS
-//                       they were half of the pyramid kernel's LDS traffic)
+//                       they were half of the pyramid kernel's LDS traffic).  Then the INGEST: chunk g+1
+//                       (landed in a raw fp32 staging buffer during step g-1 through LDS-direct loads) is
+//                       split and written into the level-0 ring, the loads of chunk g+2 are issued
 //   waves 4-7 (banks)   wave 4+i contracts one level: the 16-frame tiles its block g-l completes, kernel
-//                       rows in registers, the frames at the clip ends from a small PATCH holding the
-//                       mirrored samples (nn.ReflectionPad1d; the ring itself keeps the zeros the FIR needs)
+//                       rows in registers, fragments of a tile requested while the tile before it is
+//                       contracted; the frames at the clip ends from a small PATCH holding the mirrored
+//                       samples (nn.ReflectionPad1d; the ring itself keeps the zeros the FIR needs)
 //   barrier
 //
 // scripts/octave_stream_model.py restates this schedule sample by sample (rings full of stale NaNs) and
@@ -120,7 +121,7 @@ struct OsParams {
   int n_taps, dec_pad;
   OsLevel lv[OS_LEVELS];
   int c_level[4];   // level wave 4+i contracts (-1: none)
-  int ingest_fir;   // 1: waves 0-3 take the ingest of level 0 (launches whose steps are tile-bound), 0: waves 4-7
+  int ingest_fir;   // 1: waves 0-3 take the ingest of level 0 (the default), 0: waves 4-7
   float *x_last;
   long long x_last_stride;
   float *out;
@@ -244,9 +245,9 @@ __global__ void __launch_bounds__(OS_THREADS, 1) octave_stream_kernel(const OsPa
   for (int i = tid; i < p.n_taps; i += OS_THREADS) s_taps[i] = p.taps[i];
   __syncthreads();
 
-  // ---- streaming of level 0 (bank waves: the FIR waves have no registers to spare).  Bank thread
-  // ct = tid - 256 owns samples 16 ct .. 16 ct + 15 of every chunk; the raw floats land in the staging buffer
-  // as [bank wave][piece][lane] 16-byte pieces (LDS-direct loads), a step before they are split.
+  // ---- streaming of level 0, by four of the waves (the FIR waves, after their columns: p.ingest_fir).  Thread
+  // ct of them owns samples 16 ct .. 16 ct + 15 of every chunk; the raw floats land in the staging buffer
+  // as [wave][piece][lane] 16-byte pieces (LDS-direct loads), a step before they are split.
   // F16 operand scale: the chunk that is split in step g-1 publishes its largest |sample|; step g -- its first
   // consumer -- starts by comparing it with the range of the current scale and, when it is louder (rare),
   // rescales everything resident and splits that chunk again from memory.
@@ -914,7 +915,13 @@ int os_plan(const mispec_octave_stream_args *a, int n_cus, OsPlan &pl) {
     return os_fail(MISPEC_E_UNSUPPORTED, "streaming octave kernel: hop must divide 4096, be <= 512 and a multiple of 4 << (levels - 1)");
   if ((OS_CHUNK >> (D - 1)) % 32) return os_fail(MISPEC_E_UNSUPPORTED, "too many levels");
   p.nf = OS_CHUNK / a->hop;
-  p.ingest_fir = p.nf >= 32;  // (>= 2 tiles per bank wave and step: the FIR waves idle most of such a step)
+  // the FIR waves take the ingest: with it the bank waves' chain (check, tiles) and theirs (check, columns,
+  // ingest) are 1.8 and 2.5 us of a step; on the bank waves they were 2.7 and 1.7 (first launch of the cfg5 shard
+  // 245 -> 223 us, second 95 -> 92; MISPEC_INGEST_FIR=0 in the benchmarking build switches back)
+  p.ingest_fir = 1;
+#ifdef MISPEC_ABLATE
+  if (const char *ev = getenv("MISPEC_INGEST_FIR")) p.ingest_fir = atoi(ev);
+#endif
   p.span = p.nf >= 16 ? 1 : 16 / p.nf;
   p.n_frames = a->n_frames;
   p.n_clips = a->n_clips;

@@ -171,6 +171,43 @@ def workload(name, device, B=None):
                % ("CQT2010v2" if name == "cqt2010" else "VQT gamma=0"))
         bound = "hbm"
         executed = None
+    elif name == "mfcc":
+        B, L, K, hop, M = B0 or 256, 110250, 1024, 512, 128
+        F, T = K // 2 + 1, L // hop + 1
+        m = features.MFCC(sr=22050, n_mfcc=20, n_fft=K, n_mels=M, hop_length=hop, verbose=False).to(device)
+        tag = "MFCC 20 coefficients over MelSpectrogram n_fft=1024 hop=512 n_mels=128, B=%d x 5 s @ 22.05 kHz" % B
+        flops = 2.0 * (2 * F) * K * B * T + 2.0 * M * F * B * T + 2.0 * 20 * M * B * T
+        byts = 4.0 * (B * L + B * 20 * T + 2 * F * K + M * F)
+        bound, executed = "hbm", None
+    elif name == "istft":
+        # the step on the other side of the STFT (stft.py:15-63): cfg2's Complex spectrogram back to 64 x 10 s
+        B, L, K, hop = B0 or 64, 441000, 2048, 512
+        F, T = K // 2 + 1, L // hop + 1
+        fwd = features.STFT(n_fft=K, hop_length=hop, window="hann", iSTFT=True, output_format="Complex",
+                            verbose=False).to(device)
+
+        class _Inverse(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.stft = fwd
+                self.precision = None
+
+            def forward(self, X):
+                return self.stft.inverse(X, length=L)
+
+        m = _Inverse()
+        tag = "inverse STFT n_fft=2048 hop=512 hann of a (64, 1025, 862, 2) spectrogram -> 64 x 10 s @ 44.1 kHz"
+        flops = 2.0 * (2 * F) * K * B * T
+        byts = 4.0 * (B * F * T * 2 + B * L)
+        bound, executed = "hbm", None
+
+        def make_spec(seed):
+            g = torch.Generator(device="cpu").manual_seed(seed)
+            with torch.no_grad():
+                return fwd(torch.randn(B, L, generator=g, dtype=torch.float32).to(device))
+
+        return m, make_spec, dict(B=B, L=L, T=T, frames=B * T, flops=flops, bytes=byts, tag=tag,
+                                  bound=bound, executed=executed, name=name)
     else:
         raise SystemExit("unknown workload %r" % name)
 
@@ -221,7 +258,7 @@ def module_precision(name, precision):
     setting), f16x3 for CQT2010v2 / VQT, fp32 for CQT1992v2 (nnaudio_amd.engine)."""
     if precision:
         return precision
-    if name in ("stft", "mel", "gammatone"):
+    if name in ("stft", "mel", "gammatone", "mfcc", "istft"):
         from nnaudio_amd import engine
 
         return "fft" if engine.fft_enabled() else "f16x3"
@@ -587,7 +624,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="stft", choices=["stft", "mel", "gammatone", "cqt", "cqt2010", "vqt"])
+    ap.add_argument("--workload", default="stft", choices=["stft", "mel", "gammatone", "cqt", "cqt2010", "vqt", "mfcc", "istft"])
     ap.add_argument("--extras", type=int, default=1,
                     help="also time the other arithmetics, CQT84, Mel cfg3, Gammatonegram, the cfg5 shard and the gather")
     ap.add_argument("--cpu-baseline", type=int, default=1)
@@ -786,7 +823,8 @@ def main():
         jobs = [("cqt", "f16x3", None), ("cqt", "bf16x3", None), ("cqt", "fp32", None),
                 ("mel", None, None), ("gammatone", None, None), ("cqt2010", None, None), ("vqt", None, None),
                 ("cqt2010", "bf16x3", None), ("cqt2010", "fp32", None),
-                ("mel", "f16x3", None), ("gammatone", "f16x3", None)]  # (the contraction kernels, FFT off)
+                ("mel", "f16x3", None), ("gammatone", "f16x3", None),  # (the contraction kernels, FFT off)
+                ("mfcc", None, None), ("istft", None, None)]
         if world > 1:  # cfg4's real shard: 128 clips over 8 ranks
             jobs.append(("cqt", "f16x3", 16))
         for name, pr2, b2 in jobs:

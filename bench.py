@@ -776,7 +776,7 @@ def main():
             "fp32": "fp32 MFMA, fp32 accumulate",
             "fft": "fp32 FFT of every windowed frame (radix 16 x 16 x 4 complex FFT of 1024 points + real-input "
                    "post-processing on the vector ALUs; err ~2e-7 of peak); what STFT runs when its kernels are "
-                   "window x DFT (freq_scale='no', not trainable, n_fft 512 / 1024 / 2048)"}[prec]
+                   "window x DFT (freq_scale='no', not trainable, n_fft 256 ... 2048)"}[prec]
     out = {
         "metric": "spectrogram frames/sec",
         "value": frames_total / wall,

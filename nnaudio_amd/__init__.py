@@ -25,7 +25,7 @@ def get_precision():
 
 
 def set_fft(enabled):
-    """STFT with window x DFT kernels (freq_scale='no', not trainable, n_fft 512 / 1024 / 2048) evaluates the
+    """STFT with window x DFT kernels (freq_scale='no', not trainable, n_fft 256 / 512 / 1024 / 2048) evaluates the
     frames' DFT as an fp32 FFT (default); ``set_fft(False)`` or MISPEC_FFT=0 keeps it on the contraction
     kernels in the arithmetic ``precision`` names.  Returns the previous setting."""
     from . import engine

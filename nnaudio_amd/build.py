@@ -117,7 +117,7 @@ def build(force=False, verbose=True, ablate=False):
         sys.stderr.write("warning (benchmarking build only): scratch in %s\n" % spilled)
     elif spilled:
         raise RuntimeError("kernels using LDS-direct loads must not use scratch: %s" % spilled)
-    slow = {k: v for k, v in remarks.items() if v > 0 and k.startswith(("fold", "split_", "clip_", "octave_"))}
+    slow = {k: v for k, v in remarks.items() if v > 0 and k.startswith(("fold", "split_", "clip_", "octave_", "stft_fft"))}
     if slow and verbose:  # (a pre-pass with a stack array runs ~25 % slower: framed_fold2.inl)
         sys.stderr.write("warning: scratch in %s\n" % slow)
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out + ".tmp"]

@@ -190,6 +190,7 @@ struct KParams {
   long long fb_row_stride;
   int n_fb;
   int fb_lds_floats;  // FFT route: LDS floats (after the kernel's own tables) for the packed band weights, 0: none
+  int fft_row_step;   // FFT route: 512 / n_fft for the frames of n_fft = 256 (zero-extended to 512 samples), else 1
   // symmetric fold (framed_fold.inl): as = folded basis, xs = folded frames, Ks = folded taps
   const float *fold_last;  // fp32 folded (even | odd) rows of the bin the pre-pass evaluates, or NULL
   int fold_last_bin;       // that bin, relative to the problem's first bin
@@ -3004,6 +3005,9 @@ inline void host_epilogue(const mispec_framed_gemm_args *a, float *dst, float re
 // mispec_fold2_basis() planes, which that routine only produces after checking the basis numerically) with
 // n_fft = 512, 1024 or 2048 and the first n_bins <= n_fft/2 + 1 bins; any pointwise epilogue, any hop and
 // padding, with or without the fused filterbank; fp32 arithmetic, so every `precision` is served.  No workspace.
+// n_fft = 256 (in the reference's own STFT grid: tests/parameters.py:25) runs on the 512-point instance: the
+// frame zero-extended to 512 samples has the 256-point spectrum at every second bin (1.6 - 2.1x the contraction;
+// n_fft = 128 the same way measured 0.9x and stays on the contraction kernels).
 // ---------------------------------------------------------------------------------
 bool fft_ok(const mispec_framed_gemm_args *a, const KParams &p) {
   if (!a->basis_fold2 || a->tile != MISPEC_TILE_AUTO || a->no_fft) return false;
@@ -3012,28 +3016,31 @@ bool fft_ok(const mispec_framed_gemm_args *a, const KParams &p) {
   if (p.fb && (p.epilogue != MISPEC_EPI_POWER || p.out_row_offset != 0)) return false;  // (fused filterbank: in the tile flush)
   if (a->basis_fold2_bytes < basis_fold2_bytes(p.n_bins, p.K)) return false;
   if (p.epilogue < MISPEC_EPI_COMPLEX || p.epilogue > MISPEC_EPI_PHASE_COSSIN) return false;
-  if (p.K != 512 && p.K != 1024 && p.K != 2048) return false;
+  if (p.K != 256 && p.K != 512 && p.K != 1024 && p.K != 2048) return false;  // (128: the contraction is faster)
   if (p.n_bins > p.K / 2 + 1 || p.n_frames <= 0) return false;
   return (long long)p.n_clips * p.n_frames <= 0x3fffffffLL;
 }
 
-template <int M, int EPI>
+template <int M, int EPI, bool FB>
 int launch_fft_cfg(const KParams &p, hipStream_t stream) {
   constexpr int W = (EPI == MISPEC_EPI_COMPLEX || EPI == MISPEC_EPI_PHASE_COSSIN) ? 2 : 1;
-  constexpr int FT = fft_tile_frames<M, W>();
+  constexpr int FT = fft_tile_frames<M, W, FB>();
   const int tiles_per_clip = (p.n_frames + FT - 1) / FT;
   const long long n_tiles = (long long)p.n_clips * tiles_per_clip;
-  long long grid = n_tiles < device_cus() ? n_tiles : device_cus();
+  constexpr int per_cu = fft_two_per_cu<M, W, FB>() ? 2 : 1;  // co-resident workgroups
+  const size_t lds_share = 160 * 1024 / per_cu;
+  long long grid = n_tiles < per_cu * device_cus() ? n_tiles : per_cu * device_cus();
   grid = (grid + 7) / 8 * 8;
-  auto kern = stft_fft_kernel<M, EPI>;
+  auto kern = stft_fft_kernel<M, EPI, FB>;
   static std::atomic<unsigned long long> configured{0};
-  constexpr size_t smem0 = (stft_fft_smem<M, W>() + 15) & ~(size_t)15;
+  constexpr size_t smem0 = (stft_fft_smem<M, W, FB>() + 15) & ~(size_t)15;
   // fused filterbank: the band weights (a mel bank has ~8 non-zeros per filter) packed into whatever LDS the
   // instance leaves, up to 16 KB -- the tile flush then reads LDS only (they were L2 loads inside its loop)
   KParams q = p;
   q.fb_lds_floats = 0;
-  if (W == 1 && p.fb && smem0 + 2080 + 2048 <= 160 * 1024) {
-    const size_t room = 160 * 1024 - smem0 - 2080;  // (offsets of up to 256 filters + 1, a flag, their first bins)
+  q.fft_row_step = 2 * M / p.K;
+  if (FB && smem0 + 2080 + 2048 <= lds_share) {
+    const size_t room = lds_share - smem0 - 2080;  // (offsets of up to 256 filters + 1, a flag, their first bins)
     q.fb_lds_floats = (int)((room < 16384 ? room : 16384) / 4);
   }
   const size_t smem = smem0 + (q.fb_lds_floats ? 2080 + (size_t)q.fb_lds_floats * 4 : 0);
@@ -3049,21 +3056,22 @@ template <int M>
 int launch_fft_size(const KParams &p, hipStream_t stream) {
   switch (p.epilogue) {
     case MISPEC_EPI_COMPLEX:
-      return launch_fft_cfg<M, MISPEC_EPI_COMPLEX>(p, stream);
+      return launch_fft_cfg<M, MISPEC_EPI_COMPLEX, false>(p, stream);
     case MISPEC_EPI_MAGNITUDE:
-      return launch_fft_cfg<M, MISPEC_EPI_MAGNITUDE>(p, stream);
-    case MISPEC_EPI_POWER:
-      return launch_fft_cfg<M, MISPEC_EPI_POWER>(p, stream);
+      return launch_fft_cfg<M, MISPEC_EPI_MAGNITUDE, false>(p, stream);
+    case MISPEC_EPI_POWER:  // (fft_ok: a filterbank comes with this epilogue only)
+      return p.fb ? launch_fft_cfg<M, MISPEC_EPI_POWER, true>(p, stream)
+                  : launch_fft_cfg<M, MISPEC_EPI_POWER, false>(p, stream);
     case MISPEC_EPI_PHASE_ATAN2:
-      return launch_fft_cfg<M, MISPEC_EPI_PHASE_ATAN2>(p, stream);
+      return launch_fft_cfg<M, MISPEC_EPI_PHASE_ATAN2, false>(p, stream);
     default:
-      return launch_fft_cfg<M, MISPEC_EPI_PHASE_COSSIN>(p, stream);
+      return launch_fft_cfg<M, MISPEC_EPI_PHASE_COSSIN, false>(p, stream);
   }
 }
 
 int launch_fft(const KParams &p, hipStream_t stream) {
   return p.K == 2048 ? launch_fft_size<1024>(p, stream)
-                     : (p.K == 1024 ? launch_fft_size<512>(p, stream) : launch_fft_size<256>(p, stream));
+                     : (p.K == 1024 ? launch_fft_size<512>(p, stream) : launch_fft_size<256>(p, stream));  // (128, 256: zero-extended)
 }
 
 // MISPEC_PREC_F16X3 exists on the folded contractions, on the strip kernel and on the staged dense kernel

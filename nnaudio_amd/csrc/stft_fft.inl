@@ -41,15 +41,47 @@ template <int M, int W>
 constexpr bool fft_two_buffers() {
   return M == 1024 && W == 1;  // (n_fft = 1024 with 2 x 16 frames: Mel cfg3 0.116 -> 0.121 ms, not kept)
 }
-template <int M, int W>
+// Frames per tile of the one-buffer instances (FB: the instance with the fused filterbank).  Small tiles make
+// the workgroup small enough -- LDS and, with __launch_bounds__' second argument, 128 VGPRs -- for TWO
+// workgroups per CU (fft_two_per_cu): four waves per SIMD, and one workgroup reduces / stores its tile while
+// the other transforms.  The choices are measured ones (scripts/fft_variants_time.py).
+#ifndef MISPEC_FFT512_FT_W1
+#define MISPEC_FFT512_FT_W1 16
+#endif
+#ifndef MISPEC_FFT512_FT_W2
+#define MISPEC_FFT512_FT_W2 16
+#endif
+#ifndef MISPEC_FFT512_FT_FB
+#define MISPEC_FFT512_FT_FB 8  // (16 frames leave no LDS for the packed band weights next to a second workgroup)
+#endif
+#ifndef MISPEC_FFT256_FT_W1
+#define MISPEC_FFT256_FT_W1 32
+#endif
+#ifndef MISPEC_FFT256_FT_W2
+#define MISPEC_FFT256_FT_W2 16
+#endif
+#ifndef MISPEC_FFT256_FT_FB
+#define MISPEC_FFT256_FT_FB 32
+#endif
+template <int M, int W, bool FB = false>
 constexpr int fft_tile_row() {  // floats per tile row: the tile's frames x W + 2 of padding
-  return (fft_two_buffers<M, W>() ? 8192 / M : 16384 / M) + 2;
+  return (M == 1024 ? FFT_WAVES
+                    : M == 512 ? (FB ? MISPEC_FFT512_FT_FB : W == 1 ? MISPEC_FFT512_FT_W1 : MISPEC_FFT512_FT_W2)
+                               : (FB ? MISPEC_FFT256_FT_FB : W == 1 ? MISPEC_FFT256_FT_W1 : MISPEC_FFT256_FT_W2)) * W + 2;
 }
-template <int M, int W>
+template <int M, int W, bool FB = false>
 constexpr size_t stft_fft_smem() {
-  return (size_t)(fft_two_buffers<M, W>() ? 2 : 1) * (M + 1) * fft_tile_row<M, W>() * 4 +
+  return (size_t)(fft_two_buffers<M, W>() ? 2 : 1) * (M + 1) * fft_tile_row<M, W, FB>() * 4 +
          (size_t)FFT_WAVES * fftcore::padded_size<M>() * 8 + (fft_two_buffers<M, W>() ? 0 : 2 * (size_t)M * 8) +
          (size_t)fftcore::radix_of<M, 0>() * (fftcore::radix_of<M, 1>() - 1) * 8;  // (+ the twiddle table of pass 1)
+}
+template <int M, int W, bool FB = false>
+constexpr bool fft_two_per_cu() {  // two workgroups fit the CU's 160 KB (FB: with 6 KB each for packed band weights)
+  return 2 * (((stft_fft_smem<M, W, FB>() + 15) & ~(size_t)15) + (FB ? 6144 : 0)) <= 160 * 1024;
+}
+template <int M, int EPI, bool FB>
+constexpr int fft_min_waves() {  // waves per SIMD the register allocation must leave room for
+  return fft_two_per_cu<M, (EPI == MISPEC_EPI_COMPLEX || EPI == MISPEC_EPI_PHASE_COSSIN) ? 2 : 1, FB>() ? 4 : 2;
 }
 
 // 16 bytes per lane, global -> LDS at m0 + 16 lane, as instructions: the loads of a frame stay invisible to
@@ -142,24 +174,31 @@ __device__ __forceinline__ void fft_epilogue(const KParams &p, float re, float i
 }
 
 // frames of a tile
-template <int M, int W>
+template <int M, int W, bool FB = false>
 constexpr int fft_tile_frames() {
-  return (fft_tile_row<M, W>() - 2) / W;
+  return (fft_tile_row<M, W, FB>() - 2) / W;
 }
 
-// M = n_fft / 2; EPI = the epilogue (W = floats per output element: 2 for Complex / Phase as (cos, sin))
-template <int M, int EPI>
-__global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams p, const int tiles_per_clip) {
+// M = n_fft / 2; EPI = the epilogue (W = floats per output element: 2 for Complex / Phase as (cos, sin)); FB = with
+// the fused filterbank (p.fb; EPI = MISPEC_EPI_POWER)
+template <int M, int EPI, bool FB>
+__global__ void __launch_bounds__(FFT_WAVES * 64, (fft_min_waves<M, EPI, FB>()))
+    stft_fft_kernel(const KParams p, const int tiles_per_clip) {
   using namespace fftcore;
   constexpr int N = 2 * M, P = M / 64;
   constexpr int W = (EPI == MISPEC_EPI_COMPLEX || EPI == MISPEC_EPI_PHASE_COSSIN) ? 2 : 1;
-  constexpr int FT = fft_tile_frames<M, W>();  // frames per tile
+  constexpr int FT = fft_tile_frames<M, W, FB>();  // frames per tile
   constexpr int FPW = FT / FFT_WAVES;          // frames per wave and tile
-  constexpr int C = fft_tile_row<M, W>();      // floats per tile row (FT * W + 2)
+  constexpr int C = fft_tile_row<M, W, FB>();  // floats per tile row (FT * W + 2)
   constexpr bool DB = fft_two_buffers<M, W>();
   constexpr int TILE_FLOATS = (M + 1) * C;     // rows 0 .. M (the Nyquist bin)
   constexpr int FFT_TILE_BYTES = (DB ? 2 : 1) * TILE_FLOATS * 4;
   static_assert(FPW >= 1 && (C & 1) == 0, "tile geometry");
+  // n_fft = 256 (or any power of two below) on the 512-point instance: the frame is zero-extended to N samples (a window of n_fft
+  // taps followed by zeros), whose spectrum has the n_fft-point bins at every RS-th row of the tile
+  constexpr bool ZP = M == 256;
+  const int RS = ZP ? p.fft_row_step : 1;
+  const int half_taps = ZP ? p.K / 2 : M;  // window pairs that exist
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float *const tiles = reinterpret_cast<float *>(smem_raw);
   const int tid = threadIdx.x;
@@ -185,7 +224,8 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
     }
   } else {
     for (int m = tid; m < M; m += FFT_WAVES * 64) {
-      s_win[m] = *reinterpret_cast<const cf *>(p.a_re + 2 * m);  // row 0 of the cosine kernels is the window itself
+      // row 0 of the cosine kernels is the window itself
+      s_win[m] = m < half_taps ? *reinterpret_cast<const cf *>(p.a_re + 2 * m) : cf{0.f, 0.f};
       float sn, cs;
       sincospif(-(float)m / (float)M, &sn, &cs);
       s_wh[m] = cf{0.5f * cs, 0.5f * sn};
@@ -249,7 +289,7 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
       const bool whole = t0 + fl + 4 / W <= T;
 #pragma unroll 4
       for (int k = r0; k < n_rows; k += RPI) {
-        const cf *src = reinterpret_cast<const cf *>(tile + k * C + fl * W);
+        const cf *src = reinterpret_cast<const cf *>(tile + k * RS * C + fl * W);
         const cf lo = src[0], hi = src[1];
         float *d = oc + (long long)k * p.out_row_stride + (long long)(t0 + fl) * W;
         if (MISPEC_DBG(p, 0x8)) d = p.out + (long long)k * p.out_row_stride + (long long)fl * W;  // benchmarking: every tile onto the first one (no HBM write stream)
@@ -267,11 +307,11 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
 
   // ---- fused filterbank: the band weights packed into LDS (s_fboff[m] = start of filter m's band [lo, hi)), when
   // they fit what the launch reserved; built once by the persistent workgroup
-  int *const s_fboff = reinterpret_cast<int *>(smem_raw + ((stft_fft_smem<M, W>() + 15) & ~(size_t)15));
+  int *const s_fboff = reinterpret_cast<int *>(smem_raw + ((stft_fft_smem<M, W, FB>() + 15) & ~(size_t)15));
   int *const s_fblo = s_fboff + 260;  // first bin of filter m's band
   float *const s_fbw = reinterpret_cast<float *>(s_fboff + 520);
   bool fb_packed = false;
-  if (W == 1 && p.fb && p.fb_lds_floats > 0) {
+  if (FB && p.fb_lds_floats > 0) {
     for (int m = tid; m < p.n_fb; m += FFT_WAVES * 64) {
       int lo = p.fb_support[2 * m], hi = p.fb_support[2 * m + 1];
       lo = lo < 0 ? 0 : lo;
@@ -314,10 +354,11 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
         const int lo = s_fblo[m];
         const int nb = s_fboff[m + 1] - s_fboff[m];
         const float *w = s_fbw + s_fboff[m];
-        const float *tr = tile + lo * C + fl;
+        const int CR = C * RS;
+        const float *tr = tile + lo * CR + fl;
         cf sum = cf{0.f, 0.f};
 #pragma unroll 4
-        for (int b = 0; b < nb; ++b) sum += w[b] * *reinterpret_cast<const cf *>(tr + b * C);
+        for (int b = 0; b < nb; ++b) sum += w[b] * *reinterpret_cast<const cf *>(tr + b * CR);
         float *d = oc + (long long)m * p.out_row_stride + t0 + fl;
         if (t0 + fl < T) d[0] = sum.x;
         if (t0 + fl + 1 < T) d[1] = sum.y;
@@ -332,7 +373,7 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
       const float *w = p.fb + (long long)m * p.fb_row_stride;
       float sum = 0.f;
 #pragma unroll 4
-      for (int b = lo; b < hi; ++b) sum += w[b] * tile[b * C + fl];
+      for (int b = lo; b < hi; ++b) sum += w[b] * tile[b * RS * C + fl];
       if (t0 + fl < T) oc[(long long)m * p.out_row_stride + t0 + fl] = sum;
     }
   };
@@ -372,7 +413,7 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
       int younger = 0;  // store instructions this wave issues after the loads
       if (u == 0) {
         if (prev_oc) {
-          if (W == 1 && p.fb) {
+          if constexpr (FB) {
             flush_fb(prev_tile, prev_oc, prev_t0);  // (its stores are not counted: the wait below then also covers them)
           } else {
             flush(prev_tile, prev_oc, prev_t0);
@@ -425,6 +466,10 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
       }
 #pragma unroll
       for (int i = 0; i < P; ++i) x[i] = x[i] * (DB ? wn[DB ? i : 0] : s_win[lane + 64 * i]);
+      if (ZP && RS > 1) {  // the samples behind the frame are not part of it, whatever they are (Inf x 0)
+#pragma unroll
+        for (int i = 0; i < P; ++i) x[i] = lane + 64 * i < half_taps ? x[i] : cf{0.f, 0.f};
+      }
       // ---- M-point complex FFT   (benchmarking build: 0x4 skips the passes, 0x2 the post-processing, 0x1 the stores)
       if (!MISPEC_DBG(p, 0x4)) {
         stockham_pass<M, 0>(x, lane, twf0, store);
@@ -492,7 +537,7 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) stft_fft_kernel(const KParams 
   }
   if (prev_oc) {
     const float *const last = tiles + (DB ? ((step & 1) ^ 1) * TILE_FLOATS : 0);
-    if (W == 1 && p.fb)
+    if constexpr (FB)
       flush_fb(last, prev_oc, prev_t0);
     else
       flush(last, prev_oc, prev_t0);

@@ -22,8 +22,8 @@ from ._abi import (  # noqa: F401  (re-exported for the feature modules)
 from .basis import decimated_length
 
 # Arithmetic of the framed CONTRACTION kernels (include/mispec.h, MISPEC_PREC_*).  It does not apply to the
-# FFT route: STFT-family modules whose kernels are window x DFT (freq_scale='no', frozen, n_fft 512 / 1024 /
-# 2048) evaluate every frame's DFT as an fp32 FFT whatever `precision` says, an explicit "fp32" included
+# FFT route: STFT-family modules whose kernels are window x DFT (freq_scale='no', frozen, n_fft 256 / 512 /
+# 1024 / 2048) evaluate every frame's DFT as an fp32 FFT whatever `precision` says, an explicit "fp32" included
 # (2e-7 of the peak; `set_fft(False)` puts them on the contraction kernels, where "fp32" is the reference's
 # summation order).
 #   "fp32"   fp32 MFMA, the taps summed in the reference's order (CQT1992v2's default)
@@ -64,8 +64,8 @@ _fft = os.environ.get("MISPEC_FFT", "1") not in ("0", "false", "off")
 
 
 def set_fft(enabled):
-    """STFT-family modules whose kernels are window x DFT (``freq_scale='no'``, not trainable, n_fft 512 /
-    1024 / 2048) evaluate the frames' DFT as an FFT instead of contracting them with the kernels
+    """STFT-family modules whose kernels are window x DFT (``freq_scale='no'``, not trainable, n_fft 256 ...
+    2048) evaluate the frames' DFT as an FFT instead of contracting them with the kernels
     (csrc/stft_fft.inl); ``set_fft(False)`` (or ``MISPEC_FFT=0``) keeps every module on the contraction
     kernels -- the arithmetic ``precision`` selects.  Returns the previous setting."""
     global _fft
@@ -411,7 +411,7 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
         a.basis_fold2_bytes = planes.numel() * planes.element_size()
         a.fold2_wmax = float(wmax)
         keep.append(planes)
-        # window x DFT bases of 512 / 1024 / 2048 taps run as an FFT (fp32) unless told otherwise
+        # window x DFT bases of 256 ... 2048 taps (powers of two) run as an FFT (fp32) unless told otherwise
         a.no_fft = 0 if (fft_enabled() if fft is None else fft) else 1
     if resolve_precision(precision) == "f16x3" and need_workspace:
         a.precision = PREC_F16X3  # (the library runs what the second fold does not cover in fp32)
@@ -563,8 +563,8 @@ def fold2_basis(basis_re, basis_im, precision):
         return None
     F, K = wr.shape
     lib = _abi.load()
-    if K % 64 or not 128 <= K <= 8192 or F < 128:
-        return None
+    if K % 64 or not 128 <= K <= 8192:
+        return None  # (the contraction on these planes also wants >= 128 bins; the FFT route takes any number)
     need = lib.mispec_basis_fold2_bytes(F, K)
     if need < 0:
         return None

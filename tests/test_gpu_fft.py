@@ -1,4 +1,4 @@
-"""GPU parity of the STFT's FFT path (csrc/stft_fft.inl: window x DFT bases of 512 / 1024 / 2048 taps evaluated
+"""GPU parity of the STFT's FFT path (csrc/stft_fft.inl: window x DFT bases of 256 / 512 / 1024 / 2048 taps evaluated
 as an fp32 FFT instead of being contracted with the kernels) against the float64 oracle and against the
 contraction kernels -- through the modules and through the C ABI (engine.framed_gemm)."""
 import numpy as np
@@ -32,6 +32,9 @@ def _need_gpu():
     (2, 5000, 129, 512, 64, 0, 0, "hann"),            # center=False, a quarter of the bins
     (1, 2100, 1025, 2048, 2048, 1024, 2, "short"),    # two frames, both edge frames; win_length < n_fft
     (7, 1500, 513, 1024, 1024, 512, 1, "hann"),       # many short clips, zero padding
+    (3, 6000, 129, 256, 64, 128, 2, "hann"),          # n_fft = 256 (the reference's grid): zero-extended frames on the 512-point instance
+    (2, 5000, 100, 256, 100, 0, 0, "random"),         # ... center=False, fewer bins, asymmetric window
+    (4, 300, 129, 256, 200, 128, 2, "hann"),          # clips shorter than the 512 samples a zero-extended frame reads
 ])
 @pytest.mark.parametrize("epi", ["complex", "magnitude", "power2", "power1", "phase", "cossin"])
 def test_fft_path_against_float64(shape, epi):
@@ -119,6 +122,30 @@ def test_fft_path_is_what_the_modules_run_and_can_be_switched_off():
     assert torch.equal(a, b)
 
 
+def test_n_fft_256_on_the_fft_route_ignores_what_lies_behind_the_frame():
+    """n_fft = 256 (tests/parameters.py:25 of the reference) runs on the 512-point instance with zero-extended
+    frames: the 256 samples that follow a frame are read but are not part of it -- an Inf there must not reach it."""
+    from nnaudio_amd import engine, features
+
+    m = features.STFT(n_fft=256, hop_length=64, center=False, output_format="Magnitude", verbose=False).to(DEV)
+    x = torch.as_tensor(np.random.default_rng(4).standard_normal((2, 4000)).astype(np.float32)).to(DEV)
+    y = m(x)
+    engine.set_fft(False)
+    try:
+        g = m(x)
+    finally:
+        engine.set_fft(True)
+    assert y.shape == g.shape == (2, 129, (4000 - 256) // 64 + 1)
+    assert not torch.equal(y, g), "the contraction kernels ran"
+    assert float((y - g).abs().max()) <= 5e-6 * float(g.abs().max())
+    x2 = x.clone()
+    x2[0, 1000] = float("inf")
+    y2 = m(x2)
+    clean = (1000 - 256) // 64 + 1  # frames that end at or before sample 1000
+    assert torch.equal(y2[0, :, :clean], y[0, :, :clean]) and torch.equal(y2[1], y[1])
+    assert not torch.isfinite(y2[0, :, clean]).all()
+
+
 def test_fft_path_pure_tone_dynamic_range():
     """A sine exactly on a bin: what the other bins hold, relative to the peak (the FFT's rounding error grows
     with log n_fft, not with n_fft)."""
@@ -194,6 +221,7 @@ def test_fused_filterbank_on_the_fft_route_matches_two_kernels():
     for cls, kw in ((features.MelSpectrogram, dict(sr=22050, n_fft=1024, n_mels=128, hop_length=512)),
                     (features.MelSpectrogram, dict(sr=16000, n_fft=512, n_mels=40, hop_length=160, power=1.0)),
                     (features.MelSpectrogram, dict(sr=44100, n_fft=2048, n_mels=229, hop_length=512)),
+                    (features.MelSpectrogram, dict(sr=8000, n_fft=256, n_mels=40, hop_length=80)),  # zero-extended frames
                     (features.Gammatonegram, dict(sr=22050, n_fft=1024, n_bins=64, hop_length=512))):
         m = cls(verbose=False, **kw).to(DEV)
         y = m(x)
@@ -333,14 +361,14 @@ def test_repeated_launches_on_the_fft_route_are_bit_identical():
 
 
 def test_fft_route_random_shapes_against_the_contraction():
-    """40 random STFT problems (n_fft, hop, clip length, batch, padding, freq_bins, strided clips, epilogue incl. a
+    """60 random STFT problems (n_fft, hop, clip length, batch, padding, freq_bins, strided clips, epilogue incl. a
     general power) through both routes: the FFT path must agree with the fp32 contraction to fp32 rounding"""
     from nnaudio_amd import engine
 
     rng = np.random.default_rng(2024)
     taken = 0
-    for case in range(40):
-        K = int(rng.choice([512, 1024, 2048]))
+    for case in range(60):
+        K = int(rng.choice([256, 512, 1024, 2048]))
         hop = int(rng.choice([1, 2, 3]) * rng.integers(20, 1200)) if case % 5 else int(rng.integers(K, 2 * K))
         center = bool(rng.integers(0, 4))
         pad = K // 2 if center else 0
@@ -380,7 +408,7 @@ def test_fft_route_random_shapes_against_the_contraction():
             tol = 5e-6 * max(1.0, float(extra.get("power", 1.0)))  # (|X|^p carries p times the relative error of |X|)
             assert float((y - r).abs().max()) <= tol * float(r.abs().max()), what
         taken += not torch.equal(y, r)
-    assert taken >= 20, taken
+    assert taken >= 30, taken
 
 
 def test_layouts_streams_and_errors_on_the_fft_route(golden):

@@ -121,7 +121,8 @@ struct OsParams {
   int n_taps, dec_pad;
   OsLevel lv[OS_LEVELS];
   int c_level[4];   // level wave 4+i contracts (-1: none)
-  int ingest_fir;   // 1: waves 0-3 take the ingest of level 0 (the default), 0: waves 4-7
+  int ingest_mode;  // who streams level 0 in: 0 waves 4-7 after their tiles, 1 waves 0-3 after their columns,
+                    // 2 the bank waves WITHOUT a tile in the step, two quarters of the chunk each (os_plan)
   float *x_last;
   long long x_last_stride;
   float *out;
@@ -132,7 +133,7 @@ struct OsParams {
   int zero_bytes;   // rings + patches (start at LDS offset 0)
   int stage_off, misc_off;  // raw chunk staging (16 KB); maxima / taps staging
   unsigned long long *stamps;  // benchmarking build: phase clock of workgroup 7 (100 MHz ticks), [wave][step][12]
-  int debug;                   // benchmarking build: 1 no FIR MFMAs, 2 no bank tiles, 4 no global stores, 8 no DMA, 16 / 32 bank / FIR waves at priority 3,
+  int debug;                   // benchmarking build: 1 no FIR MFMAs, 2 no bank tiles, 4 no global stores, 8 no DMA, 16 / 32 bank / FIR waves at priority 0 (not 3 / 2),
                                // 64 no tile MFMAs, 128 tile fragments from one address, 256 no split + ring writes of the ingest, 512 no scale check
 };
 
@@ -252,9 +253,12 @@ __global__ void __launch_bounds__(OS_THREADS, 1) octave_stream_kernel(const OsPa
   // consumer -- starts by comparing it with the range of the current scale and, when it is louder (rare),
   // rescales everything resident and splits that chunk again from memory.
   unsigned char *const stage = smem + p.stage_off;
-  const bool ingest_wave = p.ingest_fir ? wave < 4 : wave >= 4;
-  const int cw = wave & 3, ct = tid & 255;  // (of the four ingesting waves)
-  const unsigned stage_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lptr_t)(stage + cw * 4096));
+  const bool ingest_wave = p.ingest_mode == 0 ? wave >= 4 : wave < 4;  // (prologue, rescale; mode 2: the steps' ingest moves around)
+  const int cw = wave & 3;
+  // the quarter of a chunk this wave is streaming in (mode 2: a wave takes two, one after the other: set_quarter)
+  int iq = cw, ct = 64 * cw + lane;
+  const unsigned stage_lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lptr_t)stage);
+  unsigned stage_lds = stage_lds0 + 4096u * (unsigned)cw;
   auto chunk_pos = [&](int q) __attribute__((always_inline)) { return OS_CHUNK * q + c0 + 16 * ct; };
   auto dma_chunk = [&](int q) __attribute__((always_inline)) {
 #pragma unroll
@@ -268,7 +272,7 @@ __global__ void __launch_bounds__(OS_THREADS, 1) octave_stream_kernel(const OsPa
     for (int h = 0; h < 4; ++h) {
       const int pos = chunk_pos(q) + 4 * h;
       if (staged && pos >= 0 && pos + 4 <= L0) {
-        const f32x4v f = *reinterpret_cast<const f32x4v *>(stage + cw * 4096 + 1024 * h + 16 * lane);
+        const f32x4v f = *reinterpret_cast<const f32x4v *>(stage + iq * 4096 + 1024 * h + 16 * lane);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[4 * h + e] = f[e];
       } else {  // (the pieces that cross an end of the clip; every piece on the slow path)
@@ -355,7 +359,7 @@ __global__ void __launch_bounds__(OS_THREADS, 1) octave_stream_kernel(const OsPa
         const unsigned m1 = wave_max_bits(v1);
         m0 = m1 > m0 ? m1 : m0;
       }
-      if (F16 && lane == 0) s_max[cw] = m0, s_max[4 + cw] = m0;
+      if (F16 && lane == 0) s_max[iq] = m0, s_max[4 + iq] = m0;
     }
     if (F16) {
       __syncthreads();
@@ -369,75 +373,135 @@ __global__ void __launch_bounds__(OS_THREADS, 1) octave_stream_kernel(const OsPa
   // ingest of level 0: thread ct owns samples 16 ct .. 16 ct + 15 of a chunk = two 16-byte pieces of ring row
   // ((c0 + 16 ct) >> 6) + 64 q (a level-0 ring has >= 128 rows: the swizzle of the row does not depend on q)
   const int ring0_off = p.lv[0].ring_off, ring0_plane = p.lv[0].plane, ring0_mask = p.lv[0].mask;
-  const int wr_row0 = (c0 + 16 * ct) >> 6;
-  int wr_col[2];
+  int wr_row0, wr_col[2];
+  unsigned dma_voff;
+  auto set_quarter = [&](int j) __attribute__((always_inline)) {
+    iq = j;
+    ct = 64 * j + lane;
+    stage_lds = stage_lds0 + 4096u * (unsigned)j;
+    wr_row0 = (c0 + 16 * ct) >> 6;
 #pragma unroll
-  for (int half = 0; half < 2; ++half)
-    wr_col[half] = ((((((c0 + 16 * ct) & 63) >> 3) + half) ^ ((wr_row0 >> 1) & 7)) << 4);
-  const unsigned dma_voff = 64u * (unsigned)ct;
+    for (int half = 0; half < 2; ++half)
+      wr_col[half] = ((((((c0 + 16 * ct) & 63) >> 3) + half) ^ ((wr_row0 >> 1) & 7)) << 4);
+    dma_voff = 64u * (unsigned)ct;
+  };
+  set_quarter(cw);
+  // the ingest of the current quarter (set_quarter), chunk inside the clip, in two halves: the staging slots into
+  // registers and the request for chunk q2 into the same slots ...
+  auto ingest_fetch = [&](int q2, bool more, f32x4v (&f)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) f[h] = *reinterpret_cast<const f32x4v *>(stage + iq * 4096 + 1024 * h + 16 * lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging slots have been read: they may be refilled
+    if (more) {
+      if (OS_CHUNK * q2 + c0 >= 0 && OS_CHUNK * (q2 + 1) + c0 <= L0)
+        os_dma64(xc + ((long long)OS_CHUNK * q2 + c0), dma_voff, stage_lds);
+      else
+        dma_chunk(q2);
+    }
+  };
+  // ... and the sixteen samples of chunk q: their largest finite magnitude for the next step's check, split, ring
+  auto ingest_commit = [&](int q, const f32x4v (&f)[4]) __attribute__((always_inline)) {
+    if (F16) {
+      // magnitudes compared as integers (bit patterns of |x| order like the values; one AND + one MAX per sample,
+      // no NaN handling): only when some |sample| >= 2^e_cur -- or is not finite -- is the true maximum formed
+      unsigned mi = 0u;
+#pragma unroll
+      for (int h = 0; h < 4; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned a = __float_as_uint(f[h][e]) & 0x7fffffffu;
+          mi = mi > a ? mi : a;
+        }
+      unsigned mb = 0u;
+      if (__builtin_amdgcn_ballot_w64(mi >= __float_as_uint(pow2f(e_cur))) != 0ull) {
+        float m = 0.f;
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) m = fmaxf(m, os_finite_abs(f[h][e]));
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+        mb = __float_as_uint(m);
+      }
+      if (lane == 0) s_max[4 * (q & 1) + iq] = mb;
+    }
+    const float xs = F16 ? pow2f(p.top - e_cur) : 1.f;
+    const int wrow = (((wr_row0 + 64 * q) & ring0_mask) << 7) + ring0_off;
+#pragma unroll
+    for (int half = 0; half < (OS_DBG(256) ? 0 : 2); ++half) {
+      unsigned h[4], l[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split2(f[2 * half + (e >> 1)][2 * (e & 1)] * xs, f[2 * half + (e >> 1)][2 * (e & 1) + 1] * xs, h[e], l[e]);
+      const int a = wrow + wr_col[half];
+      *reinterpret_cast<u32x4 *>(smem + a) = u32x4{h[0], h[1], h[2], h[3]};
+      *reinterpret_cast<u32x4 *>(smem + a + ring0_plane) = u32x4{l[0], l[1], l[2], l[3]};
+    }
+  };
+  // a chunk that crosses an end of the clip: piece by piece
+  auto ingest_slow = [&](int q, int q2, bool more) __attribute__((always_inline)) {
+    float v16[16];
+    read_chunk(q, v16, true);
+    if (F16) {
+      const unsigned m = wave_max_bits(v16);
+      if (lane == 0) s_max[4 * (q & 1) + iq] = m;
+    }
+    write_chunk(q, v16);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (more) {
+      if (OS_CHUNK * q2 + c0 >= 0 && OS_CHUNK * (q2 + 1) + c0 <= L0)
+        os_dma64(xc + ((long long)OS_CHUNK * q2 + c0), dma_voff, stage_lds);
+      else
+        dma_chunk(q2);
+    }
+  };
+  // modes 0 and 1: one quarter per wave and step, requested by the same wave a step ago (the wait for it is here)
   auto ingest_step = [&](int g, int &younger) __attribute__((always_inline)) {
       // chunk g + 1 (requested a step ago): staging buffer -> ring; its maximum for the check of the next step;
       // the request for chunk g + 2 into the same slots as soon as they have been read
       if (g + 1 <= b_e - 1) {
         wait_loads(younger);
-        OS_STAMP(2);
+        OS_STAMP(4);
         const int q = g + 1, q2 = g + 2;
         const bool more = q2 <= b_e - 1 && !OS_DBG(8);
         if (OS_CHUNK * q + c0 >= 0 && OS_CHUNK * (q + 1) + c0 <= L0) {
           // the chunk lies inside the clip (every step but the ends of the clip): no per-piece tests
           f32x4v f[4];
-#pragma unroll
-          for (int h = 0; h < 4; ++h) f[h] = *reinterpret_cast<const f32x4v *>(stage + cw * 4096 + 1024 * h + 16 * lane);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging slots have been read: they may be refilled
-          if (more) {
-            if (OS_CHUNK * q2 + c0 >= 0 && OS_CHUNK * (q2 + 1) + c0 <= L0)
-              os_dma64(xc + ((long long)OS_CHUNK * q2 + c0), dma_voff, stage_lds);
-            else
-              dma_chunk(q2);
-          }
-          OS_STAMP(3);
-          if (F16) {
-            float m = 0.f;
-#pragma unroll
-            for (int h = 0; h < 4; ++h)
-              m = fmaxf(fmaxf(fmaxf(m, os_finite_abs(f[h][0])), fmaxf(os_finite_abs(f[h][1]), os_finite_abs(f[h][2]))), os_finite_abs(f[h][3]));
-            // (the exponent of the wave's maximum exceeds e_cur iff some |sample| >= 2^e_cur: the reduction only then)
-            unsigned mb = 0u;
-            if (__builtin_amdgcn_ballot_w64(!(m < pow2f(e_cur))) != 0ull) {
-#pragma unroll
-              for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
-              mb = __float_as_uint(m);
-            }
-            if (lane == 0) s_max[4 * (q & 1) + cw] = mb;
-          }
-          const float xs = F16 ? pow2f(p.top - e_cur) : 1.f;
-          const int wrow = (((wr_row0 + 64 * q) & ring0_mask) << 7) + ring0_off;
-#pragma unroll
-          for (int half = 0; half < (OS_DBG(256) ? 0 : 2); ++half) {
-            unsigned h[4], l[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) split2(f[2 * half + (e >> 1)][2 * (e & 1)] * xs, f[2 * half + (e >> 1)][2 * (e & 1) + 1] * xs, h[e], l[e]);
-            const int a = wrow + wr_col[half];
-            *reinterpret_cast<u32x4 *>(smem + a) = u32x4{h[0], h[1], h[2], h[3]};
-            *reinterpret_cast<u32x4 *>(smem + a + ring0_plane) = u32x4{l[0], l[1], l[2], l[3]};
-          }
+          ingest_fetch(q2, more, f);
+          OS_STAMP(5);
+          ingest_commit(q, f);
         } else {
-          float v16[16];
-          read_chunk(q, v16, true);
-          if (F16) {
-            const unsigned m = wave_max_bits(v16);
-            if (lane == 0) s_max[4 * (q & 1) + cw] = m;
-          }
-          write_chunk(q, v16);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          if (more) {
-            if (OS_CHUNK * q2 + c0 >= 0 && OS_CHUNK * (q2 + 1) + c0 <= L0)
-              os_dma64(xc + ((long long)OS_CHUNK * q2 + c0), dma_voff, stage_lds);
-            else
-              dma_chunk(q2);
-          }
+          ingest_slow(q, q2, more);
         }
         younger = 0;
+      }
+  };
+  // mode 2: two quarters by a bank wave that has no tile in this step; both requests go out before the samples are
+  // worked on, and are waited for before the step's barrier (the next step's takers are other waves, and vmcnt is per
+  // wave).  (Requesting before the scale check -- the staged floats do not depend on the scale -- keeps 32 registers
+  // alive across it: spills.)
+  auto ingest_pair = [&](int g, int j0, int j1) __attribute__((always_inline)) {
+      if (g + 1 <= b_e - 1) {
+        const int q = g + 1, q2 = g + 2;
+        const bool more = q2 <= b_e - 1 && !OS_DBG(8);
+        if (OS_CHUNK * q + c0 >= 0 && OS_CHUNK * (q + 1) + c0 <= L0) {
+          f32x4v fa[4], fb[4];
+          set_quarter(j0);
+          ingest_fetch(q2, more, fa);
+          set_quarter(j1);
+          ingest_fetch(q2, more, fb);
+          OS_STAMP(5);
+          ingest_commit(q, fb);
+          set_quarter(j0);
+          ingest_commit(q, fa);
+        } else {
+          set_quarter(j0);
+          ingest_slow(q, q2, more);
+          set_quarter(j1);
+          ingest_slow(q, q2, more);
+        }
+        OS_STAMP(4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        OS_STAMP(6);
       }
   };
 
@@ -587,14 +651,16 @@ __global__ void __launch_bounds__(OS_THREADS, 1) octave_stream_kernel(const OsPa
           }
         }
       }
-      if (p.ingest_fir) ingest_step(g, fir_younger);
+      if (p.ingest_mode == 1) ingest_step(g, fir_younger);
       OS_STAMP(10);
       __syncthreads();
       OS_STAMP(11);
     }
   } else {
     // =============================== bank waves ===============================
-    if (OS_DBG(16)) __builtin_amdgcn_s_setprio(3);
+    // (above the FIR waves' 2: in launches whose steps are tile-bound -- hops of 32 .. 4, the second launch of the cfg5
+    // shard -- 96 -> 92 us; neutral where the bank waves are not the longest chain)
+    if (!OS_DBG(16)) __builtin_amdgcn_s_setprio(3);
     const int my = p.c_level[cw];
     const int fn = lane & 15, kg = lane >> 4;
     bf16x8 rh[MAXS], rl[MAXS], ih[MAXS], il[MAXS];
@@ -756,9 +822,12 @@ __global__ void __launch_bounds__(OS_THREADS, 1) octave_stream_kernel(const OsPa
 
     for (int g = g0; g < g_end; ++g) {
       OS_STAMP(0);
+      const int beta = g - my;
+      // mode 2, a step without a tile for this wave (span = 2: every other one): its own quarter of chunk g + 1 and
+      // that of the neighbour, who has a tile now (os_plan pairs levels of opposite parity) -- after the scale check
       check_scale(g);
       OS_STAMP(1);
-      const int beta = g - my;
+      if (p.ingest_mode == 2 && ((beta + 1) & 1) != 0) ingest_pair(g, cw, cw ^ 1);
       if (my >= 0 && beta >= b_a && beta < b_e && ((beta + 1) & span_mask) == 0 && !OS_DBG(2)) {
         const float xu = F16 ? pow2f(e_cur - p.top) : 1.f;
         const int f_first = (beta + 1 - span) * nf, f_end = (beta + 1) * nf;
@@ -860,7 +929,7 @@ __global__ void __launch_bounds__(OS_THREADS, 1) octave_stream_kernel(const OsPa
         OS_STAMP(8);
       }
       OS_STAMP(9);
-      if (!p.ingest_fir) ingest_step(g, younger);  // (after the tiles: VALU work runs at half speed beside the FIR waves' MFMA stream, over by now)
+      if (p.ingest_mode == 0) ingest_step(g, younger);  // (after the tiles: VALU work runs at half speed beside the FIR waves' MFMA stream)
       OS_STAMP(10);
       __syncthreads();
       OS_STAMP(11);
@@ -918,10 +987,7 @@ int os_plan(const mispec_octave_stream_args *a, int n_cus, OsPlan &pl) {
   // the FIR waves take the ingest: with it the bank waves' chain (check, tiles) and theirs (check, columns,
   // ingest) are 1.8 and 2.5 us of a step; on the bank waves they were 2.7 and 1.7 (first launch of the cfg5 shard
   // 245 -> 223 us, second 95 -> 92; MISPEC_INGEST_FIR=0 in the benchmarking build switches back)
-  p.ingest_fir = 1;
-#ifdef MISPEC_ABLATE
-  if (const char *ev = getenv("MISPEC_INGEST_FIR")) p.ingest_fir = atoi(ev);
-#endif
+  p.ingest_mode = 1;
   p.span = p.nf >= 16 ? 1 : 16 / p.nf;
   p.n_frames = a->n_frames;
   p.n_clips = a->n_clips;
@@ -961,6 +1027,18 @@ int os_plan(const mispec_octave_stream_args *a, int n_cus, OsPlan &pl) {
     }
   }
   for (int i = n_banks; i < 4; ++i) p.c_level[i] = -1;
+  // tiles of two steps (hop 512: the first launch of a CQT2010v2 / VQT): a bank wave has a tile in every other
+  // step -- level l in the steps g = l + 1 (mod 2) -- and nothing to do in between, while the FIR waves' chain
+  // (columns + ingest) is the longest of the step: the bank waves without a tile take the ingest, two quarters of
+  // the chunk each, when every pair of neighbours (4, 5) and (6, 7) contracts levels of opposite parity
+  // (first launch of the cfg5 shard: see DESIGN.md section 3.13)
+  if (p.span == 2 && n_banks == 4 && ((p.c_level[0] ^ p.c_level[1]) & 1) && ((p.c_level[2] ^ p.c_level[3]) & 1)) p.ingest_mode = 2;
+#ifdef MISPEC_ABLATE
+  if (const char *ev = getenv("MISPEC_INGEST_MODE")) {
+    const int m = atoi(ev);
+    if (m == 0 || m == 1 || (m == 2 && p.ingest_mode == 2)) p.ingest_mode = m;
+  }
+#endif
   pl.max_steps = max_steps;
   // look-ahead: c[l] = 2 c[l+1] + 128, c[l] >= K[l] / 2 - hop[l]
   for (int cD = 0;; cD += 32) {

@@ -2,6 +2,7 @@
 
   NO_STAMPS=1   ablation timings only (the phase clock costs workgroup 7 about 0.1 us per stamp)
   DBG_STAMP=0,1 debug bits of the launches the phase clock is read from (one report per entry)
+  PRECISION=bf16x3  the module's arithmetic (default: f16x3)
 """
 import os, sys
 import numpy as np
@@ -11,6 +12,7 @@ from nnaudio_amd import engine, features
 
 dev = "cuda:0"
 m = features.CQT2010v2(sr=44100, hop_length=512, n_bins=96, verbose=False).to(dev)
+m.precision = os.environ.get("PRECISION") or None  # (None: the module default, f16x3)
 B = int(os.environ.get("B", "64"))
 x = torch.randn(B, 1323000, device=dev)
 N_SLOTS = 12
@@ -41,8 +43,8 @@ engine.octave_stream = orig
 print("launches:", len(calls), [len(c[0][1]) for c in calls])
 
 
-def timeit(fn, n=20):
-    for _ in range(3):
+def timeit(fn, n=200):
+    for _ in range(100):  # (long enough for the clocks to settle: the first timing of a process is otherwise the slowest)
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -56,16 +58,19 @@ def timeit(fn, n=20):
 
 ABLATIONS = [
     (0, "full"), (1, "no FIR MFMAs"), (2, "no bank tiles"), (4, "no global stores"), (8, "no DMA"),
-    (3, "no FIR, no banks"), (15, "nothing"), (16, "bank waves prio 3"), (32, "FIR waves prio 0 (not 2)"),
+    (3, "no FIR, no banks"), (15, "nothing"), (16, "bank waves prio 0 (not 3)"), (32, "FIR waves prio 0 (not 2)"), (48, "all waves prio 0"),
     (1 | 4, "no FIR: tiles without stores"), (1 | 64, "no FIR: tiles without MFMAs"),
     (1 | 128, "no FIR: tile fragments from one address"),
     (1 | 4 | 64 | 128, "no FIR: tiles without address math, MFMAs, stores"),
     (1 | 2 | 256, "no FIR, no tiles: ingest without split + writes"), (1 | 2 | 512, "no FIR, no tiles: no scale check"),
     (1 | 2 | 8, "no FIR, no tiles: no DMA"), (1 | 2 | 8 | 256 | 512, "no FIR, no tiles: staging read + barrier only"),
 ]
-NAMES_FIR = {1: "check", 2: "setup+frag0", 3: "mfma loop", 10: "epilogue", 11: "barrier"}
-NAMES_BANK = {1: "check", 6: "edge tiles", 7: "plain: loads + MFMAs", 8: "plain: epilogue + stores", 9: "-", 2: "wait loads",
-              3: "staging read + dma issue", 10: "max+split+write", 11: "barrier"}
+if os.environ.get("ONLY"):  # e.g. ONLY=0,16,32,48
+    keep = {int(v) for v in os.environ["ONLY"].split(",")}
+    ABLATIONS = [a for a in ABLATIONS if a[0] in keep]
+NAMES_FIR = {1: "check", 2: "setup+frag0", 3: "mfma loop", 4: "epilogue + wait loads", 5: "staging read + dma issue", 10: "max+split+write", 11: "barrier"}
+NAMES_BANK = {1: "check", 5: "mode 2: fetch both quarters", 4: "mode 2: commit both", 6: "edge tiles (mode 2, no tile: wait for the requests)",
+              7: "plain: loads + MFMAs", 8: "plain: epilogue + stores", 9: "-", 10: "ingest (mode 0)", 11: "barrier"}
 
 
 def phase_report(li, a, k, dbg):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MISPEC_ABI_VERSION 10
+#define MISPEC_ABI_VERSION 11
 
 enum {
   MISPEC_OK = 0,
@@ -452,6 +452,17 @@ int mispec_power_to_db_f32(const float *spec, int32_t n_clips, int64_t clip_elem
 int mispec_istft_grad_signal_f32(const float *grad_out, int64_t grad_clip_stride, int32_t n_clips,
                                  int32_t n_frames, int32_t n_fft, const float *window, int32_t hop,
                                  int32_t start, int32_t out_len, float *u, void *stream);
+
+/*
+ * MFCC's tail in ONE launch (mel.py:263-307 = MFCC.forward after the mel spectrogram): mispec_power_to_db_f32
+ * followed by mispec_filterbank_f32 with the (n_mfcc, n_mels) DCT-II matrix `dct` (row-major), one workgroup per
+ * clip: mel (n_clips, n_mels, n_frames) -> out (n_clips, n_mfcc, n_frames).  The decibel values are the ones
+ * mispec_power_to_db_f32 produces (same expressions); the cosine sums run over the mel bands in order (fp32 FMA).
+ * top_db < 0: no floor.  MISPEC_E_UNSUPPORTED for more than 256 mel bands (a 64-frame tile in 64 KB of LDS) or
+ * n_mfcc > n_mels: use the two calls.
+ */
+int mispec_mfcc_tail_f32(const float *mel, int32_t n_clips, int32_t n_mels, int32_t n_frames, float amin, float ref,
+                         float top_db, const float *dct, int32_t n_mfcc, float *out, void *stream);
 
 /* Backward of mispec_power_to_db_f32 with respect to spec: elements above the per-clip floor pass
  * grad_out * 10 / (ln 10 * spec) (0 where spec <= amin); the floored ones hand their gradient to

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmispec.so")
 ABLATE_LIB_PATH = os.path.join(_HERE, "csrc", "libmispec_ablate.so")  # benchmarking build
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 E_INVALID, E_UNSUPPORTED, E_HIP = -1, -2, -3
 
 # enums (mirror include/mispec.h)
@@ -49,6 +49,7 @@ EXPORTS = (
     "mispec_filterbank_f32",
     "mispec_istft_grad_signal_f32",
     "mispec_power_to_db_f32",
+    "mispec_mfcc_tail_f32",
     "mispec_power_to_db_bwd_f32",
     "mispec_contract_planar_f32",
     "mispec_pad_signal_f32",
@@ -424,6 +425,11 @@ def _load(path, how):
     lib.mispec_power_to_db_bwd_f32.argtypes = [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float,
         ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+    ]
+    lib.mispec_mfcc_tail_f32.restype = ctypes.c_int
+    lib.mispec_mfcc_tail_f32.argtypes = [
+        ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
+        ctypes.c_float, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
     ]
     lib.mispec_power_to_db_f32.restype = ctypes.c_int
     lib.mispec_power_to_db_f32.argtypes = [

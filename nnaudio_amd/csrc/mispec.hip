@@ -1744,6 +1744,103 @@ __global__ void __launch_bounds__(256) power_to_db_kernel(const float *__restric
   }
 }
 
+// MFCC's tail in one launch (mel.py:263-307): power_to_db with the per-clip maximum, then the DCT -- one workgroup
+// per clip.  Pass 1 reads the clip's mel spectrogram for its maximum (the floor of top_db), pass 2 walks it in
+// tiles of 64 frames: n_mels x 64 decibel values in LDS (the same expressions as power_to_db_kernel), contracted
+// with the (n_mfcc, n_mels) cosine matrix: wave w takes coefficients KK w .. KK w + KK - 1 (+ 8 KK ..), lane = frame;
+// a wave's weights are uniform -- scalar loads straight from the matrix (10 KB: scalar cache / L2), no LDS, no VALU.
+// The second read of the clip comes out of L2 (~100 KB).  Replaces clear + clip_max + power_to_db + the filterbank
+// GEMM: four launches on a 28 MB tensor.  Few clips: several workgroups per clip (blockIdx.y), each with a share of
+// the tiles and its own pass 1.
+constexpr int MFCC_TT = 64;
+template <int KK>
+__global__ void __launch_bounds__(512, 6) mfcc_tail_kernel(const float *__restrict__ spec, int n_mels, int n_frames,
+                                                           float amin, float ref, float top_db,
+                                                           const float *__restrict__ dct, int n_mfcc,
+                                                           float *__restrict__ out, int tiles_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float *const s_tile = reinterpret_cast<float *>(smem_raw);  // [n_mels][MFCC_TT]
+  __shared__ float s_red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long clip_elems = (long long)n_mels * n_frames;
+  // blockIdx.y: a share of the clip's tiles (few clips: several workgroups per clip, each finds the maximum itself)
+  const float *const s = spec + (long long)blockIdx.x * clip_elems;
+  float *const o = out + (long long)blockIdx.x * n_mfcc * n_frames;
+  const int t_first = blockIdx.y * tiles_per_wg * MFCC_TT;
+  const int t_last = t_first + tiles_per_wg * MFCC_TT < n_frames ? t_first + tiles_per_wg * MFCC_TT : n_frames;
+  const float off = 10.0f * log10f(fmaxf(amin, ref));
+  float floor_db = -INFINITY;
+  if (top_db >= 0.f) {
+    // (many loads in flight per thread: a loop of single dependent-looking loads runs at one memory latency per trip)
+    float m = amin;
+    const long long n4 = (reinterpret_cast<uintptr_t>(s) & 15) == 0 ? clip_elems / 4 : 0;
+    const f32x4v *const s4 = reinterpret_cast<const f32x4v *>(s);
+    long long i = tid;
+    for (; i + 3 * 512 < n4; i += 4 * 512) {
+      const f32x4v a = s4[i], b = s4[i + 512], c4 = s4[i + 1024], d = s4[i + 1536];
+      m = fmaxf(m, fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3]))));
+      m = fmaxf(m, fmaxf(fmaxf(fmaxf(c4[0], c4[1]), fmaxf(c4[2], c4[3])), fmaxf(fmaxf(d[0], d[1]), fmaxf(d[2], d[3]))));
+    }
+    for (; i < n4; i += 512) {
+      const f32x4v a = s4[i];
+      m = fmaxf(m, fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])));
+    }
+    for (long long j = 4 * n4 + tid; j < clip_elems; j += 512) m = fmaxf(m, s[j]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if (lane == 0) s_red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3])), fmaxf(fmaxf(s_red[4], s_red[5]), fmaxf(s_red[6], s_red[7])));
+    floor_db = (10.0f * log10f(m) - off) - top_db;
+  }
+  const int m8 = n_mels & ~7;
+  for (int t0 = t_first; t0 < t_last; t0 += MFCC_TT) {
+    if (t0 != t_first) __syncthreads();  // (the previous tile has been contracted)
+    for (int i0 = tid; i0 < n_mels * MFCC_TT; i0 += 8 * 512) {  // (eight loads in flight per thread)
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = i0 + 512 * u, m = idx >> 6, t = idx & 63;
+        v[u] = (idx < n_mels * MFCC_TT && t0 + t < n_frames) ? s[(long long)m * n_frames + t0 + t] : amin;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = i0 + 512 * u;
+        if (idx < n_mels * MFCC_TT) s_tile[idx] = fmaxf(10.0f * log10f(fmaxf(v[u], amin)) - off, floor_db);
+      }
+    }
+    __syncthreads();
+    for (int k0 = KK * wave; k0 < n_mfcc; k0 += 8 * KK) {  // (wave-uniform)
+      float acc[KK];
+      const float *d[KK];
+#pragma unroll
+      for (int e = 0; e < KK; ++e) {
+        acc[e] = 0.f;
+        d[e] = dct + (long long)(k0 + e < n_mfcc ? k0 + e : n_mfcc - 1) * n_mels;  // (rows past the end: computed, not stored)
+      }
+      for (int m = 0; m < m8; m += 8) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = s_tile[(m + u) * MFCC_TT + lane];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int e = 0; e < KK; ++e) acc[e] = fmaf(d[e][m + u], x[u], acc[e]);
+      }
+      for (int m = m8; m < n_mels; ++m) {
+        const float x = s_tile[m * MFCC_TT + lane];
+#pragma unroll
+        for (int e = 0; e < KK; ++e) acc[e] = fmaf(d[e][m], x, acc[e]);
+      }
+      if (t0 + lane < n_frames) {
+#pragma unroll
+        for (int e = 0; e < KK; ++e)
+          if (k0 + e < n_mfcc) o[(long long)(k0 + e) * n_frames + t0 + lane] = acc[e];
+      }
+    }
+  }
+}
+
 // power_to_db backward.  Elements above the per-clip floor pass their gradient through the
 // logarithm; the floored ones hand theirs to the clip maximum (out = max(l, max(l) - top_db)).
 __global__ void __launch_bounds__(256) power_to_db_floor_sum_kernel(
@@ -3929,6 +4026,41 @@ int mispec_power_to_db_f32(const float *spec, int32_t n_clips, int64_t clip_elem
   }
   hipLaunchKernelGGL(power_to_db_kernel, grid, dim3(256), 0, s, spec, (long long)clip_elems, amin,
                      fabsf(ref), top_db, wmax, out);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+
+int mispec_mfcc_tail_f32(const float *mel, int32_t n_clips, int32_t n_mels, int32_t n_frames, float amin, float ref,
+                         float top_db, const float *dct, int32_t n_mfcc, float *out, void *stream) {
+  if (!mel || !dct || !out) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
+  if (n_clips <= 0 || n_mels <= 0 || n_frames <= 0 || n_mfcc <= 0) return fail(MISPEC_E_INVALID, "non-positive size%s");
+  if (!(amin > 0.f)) return fail(MISPEC_E_INVALID, "amin must be strictly positive%s");
+  if (mel == out) return fail(MISPEC_E_INVALID, "out must not alias mel%s");
+  const size_t smem = (size_t)n_mels * MFCC_TT * sizeof(float);
+  // workgroups: one per clip and share of its 64-frame tiles, about four per CU
+  const int n_tiles = (n_frames + MFCC_TT - 1) / MFCC_TT;
+  long long shares = (4LL * device_cus() + n_clips - 1) / n_clips;
+  shares = shares < 1 ? 1 : (shares > n_tiles ? n_tiles : shares);
+  const int tiles_per_wg = (int)((n_tiles + shares - 1) / shares);
+  const unsigned grid_y = (unsigned)((n_tiles + tiles_per_wg - 1) / tiles_per_wg);
+  if (n_mfcc > n_mels || smem > 64 * 1024)
+    return fail(MISPEC_E_UNSUPPORTED, "MFCC tail: at most 256 mel bands (a 64-frame tile in 64 KB of LDS), n_mfcc <= n_mels%s");
+  const int kk = n_mfcc >= 25 ? 4 : (n_mfcc + 7) / 8;  // coefficients per wave and trip: 8 waves x kk cover n_mfcc when it is small
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define MISPEC_MFCC_TAIL(KK)                                                                                          \
+  {                                                                                                                   \
+    static std::atomic<unsigned long long> configured{0};                                                             \
+    int rc = configure_lds(mfcc_tail_kernel<KK>, 64 * 1024, configured);                                              \
+    if (rc != MISPEC_OK) return rc;                                                                                   \
+    hipLaunchKernelGGL(mfcc_tail_kernel<KK>, dim3((unsigned)n_clips, grid_y), dim3(512), smem, st, mel, n_mels,       \
+                       n_frames, amin, fabsf(ref), top_db, dct, n_mfcc, out, tiles_per_wg);                           \
+  }
+  if (kk <= 1) MISPEC_MFCC_TAIL(1)
+  else if (kk == 2) MISPEC_MFCC_TAIL(2)
+  else if (kk == 3) MISPEC_MFCC_TAIL(3)
+  else MISPEC_MFCC_TAIL(4)
+#undef MISPEC_MFCC_TAIL
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
   return MISPEC_OK;

@@ -940,6 +940,43 @@ def power_to_db(spec, amin, ref, top_db):
     return out
 
 
+_mfcc_fused = True
+
+
+def set_mfcc_fused(enabled):
+    """MFCC's tail (power_to_db + DCT) as ONE launch where no gradient is recorded (``mispec_mfcc_tail_f32``);
+    ``False`` keeps the two calls.  Returns the previous setting."""
+    global _mfcc_fused
+    old, _mfcc_fused = _mfcc_fused, bool(enabled)
+    return old
+
+
+def mfcc_tail(mel, amin, ref, top_db, dct):
+    """``power_to_db`` followed by the DCT (mel.py:263-307) in one launch: (B, n_mels, T) -> (B, n_mfcc, T), or
+    None when the library does not serve the shape (the caller then makes the two calls)."""
+    if not _mfcc_fused or not mel.is_cuda or mel.dim() != 3:
+        return None
+    if top_db is not None and top_db < 0:
+        raise ValueError("top_db must be non-negative")
+    mel = _f32(mel, "spectrogram").contiguous()
+    dct = _f32(dct, "dct").contiguous()
+    B, M, T = mel.shape
+    K = dct.shape[0]
+    if dct.dim() != 2 or dct.shape[1] != M or dct.device != mel.device:
+        return None
+    out = torch.empty((B, K, T), dtype=torch.float32, device=mel.device)
+    lib = _abi.load()
+    with torch.cuda.device(mel.device):
+        stream = torch.cuda.current_stream(mel.device).cuda_stream
+        rc = lib.mispec_mfcc_tail_f32(mel.data_ptr(), B, M, T, float(amin), float(ref),
+                                      -1.0 if top_db is None else float(top_db), dct.data_ptr(), K, out.data_ptr(),
+                                      ctypes.c_void_p(stream))
+    if rc == _abi.E_UNSUPPORTED:
+        return None
+    _abi.check(rc)
+    return out
+
+
 class _PowerToDbFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, spec, amin, ref, top_db):

@@ -90,6 +90,11 @@ class MFCC(nn.Module):
         spec = self.melspec_layer(x)
         if self.top_db is not None and self.top_db < 0:
             raise ParameterError("top_db must be non-negative")
+        if spec.is_cuda and not engine.compiling() and not (torch.is_grad_enabled() and spec.requires_grad):
+            # nothing to differentiate: decibels + DCT in one launch (mispec_mfcc_tail_f32)
+            y = engine.mfcc_tail(spec, self._amin_f, self._ref_f, self.top_db, self._dct_basis)
+            if y is not None:
+                return y
         db = engine.power_to_db_autograd(spec, self._amin_f, self._ref_f, self.top_db)
         return engine.filterbank_autograd(self._dct_basis, db)
 

@@ -238,6 +238,36 @@ def test_fused_filterbank_on_the_fft_route_matches_two_kernels():
         assert float((y - g).abs().max() / g.abs().max()) <= 1e-5, cls.__name__
 
 
+@pytest.mark.parametrize("kw,shape,fused", [
+    (dict(sr=22050, n_mfcc=20, n_fft=1024, n_mels=128, hop_length=512), (5, 30000), True),
+    (dict(sr=16000, n_mfcc=13, n_fft=512, n_mels=40, hop_length=160, top_db=None), (3, 16000), True),
+    (dict(sr=44100, n_mfcc=40, n_fft=2048, n_mels=229, hop_length=512, top_db=30.0), (2, 50000), True),
+    (dict(sr=22050, n_mfcc=128, n_fft=1024, n_mels=128, hop_length=256), (2, 20000), True),   # as many coefficients as bands
+    (dict(sr=44100, n_mfcc=30, n_fft=2048, n_mels=300, hop_length=512), (2, 30000), False),    # > 256 bands: the two calls
+])
+def test_mfcc_tail_in_one_launch(kw, shape, fused):
+    """MFCC without a gradient to record: power_to_db + DCT as one launch (mispec_mfcc_tail_f32) == the two calls."""
+    from nnaudio_amd import engine, features
+
+    m = features.MFCC(verbose=False, **kw).to(DEV)
+    x = torch.as_tensor(np.random.default_rng(7).standard_normal(shape).astype(np.float32)).to(DEV)
+    x[0, : shape[1] // 3] *= 1e-4  # (a quiet stretch: the top_db floor is active)
+    with torch.no_grad():
+        y = m(x)
+        old = engine.set_mfcc_fused(False)
+        try:
+            r = m(x)
+        finally:
+            engine.set_mfcc_fused(old)
+    assert y.shape == r.shape
+    assert torch.equal(y, r) != fused, "fused launch %staken" % ("not " if fused else "")
+    assert float((y - r).abs().max()) <= 2e-6 * float(r.abs().max())
+    # with a gradient to record the two calls run (and agree)
+    xg = x.clone().requires_grad_(True)
+    yg = m(xg)
+    assert float((yg.detach() - r).abs().max()) <= 2e-6 * float(r.abs().max())
+
+
 @pytest.mark.parametrize("fmt", ["Magnitude", "Complex"])
 def test_backward_through_the_fft_route(fmt):
     """d loss / d waveform of a frozen STFT whose forward ran on the FFT path (the backward contracts with the

@@ -6,7 +6,7 @@ mkdir -p gpurun_out/r04_summaries
 python bench.py > gpurun_out/r04_summaries/bench_r04.log 2>&1
 tail -1 gpurun_out/r04_summaries/bench_r04.log > gpurun_out/r04_summaries/bench_r04.json
 cp bench_detail.json gpurun_out/r04_summaries/bench_detail_r04.json 2>/dev/null
-for WP in "stft auto fft" "cqt2010 auto stream" "vqt auto stream" "cqt f16x3 f16x3" "mel auto fft"; do
+for WP in "stft auto fft" "cqt2010 auto stream" "vqt auto stream" "cqt f16x3 f16x3" "mel auto fft" "mfcc auto fft"; do
   set -- $WP
   bash scripts/profile.sh r04_$1_$3 $1 $2 > /dev/null 2>&1
   cp gpurun_out/prof_r04_$1_$3/summary/*.txt gpurun_out/r04_summaries/rocprofv3_$1_$3_summary.txt

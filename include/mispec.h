@@ -195,7 +195,8 @@ typedef struct mispec_framed_gemm_args {
    * this (basis_re, basis_im, n_bins, kernel) in this `precision`; the CALLER vouches that the basis
    * has that form (the routine reports how far it is from it).  fold2_wmax = max |w| (stats[2]).  Used
    * when the shape allows (kernel % 64 == 0, 128 .. 8192, >= 128 bins, hop >= kernel/8, no supports / row
-   * scale / fused filterbank, automatic tile); takes precedence over basis_fold. */
+   * scale / fused filterbank, automatic tile); takes precedence over basis_fold.  It also opens the FFT path
+   * (mispec_framed_gemm_f32 below), which has none of these shape conditions but kernel = 256 .. 2048. */
   const void *basis_fold2;     /* or NULL                                                  */
   int64_t basis_fold2_bytes;
   float fold2_wmax;
@@ -312,7 +313,12 @@ int mispec_fold2_basis(const float *basis_re, const float *basis_im, int64_t bas
                        float *stats, void *stream);
 
 /* Launch the MFMA framed contraction.  Replaces stft.py:278-316, cqt.py:740-780,
- * utils.py:498-521 (one call per octave).                                             */
+ * utils.py:498-521 (one call per octave).
+ * The FFT path: with basis_fold2 (the proof that the kernels are window x DFT), kernel = 256, 512, 1024 or 2048,
+ * n_bins <= kernel/2 + 1, a pointwise epilogue (with or without the fused filterbank), automatic tile and
+ * no_fft == 0 the call is ONE launch that evaluates every frame's DFT as an fp32 FFT (2e-7 of the peak) whatever
+ * `precision` says -- no workspace, nothing else of the argument block changes meaning.  kernel = 256 runs as
+ * zero-extended frames on the 512-point transform.                                                        */
 int mispec_framed_gemm_f32(const mispec_framed_gemm_args *args, void *stream);
 
 /* `n` (<= 8) independent contractions in ONE launch: the octaves of CQT2010v2 / VQT

@@ -246,8 +246,8 @@ __global__ void __launch_bounds__(OS_THREADS, 1) octave_stream_kernel(const OsPa
   for (int i = tid; i < p.n_taps; i += OS_THREADS) s_taps[i] = p.taps[i];
   __syncthreads();
 
-  // ---- streaming of level 0, by four of the waves (the FIR waves, after their columns: p.ingest_fir).  Thread
-  // ct of them owns samples 16 ct .. 16 ct + 15 of every chunk; the raw floats land in the staging buffer
+  // ---- streaming of level 0 in quarters of a chunk (who takes them: p.ingest_mode).  Thread ct of the four quarters
+  // owns samples 16 ct .. 16 ct + 15 of every chunk; the raw floats land in the staging buffer
   // as [wave][piece][lane] 16-byte pieces (LDS-direct loads), a step before they are split.
   // F16 operand scale: the chunk that is split in step g-1 publishes its largest |sample|; step g -- its first
   // consumer -- starts by comparing it with the range of the current scale and, when it is louder (rare),
@@ -986,7 +986,7 @@ int os_plan(const mispec_octave_stream_args *a, int n_cus, OsPlan &pl) {
   p.nf = OS_CHUNK / a->hop;
   // the FIR waves take the ingest: with it the bank waves' chain (check, tiles) and theirs (check, columns,
   // ingest) are 1.8 and 2.5 us of a step; on the bank waves they were 2.7 and 1.7 (first launch of the cfg5 shard
-  // 245 -> 223 us, second 95 -> 92; MISPEC_INGEST_FIR=0 in the benchmarking build switches back)
+  // 245 -> 223 us, second 95 -> 92; MISPEC_INGEST_MODE=0 in the benchmarking build switches back).  Mode 2 below.
   p.ingest_mode = 1;
   p.span = p.nf >= 16 ? 1 : 16 / p.nf;
   p.n_frames = a->n_frames;

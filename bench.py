@@ -804,8 +804,9 @@ def main():
         "roofline": roofline_block(
             meta, kern_s, prec,
             kernel=("one step = ONE launch of stft_fft_kernel (fp32 FFT per frame, no pre-pass, no workspace); achieved = "
-                    "algorithmic bytes (clips in + spectrogram out + the reference's two bases, SURVEY 8d) / step device "
-                    "time against the 8 TB/s HBM peak; the matrix-pipe rooflines of the contraction kernels are under paths")
+                    "algorithmic bytes (clips in + spectrogram out + the reference's two bases, SURVEY 8d; the 16.8 MB of "
+                    "bases are counted but never read by this kernel: on the 339 MB it moves the fraction is 0.95 x this) / step "
+                    "device time against the 8 TB/s HBM peak; the matrix-pipe rooflines of the contraction kernels are under paths")
             if prec == "fft" else
                    "one step = pre-pass + main contraction; achieved = EXECUTED MFMA flops (the folded kernels run "
                    "a quarter of the dense taps, x 3 MFMAs per product for the split arithmetics) / step device "

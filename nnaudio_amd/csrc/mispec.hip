@@ -4038,14 +4038,14 @@ int mispec_mfcc_tail_f32(const float *mel, int32_t n_clips, int32_t n_mels, int3
   if (!(amin > 0.f)) return fail(MISPEC_E_INVALID, "amin must be strictly positive%s");
   if (mel == out) return fail(MISPEC_E_INVALID, "out must not alias mel%s");
   const size_t smem = (size_t)n_mels * MFCC_TT * sizeof(float);
+  if (n_mfcc > n_mels || smem > 64 * 1024)
+    return fail(MISPEC_E_UNSUPPORTED, "MFCC tail: at most 256 mel bands (a 64-frame tile in 64 KB of LDS), n_mfcc <= n_mels%s");
   // workgroups: one per clip and share of its 64-frame tiles, about four per CU
   const int n_tiles = (n_frames + MFCC_TT - 1) / MFCC_TT;
   long long shares = (4LL * device_cus() + n_clips - 1) / n_clips;
   shares = shares < 1 ? 1 : (shares > n_tiles ? n_tiles : shares);
   const int tiles_per_wg = (int)((n_tiles + shares - 1) / shares);
   const unsigned grid_y = (unsigned)((n_tiles + tiles_per_wg - 1) / tiles_per_wg);
-  if (n_mfcc > n_mels || smem > 64 * 1024)
-    return fail(MISPEC_E_UNSUPPORTED, "MFCC tail: at most 256 mel bands (a 64-frame tile in 64 KB of LDS), n_mfcc <= n_mels%s");
   const int kk = n_mfcc >= 25 ? 4 : (n_mfcc + 7) / 8;  // coefficients per wave and trip: 8 waves x kk cover n_mfcc when it is small
   hipStream_t st = static_cast<hipStream_t>(stream);
 #define MISPEC_MFCC_TAIL(KK)                                                                                          \

@@ -117,6 +117,11 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     # argument validation happens before any device work: every entry refuses NULL / bad sizes
     assert lib.mispec_power_to_db_f32(None, 1, 1, 1e-10, 1.0, 80.0, None, None, 0, None) == -1
     assert lib.mispec_power_to_db_bwd_f32(None, None, 1, 1, 1e-10, 80.0, None, None, 0, None) == -1
+    assert lib.mispec_mfcc_tail_f32(None, 1, 128, 10, 1e-10, 1.0, 80.0, None, 20, None, None) == -1
+    assert lib.mispec_mfcc_tail_f32(4096, 1, 128, 10, 0.0, 1.0, 80.0, 8192, 20, 12288, None) == -1 and b"amin" in lib.mispec_last_error()
+    assert lib.mispec_mfcc_tail_f32(4096, 1, 128, 10, 1e-10, 1.0, 80.0, 8192, 20, 4096, None) == -1 and b"alias" in lib.mispec_last_error()
+    assert lib.mispec_mfcc_tail_f32(4096, 1, 300, 10, 1e-10, 1.0, 80.0, 8192, 20, 12288, None) == -2 and b"256 mel bands" in lib.mispec_last_error()
+    assert lib.mispec_mfcc_tail_f32(4096, 1, 16, 10, 1e-10, 1.0, 80.0, 8192, 20, 12288, None) == -2  # n_mfcc > n_mels
     assert lib.mispec_istft_grad_signal_f32(None, 0, 1, 1, 1, None, 1, 0, 1, None, None) == -1
     assert lib.mispec_overlap_add_f32(None, 1, 1, 1, None, 1, 0, None, 0, 1, None) == -1
     assert lib.mispec_basis_split_bytes(0, 16, 1) == -1 and lib.mispec_basis_split_bytes(4, 48, 0) == 2 * 4 * 64 * 2
@@ -201,6 +206,7 @@ def test_cpu_tensors_take_the_host_path_or_fail_loudly():
     # MFCC and the inverse STFT have host loops too (round 4): forward of CPU tensors, no gradients
     c = features.MFCC(sr=16000, n_mfcc=13, n_fft=256, n_mels=32, hop_length=64, verbose=False)(torch.ones(1, 4000))
     assert tuple(c.shape) == (1, 13, 63) and c.device.type == "cpu" and bool(torch.isfinite(c).all())
+    assert engine.mfcc_tail(torch.ones(1, 32, 63), 1e-10, 1.0, 80.0, torch.ones(13, 32)) is None  # (the one-launch tail is a device kernel)
     inv = features.STFT(n_fft=64, hop_length=16, iSTFT=True, verbose=False)
     xr = torch.randn(2, 640, generator=torch.Generator().manual_seed(0))
     back = inv.inverse(inv(xr), length=640)

@@ -826,8 +826,11 @@ def main():
                 ("cqt2010", "bf16x3", None), ("cqt2010", "fp32", None),
                 ("mel", "f16x3", None), ("gammatone", "f16x3", None),  # (the contraction kernels, FFT off)
                 ("mfcc", None, None), ("istft", None, None)]
-        if world > 1:  # cfg4's real shard: 128 clips over 8 ranks
-            jobs.append(("cqt", "f16x3", 16))
+        if world > 1:
+            # N > 1: the per-GPU numbers above are the N = 1 line's business (every rank would repeat them, each with
+            # its barriers and reductions: minutes of wall time and thirteen more places for one rank to fall out of
+            # step with the others); what N ranks add is cfg4's real shard (128 clips over 8 ranks) and the gathers below
+            jobs = [("cqt", "f16x3", 16)]
         for name, pr2, b2 in jobs:
             if name == args.workload:
                 continue

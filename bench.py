@@ -713,7 +713,7 @@ def main():
 
             _, d = timed_steps(_F(), x, args.steps, 2, sync)
             per = d / args.steps
-            return {"name": "stft_fft_kernel<1024, MISPEC_EPI_MAGNITUDE> (fp32 radix-16/16/4 FFT of every frame on the "
+            return {"name": "stft_fft_kernel<1024, 1, false> (M = n_fft / 2, MISPEC_EPI_MAGNITUDE, no filterbank: fp32 radix-16/16/4 FFT of every frame on the "
                             "vector ALUs, one wave per frame, tile transposed through LDS)",
                     "avg_ms": per * 1e3, "algorithmic_bytes": meta["bytes"],
                     "achieved_GBps": meta["bytes"] / per / 1e9, "frac_of_hbm_peak": meta["bytes"] / per / PEAK_HBM}

@@ -52,7 +52,7 @@ def _canned(n_gpus=1):
     blk = dict(bench.roofline_block(dict(flops=4.632e11, bytes=3.559e8, bound="hbm", executed=None), 0.159e-3, "fft",
                                     traffic=3.6e8, kernel=prose),
                traffic_detail={"fetch_bytes": 1.2e8, "write_bytes": 2.4e8, "per_kernel": pk, "method": prose},
-               dominant_kernel={"name": "stft_fft_kernel<1024, MISPEC_EPI_MAGNITUDE> (" + prose + ")", "avg_ms": 0.159})
+               dominant_kernel={"name": "stft_fft_kernel<1024, 1, false> (" + prose + ")", "avg_ms": 0.159})
     path = {"frames_per_s": 1.0687613104232763e8, "ms_per_step": 0.5161863501416519, "step_device_ms": 0.515954475402832,
             "algorithmic_tflops": 897.82, "algorithmic_frac": 1.0773849658848194, "mfma_frac": 0.2690834646502573,
             "hbm_frac_on_algorithmic_bytes": 0.08621845941983243, "dominant_kernel": dict(name=prose, avg_ms=0.5),
@@ -96,7 +96,7 @@ def test_line_is_small(n_gpus, tmp_path, capsys):
         assert k in d, k
     assert d["config"]["workload"].startswith("STFT n_fft=2048 hop=512")
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
-    assert d["roofline"]["dominant_kernel"]["name"] == "stft_fft_kernel<1024, MISPEC_EPI_MAGNITUDE>"
+    assert d["roofline"]["dominant_kernel"]["name"] == "stft_fft_kernel<1024, 1, false>"
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"])
     assert set(d["paths"]) == {"fft", "f16x3", "bf16x3", "fp32"} and "mfma_frac" in d["paths"]["f16x3"]
     assert "cqt2010" in d["extra"] and "ms_per_step" in d["extra"]["cqt2010"]

@@ -539,10 +539,10 @@ def compact_line(out):
         for k, v in out["paths"].items():
             if isinstance(v, dict):
                 line["paths"][k] = _pick(v, ("ms_per_step", "mfma_frac", "hbm_frac_on_algorithmic_bytes"))
-    if "roofline_cqt84" in out:
-        b = out["roofline_cqt84"]
-        line["roofline_cqt84"] = _pick(b, ("precision", "ms_per_step", "frames_per_s", "bound", "achieved", "peak",
-                                            "unit", "frac", "algorithmic_frac", "traffic", "default_module"))
+    for k84 in ("roofline_cqt84", "roofline_cqt84_f16x3"):  # the module as it ships (default_module: true) / the opt-in arithmetic
+        if k84 in out:
+            line[k84] = _pick(out[k84], ("precision", "default_module", "ms_per_step", "frames_per_s", "bound", "achieved", "peak",
+                                         "unit", "frac", "algorithmic_frac", "traffic"))
     if "extra" in out:
         line["extra"] = {}
         for k, v in out["extra"].items():
@@ -556,6 +556,8 @@ def compact_line(out):
             e.update(_pick(blk, ("frac", "traffic")))
             if blk.get("bound"):
                 e["bound"] = blk["bound"]
+            if not blk:  # (records priced in place: the training step)
+                e.update(_pick(v, ("frac", "bound", "forward_only_ms", "precision")))
             line["extra"][k] = e
     if "gather" in out:
         g = out["gather"]
@@ -821,7 +823,7 @@ def main():
         del x
         torch.cuda.empty_cache()
         n2 = max(20, args.steps)  # every extra under the headline's rules: pre-warm + >= 20 steps
-        jobs = [("cqt", "f16x3", None), ("cqt", "bf16x3", None), ("cqt", "fp32", None),
+        jobs = [("cqt", None, None), ("cqt", "f16x3", None), ("cqt", "bf16x3", None),
                 ("mel", None, None), ("gammatone", None, None), ("cqt2010", None, None), ("vqt", None, None),
                 ("cqt2010", "bf16x3", None), ("cqt2010", "fp32", None),
                 ("mel", "f16x3", None), ("gammatone", "f16x3", None),  # (the contraction kernels, FFT off)
@@ -847,20 +849,72 @@ def main():
                 blk = roofline_block(me2, d2 / n2, pr)
                 r2.update(workload=me2["tag"], precision=pr, steps=n2, roofline=blk)
                 extra[key] = r2
-                if name == "cqt" and pr == "f16x3" and not b2:
-                    blk["kernel"] = ("one step = clip absmax + split pre-passes + framed_f16x3_strip_kernel; achieved = "
-                                     "executed MFMA flops (16-bin row tiles over the tap range of their longest bin) / "
+                if name == "cqt" and not b2 and (pr2 is None or pr2 == "f16x3"):
+                    # CQT84 is the other half of BASELINE.json's metric.  roofline_cqt84 is the module AS IT SHIPS
+                    # (default precision: fp32, the only arithmetic near the reference's own fixture bar -- the
+                    # reference's conv1d misses 0 % of its log-magnitude fixture on this MI355X and on the CPU, fp32
+                    # 0.03 %, f16x3 2.7 %: tests/test_gpu_reference_order.py); roofline_cqt84_f16x3 is the opt-in
+                    # `module.precision = "f16x3"` (4.7e-7 of the peak against float64: inside north_star's 1e-4).
+                    default = pr2 is None
+                    blk["kernel"] = (("one step = edge pre-pass + framed_gemm_kernel (fp32 MFMA tile kernel, support-aware row tiles); "
+                                      if pr == "fp32" else
+                                      "one step = clip absmax + split pre-passes + framed_%s_strip_kernel; " % pr) +
+                                     "achieved = executed MFMA flops (row tiles over the tap range of their longest bin) / "
                                      "step device time; algorithmic = useful (support-aware) flops 2*2*sum(lenghts) per frame")
-                    out["roofline_cqt84"] = dict(blk, workload=me2["tag"], precision=pr,
-                                                 frames_per_s=r2["frames_per_s"],
-                                                 ms_per_step=r2["ms_per_step"], steps=n2)
-                    traffic_jobs.append(("cqt", "f16x3", out, "roofline_cqt84"))
+                    key84 = "roofline_cqt84" if default else "roofline_cqt84_f16x3"
+                    out[key84] = dict(blk, workload=me2["tag"], precision=pr, default_module=default,
+                                      frames_per_s=r2["frames_per_s"], ms_per_step=r2["ms_per_step"], steps=n2)
+                    traffic_jobs.append(("cqt", pr2, out, key84))
                 elif pr2 is None and name != "istft":  # (its input is made by a forward STFT inside the profiled process)
                     traffic_jobs.append((name, forced, extra[key], "roofline"))
                 del m2, x2
                 torch.cuda.empty_cache()
             except Exception as e:  # extras must never take the primary number down
                 extra[key] = {"error": repr(e)}
+        if world == 1 and args.workload == "stft":
+            # A TRAINING step: nnAudio's selling point is trainable bases (stft.py:238-242).  STFT(trainable=True) on cfg2's
+            # batch, Magnitude, loss.backward(): forward on the dense contraction kernels (trained kernels are not window x
+            # DFT: no FFT route, no folds) + the epilogue adjoint + the d-basis contraction (frames x output); x needs no grad.
+            for tkey, tprec in (("stft_trainable_fwd_bwd", None), ("stft_trainable_fwd_bwd_fp32", "fp32")):
+                try:
+                    from nnaudio_amd import features
+
+                    mt = features.STFT(n_fft=2048, hop_length=512, window="hann", output_format="Magnitude", trainable=True,
+                                       verbose=False).to(device)
+                    mt.precision = tprec
+                    xt = make_input(200 + rank)
+                    nt = max(5, min(20, args.steps // 10))
+
+                    def train_step():
+                        mt.zero_grad(set_to_none=True)
+                        mt(xt).mean().backward()
+
+                    for _ in range(3):
+                        train_step()
+                    sync()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    t0 = time.perf_counter()
+                    e0.record()
+                    for _ in range(nt):
+                        train_step()
+                    e1.record()
+                    sync()
+                    wt, dt = time.perf_counter() - t0, e0.elapsed_time(e1) * 1e-3
+                    with torch.no_grad():
+                        t_fwd = timed_steps(mt, xt, nt, 2, sync)[1] / nt
+                    fl = 2.0 * meta["flops"]  # forward + d basis, each the dense contraction (2 flop per tap)
+                    pr_t = tprec or "f16x3"  # (the STFT module's default arithmetic on the contraction route)
+                    extra[tkey] = {"ms_per_step": wt / nt * 1e3, "step_device_ms": dt / nt * 1e3, "forward_only_ms": t_fwd * 1e3,
+                                   "steps": nt, "frames_per_s": meta["frames"] * nt / wt, "precision": pr_t,
+                                   "algorithmic_flops": fl, "algorithmic_tflops": fl / (dt / nt) / 1e12,
+                                   "frac": fl / (dt / nt) / PEAK[pr_t], "bound": "mfma",
+                                   "what": "STFT(trainable=True) cfg2 batch, Magnitude: zero_grad + forward + mean().backward() "
+                                           "(d wsin, d wcos); algorithmic flops = forward + d-basis contraction, dense, against the "
+                                           "fp32-equivalent MFMA peak of the arithmetic"}
+                    del mt, xt
+                    torch.cuda.empty_cache()
+                except Exception as e:
+                    extra[tkey] = {"error": repr(e)}
         out["extra"] = extra
 
     # output reassembly over xGMI (RCCL all-gather), outside the reported value: the step with the

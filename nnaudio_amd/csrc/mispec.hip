@@ -3143,7 +3143,7 @@ int launch_fft_cfg(const KParams &p, hipStream_t stream) {
   const size_t smem = smem0 + (q.fb_lds_floats ? 2080 + (size_t)q.fb_lds_floats * 4 : 0);
   int rc = configure_lds(kern, 160 * 1024, configured);
   if (rc != MISPEC_OK) return rc;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(FFT_WAVES * 64), smem, stream, q, tiles_per_clip);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(fft_waves<M, W>() * 64), smem, stream, q, tiles_per_clip);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
   return MISPEC_OK;

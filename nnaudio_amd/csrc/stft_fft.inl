@@ -37,9 +37,23 @@ constexpr int FFT_WAVES = 8;
 // step is  request samples | store the previous tile | transform into the other buffer | ONE barrier  and the
 // stores drain under the transforms; the window pairs and post-processing factors then live in registers (the
 // second buffer takes their LDS).  Other instances: one buffer of 16 .. 64 frames, two barriers per tile.
+// (A/B builds, scripts/build_variant.py: MISPEC_FFT2048_MODE 1 = ONE tile buffer of 16 frames -- two frames per wave, 64-byte row
+// segments, two barriers per tile --, tables in registers as in mode 0; 2 = workgroups of FOUR waves, two frames each, one
+// 8-frame tile buffer, TWO workgroups per CU)
+#ifndef MISPEC_FFT2048_MODE
+#define MISPEC_FFT2048_MODE 0
+#endif
+template <int M, int W>
+constexpr int fft_waves() {  // waves of a workgroup (mode 2: FOUR, two frames each, and two workgroups per CU that drift apart)
+  return (M == 1024 && W == 1 && MISPEC_FFT2048_MODE == 2) ? 4 : FFT_WAVES;
+}
+template <int M, int W>
+constexpr bool fft_reg_tables() {  // window pairs and post-processing factors in registers (their LDS goes to the tiles)
+  return M == 1024 && W == 1;
+}
 template <int M, int W>
 constexpr bool fft_two_buffers() {
-  return M == 1024 && W == 1;  // (n_fft = 1024 with 2 x 16 frames: Mel cfg3 0.116 -> 0.121 ms, not kept)
+  return M == 1024 && W == 1 && MISPEC_FFT2048_MODE == 0;  // (n_fft = 1024 with 2 x 16 frames: Mel cfg3 0.116 -> 0.121 ms, not kept)
 }
 // Frames per tile of the one-buffer instances (FB: the instance with the fused filterbank).  Small tiles make
 // the workgroup small enough -- LDS and, with __launch_bounds__' second argument, 128 VGPRs -- for TWO
@@ -65,14 +79,14 @@ constexpr bool fft_two_buffers() {
 #endif
 template <int M, int W, bool FB = false>
 constexpr int fft_tile_row() {  // floats per tile row: the tile's frames x W + 2 of padding
-  return (M == 1024 ? FFT_WAVES
+  return (M == 1024 ? ((W == 1 && MISPEC_FFT2048_MODE == 1) ? 2 * FFT_WAVES : FFT_WAVES)
                     : M == 512 ? (FB ? MISPEC_FFT512_FT_FB : W == 1 ? MISPEC_FFT512_FT_W1 : MISPEC_FFT512_FT_W2)
                                : (FB ? MISPEC_FFT256_FT_FB : W == 1 ? MISPEC_FFT256_FT_W1 : MISPEC_FFT256_FT_W2)) * W + 2;
 }
 template <int M, int W, bool FB = false>
 constexpr size_t stft_fft_smem() {
   return (size_t)(fft_two_buffers<M, W>() ? 2 : 1) * (M + 1) * fft_tile_row<M, W, FB>() * 4 +
-         (size_t)FFT_WAVES * fftcore::padded_size<M>() * 8 + (fft_two_buffers<M, W>() ? 0 : 2 * (size_t)M * 8) +
+         (size_t)fft_waves<M, W>() * fftcore::padded_size<M>() * 8 + (fft_reg_tables<M, W>() ? 0 : 2 * (size_t)M * 8) +
          (size_t)fftcore::radix_of<M, 0>() * (fftcore::radix_of<M, 1>() - 1) * 8;  // (+ the twiddle table of pass 1)
 }
 template <int M, int W, bool FB = false>
@@ -81,7 +95,8 @@ constexpr bool fft_two_per_cu() {  // two workgroups fit the CU's 160 KB (FB: wi
 }
 template <int M, int EPI, bool FB>
 constexpr int fft_min_waves() {  // waves per SIMD the register allocation must leave room for
-  return fft_two_per_cu<M, (EPI == MISPEC_EPI_COMPLEX || EPI == MISPEC_EPI_PHASE_COSSIN) ? 2 : 1, FB>() ? 4 : 2;
+  constexpr int W = (EPI == MISPEC_EPI_COMPLEX || EPI == MISPEC_EPI_PHASE_COSSIN) ? 2 : 1;
+  return (fft_two_per_cu<M, W, FB>() ? 2 : 1) * fft_waves<M, W>() / 4;
 }
 
 // 16 bytes per lane, global -> LDS at m0 + 16 lane, as instructions: the loads of a frame stay invisible to
@@ -182,15 +197,17 @@ constexpr int fft_tile_frames() {
 // M = n_fft / 2; EPI = the epilogue (W = floats per output element: 2 for Complex / Phase as (cos, sin)); FB = with
 // the fused filterbank (p.fb; EPI = MISPEC_EPI_POWER)
 template <int M, int EPI, bool FB>
-__global__ void __launch_bounds__(FFT_WAVES * 64, (fft_min_waves<M, EPI, FB>()))
+__global__ void __launch_bounds__((fft_waves<M, (EPI == MISPEC_EPI_COMPLEX || EPI == MISPEC_EPI_PHASE_COSSIN) ? 2 : 1>() * 64), (fft_min_waves<M, EPI, FB>()))
     stft_fft_kernel(const KParams p, const int tiles_per_clip) {
   using namespace fftcore;
   constexpr int N = 2 * M, P = M / 64;
   constexpr int W = (EPI == MISPEC_EPI_COMPLEX || EPI == MISPEC_EPI_PHASE_COSSIN) ? 2 : 1;
   constexpr int FT = fft_tile_frames<M, W, FB>();  // frames per tile
-  constexpr int FPW = FT / FFT_WAVES;          // frames per wave and tile
+  constexpr int NW = fft_waves<M, W>();            // waves of the workgroup
+  constexpr int FPW = FT / NW;          // frames per wave and tile
   constexpr int C = fft_tile_row<M, W, FB>();  // floats per tile row (FT * W + 2)
   constexpr bool DB = fft_two_buffers<M, W>();
+  constexpr bool RT = fft_reg_tables<M, W>();
   constexpr int TILE_FLOATS = (M + 1) * C;     // rows 0 .. M (the Nyquist bin)
   constexpr int FFT_TILE_BYTES = (DB ? 2 : 1) * TILE_FLOATS * 4;
   static_assert(FPW >= 1 && (C & 1) == 0, "tile geometry");
@@ -208,14 +225,21 @@ __global__ void __launch_bounds__(FFT_WAVES * 64, (fft_min_waves<M, EPI, FB>()))
 
   // ---- window pairs (w[2m], w[2m+1]) and post-processing factors e^(-2 pi i k / N) / 2: per-workgroup tables,
   // or (two tile buffers) the lane's own in registers
-  cf *const s_win = reinterpret_cast<cf *>(smem_raw + FFT_TILE_BYTES) + FFT_WAVES * padded_size<M>();
+  cf *const s_win = reinterpret_cast<cf *>(smem_raw + FFT_TILE_BYTES) + NW * padded_size<M>();
   cf *const s_wh = s_win + M;
   typedef __attribute__((address_space(3))) void *lptr_t;
   const unsigned buf_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lptr_t)buf);
-  cf wn[DB ? P : 1], whr[DB ? P / 2 : 1];
-  if constexpr (DB) {
+  cf wn[RT ? P : 1], whr[RT ? P / 2 : 1];
+  if constexpr (RT) {
 #pragma unroll
     for (int i = 0; i < P; ++i) wn[i] = *reinterpret_cast<const cf *>(p.a_re + 2 * (lane + 64 * i));
+    // The window pairs are the only values of the tile loop that come from global LOADS the compiler knows about.
+    // Pin them here: hipcc's waitcnt pass otherwise carries "wn[i] may still be in flight" into the loop (the loop
+    // header merges the prologue's state) and places s_waitcnt vmcnt(6) / (2) / (0) in front of the window
+    // multiplications of EVERY frame -- i.e. right behind the hand-stated fft_wait_vm the wave waited for the
+    // flush's stores it had just issued (round 5: found in the ISA; the stores' acknowledgements take ~2 us).
+#pragma unroll
+    for (int i = 0; i < P; ++i) asm volatile("" : "+v"(wn[i]));
 #pragma unroll
     for (int i = 0; i < P / 2; ++i) {
       float sn, cs;
@@ -223,7 +247,7 @@ __global__ void __launch_bounds__(FFT_WAVES * 64, (fft_min_waves<M, EPI, FB>()))
       whr[i] = cf{0.5f * cs, 0.5f * sn};
     }
   } else {
-    for (int m = tid; m < M; m += FFT_WAVES * 64) {
+    for (int m = tid; m < M; m += NW * 64) {
       // row 0 of the cosine kernels is the window itself
       s_win[m] = m < half_taps ? *reinterpret_cast<const cf *>(p.a_re + 2 * m) : cf{0.f, 0.f};
       float sn, cs;
@@ -236,8 +260,8 @@ __global__ void __launch_bounds__(FFT_WAVES * 64, (fft_min_waves<M, EPI, FB>()))
   // factors (as registers they are 30 VGPRs of the N = 2048 instance, which then has no room to request the
   // next frame's samples while it transforms this one)
   constexpr int R0 = radix_of<M, 0>(), R1 = radix_of<M, 1>();
-  cf *const s_tw1 = DB ? s_win : s_wh + M;
-  for (int i = tid; i < R0 * (R1 - 1); i += FFT_WAVES * 64) {
+  cf *const s_tw1 = RT ? s_win : s_wh + M;
+  for (int i = tid; i < R0 * (R1 - 1); i += NW * 64) {
     const int k = i / (R1 - 1), r = i % (R1 - 1) + 1;
     float sn, cs;
     sincospif(-2.f * (float)(r * k) / (float)(R0 * R1), &sn, &cs);
@@ -283,7 +307,7 @@ __global__ void __launch_bounds__(FFT_WAVES * 64, (fft_min_waves<M, EPI, FB>()))
   // tile -> memory: a lane stores 4 floats of a row (4 / W frames)
   auto flush = [&](const float *tile, float *oc, int t0) __attribute__((always_inline)) {
     constexpr int LPR = FT * W / 4;               // lanes per row
-    constexpr int RPI = FFT_WAVES * 64 / LPR;     // rows per iteration
+    constexpr int RPI = NW * 64 / LPR;     // rows per iteration
     const int fl = (tid % LPR) * (4 / W), r0 = tid / LPR;  // first frame of the lane's quad
     if (t0 + fl < T && !MISPEC_DBG(p, 0x1)) {
       const bool whole = t0 + fl + 4 / W <= T;
@@ -312,7 +336,7 @@ __global__ void __launch_bounds__(FFT_WAVES * 64, (fft_min_waves<M, EPI, FB>()))
   float *const s_fbw = reinterpret_cast<float *>(s_fboff + 520);
   bool fb_packed = false;
   if (FB && p.fb_lds_floats > 0) {
-    for (int m = tid; m < p.n_fb; m += FFT_WAVES * 64) {
+    for (int m = tid; m < p.n_fb; m += NW * 64) {
       int lo = p.fb_support[2 * m], hi = p.fb_support[2 * m + 1];
       lo = lo < 0 ? 0 : lo;
       hi = hi > n_rows ? n_rows : hi;
@@ -332,7 +356,7 @@ __global__ void __launch_bounds__(FFT_WAVES * 64, (fft_min_waves<M, EPI, FB>()))
     __syncthreads();
     fb_packed = s_fboff[257] != 0;
     if (fb_packed) {
-      for (int m = wave; m < p.n_fb; m += FFT_WAVES) {
+      for (int m = wave; m < p.n_fb; m += NW) {
         int lo = p.fb_support[2 * m], hi = p.fb_support[2 * m + 1];
         lo = lo < 0 ? 0 : lo;
         hi = hi > n_rows ? n_rows : hi;
@@ -349,7 +373,7 @@ __global__ void __launch_bounds__(FFT_WAVES * 64, (fft_min_waves<M, EPI, FB>()))
   auto flush_fb = [&](const float *tile, float *oc, int t0) __attribute__((always_inline)) {
     if (MISPEC_DBG(p, 0x1)) return;
     if (fb_packed) {
-      for (int idx = tid; idx < p.n_fb * (FT / 2); idx += FFT_WAVES * 64) {
+      for (int idx = tid; idx < p.n_fb * (FT / 2); idx += NW * 64) {
         const int m = idx / (FT / 2), fl = 2 * (idx - m * (FT / 2));
         const int lo = s_fblo[m];
         const int nb = s_fboff[m + 1] - s_fboff[m];
@@ -365,7 +389,7 @@ __global__ void __launch_bounds__(FFT_WAVES * 64, (fft_min_waves<M, EPI, FB>()))
       }
       return;
     }
-    for (int idx = tid; idx < p.n_fb * FT; idx += FFT_WAVES * 64) {
+    for (int idx = tid; idx < p.n_fb * FT; idx += NW * 64) {
       const int m = idx / FT, fl = idx - m * FT;
       int lo = p.fb_support[2 * m], hi = p.fb_support[2 * m + 1];
       lo = lo < 0 ? 0 : lo;
@@ -385,9 +409,12 @@ __global__ void __launch_bounds__(FFT_WAVES * 64, (fft_min_waves<M, EPI, FB>()))
   }
   float *prev_oc = nullptr;  // the tile waiting to be stored
   int prev_t0 = 0, step = 0;
+  bool pre = false;          // the first frame of this wave in the coming tile has been requested already (see below)
   for (int it = blockIdx.x >> 3; it < per_xcd; it += (nwg + 7) >> 3) {
     const int tile_id = (blockIdx.x & 7) * per_xcd + it;
     if (tile_id >= n_tiles) continue;  // (workgroup-uniform)
+    // the tile after this one (tile ids grow with `it`: behind the first one past the end there is none)
+    const int tile_nx = (it + ((nwg + 7) >> 3) < per_xcd) ? tile_id + ((nwg + 7) >> 3) : n_tiles;
     const int c = tile_id / tiles_per_clip;
     const int t0 = (tile_id - c * tiles_per_clip) * FT;
     const float *const xc = p.x + (long long)c * p.x_clip_stride;
@@ -405,11 +432,12 @@ __global__ void __launch_bounds__(FFT_WAVES * 64, (fft_min_waves<M, EPI, FB>()))
       cf x[P];
       const bool live = t < T;
       const bool fast = u == 0 ? (live && pos0 >= 0 && pos0 + N <= L) : fast_n;
-      if (u == 0 && fast) {  // the frame as it lies in memory -> the wave's exchange buffer (idle here), 1 KB per instruction
+      if (u == 0 && fast && !pre) {  // the frame as it lies in memory -> the wave's exchange buffer (idle here), 1 KB per instruction
 #pragma unroll
         for (int j = 0; j < N / 256; ++j)
           fft_dma16((MISPEC_DBG(p, 0x40) ? p.x : xc + pos0) + 256 * j + 4 * lane, buf_lds + 1024 * j);  // (0x40: every frame = the first 8 KB)
       }
+      if (u == 0) pre = false;
       int younger = 0;  // store instructions this wave issues after the loads
       if (u == 0) {
         if (prev_oc) {
@@ -417,7 +445,7 @@ __global__ void __launch_bounds__(FFT_WAVES * 64, (fft_min_waves<M, EPI, FB>()))
             flush_fb(prev_tile, prev_oc, prev_t0);  // (its stores are not counted: the wait below then also covers them)
           } else {
             flush(prev_tile, prev_oc, prev_t0);
-            constexpr int LPR = FT * W / 4, RPI = FFT_WAVES * 64 / LPR;
+            constexpr int LPR = FT * W / 4, RPI = NW * 64 / LPR;
             const int r_min = wave * 64 / LPR;
             younger += (n_rows > r_min && !MISPEC_DBG(p, 0x1)) ? (n_rows - r_min + RPI - 1) / RPI : 0;
           }
@@ -465,7 +493,7 @@ __global__ void __launch_bounds__(FFT_WAVES * 64, (fft_min_waves<M, EPI, FB>()))
         }
       }
 #pragma unroll
-      for (int i = 0; i < P; ++i) x[i] = x[i] * (DB ? wn[DB ? i : 0] : s_win[lane + 64 * i]);
+      for (int i = 0; i < P; ++i) x[i] = x[i] * (RT ? wn[RT ? i : 0] : s_win[lane + 64 * i]);
       if (ZP && RS > 1) {  // the samples behind the frame are not part of it, whatever they are (Inf x 0)
 #pragma unroll
         for (int i = 0; i < P; ++i) x[i] = lane + 64 * i < half_taps ? x[i] : cf{0.f, 0.f};
@@ -501,12 +529,37 @@ __global__ void __launch_bounds__(FFT_WAVES * 64, (fft_min_waves<M, EPI, FB>()))
         float *const ta = tile + lane * C + W * f;
         float *const tb = tile + (M - lane) * C + W * f;
         const float ims = -p.im_sign;
+        // the mirrored values first: behind them the exchange buffer is idle until this wave's next frame, and the FIRST
+        // frame of its NEXT tile is requested right here (round 5) -- it travels under the post-processing, the barrier
+        // and the flush instead of being asked for at the top of the next step and waited for at once (the wave's own
+        // buffer: no other wave is concerned; the request still precedes the flush's stores, so fft_wait_vm's count of
+        // younger operations is what it was)
+        // (only the instances with two waves per SIMD: those that run two workgroups per CU live within 128 VGPRs, where
+        // the eight values held across the request spill, and have four waves per SIMD to cover the latency anyway)
+        constexpr bool EARLY = fft_min_waves<M, EPI, FB>() <= 2;
+        cf zmv[EARLY ? P / 2 : 1];
+        if constexpr (EARLY) {
+#pragma unroll
+          for (int i = 0; i < P / 2; ++i) zmv[i] = zmp[-68 * i];
+        }
+        if (EARLY && u == FPW - 1 && tile_nx < n_tiles && !MISPEC_DBG(p, 0x80)) {
+          const int cn = tile_nx / tiles_per_clip;
+          const int tn = (tile_nx - cn * tiles_per_clip) * FT + wave * FPW;
+          const long long posn = (long long)tn * hop - p.pad;
+          if (tn < T && posn >= 0 && posn + N <= L) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the reads above have left the buffer)
+            const float *const src = (MISPEC_DBG(p, 0x40) ? p.x : p.x + (long long)cn * p.x_clip_stride + posn) + 4 * lane;
+#pragma unroll
+            for (int j = 0; j < N / 256; ++j) fft_dma16(src + 256 * j, buf_lds + 1024 * j);
+            pre = true;
+          }
+        }
 #pragma unroll
         for (int i = 0; i < P / 2; ++i) {
-          cf zm = zmp[-68 * i];
+          cf zm = EARLY ? zmv[EARLY ? i : 0] : zmp[-68 * i];
           if (i == 0) zm = lane == 0 ? x[0] : zm;  // bin 0 pairs with itself: (X[0], Nyquist bin)
           cf xk, xm;
-          real_post_pair(x[i], zm, DB ? whr[DB ? i : 0] : whp[64 * i], xk, xm);
+          real_post_pair(x[i], zm, RT ? whr[RT ? i : 0] : whp[64 * i], xk, xm);
           float a0, a1, b0, b1;
           fft_epilogue<EPI>(p, xk.x, ims * xk.y, a0, a1);
           fft_epilogue<EPI>(p, xm.x, ims * xm.y, b0, b1);

@@ -378,3 +378,56 @@ def test_strip_plan_declines_what_the_kernel_does_not_cover():
     assert lib.mispec_strip_plan(ctypes.byref(a), 256, buf, 300) == 0
     a, _ = _plan_args(m, 4, 441000, keep)
     assert lib.mispec_strip_plan(ctypes.byref(a), 0, buf, 300) == -1
+
+
+def test_documented_build_line_names_every_unit():
+    """the hand-written hipcc line must compile every translation unit build.py compiles (since
+    ABI 11 there are two: a library built from mispec.hip alone lacks mispec_octave_stream_*), and the units' objects
+    together must define every function include/mispec.h declares."""
+    import subprocess
+
+    from nnaudio_amd import build
+
+    build.build(verbose=False)
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = text[text.index("## 1. Build"):text.index("## 2.")]
+    line = " ".join(ln.rstrip("\\").strip() for ln in block.splitlines() if "hipcc" in ln or ln.strip().startswith("nnaudio_amd/csrc/"))
+    for src, _ in build.UNITS:
+        assert os.path.relpath(src, ROOT) in line, (src, line)
+    assert "-shared" in line and "gfx950" in line and "-I include" in line
+    defined = set()
+    objdir = os.path.join(os.path.dirname(build.SRC), "_obj")
+    for src, _ in build.UNITS:
+        obj = os.path.join(objdir, os.path.basename(src).replace(".hip", ".o"))
+        nm = subprocess.run(["nm", "--defined-only", obj], capture_output=True, text=True, check=True).stdout
+        defined |= {ln.split()[-1] for ln in nm.splitlines() if ln.split()[1:2] == ["T"]}
+    missing = [n for n in _declared_functions() if n not in defined]
+    assert not missing, missing
+
+
+def test_scratch_guard_sees_cached_objects(tmp_path, monkeypatch):
+    """the refusal of a spilling build must not depend on the object having been compiled in THIS call.  The
+    remarks travel with the object (obj.remarks.json); an object without a record, or one compiled with other flags, is
+    stale; a refused build takes the offending objects off the disk."""
+    import json
+
+    from nnaudio_amd import build
+
+    # the allow-list: framed_* / octave_stream* never, stft_fft_* / istft_* only the listed instances within their bytes
+    r = {"framed_fold_kernelENS_7KParamsE": 8, "octave_stream_kernelILi6ELb1EEvNS_3OSPE": 4,
+         "stft_fft_kernelILi512ELi2ELb0EEEvNS_7KParamsEi": 20, "stft_fft_kernelILi1024ELi1ELb0EEEvNS_7KParamsEi": 4,
+         "istft_ola_fft_kernelILi1024EEEvPKfiiS2_iiiPfxiii": 12, "fold2_frames_kernel": 64, "clean": 0}
+    bad = build.refused_scratch(r, ablate=False)
+    assert set(bad) == {"framed_fold_kernelENS_7KParamsE", "octave_stream_kernelILi6ELb1EEvNS_3OSPE",
+                        "stft_fft_kernelILi1024ELi1ELb0EEEvNS_7KParamsEi"}
+    assert "octave_stream_kernelILi6ELb1EEvNS_3OSPE" not in build.refused_scratch(r, ablate=True)  # (benchmarking build: warned)
+    # the record next to an object
+    obj = str(tmp_path / "unit.o")
+    assert build._cached_remarks(obj, False) is None             # no object, no record
+    open(obj, "w").write("x")
+    assert build._cached_remarks(obj, False) is None             # an object without a record is stale
+    json.dump({"flags": build._flags_key(False), "scratch": {"framed_x": 16}}, open(build._sidecar(obj), "w"))
+    assert build._cached_remarks(obj, False) == {"framed_x": 16}  # ... seen again by every later build() call
+    assert build._cached_remarks(obj, True) is None              # other defines: stale whatever its date
+    build._discard(obj)
+    assert not os.path.exists(obj) and not os.path.exists(build._sidecar(obj))

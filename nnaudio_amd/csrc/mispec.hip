@@ -3141,6 +3141,9 @@ int launch_fft_cfg(const KParams &p, hipStream_t stream) {
     q.fb_lds_floats = (int)((room < 16384 ? room : 16384) / 4);
   }
   const size_t smem = smem0 + (q.fb_lds_floats ? 2080 + (size_t)q.fb_lds_floats * 4 : 0);
+#if MISPEC_FFT_STAMPS
+  if (const char *sp = getenv("MISPEC_FFT_STAMPS")) q.job_counter = reinterpret_cast<unsigned *>(strtoull(sp, nullptr, 0));
+#endif
   int rc = configure_lds(kern, 160 * 1024, configured);
   if (rc != MISPEC_OK) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(fft_waves<M, W>() * 64), smem, stream, q, tiles_per_clip);

@@ -43,6 +43,25 @@ constexpr int FFT_WAVES = 8;
 #ifndef MISPEC_FFT2048_MODE
 #define MISPEC_FFT2048_MODE 0
 #endif
+#ifndef MISPEC_FFT_ROWSWAP  // (A/B: 0 = the second exchange of the 1024-point transform through LDS like the first, instead of row swaps)
+#define MISPEC_FFT_ROWSWAP 1
+#endif
+// Phase clock (variant builds only: -DMISPEC_FFT_STAMPS=1, scripts/fft_stamps.py): lane 0 of waves 0 and NW / 2 of workgroup 8
+// writes s_memtime at the phase boundaries of tile steps 4 .. 11 to the buffer named by the environment variable
+// MISPEC_FFT_STAMPS (launch_fft_cfg hands it over in KParams::job_counter, which this kernel does not use otherwise).
+#ifndef MISPEC_FFT_STAMPS
+#define MISPEC_FFT_STAMPS 0
+#endif
+#if MISPEC_FFT_STAMPS
+#define FFT_STAMP(k)                                                                                              \
+  do {                                                                                                            \
+    if (p.job_counter && blockIdx.x == 8 && lane == 0 && (wave == 0 || wave == NW / 2) && step >= 4 && step < 12) \
+      reinterpret_cast<unsigned long long *>(p.job_counter)[(((wave != 0) * 8 + (step - 4)) * 16) + (k)] =        \
+          __builtin_readcyclecounter();                                                                           \
+  } while (0)
+#else
+#define FFT_STAMP(k) do { } while (0)
+#endif
 template <int M, int W>
 constexpr int fft_waves() {  // waves of a workgroup (mode 2: FOUR, two frames each, and two workgroups per CU that drift apart)
   return (M == 1024 && W == 1 && MISPEC_FFT2048_MODE == 2) ? 4 : FFT_WAVES;
@@ -188,6 +207,45 @@ __device__ __forceinline__ void fft_epilogue(const KParams &p, float re, float i
   }
 }
 
+// ... and from the squared magnitude s = re^2 + im^2 + eps (Magnitude / Power: the post-processing below forms it packed)
+template <int EPI>
+__device__ __forceinline__ float fft_epilogue_sq(const KParams &p, float s) {
+  if constexpr (EPI == MISPEC_EPI_MAGNITUDE)
+    return __builtin_amdgcn_sqrtf(s);  // (v_sqrt_f32: 1 ulp; sqrtf's fix-up code is 12 instructions per bin)
+  else
+    return (p.power == 2.0f && p.eps == 0.f) ? s : (p.power == 1.0f ? sqrtf(s) : powf(sqrtf(s), p.power));
+}
+
+// Real-input post-processing of the pair (k, M - k) as EIGHT packed instructions (round 5: the compiler's version of
+// fft_core.h real_post_pair + the epilogue was 23 per pair, and this kernel is bound by the instructions its two waves per SIMD
+// can issue, not by the vector pipe's throughput).  The spectrum arrives HALVED (the window registers / table carry the factor
+// 1/2 of the formula) and w = e^(-2 pi i k / N) in full:
+//   S = zk + conj(zm), D = zk - conj(zm), wb = D w;   X[k] = (S.x + wb.y, S.y - wb.x),  X[M - k] = (S.x - wb.y, -(S.y + wb.x))
+// fft_post_pair_sq returns (|X[k]|^2, |X[M - k]|^2) + eps, formed from the re parts of both and the im parts of both side by
+// side; fft_post_pair_c the two complex values.  op_sel / op_sel_hi pick the 32-bit half of a source that feeds the low / high
+// lane of the packed operation, neg_lo / neg_hi negate it (checked against the plain formula: experiments/pk_post).
+__device__ __forceinline__ fftcore::cf fft_post_pair_sq(fftcore::cf zk, fftcore::cf zm, fftcore::cf w, fftcore::cf eps2) {
+  fftcore::cf S, D, t, wb, X, Y, q, r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(S) : "v"(zk), "v"(zm));
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(D) : "v"(zk), "v"(zm));
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(D), "v"(w));                                                // (D.x w.x, D.y w.x)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(wb) : "v"(D), "v"(w), "v"(t));  // + (-D.y w.y, D.x w.y)
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(X) : "v"(S), "v"(wb));                    // (S.x + wb.y, S.x - wb.y)
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(Y) : "v"(S), "v"(wb));                    // (S.y - wb.x, S.y + wb.x)
+  asm("v_pk_fma_f32 %0, %1, %1, %2" : "=v"(q) : "v"(Y), "v"(eps2));
+  asm("v_pk_fma_f32 %0, %1, %1, %2" : "=v"(r) : "v"(X), "v"(q));
+  return r;
+}
+__device__ __forceinline__ void fft_post_pair_c(fftcore::cf zk, fftcore::cf zm, fftcore::cf w, fftcore::cf &xk, fftcore::cf &xm) {
+  fftcore::cf S, D, t, wb;
+  asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(S) : "v"(zk), "v"(zm));
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(D) : "v"(zk), "v"(zm));
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(D), "v"(w));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(wb) : "v"(D), "v"(w), "v"(t));
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(xk) : "v"(S), "v"(wb));                    // (S.x + wb.y, S.y - wb.x)
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,1]" : "=v"(xm) : "v"(S), "v"(wb));       // (S.x - wb.y, -S.y - wb.x)
+}
+
 // frames of a tile
 template <int M, int W, bool FB = false>
 constexpr int fft_tile_frames() {
@@ -223,7 +281,7 @@ __global__ void __launch_bounds__((fft_waves<M, (EPI == MISPEC_EPI_COMPLEX || EP
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   cf *const buf = reinterpret_cast<cf *>(smem_raw + FFT_TILE_BYTES) + wave * padded_size<M>();
 
-  // ---- window pairs (w[2m], w[2m+1]) and post-processing factors e^(-2 pi i k / N) / 2: per-workgroup tables,
+  // ---- window pairs (w[2m], w[2m+1]) / 2 and post-processing factors e^(-2 pi i k / N): per-workgroup tables,
   // or (two tile buffers) the lane's own in registers
   cf *const s_win = reinterpret_cast<cf *>(smem_raw + FFT_TILE_BYTES) + NW * padded_size<M>();
   cf *const s_wh = s_win + M;
@@ -232,7 +290,7 @@ __global__ void __launch_bounds__((fft_waves<M, (EPI == MISPEC_EPI_COMPLEX || EP
   cf wn[RT ? P : 1], whr[RT ? P / 2 : 1];
   if constexpr (RT) {
 #pragma unroll
-    for (int i = 0; i < P; ++i) wn[i] = *reinterpret_cast<const cf *>(p.a_re + 2 * (lane + 64 * i));
+    for (int i = 0; i < P; ++i) wn[i] = 0.5f * *reinterpret_cast<const cf *>(p.a_re + 2 * (lane + 64 * i));  // (window / 2: see fft_post_pair_sq)
     // The window pairs are the only values of the tile loop that come from global LOADS the compiler knows about.
     // Pin them here: hipcc's waitcnt pass otherwise carries "wn[i] may still be in flight" into the loop (the loop
     // header merges the prologue's state) and places s_waitcnt vmcnt(6) / (2) / (0) in front of the window
@@ -244,15 +302,15 @@ __global__ void __launch_bounds__((fft_waves<M, (EPI == MISPEC_EPI_COMPLEX || EP
     for (int i = 0; i < P / 2; ++i) {
       float sn, cs;
       sincospif(-(float)(lane + 64 * i) / (float)M, &sn, &cs);
-      whr[i] = cf{0.5f * cs, 0.5f * sn};
+      whr[i] = cf{cs, sn};
     }
   } else {
     for (int m = tid; m < M; m += NW * 64) {
       // row 0 of the cosine kernels is the window itself
-      s_win[m] = m < half_taps ? *reinterpret_cast<const cf *>(p.a_re + 2 * m) : cf{0.f, 0.f};
+      s_win[m] = m < half_taps ? 0.5f * *reinterpret_cast<const cf *>(p.a_re + 2 * m) : cf{0.f, 0.f};  // (window / 2: see fft_post_pair_sq)
       float sn, cs;
       sincospif(-(float)m / (float)M, &sn, &cs);
-      s_wh[m] = cf{0.5f * cs, 0.5f * sn};
+      s_wh[m] = cf{cs, sn};
     }
     __syncthreads();
   }
@@ -409,6 +467,11 @@ __global__ void __launch_bounds__((fft_waves<M, (EPI == MISPEC_EPI_COMPLEX || EP
   }
   float *prev_oc = nullptr;  // the tile waiting to be stored
   int prev_t0 = 0, step = 0;
+  const int n_flush_stores = [&]() {
+    constexpr int LPR = FT * W / 4, RPI = NW * 64 / LPR;
+    const int r_min = wave * 64 / LPR;
+    return (n_rows > r_min && !MISPEC_DBG(p, 0x1)) ? (n_rows - r_min + RPI - 1) / RPI : 0;
+  }();
   bool pre = false;          // the first frame of this wave in the coming tile has been requested already (see below)
   for (int it = blockIdx.x >> 3; it < per_xcd; it += (nwg + 7) >> 3) {
     const int tile_id = (blockIdx.x & 7) * per_xcd + it;
@@ -423,6 +486,7 @@ __global__ void __launch_bounds__((fft_waves<M, (EPI == MISPEC_EPI_COMPLEX || EP
     const float *const prev_tile = tiles + (DB ? ((step & 1) ^ 1) * TILE_FLOATS : 0);
     cf xn[P];             // samples of the wave's next frame of this tile, requested a frame ahead
     bool fast_n = false;
+    FFT_STAMP(0);
 #pragma unroll 1
     for (int u = 0; u < FPW; ++u) {
       const int f = wave * FPW + u, t = t0 + f;
@@ -437,24 +501,28 @@ __global__ void __launch_bounds__((fft_waves<M, (EPI == MISPEC_EPI_COMPLEX || EP
         for (int j = 0; j < N / 256; ++j)
           fft_dma16((MISPEC_DBG(p, 0x40) ? p.x : xc + pos0) + 256 * j + 4 * lane, buf_lds + 1024 * j);  // (0x40: every frame = the first 8 KB)
       }
+      const bool had_pre = u == 0 && pre;
       if (u == 0) pre = false;
       int younger = 0;  // store instructions this wave issues after the loads
       if (u == 0) {
         if (prev_oc) {
           if constexpr (FB) {
-            flush_fb(prev_tile, prev_oc, prev_t0);  // (its stores are not counted: the wait below then also covers them)
+            // (the reduction's stores are not counted -- their number depends on the bands --: a frame requested early is
+            // waited for BEFORE them, when nothing younger than it is in flight; one requested just now after them, with them)
+            if (had_pre) fft_wait_vm(0);
+            flush_fb(prev_tile, prev_oc, prev_t0);
           } else {
             flush(prev_tile, prev_oc, prev_t0);
-            constexpr int LPR = FT * W / 4, RPI = NW * 64 / LPR;
-            const int r_min = wave * 64 / LPR;
-            younger += (n_rows > r_min && !MISPEC_DBG(p, 0x1)) ? (n_rows - r_min + RPI - 1) / RPI : 0;
+            younger += n_flush_stores;
           }
         }
         if constexpr (!DB) __syncthreads();  // the only buffer: everyone has read the tile before it is refilled
       }
+      FFT_STAMP(1);
       if (!live) continue;
       if (fast && u == 0) {
-        fft_wait_vm(younger);
+        if (!(FB && had_pre && prev_oc)) fft_wait_vm(younger);
+        FFT_STAMP(2);
         const cf *const plain = buf;
 #pragma unroll
         for (int i = 0; i < P; ++i) x[i] = plain[lane + 64 * i];
@@ -499,16 +567,21 @@ __global__ void __launch_bounds__((fft_waves<M, (EPI == MISPEC_EPI_COMPLEX || EP
         for (int i = 0; i < P; ++i) x[i] = lane + 64 * i < half_taps ? x[i] : cf{0.f, 0.f};
       }
       // ---- M-point complex FFT   (benchmarking build: 0x4 skips the passes, 0x2 the post-processing, 0x1 the stores)
+      FFT_STAMP(3);
       if (!MISPEC_DBG(p, 0x4)) {
         stockham_pass<M, 0>(x, lane, twf0, store);
+        FFT_STAMP(4);
         reload(x);
-        if constexpr (M == 1024) {
+        FFT_STAMP(5);
+        if constexpr (M == 1024 && MISPEC_FFT_ROWSWAP) {
           stockham_pass<M, 1>(x, lane, twf1, [](int, cf) {});
+          FFT_STAMP(6);
           fft_rows_to_slots(x);
         } else {
           stockham_pass<M, 1>(x, lane, twf1, store);
           reload(x);
         }
+        FFT_STAMP(7);
         // (the last pass leaves the spectrum in the lanes' slots; the buffer only serves the mirrored reads of
         // the post-processing, which touch the upper half)
         stockham_pass<M, 2>(x, lane, twf2, [&](int o, cf v) __attribute__((always_inline)) {
@@ -520,6 +593,7 @@ __global__ void __launch_bounds__((fft_waves<M, (EPI == MISPEC_EPI_COMPLEX || EP
         }
       }
       wave_sync();
+      FFT_STAMP(8);
       // ---- real-input post-processing of the pairs (k, M - k), k = lane + 64 i < M/2, epilogue, into the
       // tile.  Every address is a per-lane base + a compile-time multiple of i: mirror Z[M - k] at
       // pad(M - lane) - 68 i, rows k and M - k of the tile.
@@ -554,15 +628,23 @@ __global__ void __launch_bounds__((fft_waves<M, (EPI == MISPEC_EPI_COMPLEX || EP
             pre = true;
           }
         }
+        FFT_STAMP(9);
 #pragma unroll
         for (int i = 0; i < P / 2; ++i) {
           cf zm = EARLY ? zmv[EARLY ? i : 0] : zmp[-68 * i];
           if (i == 0) zm = lane == 0 ? x[0] : zm;  // bin 0 pairs with itself: (X[0], Nyquist bin)
-          cf xk, xm;
-          real_post_pair(x[i], zm, RT ? whr[RT ? i : 0] : whp[64 * i], xk, xm);
-          float a0, a1, b0, b1;
-          fft_epilogue<EPI>(p, xk.x, ims * xk.y, a0, a1);
-          fft_epilogue<EPI>(p, xm.x, ims * xm.y, b0, b1);
+          const cf wk = RT ? whr[RT ? i : 0] : whp[64 * i];
+          float a0, a1 = 0.f, b0, b1 = 0.f;
+          if constexpr (EPI == MISPEC_EPI_MAGNITUDE || EPI == MISPEC_EPI_POWER) {
+            const cf sq = fft_post_pair_sq(x[i], zm, wk, cf{p.eps, p.eps});
+            a0 = fft_epilogue_sq<EPI>(p, sq.x);
+            b0 = fft_epilogue_sq<EPI>(p, sq.y);
+          } else {
+            cf xk, xm;
+            fft_post_pair_c(x[i], zm, wk, xk, xm);
+            fft_epilogue<EPI>(p, xk.x, ims * xk.y, a0, a1);
+            fft_epilogue<EPI>(p, xm.x, ims * xm.y, b0, b1);
+          }
           if constexpr (W == 2)
             *reinterpret_cast<cf *>(ta + 64 * C * i) = cf{a0, a1};
           else
@@ -574,7 +656,7 @@ __global__ void __launch_bounds__((fft_waves<M, (EPI == MISPEC_EPI_COMPLEX || EP
         }
         // bin M/2 is its own mirror: X = conj(Z[M/2]), lane 0's slot P/2
         float h0, h1;
-        fft_epilogue<EPI>(p, x[P / 2].x, -ims * x[P / 2].y, h0, h1);
+        fft_epilogue<EPI>(p, 2.f * x[P / 2].x, -ims * 2.f * x[P / 2].y, h0, h1);  // (the halved spectrum)
         if (lane == 0) {
           float *th = tile + (M / 2) * C + W * f;
           th[0] = h0;
@@ -583,7 +665,10 @@ __global__ void __launch_bounds__((fft_waves<M, (EPI == MISPEC_EPI_COMPLEX || EP
       }
       wave_sync();  // the mirrored reads are done before the next frame's first pass overwrites the buffer
     }
+    FFT_STAMP(10);
+    FFT_STAMP(11);
     __syncthreads();  // the tile is complete (two buffers: and the other one has been read out)
+    FFT_STAMP(12);
     prev_oc = oc;
     prev_t0 = t0;
     ++step;

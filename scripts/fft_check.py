@@ -44,7 +44,7 @@ if "--ablate" in sys.argv:
     engine.set_fft(True)
     prep = engine.prepare_basis(m.wcos, m.wsin, "fp32", hop=512)
     A = 0x10000000
-    for bits in (0, 0x40, 0x48, 0x41, 8, 1, 2, 4, 7):
+    for bits in (0, 0x80, 0x40, 0x48, 0x41, 8, 1, 2, 4, 6, 7):
         fn = lambda: engine.framed_gemm(x, m.wcos, m.wsin, hop=512, pad=1024, pad_mode=2, epilogue=engine.EPI_MAGNITUDE,
                                         precision="fp32", _debug=A | bits, **prep)
         print("ablation bits %x: %.4f ms" % (bits, timeit(fn)), flush=True)

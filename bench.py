@@ -947,7 +947,16 @@ def main():
             # the same for the shards the reference's multi-GPU configs name: cfg4 (CQT1992v2, 128 clips over 8
             # ranks = 16 per rank) and cfg5 (CQT2010v2, 512 clips over 8 ranks = 64 per rank; per-rank work
             # fixed as N grows, like the headline)
+            def all_ranks_ok(ok):
+                """One rank failing while the others enter a collective is a hang, not an error record: agree first."""
+                t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                return bool(t.item() > 0.5)
+
             for key, name, pr2, b2 in (("cqt_cfg4_shard", "cqt", "f16x3", 16), ("cqt2010_cfg5_shard", "cqt2010", None, None)):
+                # rank-local part (construction, allocation, the un-gathered timing's kernels) under try; every collective
+                # (max_over_ranks, the sharded module's all-gather) only after all ranks have said they got this far
+                err, st = None, {}
                 try:
                     m2, mk2, me2 = workload(name, device, B=b2)
                     m2.precision = pr2
@@ -957,19 +966,30 @@ def main():
                     lo2, hi2 = D.shard_bounds(B2 * world, world, rank)
                     full2[lo2:hi2].copy_(x2)
                     sm2 = D.ShardedModule(m2)
-                    w0, d0 = timed_steps(m2, x2, n3, 3, sync)
-                    w0, d0 = max_over_ranks(w0, d0)
-                    w1, d1 = timed_steps(sm2, full2, n3, 3, sync)
-                    w1, d1 = max_over_ranks(w1, d1)
                     with torch.no_grad():
-                        yb = sm2(full2)[lo2:hi2].numel() * 4.0
-                    out["gather"][key] = {"with_gather_ms_per_step": w1 / n3 * 1e3, "without_gather_ms_per_step": w0 / n3 * 1e3,
-                                          "frames_per_s_with_gather": me2["frames"] * world * n3 / w1, "bytes_per_rank": yb,
-                                          "workload": me2["tag"]}
-                    del m2, sm2, x2, full2
-                    torch.cuda.empty_cache()
+                        m2(x2)  # (builds the cached operands; any unsupported-shape error shows here, on this rank alone)
+                    torch.cuda.synchronize()
+                    st = dict(m2=m2, x2=x2, full2=full2, sm2=sm2, me2=me2, lo2=lo2, hi2=hi2)
                 except Exception as e:
-                    out["gather"][key] = {"error": repr(e)[:200]}
+                    err = repr(e)[:200]
+                if not all_ranks_ok(err is None):
+                    out["gather"][key] = {"error": err or "another rank failed before the collectives"}
+                    st.clear()
+                    torch.cuda.empty_cache()
+                    continue
+                m2, x2, full2, sm2, me2, lo2, hi2 = (st[k] for k in ("m2", "x2", "full2", "sm2", "me2", "lo2", "hi2"))
+                w0, d0 = timed_steps(m2, x2, n3, 3, sync)
+                w0, d0 = max_over_ranks(w0, d0)
+                w1, d1 = timed_steps(sm2, full2, n3, 3, sync)
+                w1, d1 = max_over_ranks(w1, d1)
+                with torch.no_grad():
+                    yb = sm2(full2)[lo2:hi2].numel() * 4.0
+                out["gather"][key] = {"with_gather_ms_per_step": w1 / n3 * 1e3, "without_gather_ms_per_step": w0 / n3 * 1e3,
+                                      "frames_per_s_with_gather": me2["frames"] * world * n3 / w1, "bytes_per_rank": yb,
+                                      "workload": me2["tag"]}
+                del m2, sm2, x2, full2
+                st.clear()
+                torch.cuda.empty_cache()
         except Exception as e:
             out["gather"] = {"error": repr(e)}
 

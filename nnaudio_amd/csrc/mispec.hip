@@ -112,7 +112,7 @@ __device__ __forceinline__ float clip_unscale_of(unsigned absmax_bits) {
   return pow2f(absmax_exponent(__uint_as_float(absmax_bits)) - F16_TOP);
 }
 
-constexpr int KC = 32;   // K depth of one LDS stage
+constexpr int KC = MISPEC_SPLIT_KC;   // K depth of one LDS stage (mispec_internal.h: the split planes' row granule)
 constexpr int LDT = 36;  // LDS row stride in floats: 16-B aligned rows, conflict-free ds_read_b128
 
 // BMODE_PLANAR_T: planar operand, output stored rows-innermost (frame-major): the iSTFT frames
@@ -235,7 +235,7 @@ struct EdgePlan {
   long long stride;  // floats per clip
 };
 
-inline int round_up_kc(int k) { return (k + KC - 1) / KC * KC; }
+inline int round_up_kc(int k) { return mispec_split_row_taps(k); }
 
 EdgePlan plan_edges(int n_samples, int kernel, int hop, int pad, int n_frames) {
   EdgePlan e{};
@@ -3581,7 +3581,7 @@ int mispec_power_to_db_host_f32(const float *spec, int32_t n_clips, int64_t clip
   if (n_clips <= 0 || clip_elems <= 0) return fail(MISPEC_E_INVALID, "non-positive size%s");
   if (!(amin > 0.f)) return fail(MISPEC_E_INVALID, "amin must be positive%s");
   // the arithmetic of power_to_db_kernel (mel.py:263-279), one clip per work item
-  const float off = 10.0f * log10f(fmaxf(amin, ref));
+  const float off = 10.0f * log10f(fmaxf(amin, fabsf(ref)));  // (|ref|: as the device entries and the reference, mel.py:276)
   host_parallel_for(n_clips, [&](long long c) {
     const float *sp = spec + c * clip_elems;
     float *o = out + c * clip_elems;

@@ -1003,14 +1003,14 @@ int os_plan(const mispec_octave_stream_args *a, int n_cus, OsPlan &pl) {
     if (v.bank_split) {
       if (v.n_bins <= 0 || v.n_bins > 16 || v.kernel < 16 || v.kernel % 16 || v.kernel > 256)
         return os_fail(MISPEC_E_UNSUPPORTED, "streaming octave kernel: <= 16 bins, kernel a multiple of 16 up to 256");
-      const long long planes = 4LL * v.n_bins * ((v.kernel + 31) / 32 * 32) * 2;
+      const long long planes = 4LL * v.n_bins * mispec_split_row_taps(v.kernel) * 2;
       if (v.bank_split_bytes < planes + (f16 ? 2LL * v.n_bins * 4 : 0)) return os_fail(MISPEC_E_INVALID, "bank_split too small");
       if (v.pad_mode != MISPEC_PAD_ZERO && v.pad_mode != MISPEC_PAD_REFLECT) return os_fail(MISPEC_E_INVALID, "bad pad_mode");
       if ((long long)(a->n_frames - 1) * o.hop > L) return os_fail(MISPEC_E_INVALID, "n_frames overruns the padded signal");
       // no frame (and no 16-frame tile) may touch both ends of the level
       if (L < 16LL * o.hop + 2LL * v.kernel) return os_fail(MISPEC_E_UNSUPPORTED, "streaming octave kernel: clip too short");
       o.K = v.kernel;
-      o.Ks = (v.kernel + 31) / 32 * 32;
+      o.Ks = mispec_split_row_taps(v.kernel);  // (the row stride mispec_split_basis_* laid the bank out with)
       o.n_rows = v.n_bins;
       o.out_row0 = v.out_row_offset;
       o.reflect = v.pad_mode == MISPEC_PAD_REFLECT;
@@ -1137,6 +1137,9 @@ int mispec_octave_stream_f32(const mispec_octave_stream_args *a, void *stream) {
         (long long)(v.out_row_offset + v.n_bins) * a->out_row_stride + 2LL * a->n_frames + 32 >= (1LL << 29))
       return os_fail(MISPEC_E_UNSUPPORTED, "streaming octave kernel: a clip's output must stay below 2^29 elements");
   }
+  // x_last receives the deepest level of every clip (16-byte stores): a clip's slot must hold it, on 4-float granules
+  if (a->x_last && (a->x_last_clip_stride < pl.p.lv[a->n_levels - 1].L || (a->x_last_clip_stride & 3) != 0))
+    return os_fail(MISPEC_E_INVALID, "x_last_clip_stride must be a multiple of 4 and at least the deepest level's length");
   OsParams &p = pl.p;
   p.x = a->x;
   p.x_clip_stride = a->x_clip_stride;

@@ -13,8 +13,17 @@ name = os.environ.get("VARIANT", "st")
 lib = _abi._load(os.path.join(os.path.dirname(_abi.LIB_PATH), "libmispec_%s.so" % name), "scripts/build_variant.py")
 _abi._lib = lib
 dev = "cuda:0"
-m = features.STFT(n_fft=2048, hop_length=512, output_format="Magnitude", verbose=False).to(dev)
-x = torch.randn(64, 441000, device=dev)
+what = os.environ.get("WHAT", "stft2048")
+if what == "mel":      # cfg3
+    m = features.MelSpectrogram(sr=22050, n_fft=1024, n_mels=128, hop_length=512, verbose=False).to(dev)
+    x = torch.randn(256, 110250, device=dev)
+elif what == "stft1024":
+    m = features.STFT(n_fft=1024, hop_length=256, output_format="Magnitude", verbose=False).to(dev)
+    x = torch.randn(64, 441000, device=dev)
+else:
+    m = features.STFT(n_fft=2048, hop_length=512, output_format="Magnitude", verbose=False).to(dev)
+    x = torch.randn(64, 441000, device=dev)
+print("workload:", what)
 stamps = torch.zeros(2 * 8 * 16, dtype=torch.int64, device=dev)
 with torch.no_grad():
     for _ in range(30):

@@ -496,4 +496,9 @@ def test_fused_inverse_refuses_what_it_does_not_serve():
     m = features.STFT(n_fft=1024, hop_length=200, iSTFT=True, output_format="Complex", verbose=False).to(DEV)
     x = torch.randn(2, 9000, generator=torch.Generator().manual_seed(1)).to(DEV)
     y = m.inverse(m(x), length=9000)
-    assert float((y - x).abs().max()) < 1e-3 * float(x.abs().max()) or y.shape == x.shape
+    assert y.shape == x.shape
+    # the reconstruction where the window sum is well conditioned (inside the first / last frame's taper it is not: hop = 200
+    # does not divide n_fft) must be the signal: the two-launch route is checked here, not merely taken
+    inner = slice(1024, 9000 - 1024)
+    err = float((y[:, inner] - x[:, inner]).abs().max())
+    assert err < 1e-4 * float(x.abs().max()), err

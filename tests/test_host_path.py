@@ -95,3 +95,16 @@ def test_host_path_mfcc_and_inverse_stft(golden, name):
         assert_parity(y_r, ref, rel=1e-4, what=name + " vs reference")
     else:
         assert_parity(y, ref, rel=2e-4, what=name + " vs reference")
+
+
+def test_host_power_to_db_takes_the_magnitude_of_ref():
+    """the reference (mel.py:276) and the device entries use |ref|; the host entry must too."""
+    from nnaudio_amd import engine
+
+    spec = torch.rand(2, 5, 7) + 1e-3
+    a = engine.power_to_db(spec, 1e-10, 2.5, 80.0)
+    b = engine.power_to_db(spec, 1e-10, -2.5, 80.0)
+    assert torch.equal(a, b)
+    want = 10.0 * torch.log10(torch.clamp(spec, min=1e-10)) - 10.0 * np.log10(2.5)
+    want = torch.maximum(want, want.amax(dim=(1, 2), keepdim=True) - 80.0)
+    assert float((a - want).abs().max()) < 1e-4

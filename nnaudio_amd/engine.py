@@ -113,6 +113,17 @@ def resolve_precision(name=None, default="fp32"):
     return name
 
 
+_side_streams = {}
+
+
+def _side_stream(dev, i):
+    """A few persistent side streams per device (the backward's split-K chunks run on them side by side)."""
+    key = (torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device(), i)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=dev)
+    return _side_streams[key]
+
+
 class DerivedCache:
     """A tensor derived from a module's basis buffers (kernel supports, split-bf16 planes),
     rebuilt whenever the buffers are replaced or modified in place (``load_state_dict``,
@@ -1234,12 +1245,17 @@ class _FramedGemmFn(torch.autograd.Function):
         hop, pad, pad_mode = int(kw["hop"]), int(kw["pad"]), int(kw["pad_mode"])
         scale = kw.get("row_scale")
         im_sign = float(kw.get("im_sign", -1.0))
-        # (u, v): the Complex epilogue of the same contraction, in the exact fp32 arithmetic
-        zkw = dict(kw, epilogue=EPI_COMPLEX, precision="fp32", row_support=None, out=None,
-                   out_rows_total=None, out_row_offset=0)
-        zkw.pop("basis_split", None)
-        zkw.pop("basis_fold", None)   # (planes in the forward's precision, not in fp32)
-        zkw.pop("basis_fold2", None)
+        # (u, v): the Complex epilogue of the same contraction IN THE FORWARD'S OWN ARITHMETIC, on its own derived
+        # operands (round 5: recomputed in fp32 it was 4.7 of the 11 ms of a cfg2-sized training step whose forward --
+        # f16x3, the STFT module's default -- takes 1.25; the forward's values are what the loss saw)
+        # (measured against a float64 evaluation, scripts/grad_vs_float64.py: d wcos of a Magnitude STFT -- ill-conditioned where
+        # a bin's |z| crosses zero -- 6.8e-4 of its maximum with the fp32 recomputation, 4.9e-4 with f16x3; bf16x3's 5e-6 of the
+        # peak in z becomes 4e-2 there, so a bf16x3 forward keeps the fp32 recomputation)
+        zkw = dict(kw, epilogue=EPI_COMPLEX, out=None, out_rows_total=None, out_row_offset=0)
+        if resolve_precision(kw.get("precision")) == "bf16x3":
+            zkw.update(precision="fp32", row_support=None)
+            for k in ("basis_split", "basis_fold", "basis_fold2"):  # (planes in the forward's precision, not in fp32)
+                zkw.pop(k, None)
         z = framed_gemm(xs, wr, wi, **zkw)
         T = z.shape[2]
         go = _f32(grad_out, "grad_output").contiguous()
@@ -1277,19 +1293,58 @@ class _FramedGemmFn(torch.autograd.Function):
                 raise RuntimeError(
                     "backward of the framed contraction: one clip's frame matrix (%d taps x %d frames) "
                     "exceeds the kernel's int32 range; shorten the clips" % (K, T))
-            dw = None
-            for b0 in range(0, B, per):
-                b1 = min(B, b0 + per)
+            use16 = resolve_precision(kw.get("precision")) == "f16x3" and 2 * F > 128
+            # The d-basis contraction has (2F x K) outputs and B*T taps: 8 x 8 tiles of the staged dense kernel for an STFT
+            # of 2048 -- a quarter of the device.  Its sum over the clips is split into up to four chunks of clips whose
+            # contractions run side by side on side streams (split-K by hand: 64 workgroups each), added in chunk order.
+            n_par = 1
+            if use16 and B >= 8 and not torch.cuda.is_current_stream_capturing():
+                n_par = 4
+                per = min(per, (B + n_par - 1) // n_par)
+
+            def d_basis_chunk(b0, b1):
                 nb = (b1 - b0) * T
                 xt = torch.empty((K, nb), dtype=torch.float32, device=dev)
                 with torch.cuda.device(dev):
+                    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
                     _abi.check(lib.mispec_frames_transpose_f32(xp[b0:b1].data_ptr(), Lp, b1 - b0, T, hop, K,
-                                                               xt.data_ptr(), stream))
-                gc = g[:, :, b0:b1].reshape(2 * F, nb) if per >= B else g[:, :, b0:b1].reshape(2 * F, nb).contiguous()
-                part = framed_gemm(xt.reshape(1, K * nb), gc, None, hop=nb, pad=0,
+                                                               xt.data_ptr(), st))
+                gc = g[:, :, b0:b1].reshape(2 * F, nb) if b1 - b0 >= B else g[:, :, b0:b1].reshape(2 * F, nb).contiguous()
+                if use16 and nb % 2 == 0:
+                    # the forward's arithmetic for its adjoint too (round 5): (g_re, g_im) as the complex "basis" of the
+                    # staged dense f16x3 kernel (scaled fp16 pairs per row, split here: G changes every step), Complex
+                    # epilogue = (d basis_re, d basis_im) side by side
+                    g0, g1 = gc[:F], gc[F:]
+                    pc = framed_gemm(xt.reshape(1, K * nb), g0, g1, hop=nb, pad=0, pad_mode=PAD_NONE,
+                                     epilogue=EPI_COMPLEX, im_sign=1.0, precision="f16x3",
+                                     basis_split=split_basis_f16(g0, g1))[0]  # (F, K, 2)
+                    return torch.cat((pc[..., 0], pc[..., 1]), 0)
+                return framed_gemm(xt.reshape(1, K * nb), gc, None, hop=nb, pad=0,
                                    pad_mode=PAD_NONE, epilogue=EPI_REAL, im_sign=1.0, precision="fp32")[0]
-                dw = part if dw is None else dw.add_(part)
-                del xt
+
+            chunks = [(b0, min(B, b0 + per)) for b0 in range(0, B, per)]
+            dw = None
+            if n_par > 1 and len(chunks) > 1:
+                cur = torch.cuda.current_stream(dev)
+                start = torch.cuda.Event()
+                start.record(cur)
+                done = []
+                for i, (b0, b1) in enumerate(chunks):
+                    side = _side_stream(dev, i % n_par)
+                    side.wait_event(start)
+                    with torch.cuda.stream(side):
+                        part = d_basis_chunk(b0, b1)
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                    done.append((part, ev))
+                for part, ev in done:
+                    cur.wait_event(ev)
+                    part.record_stream(cur)
+                    dw = part if dw is None else dw.add_(part)
+            else:
+                for b0, b1 in chunks:
+                    part = d_basis_chunk(b0, b1)
+                    dw = part if dw is None else dw.add_(part)
             gre = dw[:F].reshape(basis_re.shape)
             gim = dw[F:].reshape(basis_im.shape)
             del xp

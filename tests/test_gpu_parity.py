@@ -1160,6 +1160,36 @@ def test_backward_stft(fmt, pad_mode, center, both_stft_routes):
     _grad_close(got[2], ws.grad, "d wsin")
 
 
+def test_backward_in_the_forwards_arithmetic_and_split_over_clips():
+    """Round 5: under ``precision = "f16x3"`` (the STFT module's default) the backward recomputes the Complex values in the
+    forward's own arithmetic and runs the d-basis contraction on the staged dense f16x3 kernel, its sum over the clips
+    split into four chunks on side streams (B >= 8).  Both arithmetics against a float64 evaluation of the same loss: the
+    gradient of a Magnitude is ill-conditioned where a bin's |z| crosses zero (d wcos at the DC bin), so the bar is what
+    fp32 itself reaches there, and f16x3 must be no worse than twice that."""
+    from nnaudio_amd import features
+
+    x = torch.randn(8, 20224, generator=torch.Generator().manual_seed(31)).to(DEV)  # (80 frames per clip: even chunks)
+    err = {}
+    for prec in ("fp32", None):
+        m = features.STFT(n_fft=1024, hop_length=256, trainable=True, output_format="Magnitude", verbose=False).to(DEV)
+        m.precision = prec
+        y = m(x)
+        w = torch.randn(y.shape, generator=torch.Generator().manual_seed(32)).to(DEV)
+        (y * w).sum().backward()
+        torch.cuda.synchronize()
+        wc = m.wcos.detach().double().reshape(513, 1024).requires_grad_(True)
+        ws = m.wsin.detach().double().reshape(513, 1024).requires_grad_(True)
+        xp = torch.nn.functional.pad(x.double()[:, None, :], (512, 512), mode="reflect")[:, 0]
+        fr = xp.unfold(1, 1024, 256)
+        re, im = torch.einsum("btk,fk->bft", fr, wc), torch.einsum("btk,fk->bft", fr, ws)
+        (torch.sqrt(re ** 2 + im ** 2 + 1e-8) * w.double()).sum().backward()
+        err[prec] = [float((a.double().reshape(513, 1024) - b).abs().max() / b.abs().max())
+                     for a, b in ((m.wcos.grad, wc.grad), (m.wsin.grad, ws.grad))]
+        print("STFT(trainable) backward, precision %s: d wcos %.2e, d wsin %.2e of the maximum (float64 reference)" % (prec, *err[prec]))
+    assert max(err["fp32"]) <= 3e-3 and max(err[None]) <= 3e-3
+    assert err[None][0] <= 2 * err["fp32"][0] + 1e-5 and err[None][1] <= 2 * err["fp32"][1] + 1e-5
+
+
 @pytest.mark.parametrize("fmt", ["Magnitude", "Complex", "Phase"])
 def test_backward_cqt1992v2(fmt):
     from nnaudio_amd import features

@@ -126,6 +126,15 @@ def workload(name, device, B=None):
         bound = "mfma"
         bins, taps = fold_geometry(F, K, False)
         executed = 2.0 * (2 * bins) * taps * up(B * T, 128)  # products; x 3 MFMAs for the split arithmetics
+    elif name == "stft4096":
+        # n_fft = 4096 (a common music setting): the composite instance of the FFT route (two 2048-point halves + a butterfly)
+        B, L, K, hop = B0 or 64, 441000, 4096, 1024
+        F, T = K // 2 + 1, L // hop + 1
+        m = features.STFT(n_fft=K, hop_length=hop, window="hann", output_format="Magnitude", verbose=False).to(device)
+        flops = 2.0 * (2 * F) * K * B * T
+        byts = 4.0 * (B * L + B * F * T + 2 * F * K)
+        tag = "STFT n_fft=4096 hop=1024 hann, B=%d x 10 s @ 44.1 kHz, Magnitude" % B
+        bound, executed = "hbm", None
     elif name in ("mel", "gammatone"):
         B, L, K, hop, M = (B0 or 256, 110250, 1024, 512, 128) if name == "mel" else (B0 or 64, 441000, 2048, 512, 64)
         F, T = K // 2 + 1, L // hop + 1
@@ -258,7 +267,7 @@ def module_precision(name, precision):
     setting), f16x3 for CQT2010v2 / VQT, fp32 for CQT1992v2 (nnaudio_amd.engine)."""
     if precision:
         return precision
-    if name in ("stft", "mel", "gammatone", "mfcc", "istft"):
+    if name in ("stft", "stft4096", "mel", "gammatone", "mfcc", "istft"):
         from nnaudio_amd import engine
 
         return "fft" if engine.fft_enabled() else "f16x3"
@@ -626,7 +635,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="stft", choices=["stft", "mel", "gammatone", "cqt", "cqt2010", "vqt", "mfcc", "istft"])
+    ap.add_argument("--workload", default="stft", choices=["stft", "stft4096", "mel", "gammatone", "cqt", "cqt2010", "vqt", "mfcc", "istft"])
     ap.add_argument("--extras", type=int, default=1,
                     help="also time the other arithmetics, CQT84, Mel cfg3, Gammatonegram, the cfg5 shard and the gather")
     ap.add_argument("--cpu-baseline", type=int, default=1)
@@ -827,7 +836,7 @@ def main():
                 ("mel", None, None), ("gammatone", None, None), ("cqt2010", None, None), ("vqt", None, None),
                 ("cqt2010", "bf16x3", None), ("cqt2010", "fp32", None),
                 ("mel", "f16x3", None), ("gammatone", "f16x3", None),  # (the contraction kernels, FFT off)
-                ("mfcc", None, None), ("istft", None, None)]
+                ("mfcc", None, None), ("istft", None, None), ("stft4096", None, None)]
         if world > 1:
             # N > 1: the per-GPU numbers above are the N = 1 line's business (every rank would repeat them, each with
             # its barriers and reductions: minutes of wall time and thirteen more places for one rank to fall out of

@@ -3174,6 +3174,160 @@ int launch_fft(const KParams &p, hipStream_t stream) {
                      : (p.K == 1024 ? launch_fft_size<512>(p, stream) : launch_fft_size<256>(p, stream));  // (128, 256: zero-extended)
 }
 
+// ---------------------------------------------------------------------------------
+// n_fft = 4096 on the FFT route (round 5; VERDICT r4: STFT(n_fft = 4096) fell to the contraction kernels at ~3 x the
+// cost) -- COMPOSITE, decimation in time over the 2048-point instance:
+//   y_e[n] = y[2n], y_o[n] = y[2n+1]  (y = the padded clip, w the window)
+//   E = RFFT_2048(w_e y_e), O = RFFT_2048(w_o y_o)   two launches of stft_fft_kernel<1024, MISPEC_EPI_COMPLEX>
+//   X[k] = E[k] + W^k O[k],  X[2048 - k] = conj(E[k] - W^k O[k]),  W = e^(-2 pi i / 4096),  k = 0 .. 1024
+// Launches: fft4096_split_kernel (virtual padding applied, clips de-interleaved into the workspace -- reflect padding does
+// not commute with the de-interleave when the clip length is even, so the padded streams are materialised --, the window's
+// even / odd taps), the two transforms (pad 0, hop / 2), fft4096_combine_kernel (the butterfly above + the pointwise
+// epilogue of the FFT kernel, rows k and 2048 - k of the output).  Moves ~4 x the bytes of a native instance (E and O pass
+// through HBM as complex spectrograms) and still undercuts the contraction kernels; hop and pad must be even, no fused
+// filterbank.  Workspace: mispec_framed_gemm_workspace_bytes().
+// ---------------------------------------------------------------------------------
+namespace {
+struct Fft4096Plan {
+  bool ok;
+  long long Lh, slot, off_xo, off_w, off_E, off_O, bytes;
+};
+
+Fft4096Plan plan_fft4096(const mispec_framed_gemm_args *a, const KParams &p) {
+  Fft4096Plan pl = {};
+  if (!a->basis_fold2 || a->tile != MISPEC_TILE_AUTO || a->no_fft || p.K != 4096) return pl;
+  if (MISPEC_DBG(p, 0x100000) || MISPEC_DBG(p, 0x40000000) || MISPEC_DBG(p, 0x08000000)) return pl;  // A/B runs
+  if (!p.a_im || p.row_support || p.row_scale || p.fb || (p.hop & 1) || (p.pad & 1)) return pl;
+  if (a->basis_fold2_bytes < basis_fold2_bytes(p.n_bins, p.K)) return pl;
+  if (p.epilogue < MISPEC_EPI_COMPLEX || p.epilogue > MISPEC_EPI_PHASE_COSSIN) return pl;
+  if (p.n_bins > 2049 || p.n_frames <= 0 || (long long)p.n_clips * p.n_frames > 0x3fffffffLL) return pl;
+  const long long Lp = (long long)p.n_samples + 2LL * p.pad;
+  pl.Lh = (Lp + 1) / 2;
+  if (pl.Lh + 64 > 0x7fffffffLL) return pl;
+  pl.slot = (pl.Lh + 63) / 64 * 64;
+  const long long spec = (long long)p.n_clips * 1025 * p.n_frames * 2;  // floats of E (and of O)
+  pl.off_xo = pl.slot * p.n_clips;
+  pl.off_w = 2 * pl.off_xo;
+  pl.off_E = pl.off_w + 4096;
+  pl.off_O = pl.off_E + spec;
+  pl.bytes = (pl.off_O + spec) * (long long)sizeof(float);
+  pl.ok = true;
+  return pl;
+}
+
+__global__ void __launch_bounds__(256) fft4096_split_kernel(const float *__restrict__ x, long long x_clip_stride, int L, int pad,
+                                                            int pad_mode, const float *__restrict__ win, float *__restrict__ xe,
+                                                            float *__restrict__ xo, long long slot, long long Lh,
+                                                            float *__restrict__ w) {
+  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (b == 0 && j < 2048) {  // row 0 of the cosine kernels is the window itself
+    w[j] = win[2 * j];
+    w[2048 + j] = win[2 * j + 1];
+  }
+  if (j >= slot) return;
+  float v[2] = {0.f, 0.f};
+  if (j < Lh) {
+    const float *xc = x + (long long)b * x_clip_stride;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      long long q = 2 * j + e - pad;
+      if (pad_mode == MISPEC_PAD_REFLECT) {
+        q = q < 0 ? -q : q;
+        q = q >= L ? 2LL * L - 2 - q : q;
+      }
+      v[e] = (q >= 0 && q < L) ? xc[q] : 0.f;
+    }
+  }
+  xe[(long long)b * slot + j] = v[0];
+  xo[(long long)b * slot + j] = v[1];
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(256) fft4096_combine_kernel(const KParams p, const float *__restrict__ E, const float *__restrict__ O) {
+  typedef float f2u __attribute__((ext_vector_type(2)));
+  constexpr int W = (EPI == MISPEC_EPI_COMPLEX || EPI == MISPEC_EPI_PHASE_COSSIN) ? 2 : 1;
+  const int t = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y, b = blockIdx.z;
+  const int T = p.n_frames;
+  if (t >= T) return;
+  const long long at = ((long long)b * 1025 + k) * T + t;
+  const f2u e = reinterpret_cast<const f2u *>(E)[at], o = reinterpret_cast<const f2u *>(O)[at];
+  float sn, cs;
+  sincospif(-(float)k / 2048.f, &sn, &cs);  // W^k = e^(-2 pi i k / 4096)
+  const float wr = o.x * cs - o.y * sn, wi = o.x * sn + o.y * cs;
+  const float ims = -p.im_sign;
+  float *const oc = p.out + (long long)b * p.out_clip_stride + (long long)p.out_row_offset * p.out_row_stride + (long long)t * W;
+  if (k < p.n_bins) {
+    float v0, v1;
+    fft_epilogue<EPI>(p, e.x + wr, ims * (e.y + wi), v0, v1);
+    float *d = oc + (long long)k * p.out_row_stride;
+    d[0] = v0;
+    if constexpr (W == 2) d[1] = v1;
+  }
+  if (k != 1024 && 2048 - k < p.n_bins) {  // X[2048 - k] = conj(E[k] - W^k O[k])
+    float v0, v1;
+    fft_epilogue<EPI>(p, e.x - wr, ims * -(e.y - wi), v0, v1);
+    float *d = oc + (long long)(2048 - k) * p.out_row_stride;
+    d[0] = v0;
+    if constexpr (W == 2) d[1] = v1;
+  }
+}
+
+int launch_fft4096(const KParams &p, const mispec_framed_gemm_args *a, const Fft4096Plan &pl, hipStream_t stream) {
+  if (!a->workspace || a->workspace_bytes < pl.bytes)
+    return fail(MISPEC_E_INVALID, "workspace too small: size it with the *_workspace_bytes query%s");
+  float *const ws = static_cast<float *>(a->workspace);
+  float *const xe = ws, *const xo = ws + pl.off_xo, *const w = ws + pl.off_w, *const E = ws + pl.off_E, *const O = ws + pl.off_O;
+  hipLaunchKernelGGL(fft4096_split_kernel, dim3((unsigned)((pl.slot + 255) / 256), (unsigned)p.n_clips), dim3(256), 0, stream, p.x,
+                     p.x_clip_stride, p.n_samples, p.pad, p.pad_mode, p.a_re, xe, xo, pl.slot, pl.Lh, w);
+  for (int h = 0; h < 2; ++h) {
+    KParams q = p;
+    q.x = h ? xo : xe;
+    q.x_clip_stride = pl.slot;
+    q.n_samples = (int)pl.Lh;
+    q.hop = p.hop / 2;
+    q.pad = 0;
+    q.pad_mode = MISPEC_PAD_NONE;
+    q.K = 2048;
+    q.n_bins = 1025;
+    q.a_re = w + 2048 * h;
+    q.a_im = w + 2048 * h;  // (not read)
+    q.a_row_stride = 2048;
+    q.epilogue = MISPEC_EPI_COMPLEX;
+    q.im_sign = -1.f;  // (re, im) of the DFT itself
+    q.eps = 0.f;
+    q.out = h ? O : E;
+    q.out_clip_stride = 1025LL * p.n_frames * 2;
+    q.out_row_stride = 2LL * p.n_frames;
+    q.out_row_offset = 0;
+    q.fb = nullptr;
+    const int rc = launch_fft_cfg<1024, MISPEC_EPI_COMPLEX, false>(q, stream);
+    if (rc != MISPEC_OK) return rc;
+  }
+  const dim3 grid((unsigned)((p.n_frames + 255) / 256), 1025u, (unsigned)p.n_clips);
+  switch (p.epilogue) {
+    case MISPEC_EPI_COMPLEX:
+      hipLaunchKernelGGL(fft4096_combine_kernel<MISPEC_EPI_COMPLEX>, grid, dim3(256), 0, stream, p, E, O);
+      break;
+    case MISPEC_EPI_MAGNITUDE:
+      hipLaunchKernelGGL(fft4096_combine_kernel<MISPEC_EPI_MAGNITUDE>, grid, dim3(256), 0, stream, p, E, O);
+      break;
+    case MISPEC_EPI_POWER:
+      hipLaunchKernelGGL(fft4096_combine_kernel<MISPEC_EPI_POWER>, grid, dim3(256), 0, stream, p, E, O);
+      break;
+    case MISPEC_EPI_PHASE_ATAN2:
+      hipLaunchKernelGGL(fft4096_combine_kernel<MISPEC_EPI_PHASE_ATAN2>, grid, dim3(256), 0, stream, p, E, O);
+      break;
+    default:
+      hipLaunchKernelGGL(fft4096_combine_kernel<MISPEC_EPI_PHASE_COSSIN>, grid, dim3(256), 0, stream, p, E, O);
+      break;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+}  // namespace
+
 // MISPEC_PREC_F16X3 exists on the folded contractions, on the strip kernel and on the staged dense kernel
 // (complex bases of more than 64 bins): every other shape runs in MISPEC_PREC_F32 on the tile kernels
 // (operands prepared for MISPEC_PREC_F16X3 are not offered to them)
@@ -3207,6 +3361,10 @@ int64_t mispec_framed_gemm_workspace_bytes(const mispec_framed_gemm_args *args) 
   int rc = fill_params(args, p);
   if (rc != MISPEC_OK) return rc;
   if (fft_ok(args, p)) return 0;
+  {
+    const Fft4096Plan f4 = plan_fft4096(args, p);
+    if (f4.ok) return f4.bytes;
+  }
   mispec_framed_gemm_args local;
   if (f16_downgrade(args, p, local)) args = &local;
   const Fold2Plan f2 = plan_fold2(args, p);
@@ -3275,6 +3433,10 @@ int mispec_framed_gemm_f32(const mispec_framed_gemm_args *args, void *stream) {
   if (rc != MISPEC_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (fft_ok(args, p)) return launch_fft(p, s);
+  {
+    const Fft4096Plan f4 = plan_fft4096(args, p);
+    if (f4.ok) return launch_fft4096(p, args, f4, s);
+  }
   mispec_framed_gemm_args local;
   if (f16_downgrade(args, p, local)) args = &local;
   if (p.fb && (args->tile != MISPEC_TILE_AUTO || MISPEC_DBG(p, 0x2000)))

@@ -65,7 +65,7 @@ _fft = os.environ.get("MISPEC_FFT", "1") not in ("0", "false", "off")
 
 def set_fft(enabled):
     """STFT-family modules whose kernels are window x DFT (``freq_scale='no'``, not trainable, n_fft 256 ...
-    2048) evaluate the frames' DFT as an FFT instead of contracting them with the kernels
+    2048, and 4096 as a composite of two 2048-point halves) evaluate the frames' DFT as an FFT instead of contracting them with the kernels
     (csrc/stft_fft.inl); ``set_fft(False)`` (or ``MISPEC_FFT=0``) keeps every module on the contraction
     kernels -- the arithmetic ``precision`` selects.  Returns the previous setting."""
     global _fft

@@ -106,6 +106,12 @@ def main():
          dict(n_fft=1024, hop_length=128, window="ones", output_format="Complex"), "x_short")
     case("stft_2048_hann_h512", "STFT",
          dict(n_fft=2048, hop_length=512, window="hann", output_format="Magnitude"), "x_1s22k")
+    # n_fft = 4096 (round 5: the composite instance of the FFT route): default hop with reflect padding, and an even hop that
+    # does not divide n_fft with the Complex output
+    case("stft_4096_hann_h1024", "STFT",
+         dict(n_fft=4096, hop_length=1024, window="hann", output_format="Magnitude"), "x_1s22k")
+    case("stft_4096_complex_h600", "STFT",
+         dict(n_fft=4096, hop_length=600, window="hamming", output_format="Complex"), "x_1s22k")
     case("stft_256_defaulthop", "STFT", dict(n_fft=256, hop_length=None, output_format="Complex"),
          "x_short")
     case("stft_winlen400", "STFT",

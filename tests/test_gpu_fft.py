@@ -35,6 +35,10 @@ def _need_gpu():
     (3, 6000, 129, 256, 64, 128, 2, "hann"),          # n_fft = 256 (the reference's grid): zero-extended frames on the 512-point instance
     (2, 5000, 100, 256, 100, 0, 0, "random"),         # ... center=False, fewer bins, asymmetric window
     (4, 300, 129, 256, 200, 128, 2, "hann"),          # clips shorter than the 512 samples a zero-extended frame reads
+    (2, 40000, 2049, 4096, 1024, 2048, 2, "hann"),    # n_fft = 4096 (round 5): the composite instance -- two 2048-point halves + a butterfly
+    (1, 30011, 1500, 4096, 600, 2048, 1, "random"),   # ... odd clip length, zero padding, hop not a divisor, freq_bins, asymmetric window
+    (3, 9000, 2049, 4096, 4096, 0, 0, "hamming"),     # ... center=False, two frames per clip
+    (2, 30000, 2049, 4096, 1024, 2048, 2, "short"),   # ... even clip length under reflect padding (the de-interleave does not commute with it)
 ])
 @pytest.mark.parametrize("epi", ["complex", "magnitude", "power2", "power1", "phase", "cossin"])
 def test_fft_path_against_float64(shape, epi):
@@ -111,7 +115,8 @@ def test_fft_path_is_what_the_modules_run_and_can_be_switched_off():
     finally:
         nnaudio_amd.set_fft(True)
     assert torch.equal(a, b)
-    # n_fft = 4096 is not served by the FFT kernels: the contraction runs, switch or not
+    # n_fft = 4096 (round 5): the composite instance of the FFT route -- fp32-class agreement with the contraction; an odd hop
+    # (the de-interleave needs an even one) and n_fft = 8192 stay on the contraction kernels, switch or not
     big = features.STFT(n_fft=4096, hop_length=1024, output_format="Magnitude", verbose=False).to(DEV)
     a = big(x)
     nnaudio_amd.set_fft(False)
@@ -119,7 +124,16 @@ def test_fft_path_is_what_the_modules_run_and_can_be_switched_off():
         b = big(x)
     finally:
         nnaudio_amd.set_fft(True)
-    assert torch.equal(a, b)
+    assert not torch.equal(a, b) and float((a - b).abs().max() / b.abs().max()) <= 3e-6
+    for kw in (dict(n_fft=4096, hop_length=1023), dict(n_fft=8192, hop_length=2048)):
+        other = features.STFT(output_format="Magnitude", verbose=False, **kw).to(DEV)
+        a = other(x)
+        nnaudio_amd.set_fft(False)
+        try:
+            b = other(x)
+        finally:
+            nnaudio_amd.set_fft(True)
+        assert torch.equal(a, b), kw
 
 
 def test_n_fft_256_on_the_fft_route_ignores_what_lies_behind_the_frame():

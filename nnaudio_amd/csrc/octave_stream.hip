@@ -681,6 +681,16 @@ __global__ void __launch_bounds__(OS_THREADS, 1) octave_stream_kernel(const OsPa
           il[s] = *reinterpret_cast<const bf16x8 *>(aim + v.bank_plane + 32 * s);
         }
       }
+      // (round 5, scripts/isa_waits.py: values that come from global LOADS in this prologue and are used in the tile loop must be
+      // pinned here -- hipcc's waitcnt pass otherwise carries "may still be in flight" into the loop and puts s_waitcnt vmcnt(0) in
+      // front of their uses, where it waits for the stores the wave has just issued)
+#pragma unroll
+      for (int s = 0; s < MAXS; ++s) {
+        asm volatile("" : "+v"(rh[s]));
+        asm volatile("" : "+v"(rl[s]));
+        asm volatile("" : "+v"(ih[s]));
+        asm volatile("" : "+v"(il[s]));
+      }
     }
     const OsLevel &v = p.lv[my >= 0 ? my : 0];
     const int v_L = v.L, v_hop = v.hop, v_K = v.K, v_half = v.K / 2, v_n_rows = v.n_rows, v_row0 = v.out_row0;
@@ -699,6 +709,8 @@ __global__ void __launch_bounds__(OS_THREADS, 1) octave_stream_kernel(const OsPa
       if (F16 && my >= 0 && bin < v_n_rows) s *= v_unscale[bin];
       bsc[e] = s;
     }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(bsc[e]));  // (pinned: see the bank fragments above)
 
     // the patch of one clip end: rows rho0 .. rho0 + 7 of the level with the mirrored samples beyond the end
     auto build_patch = [&](int rho0) __attribute__((always_inline)) {

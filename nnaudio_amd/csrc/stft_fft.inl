@@ -838,6 +838,11 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) istft_fft_kernel(const float *
         stockham_pass<M, 2>(x, lane, twf2, [](int, cf) {});
       }
       wave_sync();
+      // (round 5: the next tile's rows -- plain loads requested before this transform -- are pinned HERE, in front of this
+      // iteration's stores: hipcc otherwise waits for them with vmcnt(0) at the top of the next iteration, i.e. for the stores
+      // it has just issued -- scripts/isa_waits.py)
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) asm volatile("" : "+v"(g[j]));
       float *const out = frames + ((long long)c * T + t) * N;
 #pragma unroll
       for (int i = 0; i < P; ++i)  // z = conj(FFT(conj Z)): y[2m] = Re, y[2m + 1] = -Im
@@ -1042,6 +1047,11 @@ __global__ void __launch_bounds__(FFT_WAVES * 64) istft_ola_fft_kernel(const flo
         *reinterpret_cast<cf *>(fb + n) = cf{x[i].x * w.x * inv_n, -x[i].y * w.y * inv_n};
       }
     }
+    // (round 5: the next tile's rows -- plain loads requested before this transform -- are pinned HERE, in front of the
+    // overlap-add's stores: hipcc otherwise waits for them with vmcnt(0) at the top of the next iteration, i.e. for the
+    // stores it has just issued -- scripts/isa_waits.py)
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) asm volatile("" : "+v"(g[j]));
     __syncthreads();  // the frames of the tile stand in the exchange buffers
     {
       const bool emit = tl >= ta;

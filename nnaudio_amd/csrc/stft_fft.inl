@@ -40,6 +40,9 @@ constexpr int FFT_WAVES = 8;
 // (A/B builds, scripts/build_variant.py: MISPEC_FFT2048_MODE 1 = ONE tile buffer of 16 frames -- two frames per wave, 64-byte row
 // segments, two barriers per tile --, tables in registers as in mode 0; 2 = workgroups of FOUR waves, two frames each, one
 // 8-frame tile buffer, TWO workgroups per CU)
+#ifndef MISPEC_FB_UNROLL  // bins of a filter's band whose LDS reads are in flight together (flush_fb: the loop is a chain of LDS latencies)
+#define MISPEC_FB_UNROLL 4
+#endif
 #ifndef MISPEC_FFT2048_MODE
 #define MISPEC_FFT2048_MODE 0
 #endif
@@ -439,7 +442,7 @@ __global__ void __launch_bounds__((fft_waves<M, (EPI == MISPEC_EPI_COMPLEX || EP
         const int CR = C * RS;
         const float *tr = tile + lo * CR + fl;
         cf sum = cf{0.f, 0.f};
-#pragma unroll 4
+#pragma unroll MISPEC_FB_UNROLL
         for (int b = 0; b < nb; ++b) sum += w[b] * *reinterpret_cast<const cf *>(tr + b * CR);
         float *d = oc + (long long)m * p.out_row_stride + t0 + fl;
         if (t0 + fl < T) d[0] = sum.x;

@@ -45,8 +45,11 @@ Rank 0 prints ONE JSON line: metric = spectrogram frames/s (whole job), plus
                      given, timed with the same pre-warm and step count as the headline and priced
                      against both rooflines (with live traffic); at N > 1 also cfg4's real shard
                      (CQT1992v2, 16 clips per rank);
-  "cpu_baseline":    the numpy port of the reference algorithm (oracle/, float32 BLAS) timed on
-                     this host on a bounded sample of the same workload (rank 0, N=1 only).
+  "cpu_baseline":    the reference forward's operator sequence (pad + 2 x F.conv1d + sqrt, stft.py:278-316) on torch's CPU
+                     kernels with the module's own buffers -- what nnAudio itself executes on a CPU; a restatement (kind
+                     "port": the reference package is not on the GPU box) -- timed on this host on a bounded sample of the
+                     same workload (rank 0, N=1 only); beside it the numpy port the parity tests check against
+                     ("numpy_port"), torch.stft ("librosa_equivalent") and the same restatement for CQT84 ("cqt84").
 """
 import argparse
 import csv
@@ -418,42 +421,60 @@ def dynamic_range_db(device, precision):
 
 
 def cpu_baseline(budget_s=15.0):
-    """The oracle (numpy restatement of the reference's conv1d STFT, float32 BLAS) on a
-    bounded sample of the configs[1] workload: n clips of 10 s; frames/s."""
+    """CPU baselines on this host, each on a bounded sample of its workload (frames/s):
+      value               the reference forward's OPERATOR SEQUENCE for configs[1] (stft.py:278-316: ReflectionPad1d, two F.conv1d
+                          with wcos / wsin, sqrt of the squares) on torch's CPU kernels with the module's own buffers -- what nnAudio
+                          itself executes on a CPU; the reference package is not on the GPU box, so this is a restatement
+                          (kind "port"), not an import (VERDICT r4 "missing" 7)
+      numpy_port          oracle/spectral_oracle.py (numpy float32 BLAS), the checker the parity tests use
+      librosa_equivalent  torch.stft(...).abs(): the FFT algorithm librosa.stft runs (librosa cannot be installed)
+      cqt84               the same operator-sequence restatement for CQT1992v2 84 bins (cqt.py:740-772)"""
+    import torch.nn.functional as Fnn
+
     from nnaudio_amd import features
     from oracle import spectral_oracle as O
 
     m = features.STFT(n_fft=2048, hop_length=512, window="hann", output_format="Magnitude",
                       verbose=False)
-    wsin, wcos = m.wsin.numpy(), m.wcos.numpy()
     rng = np.random.default_rng(0)
-    x = rng.standard_normal((1, 441000)).astype(np.float32)
-    t0 = time.perf_counter()
-    O.stft(x, wsin, wcos, 512, output_format="Magnitude", acc=np.float32)
-    one = time.perf_counter() - t0
-    n = int(max(1, min(64, budget_s / max(one, 1e-3))))
+    n = 8
     x = rng.standard_normal((n, 441000)).astype(np.float32)
-    reps, dt = 0, 0.0
-    t0 = time.perf_counter()
-    while dt < budget_s and reps < 50:  # repeat the sample until ~budget_s of CPU work
-        O.stft(x, wsin, wcos, 512, output_format="Magnitude", acc=np.float32)
-        reps += 1
-        dt = time.perf_counter() - t0
-    try:
-        from threadpoolctl import threadpool_info
+    xt = torch.from_numpy(x)
+    wc_t, ws_t = m.wcos.detach(), m.wsin.detach()
 
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count()])
-    except Exception:
-        cores = os.cpu_count()
-    out = dict(value=reps * n * 862 / dt, unit="frames/s", cores=int(cores), kind="port",
-               sample="%d x %d of 64 clips (10 s @ 44.1 kHz) of configs[1], numpy float32 BLAS port "
-                      "of the reference conv1d STFT (oracle/spectral_oracle.py; the reference itself "
-                      "is not on the GPU box), %.1f s" % (reps, n, dt))
-    # beside it, bounded to a few seconds each: the FFT route librosa.stft takes (librosa itself is
-    # not installable here: SURVEY.md 8d "librosa-equivalent"), and the port of the reference's
-    # CQT1992v2 on the CQT84 workload of the metric
+    def ref_ops():
+        xp = Fnn.pad(xt[:, None, :], (1024, 1024), mode="reflect")
+        re, im = Fnn.conv1d(xp, wc_t, stride=512), Fnn.conv1d(xp, ws_t, stride=512)
+        return torch.sqrt(re.pow(2) + im.pow(2))
+
+    with torch.no_grad():
+        ref_ops()
+        t0 = time.perf_counter()
+        reps, dt = 0, 0.0
+        while dt < budget_s and reps < 200:  # repeat the sample until ~budget_s of CPU work
+            ref_ops()
+            reps += 1
+            dt = time.perf_counter() - t0
+    cores = int(torch.get_num_threads())
+    out = dict(value=reps * n * 862 / dt, unit="frames/s", cores=cores, kind="port",
+               sample="%d x %d of 64 clips (10 s @ 44.1 kHz) of configs[1]: the reference forward's operator sequence (pad + 2 x "
+                      "F.conv1d + sqrt, stft.py:278-316) on torch's CPU kernels with the module's buffers; the reference package "
+                      "itself is not on the GPU box, %.1f s" % (reps, n, dt))
     try:
-        xt = torch.from_numpy(x[: min(n, 16)])
+        wsin, wcos = m.wsin.numpy(), m.wcos.numpy()
+        xs = x[:2]
+        t0 = time.perf_counter()
+        reps1 = 0
+        while time.perf_counter() - t0 < 5.0 and reps1 < 20:
+            O.stft(xs, wsin, wcos, 512, output_format="Magnitude", acc=np.float32)
+            reps1 += 1
+        dt1 = time.perf_counter() - t0
+        out["numpy_port"] = dict(value=reps1 * xs.shape[0] * 862 / dt1, unit="frames/s",
+                                 what="oracle/spectral_oracle.py (numpy float32 BLAS restatement, the parity checker), "
+                                      "%d clips x %d, %.1f s" % (xs.shape[0], reps1, dt1))
+    except Exception as e:
+        out["numpy_port"] = {"error": repr(e)}
+    try:
         win = torch.hann_window(2048, periodic=True)
         t0 = time.perf_counter()
         reps2 = 0
@@ -463,7 +484,7 @@ def cpu_baseline(budget_s=15.0):
             reps2 += 1
         dt2 = time.perf_counter() - t0
         out["librosa_equivalent"] = dict(
-            value=reps2 * xt.shape[0] * 862 / dt2, unit="frames/s", cores=int(torch.get_num_threads()),
+            value=reps2 * xt.shape[0] * 862 / dt2, unit="frames/s", cores=cores,
             what="torch.stft(n_fft=2048, hop=512, hann, reflect).abs() on CPU: the FFT algorithm of "
                  "librosa.stft (librosa is not installed), %d clips x %d, %.1f s" % (xt.shape[0], reps2, dt2))
     except Exception as e:
@@ -471,17 +492,26 @@ def cpu_baseline(budget_s=15.0):
     try:
         c = features.CQT1992v2(sr=44100, hop_length=512, fmin=32.70, n_bins=84, bins_per_octave=12,
                                verbose=False)
-        kr, ki, ln = c.cqt_kernels_real.numpy(), c.cqt_kernels_imag.numpy(), c.lenghts.numpy()
-        xc = x[:2]
-        t0 = time.perf_counter()
-        reps3 = 0
-        while time.perf_counter() - t0 < 6.0 and reps3 < 20:
-            O.cqt1992v2(xc, kr, ki, ln, 512, output_format="Magnitude", acc=np.float32)
-            reps3 += 1
-        dt3 = time.perf_counter() - t0
-        out["cqt84"] = dict(value=reps3 * xc.shape[0] * 862 / dt3, unit="frames/s", cores=int(cores), kind="port",
-                            sample="%d x %d clips (10 s @ 44.1 kHz), numpy float32 BLAS port of the "
-                                   "reference CQT1992v2 (dense 32768-tap conv1d), %.1f s"
+        kr, ki, ln = c.cqt_kernels_real.detach(), c.cqt_kernels_imag.detach(), c.lenghts.detach()
+        xc = xt[:2]
+
+        def cqt_ops():
+            xp = Fnn.pad(xc[:, None, :], (c.kernel_width // 2, c.kernel_width // 2), mode="reflect")
+            re = Fnn.conv1d(xp, kr, stride=512) * torch.sqrt(ln.view(-1, 1))
+            im = -Fnn.conv1d(xp, ki, stride=512) * torch.sqrt(ln.view(-1, 1))
+            return torch.sqrt(re.pow(2) + im.pow(2))
+
+        with torch.no_grad():
+            cqt_ops()
+            t0 = time.perf_counter()
+            reps3 = 0
+            while time.perf_counter() - t0 < 6.0 and reps3 < 50:
+                cqt_ops()
+                reps3 += 1
+            dt3 = time.perf_counter() - t0
+        out["cqt84"] = dict(value=reps3 * xc.shape[0] * 862 / dt3, unit="frames/s", cores=cores, kind="port",
+                            sample="%d x %d clips (10 s @ 44.1 kHz): the reference CQT1992v2 forward's operator sequence (pad + 2 x "
+                                   "F.conv1d with the 32768-tap kernels + sqrt, cqt.py:740-772) on torch's CPU kernels, %.1f s"
                                    % (reps3, xc.shape[0], dt3))
     except Exception as e:
         out["cqt84"] = {"error": repr(e)}
@@ -579,7 +609,7 @@ def compact_line(out):
         c.setdefault("value", None)
         c.setdefault("cores", None)
         c["sample"] = (cb.get("sample") or "")[:100]
-        for sub in ("librosa_equivalent", "cqt84"):
+        for sub in ("numpy_port", "librosa_equivalent", "cqt84"):
             if isinstance(cb.get(sub), dict) and "value" in cb[sub]:
                 c[sub] = {"value": _r(cb[sub]["value"])}
         line["cpu_baseline"] = c

@@ -318,9 +318,10 @@ int mispec_fold2_basis(const float *basis_re, const float *basis_im, int64_t bas
  * n_bins <= kernel/2 + 1, a pointwise epilogue (with or without the fused filterbank), automatic tile and
  * no_fft == 0 the call is ONE launch that evaluates every frame's DFT as an fp32 FFT (2e-7 of the peak) whatever
  * `precision` says -- no workspace, nothing else of the argument block changes meaning.  kernel = 256 runs as
- * zero-extended frames on the 512-point transform.  kernel = 4096 (even hop and pad, no fused filterbank) runs
- * COMPOSITE: the padded clips de-interleaved into the workspace, two 2048-point transforms of the even / odd
- * samples, a butterfly + epilogue launch -- sized by mispec_framed_gemm_workspace_bytes() like every other route. */
+ * zero-extended frames on the 512-point transform.  kernel = 4096 (even hop and pad, no fused filterbank, not the
+ * (cos, sin) phase format) runs COMPOSITE: the padded clips de-interleaved into the workspace, two 2048-point
+ * transforms of the even / odd samples, the second one's flush forming the butterfly + epilogue -- workspace
+ * sized by mispec_framed_gemm_workspace_bytes() like every other route. */
 int mispec_framed_gemm_f32(const mispec_framed_gemm_args *args, void *stream);
 
 /* `n` (<= 8) independent contractions in ONE launch: the octaves of CQT2010v2 / VQT

@@ -130,9 +130,9 @@ def _compile(src, obj, ablate, verbose):
 #     experiments/ldsdma_hazard), so scratch there is slow, not wrong -- but it must not appear unnoticed: refused unless
 #     the instance is on this list with the bytes per lane it is known to have (review them when they change).
 SCRATCH_ALLOWED = {
-    "stft_fft_kernelILi512ELi2ELb0EE": 32,    # n_fft = 1024 Power, two workgroups per CU (128 VGPRs)
-    "stft_fft_kernelILi512ELi3ELb0EE": 32,    # ... atan2 phase
-    "stft_fft_kernelILi512ELi1ELb0EE": 32,    # ... Magnitude
+    "stft_fft_kernelILi512ELi2ELb0E": 32,     # n_fft = 1024 Power, two workgroups per CU (128 VGPRs)
+    "stft_fft_kernelILi512ELi3ELb0E": 32,     # ... atan2 phase
+    "stft_fft_kernelILi512ELi1ELb0E": 32,     # ... Magnitude
     "istft_ola_fft_kernelILi1024EE": 32,       # the fused inverse at n_fft = 2048 (256 VGPRs + a few spilled values)
 }
 

@@ -191,6 +191,8 @@ struct KParams {
   int n_fb;
   int fb_lds_floats;  // FFT route: LDS floats (after the kernel's own tables) for the packed band weights, 0: none
   int fft_row_step;   // FFT route: 512 / n_fft for the frames of n_fft = 256 (zero-extended to 512 samples), else 1
+  const float *cmb_E;  // FFT route, n_fft = 4096 composite: the even samples' spectrum (n_clips, 1025, n_frames, 2) -- the Complex
+                       // 2048-point instance then stores X[k] = E[k] + W^k O[k] and X[2048 - k] instead of its own tile (stft_fft.inl)
   // symmetric fold (framed_fold.inl): as = folded basis, xs = folded frames, Ks = folded taps
   const float *fold_last;  // fp32 folded (even | odd) rows of the bin the pre-pass evaluates, or NULL
   int fold_last_bin;       // that bin, relative to the problem's first bin
@@ -3118,7 +3120,7 @@ bool fft_ok(const mispec_framed_gemm_args *a, const KParams &p) {
   return (long long)p.n_clips * p.n_frames <= 0x3fffffffLL;
 }
 
-template <int M, int EPI, bool FB>
+template <int M, int EPI, bool FB, int CEPI = -1>
 int launch_fft_cfg(const KParams &p, hipStream_t stream) {
   constexpr int W = (EPI == MISPEC_EPI_COMPLEX || EPI == MISPEC_EPI_PHASE_COSSIN) ? 2 : 1;
   constexpr int FT = fft_tile_frames<M, W, FB>();
@@ -3128,7 +3130,7 @@ int launch_fft_cfg(const KParams &p, hipStream_t stream) {
   const size_t lds_share = 160 * 1024 / per_cu;
   long long grid = n_tiles < per_cu * device_cus() ? n_tiles : per_cu * device_cus();
   grid = (grid + 7) / 8 * 8;
-  auto kern = stft_fft_kernel<M, EPI, FB>;
+  auto kern = stft_fft_kernel<M, EPI, FB, CEPI>;
   static std::atomic<unsigned long long> configured{0};
   constexpr size_t smem0 = (stft_fft_smem<M, W, FB>() + 15) & ~(size_t)15;
   // fused filterbank: the band weights (a mel bank has ~8 non-zeros per filter) packed into whatever LDS the
@@ -3182,10 +3184,11 @@ int launch_fft(const KParams &p, hipStream_t stream) {
 //   X[k] = E[k] + W^k O[k],  X[2048 - k] = conj(E[k] - W^k O[k]),  W = e^(-2 pi i / 4096),  k = 0 .. 1024
 // Launches: fft4096_split_kernel (virtual padding applied, clips de-interleaved into the workspace -- reflect padding does
 // not commute with the de-interleave when the clip length is even, so the padded streams are materialised --, the window's
-// even / odd taps), the two transforms (pad 0, hop / 2), fft4096_combine_kernel (the butterfly above + the pointwise
-// epilogue of the FFT kernel, rows k and 2048 - k of the output).  Moves ~4 x the bytes of a native instance (E and O pass
-// through HBM as complex spectrograms) and still undercuts the contraction kernels; hop and pad must be even, no fused
-// filterbank.  Workspace: mispec_framed_gemm_workspace_bytes().
+// even / odd taps), then the two transforms (pad 0, hop / 2): the first writes E as a complex spectrogram into the workspace,
+// the second keeps O in its LDS tile and its flush (stft_fft.inl, flush_cmb) reads E, forms the butterfly above and stores
+// rows k and 2048 - k of the caller's output through the caller's pointwise epilogue.  E passes through HBM once each way
+// (~2.3 x the bytes of a native instance); hop and pad must be even, no fused filterbank.
+// Workspace: mispec_framed_gemm_workspace_bytes().
 // ---------------------------------------------------------------------------------
 namespace {
 struct Fft4096Plan {
@@ -3199,7 +3202,8 @@ Fft4096Plan plan_fft4096(const mispec_framed_gemm_args *a, const KParams &p) {
   if (MISPEC_DBG(p, 0x100000) || MISPEC_DBG(p, 0x40000000) || MISPEC_DBG(p, 0x08000000)) return pl;  // A/B runs
   if (!p.a_im || p.row_support || p.row_scale || p.fb || (p.hop & 1) || (p.pad & 1)) return pl;
   if (a->basis_fold2_bytes < basis_fold2_bytes(p.n_bins, p.K)) return pl;
-  if (p.epilogue < MISPEC_EPI_COMPLEX || p.epilogue > MISPEC_EPI_PHASE_COSSIN) return pl;
+  // (the (cos, sin) phase format -- CQT's, never an STFT module's -- spills in the second transform's flush: contraction kernels)
+  if (p.epilogue < MISPEC_EPI_COMPLEX || p.epilogue >= MISPEC_EPI_PHASE_COSSIN) return pl;
   if (p.n_bins > 2049 || p.n_frames <= 0 || (long long)p.n_clips * p.n_frames > 0x3fffffffLL) return pl;
   const long long Lp = (long long)p.n_samples + 2LL * p.pad;
   pl.Lh = (Lp + 1) / 2;
@@ -3209,8 +3213,8 @@ Fft4096Plan plan_fft4096(const mispec_framed_gemm_args *a, const KParams &p) {
   pl.off_xo = pl.slot * p.n_clips;
   pl.off_w = 2 * pl.off_xo;
   pl.off_E = pl.off_w + 4096;
-  pl.off_O = pl.off_E + spec;
-  pl.bytes = (pl.off_O + spec) * (long long)sizeof(float);
+  pl.off_O = 0;  // (the odd samples' spectrum never leaves the second transform's tile)
+  pl.bytes = (pl.off_E + spec) * (long long)sizeof(float);
   pl.ok = true;
   return pl;
 }
@@ -3243,41 +3247,11 @@ __global__ void __launch_bounds__(256) fft4096_split_kernel(const float *__restr
   xo[(long long)b * slot + j] = v[1];
 }
 
-template <int EPI>
-__global__ void __launch_bounds__(256) fft4096_combine_kernel(const KParams p, const float *__restrict__ E, const float *__restrict__ O) {
-  typedef float f2u __attribute__((ext_vector_type(2)));
-  constexpr int W = (EPI == MISPEC_EPI_COMPLEX || EPI == MISPEC_EPI_PHASE_COSSIN) ? 2 : 1;
-  const int t = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y, b = blockIdx.z;
-  const int T = p.n_frames;
-  if (t >= T) return;
-  const long long at = ((long long)b * 1025 + k) * T + t;
-  const f2u e = reinterpret_cast<const f2u *>(E)[at], o = reinterpret_cast<const f2u *>(O)[at];
-  float sn, cs;
-  sincospif(-(float)k / 2048.f, &sn, &cs);  // W^k = e^(-2 pi i k / 4096)
-  const float wr = o.x * cs - o.y * sn, wi = o.x * sn + o.y * cs;
-  const float ims = -p.im_sign;
-  float *const oc = p.out + (long long)b * p.out_clip_stride + (long long)p.out_row_offset * p.out_row_stride + (long long)t * W;
-  if (k < p.n_bins) {
-    float v0, v1;
-    fft_epilogue<EPI>(p, e.x + wr, ims * (e.y + wi), v0, v1);
-    float *d = oc + (long long)k * p.out_row_stride;
-    d[0] = v0;
-    if constexpr (W == 2) d[1] = v1;
-  }
-  if (k != 1024 && 2048 - k < p.n_bins) {  // X[2048 - k] = conj(E[k] - W^k O[k])
-    float v0, v1;
-    fft_epilogue<EPI>(p, e.x - wr, ims * -(e.y - wi), v0, v1);
-    float *d = oc + (long long)(2048 - k) * p.out_row_stride;
-    d[0] = v0;
-    if constexpr (W == 2) d[1] = v1;
-  }
-}
-
 int launch_fft4096(const KParams &p, const mispec_framed_gemm_args *a, const Fft4096Plan &pl, hipStream_t stream) {
   if (!a->workspace || a->workspace_bytes < pl.bytes)
     return fail(MISPEC_E_INVALID, "workspace too small: size it with the *_workspace_bytes query%s");
   float *const ws = static_cast<float *>(a->workspace);
-  float *const xe = ws, *const xo = ws + pl.off_xo, *const w = ws + pl.off_w, *const E = ws + pl.off_E, *const O = ws + pl.off_O;
+  float *const xe = ws, *const xo = ws + pl.off_xo, *const w = ws + pl.off_w, *const E = ws + pl.off_E;
   hipLaunchKernelGGL(fft4096_split_kernel, dim3((unsigned)((pl.slot + 255) / 256), (unsigned)p.n_clips), dim3(256), 0, stream, p.x,
                      p.x_clip_stride, p.n_samples, p.pad, p.pad_mode, p.a_re, xe, xo, pl.slot, pl.Lh, w);
   for (int h = 0; h < 2; ++h) {
@@ -3289,41 +3263,35 @@ int launch_fft4096(const KParams &p, const mispec_framed_gemm_args *a, const Fft
     q.pad = 0;
     q.pad_mode = MISPEC_PAD_NONE;
     q.K = 2048;
-    q.n_bins = 1025;
     q.a_re = w + 2048 * h;
     q.a_im = w + 2048 * h;  // (not read)
     q.a_row_stride = 2048;
-    q.epilogue = MISPEC_EPI_COMPLEX;
-    q.im_sign = -1.f;  // (re, im) of the DFT itself
-    q.eps = 0.f;
-    q.out = h ? O : E;
-    q.out_clip_stride = 1025LL * p.n_frames * 2;
-    q.out_row_stride = 2LL * p.n_frames;
-    q.out_row_offset = 0;
     q.fb = nullptr;
-    const int rc = launch_fft_cfg<1024, MISPEC_EPI_COMPLEX, false>(q, stream);
+    if (h == 0) {  // E = RFFT_2048(w_e y_e): (re, im) of the DFT itself into the workspace
+      q.n_bins = 1025;
+      q.epilogue = MISPEC_EPI_COMPLEX;
+      q.im_sign = -1.f;
+      q.eps = 0.f;
+      q.out = E;
+      q.out_clip_stride = 1025LL * p.n_frames * 2;
+      q.out_row_stride = 2LL * p.n_frames;
+      q.out_row_offset = 0;
+    } else {       // O stays in the transform's tile: its flush reads E and stores the caller's rows k and 2048 - k (the caller's
+      q.cmb_E = E;  // epilogue, sign, bins and output strides are the ones already in q)
+    }
+    int rc;
+    if (h == 0) {
+      rc = launch_fft_cfg<1024, MISPEC_EPI_COMPLEX, false>(q, stream);
+    } else {
+      switch (p.epilogue) {
+        case MISPEC_EPI_COMPLEX: rc = launch_fft_cfg<1024, MISPEC_EPI_COMPLEX, false, MISPEC_EPI_COMPLEX>(q, stream); break;
+        case MISPEC_EPI_MAGNITUDE: rc = launch_fft_cfg<1024, MISPEC_EPI_COMPLEX, false, MISPEC_EPI_MAGNITUDE>(q, stream); break;
+        case MISPEC_EPI_POWER: rc = launch_fft_cfg<1024, MISPEC_EPI_COMPLEX, false, MISPEC_EPI_POWER>(q, stream); break;
+        default: rc = launch_fft_cfg<1024, MISPEC_EPI_COMPLEX, false, MISPEC_EPI_PHASE_ATAN2>(q, stream); break;
+      }
+    }
     if (rc != MISPEC_OK) return rc;
   }
-  const dim3 grid((unsigned)((p.n_frames + 255) / 256), 1025u, (unsigned)p.n_clips);
-  switch (p.epilogue) {
-    case MISPEC_EPI_COMPLEX:
-      hipLaunchKernelGGL(fft4096_combine_kernel<MISPEC_EPI_COMPLEX>, grid, dim3(256), 0, stream, p, E, O);
-      break;
-    case MISPEC_EPI_MAGNITUDE:
-      hipLaunchKernelGGL(fft4096_combine_kernel<MISPEC_EPI_MAGNITUDE>, grid, dim3(256), 0, stream, p, E, O);
-      break;
-    case MISPEC_EPI_POWER:
-      hipLaunchKernelGGL(fft4096_combine_kernel<MISPEC_EPI_POWER>, grid, dim3(256), 0, stream, p, E, O);
-      break;
-    case MISPEC_EPI_PHASE_ATAN2:
-      hipLaunchKernelGGL(fft4096_combine_kernel<MISPEC_EPI_PHASE_ATAN2>, grid, dim3(256), 0, stream, p, E, O);
-      break;
-    default:
-      hipLaunchKernelGGL(fft4096_combine_kernel<MISPEC_EPI_PHASE_COSSIN>, grid, dim3(256), 0, stream, p, E, O);
-      break;
-  }
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
   return MISPEC_OK;
 }
 }  // namespace

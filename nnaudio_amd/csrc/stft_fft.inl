@@ -257,7 +257,8 @@ constexpr int fft_tile_frames() {
 
 // M = n_fft / 2; EPI = the epilogue (W = floats per output element: 2 for Complex / Phase as (cos, sin)); FB = with
 // the fused filterbank (p.fb; EPI = MISPEC_EPI_POWER)
-template <int M, int EPI, bool FB>
+// CEPI >= 0: the n_fft = 4096 composite's second transform (see cmb below), CEPI = the CALLER'S epilogue
+template <int M, int EPI, bool FB, int CEPI = -1>
 __global__ void __launch_bounds__((fft_waves<M, (EPI == MISPEC_EPI_COMPLEX || EPI == MISPEC_EPI_PHASE_COSSIN) ? 2 : 1>() * 64), (fft_min_waves<M, EPI, FB>()))
     stft_fft_kernel(const KParams p, const int tiles_per_clip) {
   using namespace fftcore;
@@ -350,7 +351,12 @@ __global__ void __launch_bounds__((fft_waves<M, (EPI == MISPEC_EPI_COMPLEX || EP
 
   const int n_tiles = p.n_clips * tiles_per_clip;
   const int hop = p.hop, L = p.n_samples, T = p.n_frames;
-  const int n_rows = p.n_bins < M + 1 ? p.n_bins : M + 1;  // rows of the tile that are stored
+  // n_fft = 4096 composite (mispec.hip launch_fft4096): this instance transforms the ODD samples; its tile (O) is not stored, the
+  // flush reads E (p.cmb_E) and writes X[k] = E[k] + W^k O[k] and X[2048 - k] = conj(E[k] - W^k O[k]) through the caller's epilogue
+  constexpr bool CMB_OK = CEPI >= 0;
+  static_assert(!CMB_OK || (M == 1024 && EPI == MISPEC_EPI_COMPLEX && !FB), "the composite's second transform is the Complex 2048-point instance");
+  constexpr bool cmb = CMB_OK;
+  const int n_rows = cmb ? M + 1 : (p.n_bins < M + 1 ? p.n_bins : M + 1);  // rows of the tile that are stored
   // wave-level ordering of the exchange buffer: the LDS executes a wave's instructions in order; only the
   // compiler has to be kept from moving accesses across
   auto wave_sync = []() __attribute__((always_inline)) {
@@ -385,6 +391,70 @@ __global__ void __launch_bounds__((fft_waves<M, (EPI == MISPEC_EPI_COMPLEX || EP
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (t0 + fl + e / W < T) d[e] = v[e];
+        }
+      }
+    }
+  };
+
+  // ---- n_fft = 4096 composite: rows of E for the tile just transformed, requested at the end of its step (ahead of the barrier;
+  // the flush at the top of the next step uses them); lane = (row r0 + 128 j, frame pair fl)
+  constexpr int CNIT = CMB_OK ? (M + 1 + NW * 64 / (FT * W / 4) - 1) / (NW * 64 / (FT * W / 4)) : 1;
+  f32x4v ce[CNIT];
+  auto cmb_request = [&](int c, int t0) __attribute__((always_inline)) {
+    constexpr int LPR = FT * W / 4, RPI = NW * 64 / LPR;
+    const int fl = (tid % LPR) * (4 / W), r0 = tid / LPR;
+#pragma unroll
+    for (int j = 0; j < CNIT; ++j) {
+      const int k = r0 + RPI * j;
+      ce[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+      if (k <= M && t0 + fl < T) {
+        const float *src = p.cmb_E + (((long long)c * (M + 1) + k) * T + t0 + fl) * 2;
+        if (t0 + fl + 1 < T) {
+          const f32x4u v = *reinterpret_cast<const f32x4u *>(src);
+          ce[j] = f32x4v{v[0], v[1], v[2], v[3]};
+        } else {
+          ce[j] = f32x4v{src[0], src[1], 0.f, 0.f};
+        }
+      }
+    }
+  };
+  auto cmb_epilogue = [&](float re, float im, float &v0, float &v1) __attribute__((always_inline)) {
+    fft_epilogue<CMB_OK ? CEPI : MISPEC_EPI_COMPLEX>(p, re, im, v0, v1);  // (the CALLER'S epilogue; this instance's own -- Complex -- only shapes the tile)
+  };
+  auto flush_cmb = [&](const float *tile, float *oc, int t0) __attribute__((always_inline)) {
+    constexpr int LPR = FT * W / 4, RPI = NW * 64 / LPR;
+    const int fl = (tid % LPR) * (4 / W), r0 = tid / LPR;
+    if (t0 + fl >= T || MISPEC_DBG(p, 0x1)) return;
+    constexpr int wo = (CEPI == MISPEC_EPI_COMPLEX || CEPI == MISPEC_EPI_PHASE_COSSIN) ? 2 : 1;  // floats per output
+    const float ims = -p.im_sign;
+    const bool two = t0 + fl + 1 < T;
+#pragma unroll
+    for (int j = 0; j < CNIT; ++j) {
+      const int k = r0 + RPI * j;
+      if (k > M) continue;
+      const cf *src = reinterpret_cast<const cf *>(tile + k * C + fl * W);
+      const cf o0 = src[0], o1 = src[1];
+      // W^k = e^(-2 pi i k / 4096): the post-processing table holds e^(-2 pi i m / 2048) -- every second power
+      cf wk = s_wh[k >> 1];
+      if (k & 1) wk = cmul(wk, cf{0.99999882345170188f, -0.0015339801862847655f});  // x e^(-2 pi i / 4096)
+      const cf e0 = cf{ce[j][0], ce[j][1]}, e1 = cf{ce[j][2], ce[j][3]};
+      const cf w0 = cmul(o0, wk), w1 = cmul(o1, wk);
+      float v[2][2][2];  // [row k | row 2048 - k][frame][component]
+      cmb_epilogue(e0.x + w0.x, ims * (e0.y + w0.y), v[0][0][0], v[0][0][1]);
+      cmb_epilogue(e1.x + w1.x, ims * (e1.y + w1.y), v[0][1][0], v[0][1][1]);
+      cmb_epilogue(e0.x - w0.x, ims * -(e0.y - w0.y), v[1][0][0], v[1][0][1]);  // conj(E - W O)
+      cmb_epilogue(e1.x - w1.x, ims * -(e1.y - w1.y), v[1][1][0], v[1][1][1]);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int row = h ? 2 * M - k : k;
+        if (row >= p.n_bins || (h && k == M)) continue;
+        float *d = oc + (long long)row * p.out_row_stride + (long long)(t0 + fl) * wo;
+        if (wo == 2) {
+          *reinterpret_cast<cf *>(d) = cf{v[h][0][0], v[h][0][1]};
+          if (two) *reinterpret_cast<cf *>(d + 2) = cf{v[h][1][0], v[h][1][1]};
+        } else {
+          d[0] = v[h][0][0];
+          if (two) d[1] = v[h][1][0];
         }
       }
     }
@@ -514,6 +584,9 @@ __global__ void __launch_bounds__((fft_waves<M, (EPI == MISPEC_EPI_COMPLEX || EP
             // waited for BEFORE them, when nothing younger than it is in flight; one requested just now after them, with them)
             if (had_pre) fft_wait_vm(0);
             flush_fb(prev_tile, prev_oc, prev_t0);
+          } else if (cmb) {
+            if (had_pre) fft_wait_vm(0);  // (loads and stores of this flush are not counted: as with the fused filterbank)
+            flush_cmb(prev_tile, prev_oc, prev_t0);
           } else {
             flush(prev_tile, prev_oc, prev_t0);
             younger += n_flush_stores;
@@ -524,7 +597,7 @@ __global__ void __launch_bounds__((fft_waves<M, (EPI == MISPEC_EPI_COMPLEX || EP
       FFT_STAMP(1);
       if (!live) continue;
       if (fast && u == 0) {
-        if (!(FB && had_pre && prev_oc)) fft_wait_vm(younger);
+        if (!((FB || cmb) && had_pre && prev_oc)) fft_wait_vm(younger);
         FFT_STAMP(2);
         const cf *const plain = buf;
 #pragma unroll
@@ -605,7 +678,7 @@ __global__ void __launch_bounds__((fft_waves<M, (EPI == MISPEC_EPI_COMPLEX || EP
         const cf *const whp = s_wh + lane;
         float *const ta = tile + lane * C + W * f;
         float *const tb = tile + (M - lane) * C + W * f;
-        const float ims = -p.im_sign;
+        const float ims = cmb ? 1.f : -p.im_sign;  // (composite: the tile holds O itself)
         // the mirrored values first: behind them the exchange buffer is idle until this wave's next frame, and the FIRST
         // frame of its NEXT tile is requested right here (round 5) -- it travels under the post-processing, the barrier
         // and the flush instead of being asked for at the top of the next step and waited for at once (the wave's own
@@ -669,6 +742,9 @@ __global__ void __launch_bounds__((fft_waves<M, (EPI == MISPEC_EPI_COMPLEX || EP
       wave_sync();  // the mirrored reads are done before the next frame's first pass overwrites the buffer
     }
     FFT_STAMP(10);
+    // (composite: E's rows for THIS tile, used by the flush at the top of the next step -- requested here, behind the transform:
+    // held across it they made the instance spill; they travel under the barrier and the next step's waits)
+    if (cmb) cmb_request(c, t0);
     FFT_STAMP(11);
     __syncthreads();  // the tile is complete (two buffers: and the other one has been read out)
     FFT_STAMP(12);
@@ -680,6 +756,8 @@ __global__ void __launch_bounds__((fft_waves<M, (EPI == MISPEC_EPI_COMPLEX || EP
     const float *const last = tiles + (DB ? ((step & 1) ^ 1) * TILE_FLOATS : 0);
     if constexpr (FB)
       flush_fb(last, prev_oc, prev_t0);
+    else if (cmb)
+      flush_cmb(last, prev_oc, prev_t0);
     else
       flush(last, prev_oc, prev_t0);
   }

@@ -415,11 +415,11 @@ def test_scratch_guard_sees_cached_objects(tmp_path, monkeypatch):
 
     # the allow-list: framed_* / octave_stream* never, stft_fft_* / istft_* only the listed instances within their bytes
     r = {"framed_fold_kernelENS_7KParamsE": 8, "octave_stream_kernelILi6ELb1EEvNS_3OSPE": 4,
-         "stft_fft_kernelILi512ELi2ELb0EEEvNS_7KParamsEi": 20, "stft_fft_kernelILi1024ELi1ELb0EEEvNS_7KParamsEi": 4,
+         "stft_fft_kernelILi512ELi2ELb0ELin1EEEvNS_7KParamsEi": 20, "stft_fft_kernelILi1024ELi1ELb0ELin1EEEvNS_7KParamsEi": 4,
          "istft_ola_fft_kernelILi1024EEEvPKfiiS2_iiiPfxiii": 12, "fold2_frames_kernel": 64, "clean": 0}
     bad = build.refused_scratch(r, ablate=False)
     assert set(bad) == {"framed_fold_kernelENS_7KParamsE", "octave_stream_kernelILi6ELb1EEvNS_3OSPE",
-                        "stft_fft_kernelILi1024ELi1ELb0EEEvNS_7KParamsEi"}
+                        "stft_fft_kernelILi1024ELi1ELb0ELin1EEEvNS_7KParamsEi"}
     assert "octave_stream_kernelILi6ELb1EEvNS_3OSPE" not in build.refused_scratch(r, ablate=True)  # (benchmarking build: warned)
     # the record next to an object
     obj = str(tmp_path / "unit.o")

@@ -58,7 +58,10 @@ def test_fft_path_against_float64(shape, epi):
                 "phase": (engine.EPI_PHASE_ATAN2, {}), "cossin": (engine.EPI_PHASE_COSSIN, {})}[epi]
     y = engine.framed_gemm(xd, wrd, wid, epilogue=e, **kw, **extra, **prep)
     y_gemm = engine.framed_gemm(xd, wrd, wid, epilogue=e, fft=False, **kw, **extra, **prep)
-    assert y.shape == y_gemm.shape and not torch.equal(y, y_gemm), "the contraction kernels ran"
+    if K == 4096 and epi == "cossin":   # the one epilogue the composite instance refuses (mispec.hip plan_fft4096): contraction kernels
+        assert torch.equal(y, y_gemm)
+    else:
+        assert y.shape == y_gemm.shape and not torch.equal(y, y_gemm), "the contraction kernels ran"
     y = y.cpu().numpy()
     what = "fft %s %s" % (shape, epi)
     mag = np.sqrt(re * re + im * im)

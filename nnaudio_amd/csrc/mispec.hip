@@ -43,7 +43,7 @@
 // tiles, 0x40000 no epilogue, 0x80000 two K stages only, 0x100000 bf16x3: dense (unfolded) kernel,
 // 0x200000 fold: chunks of clips; fold pre-pass: 0x40 no global stores, 0x80 no global loads, 0x200
 // without the last bin; fused filterbank: 0x400 no walk, 0x10000 walk without stores, 0x400000 plain
-// stores instead of atomics.
+// stores instead of atomics; 0x10000000 support-aware fp32 tiles: 32-row MFMA tiles (round 4) instead of 16-row.
 // In the product library MISPEC_DBG() is the constant false (the branches compile away) and a
 // non-zero `reserved` is rejected.
 //
@@ -468,13 +468,21 @@ __device__ __forceinline__ void filterbank_from_tile(const KParams &p, float *P,
 //
 // MISPEC_DBG bits: see the file header (benchmarking build only).
 // ---------------------------------------------------------------------------------
-template <int WM, int WN, int MR, int NR, int BMODE, int AMODE, bool MASKED, bool GLDS>
+//
+// T16 (round 5; support-aware banks, every wave owning all row tiles of 32 frames: the CQT1992v2 bank in fp32): the
+// same stages multiplied as 16 x 16 x 4 MFMA tiles, so that a K stage is skipped per 16 basis rows = 8 complex bins
+// instead of 16.  The CQT84 bank's supports shrink by 2^(1/12) per bin: 16-bin tiles execute 1.49 x the useful
+// products, 8-bin tiles 1.22 x; MFMA rate and LDS fragment traffic per product are those of the 32 x 32 x 2 tiles.
+template <int WM, int WN, int MR, int NR, int BMODE, int AMODE, bool MASKED, bool GLDS, bool T16 = false>
 __device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_index,
                                                  const int wg_count) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * MR * 32;
   constexpr int BN = WN * NR * 32;
-  constexpr int MT = WM * MR;
+  constexpr int TR = T16 ? 16 : 32;           // rows of a support tile
+  constexpr int MT = WM * MR * (T16 ? 2 : 1);  // support tiles of the workgroup
+  static_assert(!T16 || (GLDS && MASKED && WM == 1 && NR == 1 && BMODE == BMODE_FRAMED && AMODE == AMODE_ROWS && MR <= 8),
+                "16-row tiles: the support-aware LDS-direct instance");
   static_assert(NT == 256, "loader geometry assumes 256 threads");
   constexpr int APASS = BM / 32;
   constexpr int BPASS = BN / 32;  // framed mode
@@ -560,13 +568,13 @@ __device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_
                      : p.x + (long long)c * p.x_clip_stride + (long long)t * (p.x_col_stride ? p.x_col_stride : 1);
   }
   if (tid < MT) {
-    const int row_lo = m0 + tid * 32;
+    const int row_lo = m0 + tid * TR;
     int lo = 0, hi = 0;
     if (AMODE == AMODE_TOEPLITZ) {
       if (row_lo < p.n_bins) hi = p.K;
     } else {
       const int bin_lo = row_lo / rpb;
-      int bin_hi = (row_lo + 32 + rpb - 1) / rpb;
+      int bin_hi = (row_lo + TR + rpb - 1) / rpb;
       bin_hi = bin_hi < p.n_bins ? bin_hi : p.n_bins;
       if (bin_lo < bin_hi) {
         if (p.row_support) {
@@ -731,6 +739,66 @@ __device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
 
+  // T16: wave tile = 2*MR x 2 tiles of 16 x 16; element e of lane (l16, lq) is D[row 4*lq + e][col l16]
+  typedef float f32x4a __attribute__((ext_vector_type(4)));
+  constexpr int MR16 = T16 ? 2 * MR : 1;
+  f32x4a acc16[MR16][2];
+  if (T16) {
+#pragma unroll
+    for (int m = 0; m < MR16; ++m)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc16[m][h][e] = 0.f;
+  }
+  // One K stage as 16 x 16 x 4 tiles: 2 K groups of 16 taps.  v_mfma_f32_16x16x4_f32 IS an fp32 FMA chain through its four
+  // k lanes in ascending order (experiments/tap_order/mfma_order.hip: bit-identical on 51 200 random results; a single
+  // rounding of the exact sum matches 67 %), so with lane (l16, lq) supplying tap 16q + 4s + lq of basis row / frame l16
+  // to MFMA s, an accumulator is ONE float32 FMA chain over the taps in ascending order: the arithmetic of the
+  // reference's conv1d (its fixture's near-silent bins record that chain's rounding: tests/test_reference_order.py).
+  // The four taps of a lane are four ds_read_b32 (chunk 4q + s of the LDS-direct layout, swizzle undone; conflict free:
+  // the 64 lanes of a read cover 64 banks once).  MRA = leading 16-row tiles multiplied; the fragments of group q + 1 are
+  // read under the MFMAs of group q.
+  int coff[KC / 4];  // dword offset of tap chunk c in this lane's rows
+  {
+    const int fsw = ((lane & 15) >> 1) & 7;
+#pragma unroll
+    for (int c = 0; c < KC / 4; ++c) coff[c] = 4 * (c ^ fsw) + (lane >> 4);
+  }
+  auto mfma_stage16 = [&](int buf, unsigned mask, auto mra_tag, auto use_mask_tag) __attribute__((always_inline)) {
+    constexpr int MRA = decltype(mra_tag)::value;
+    constexpr bool USE_MASK = decltype(use_mask_tag)::value;
+    const float *a_base = sA + buf * A_STAGE + (lane & 15) * LROW;
+    const float *b_base = sB + buf * B_STAGE + (wn * 32 + (lane & 15)) * LROW;
+    float av[2][MRA][4], bv[2][2][4];
+    auto load_frags = [&](int q, int slot) __attribute__((always_inline)) {
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int off = coff[4 * q + s4];
+#pragma unroll
+        for (int m = 0; m < MRA; ++m) av[slot][m][s4] = a_base[m * 16 * LROW + off];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) bv[slot][h][s4] = b_base[h * 16 * LROW + off];
+      }
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int q = 0; q < KC / 16; ++q) {
+      if (q + 1 < KC / 16) load_frags(q + 1, (q + 1) & 1);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+        for (int m = 0; m < MRA; ++m) {
+          if ((!USE_MASK || ((mask >> m) & 1u)) && !MISPEC_DBG(p, 16)) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+              acc16[m][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q & 1][m][s4], bv[q & 1][h][s4], acc16[m][h], 0, 0, 0);
+          }
+        }
+      }
+    }
+  };
+
   // One K stage out of LDS buffer `buf`: 4 K groups of 8; lane (li, lh) supplies k = 8q+4lh+s to
   // MFMA s of group q.  `mid0` / `mid1` run after groups 0 / 1 (LDS stores of the next stage and
   // global loads of the one after), i.e. inside the MFMA stream.  MRA = number of this wave's
@@ -796,7 +864,7 @@ __device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_
     if (GLDS) {
       // LDS-direct: stage c+1 is DMA'd into the other buffer while stage c is multiplied; the
       // barrier at the end of the iteration (which carries the vmcnt(0)) publishes it.
-      constexpr int NA = decltype(na_tag)::value;
+      constexpr int NA = T16 ? (decltype(na_tag)::value + 1) / 2 : decltype(na_tag)::value;  // 32-row passes moved
       auto dma_stage = [&](int c, int buf) __attribute__((always_inline)) {
         const int kc = kb + c * KC;
         typedef __attribute__((address_space(1))) const void *gptr_t;
@@ -817,13 +885,17 @@ __device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_
       for (int c = c0; c < c1; ++c) {
         const int buf = (c - c0) & 1;
         if ((c + 1) < c1 && !MISPEC_DBG(p, 1)) dma_stage(c + 1, buf ^ 1);
-        mfma_stage(
-            buf, stage_mask(kb + c * KC), !MISPEC_DBG(p, 8) || c == c0, mra_tag, use_mask_tag,
-            [&]() __attribute__((always_inline)) {}, [&]() __attribute__((always_inline)) {});
+        if constexpr (T16)
+          mfma_stage16(buf, stage_mask(kb + c * KC), mra_tag, use_mask_tag);
+        else
+          mfma_stage(
+              buf, stage_mask(kb + c * KC), !MISPEC_DBG(p, 8) || c == c0, mra_tag, use_mask_tag,
+              [&]() __attribute__((always_inline)) {}, [&]() __attribute__((always_inline)) {});
         if (!MISPEC_DBG(p, 4)) lds_dma_barrier();
       }
       return;
     }
+    if constexpr (!GLDS) {
     load_a(kb + c0 * KC, na_tag);
     load_b(kb + c0 * KC);
     store_stage(0, na_tag);
@@ -849,11 +921,13 @@ __device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_
           });
       if (!MISPEC_DBG(p, 4)) __syncthreads();
     }
+    }
   };
   using std::integral_constant;
   constexpr bool PHASED = MASKED && (WM == 1) && (AMODE == AMODE_ROWS);
+  constexpr int MRT = T16 ? 2 * MR : MR;  // support tiles per wave (every wave owns all of them when PHASED)
   if (!PHASED) {
-    run_stages(0, nloop, integral_constant<int, APASS>{}, integral_constant<int, MR>{},
+    run_stages(0, nloop, integral_constant<int, T16 ? MRT : APASS>{}, integral_constant<int, MRT>{},
                integral_constant<bool, MASKED>{});
   } else {
     // Support-aware contraction, every wave owns all MR row tiles (WM == 1).  Runs of stages in
@@ -869,9 +943,9 @@ __device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_
       if (c1 - c >= 4) {  // short runs are not worth a pipeline restart
         // one loop instance per prefix length 1 .. MR-1 (instances beyond MR are never formed)
 #define MISPEC_PREFIX_RUN(N)                                                               \
-  if (!done && (N) < MR && m == ((1u << (N)) - 1u)) {                                        \
-    run_stages(c, c1, integral_constant<int, ((N) < MR ? (N) : 1)>{},                        \
-               integral_constant<int, ((N) < MR ? (N) : 1)>{}, integral_constant<bool, false>{}); \
+  if (!done && (N) < MRT && m == ((1u << (N)) - 1u)) {                                       \
+    run_stages(c, c1, integral_constant<int, ((N) < MRT ? (N) : 1)>{},                       \
+               integral_constant<int, ((N) < MRT ? (N) : 1)>{}, integral_constant<bool, false>{}); \
     done = true;                                                                           \
   }
         MISPEC_PREFIX_RUN(1)
@@ -884,7 +958,7 @@ __device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_
 #undef MISPEC_PREFIX_RUN
       }
       if (!done)
-        run_stages(c, c1, integral_constant<int, APASS>{}, integral_constant<int, MR>{},
+        run_stages(c, c1, integral_constant<int, T16 ? MRT : APASS>{}, integral_constant<int, MRT>{},
                    integral_constant<bool, true>{});
       c = c1;
     }
@@ -907,10 +981,13 @@ __device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_
     load_b(kc);  // in bounds by construction (frames are runs of >= Kr floats)
     store_stage(0, std::integral_constant<int, APASS>{});
     __syncthreads();
-    mfma_stage(
-        0, stage_mask(kc), true, std::integral_constant<int, MR>{},
-        std::integral_constant<bool, MASKED>{}, [&]() __attribute__((always_inline)) {},
-        [&]() __attribute__((always_inline)) {});
+    if constexpr (T16)
+      mfma_stage16(0, stage_mask(kc), std::integral_constant<int, MRT>{}, std::integral_constant<bool, true>{});
+    else
+      mfma_stage(
+          0, stage_mask(kc), true, std::integral_constant<int, MR>{},
+          std::integral_constant<bool, MASKED>{}, [&]() __attribute__((always_inline)) {},
+          [&]() __attribute__((always_inline)) {});
   }
 
   // ---- epilogue.  Accumulator element e of lane (li, lh) is D[row = (e&3) + 8*(e>>2) + 4*lh][col = li].
@@ -919,7 +996,7 @@ __device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_
   // indexing only in the ds_write fan-out) and so that stores are contiguous along the
   // innermost output dimension for both store modes.
   __syncthreads();  // every wave is done with the K-stage buffers
-  if (BMODE == BMODE_FRAMED && AMODE == AMODE_ROWS && MR * NR <= 4 && p.fb) {  // (automatic tiles)
+  if (!T16 && BMODE == BMODE_FRAMED && AMODE == AMODE_ROWS && MR * NR <= 4 && p.fb) {  // (automatic tiles)
     // fused filterbank reduction (mel.py:184-189): the tile's |X|^power goes to LDS, bins x
     // frames, and filterbank_from_tile reduces it over the bins of every filter's band.  A lane
     // holds re and im of a bin in adjacent accumulator elements (interleaved rows).
@@ -955,9 +1032,19 @@ __device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_
 #pragma unroll
       for (int n = 0; n < NR; ++n) {
         if (ti == m * NR + n) {
+          if constexpr (T16) {  // (NR == 1) four 16 x 16 tiles of the 32 x 32 patch
 #pragma unroll
-          for (int e = 0; e < 16; ++e)
-            sC[((e & 3) + 8 * (e >> 2) + 4 * lh) * LDC + li] = acc[m][n][e];
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+              for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  sC[(16 * half + 4 * (lane >> 4) + e) * LDC + 16 * h + (lane & 15)] = acc16[T16 ? 2 * m + half : 0][h][e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+              sC[((e & 3) + 8 * (e >> 2) + 4 * lh) * LDC + li] = acc[m][n][e];
+          }
         }
       }
     }
@@ -1025,9 +1112,9 @@ __device__ __forceinline__ void framed_gemm_body(const KParams &p, const int wg_
   }
 }
 
-template <int WM, int WN, int MR, int NR, int BMODE, int AMODE, bool MASKED, bool GLDS>
+template <int WM, int WN, int MR, int NR, int BMODE, int AMODE, bool MASKED, bool GLDS, bool T16 = false>
 __global__ void __launch_bounds__(WM *WN * 64) framed_gemm_kernel(const KParams p) {
-  framed_gemm_body<WM, WN, MR, NR, BMODE, AMODE, MASKED, GLDS>(p, blockIdx.x, gridDim.x);
+  framed_gemm_body<WM, WN, MR, NR, BMODE, AMODE, MASKED, GLDS, T16>(p, blockIdx.x, gridDim.x);
 }
 
 #include "framed_bf16x3.inl"
@@ -1265,7 +1352,7 @@ constexpr size_t cfg_smem() {
   constexpr int A_STAGE = BM * LROW;
   constexpr int B_STAGE = (BMODE == BMODE_FRAMED) ? BN * LROW : KC * BN;
   return sizeof(float) * 2 * (A_STAGE + B_STAGE) + sizeof(const float *) * BN +
-         sizeof(int) * 2 * (WM * MR);
+         sizeof(int) * 4 * (WM * MR);  // (K ranges of up to 2 * WM * MR support tiles)
 }
 
 // fill the tiling fields of p for a tile shape; returns the number of workgroups (or < 0)
@@ -1307,13 +1394,13 @@ int configure_lds(K kern, size_t smem, std::atomic<unsigned long long> &configur
 }
 
 template <int WM, int WN, int MR, int NR, int BMODE, int AMODE = AMODE_ROWS, bool MASKED = true,
-          bool GLDS = false>
+          bool GLDS = false, bool T16 = false>
 int launch_cfg(KParams p, hipStream_t stream) {
   constexpr size_t smem = cfg_smem<WM, WN, MR, NR, BMODE, GLDS>();
   const long long grid = prepare_tiling<WM, WN, MR, NR, AMODE>(p);
   if (grid < 0) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
   if (grid == 0) return MISPEC_OK;
-  auto kern = framed_gemm_kernel<WM, WN, MR, NR, BMODE, AMODE, MASKED, GLDS>;
+  auto kern = framed_gemm_kernel<WM, WN, MR, NR, BMODE, AMODE, MASKED, GLDS, T16>;
   static std::atomic<unsigned long long> configured{0};
   int rc = configure_lds(kern, smem, configured);
   if (rc != MISPEC_OK) return rc;
@@ -1361,6 +1448,10 @@ template <int WM, int WN, int MR, int NR>
 int launch_pick_mask(const KParams &p, bool masked, hipStream_t stream) {
   const bool g = glds_ok(p);
   if (masked) {
+    // every wave owning all row tiles of 32 frames (the TALL shapes): supports at 16-row granularity
+    if constexpr (WM == 1 && NR == 1 && MR <= 4)
+      if (g && !p.fb && !MISPEC_DBG(p, 0x10000000))
+        return launch_cfg<WM, WN, MR, NR, BMODE_FRAMED, AMODE_ROWS, true, true, true>(p, stream);
     if (g) return launch_cfg<WM, WN, MR, NR, BMODE_FRAMED, AMODE_ROWS, true, true>(p, stream);
     return launch_cfg<WM, WN, MR, NR, BMODE_FRAMED, AMODE_ROWS, true, false>(p, stream);
   }
@@ -1396,11 +1487,12 @@ int launch_tile(const KParams &p, int tile, hipStream_t stream) {
 }
 
 int auto_tile(int rows, bool support) {
+  // support-aware: every wave owns all row tiles of the workgroup, so skipped K stages shorten the whole workgroup
+  // instead of idling some of its waves -- and (round 5) this is the instance that multiplies 16-row tiles with the taps
+  // in ascending order, one float32 FMA chain per output like the reference's conv1d: banks of ANY size take it
+  if (support) return MISPEC_TILE_128x128_TALL;
   if (rows <= 32) return MISPEC_TILE_32x256;
   if (rows <= 64) return MISPEC_TILE_64x256;
-  // support-aware: every wave owns all 4 row tiles of the workgroup, so skipped K stages
-  // shorten the whole workgroup instead of idling some of its waves
-  if (support) return MISPEC_TILE_128x128_TALL;
   return MISPEC_TILE_128x128;
 }
 
@@ -3810,7 +3902,7 @@ int mispec_framed_gemm_group_f32(const mispec_framed_gemm_args *args, int32_t n,
     if (ps[i].fb) return fail(MISPEC_E_UNSUPPORTED, "fused filterbank: not in grouped launches%s");
     const int rows = ps[i].n_bins * (ps[i].a_im ? 2 : 1);
     const int t = args[i].tile != MISPEC_TILE_AUTO ? args[i].tile
-                                                    : auto_tile(rows, ps[i].row_support != nullptr);
+                                                    : auto_tile(rows, false);  // (grouped launches are unmasked)
     if (i == 0) tile = t;
     if (t != tile || (t != MISPEC_TILE_32x256 && t != MISPEC_TILE_64x256))
       return fail(MISPEC_E_UNSUPPORTED,

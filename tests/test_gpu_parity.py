@@ -88,8 +88,10 @@ GT_CASES = [
 # elements; the conditioned ones -- above 1 % of the peak -- must all pass in every arithmetic),
 # and from which energy its phase is compared.  The near-silent bins of a sweep carry 1e-9 of the
 # peak; the fixture there records the rounding noise of the reference's own summation ORDER:
-#   fp32   the tile kernels sum the taps in the reference's order: 0.03 % miss -- the fixture bar
-#          (0.5 %; an exact float64 evaluation misses 0.13 %)
+#   fp32   CQT1992v2 (round 5): the support-aware tile kernel accumulates ONE float32 FMA chain over the taps in
+#          ascending order -- the reference's conv1d arithmetic, bit-identical to MIOpen's on this GPU -- and misses
+#          NOTHING, like the reference (tests/test_reference_order.py runs the six assertions verbatim); the bar is the
+#          reference's own, 1e-4 allowed.  CQT2010v2 (octave path: 0.5 %; an exact float64 evaluation misses 0.13 %)
 #   f16x3  fp32-class operands (2e-6 of the peak at most, see test_cfg4_*), but CQT1992v2 runs on the
 #          strip kernel, whose hop-periodic tap order leaves partial sums of ~0.3 x peak in silent
 #          bins (aliases of the sweep): 2.7 % / 0.1 % miss on the MI355X (log / linear sweep; exact
@@ -97,7 +99,7 @@ GT_CASES = [
 #          is why CQT1992v2's default precision stays fp32.  CQT2010v2 (octave path) meets the bar.
 #   bf16x3 5e-6 of the peak is the size of those bins: 57 % / 74 %
 # The measured fractions are pinned (with margin) so that they cannot grow unnoticed.
-GT_MAX_MISS = {"fp32": {"1992": 5e-3, "2010": 5e-3}, "f16x3": {"1992": 0.04, "2010": 5e-3},
+GT_MAX_MISS = {"fp32": {"1992": 1e-4, "2010": 5e-3}, "f16x3": {"1992": 0.04, "2010": 5e-3},
                "bf16x3": {"1992": 0.80, "2010": 0.80}}
 GT_PHASE_FLOOR = {"fp32": 1e-3, "f16x3": 1e-3, "bf16x3": 1e-2}
 
@@ -125,7 +127,7 @@ def test_reference_ground_truths(golden, sweep, method, cls, tagc, fmt, tag, pre
 def test_reference_ground_truths_f16x3_natural_order(golden, sweep, method):
     """CQT1992v2 f16x3 with ``hop_periodic = False`` (staged dense kernel, taps in their natural order):
     0.58 % / 0.21 % of the log-magnitude elements miss the reference's tolerance on the MI355X (strip kernel:
-    2.7 %; fp32 tile kernels 0.03 %) -- pinned with margin."""
+    2.7 %; fp32 tile kernels 0) -- pinned with margin."""
     case = dict(cls="CQT1992v2", ctor=dict(sr=44100, fmin=55, n_bins=207, bins_per_octave=24,
                                            output_format="Magnitude"), fwd={})
     mod = build_module(case, DEV)

@@ -896,12 +896,12 @@ def main():
                 extra[key] = r2
                 if name == "cqt" and not b2 and (pr2 is None or pr2 == "f16x3"):
                     # CQT84 is the other half of BASELINE.json's metric.  roofline_cqt84 is the module AS IT SHIPS
-                    # (default precision: fp32, the only arithmetic near the reference's own fixture bar -- the
-                    # reference's conv1d misses 0 % of its log-magnitude fixture on this MI355X and on the CPU, fp32
-                    # 0.03 %, f16x3 2.7 %: tests/test_gpu_reference_order.py); roofline_cqt84_f16x3 is the opt-in
+                    # (default precision: fp32 = one float32 FMA chain over the taps per output, bit-identical to torch's
+                    # conv1d on this MI355X; the reference's six CQT1992v2 fixture assertions pass verbatim, f16x3 misses
+                    # 2.7 % of the log-magnitude one: tests/test_reference_order.py); roofline_cqt84_f16x3 is the opt-in
                     # `module.precision = "f16x3"` (4.7e-7 of the peak against float64: inside north_star's 1e-4).
                     default = pr2 is None
-                    blk["kernel"] = (("one step = edge pre-pass + framed_gemm_kernel (fp32 MFMA tile kernel, support-aware row tiles); "
+                    blk["kernel"] = (("one step = edge pre-pass + framed_gemm_kernel<.., T16> (fp32 16x16x4 MFMA tiles, supports per 8 bins, taps ascending = the reference's FMA chain); "
                                       if pr == "fp32" else
                                       "one step = clip absmax + split pre-passes + framed_%s_strip_kernel; " % pr) +
                                      "achieved = executed MFMA flops (row tiles over the tap range of their longest bin) / "

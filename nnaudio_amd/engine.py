@@ -26,7 +26,7 @@ from .basis import decimated_length
 # 1024 / 2048) evaluate every frame's DFT as an fp32 FFT whatever `precision` says, an explicit "fp32" included
 # (2e-7 of the peak; `set_fft(False)` puts them on the contraction kernels, where "fp32" is the reference's
 # summation order).
-#   "fp32"   fp32 MFMA, the taps summed in the reference's order (CQT1992v2's default)
+#   "fp32"   fp32 MFMA; banks with supports: one float32 FMA chain over the taps per output = the reference's conv1d (CQT1992v2's default)
 #   "bf16x3" split-bf16 operands on the 16x faster bf16 MFMA, fp32 accumulate: ~5e-6 of the
 #            spectrum peak, inside the 1e-4 bar; problems it does not cover run in fp32
 #   "f16x3"  the same three MFMAs per product on (hi, lo) fp16 pairs of power-of-two scaled

@@ -121,16 +121,18 @@ class CQT1992v2(nn.Module):
             # banks with supports: the strip kernel (fragment-order copy), unless ``hop_periodic = False``
             # asks for the staged dense kernel on row-major planes -- taps in their natural order: 0.6 % of
             # the reference's log-magnitude fixture elements miss its tolerance instead of 2.7 % (fp32 tile
-            # kernels: 0.03 %; the comb-ordered partial sums of the hop-periodic kernels are orders of
+            # kernels: none; the comb-ordered partial sums of the hop-periodic kernels are orders of
             # magnitude larger than a silent bin), at 2.5 x the time.  Trainable banks: the dense kernel.
             if getattr(self, "hop_periodic", True) and sup is not None:
                 split = self._split.get((kr, ki), lambda: engine.frag_basis_f16(kr, ki), extra=precision + "-strip")
             else:
                 split = self._split.get((kr, ki), lambda: engine.split_basis_f16(kr, ki), extra=precision)
-        # (fp32 stays on the tile kernels, which sum the taps in the reference's order: the strip
+        # (fp32 stays on the tile kernels, which accumulate ONE float32 FMA chain over the taps in ascending
+        # order -- the reference's conv1d arithmetic: bit-identical to torch's conv1d on the MI355X, the
+        # reference's six fixture assertions pass verbatim (tests/test_reference_order.py).  The strip
         # kernel also exists in fp32 -- engine.frag_basis_f32, 20-50 % faster -- but its hop-periodic
         # order leaves different rounding noise in the near-silent bins, and 4.7 % of them then miss
-        # the reference's verbatim log-magnitude tolerance on its own ground truth, against 0.03 %)
+        # the reference's verbatim log-magnitude tolerance on its own ground truth)
         return engine.framed_gemm_autograd(
             x, self.cqt_kernels_real, self.cqt_kernels_imag, hop=self.hop_length, pad=pad,
             pad_mode=mode, epilogue=epi, im_sign=-1.0, eps=1e-8 if self.trainable else 0.0,

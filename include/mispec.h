@@ -72,7 +72,9 @@ enum {
   MISPEC_TILE_256x128 = 6,
   MISPEC_TILE_256x128_SQ = 7, /* 2x2 waves, 128x64 per wave: one wave per SIMD           */
   MISPEC_TILE_128x256_SQ = 8, /* 2x2 waves, 64x128 per wave                              */
-  MISPEC_TILE_256x256 = 9     /* 2x2 waves, 128x128 per wave (256 accumulator registers)  */
+  MISPEC_TILE_256x256 = 9,    /* 2x2 waves, 128x128 per wave (256 accumulator registers)  */
+  MISPEC_TILE_64x64 = 10      /* 2x2 waves, one 32x32 tile per wave: few rows x short kernels x many frames (a dense   */
+                              /* filterbank over frame-major spectra) -- 4x the workgroups of 64x256                   */
 };
 
 /* arithmetic of the framed contraction (the north star allows "MFMA bf16/fp32" at 1e-4 rel) */
@@ -165,7 +167,13 @@ typedef struct mispec_framed_gemm_args {
   const int32_t *fb_support;   /* (n_fb, 2)                                                */
   int64_t fb_row_stride;
   int32_t n_fb;
-  int32_t reserved3;           /* must be 0                                                */
+  int32_t out_frame_major;     /* 0: out[c, row, t] as the strides above say.  1 (round 5): FRAME-MAJOR -- element  */
+                               /* (c, bin, t) at out + c out_clip_stride + t out_row_stride + bin, the floats       */
+                               /* [n_bins, out_row_stride) of every frame's row zeroed: the spectrum as the framed  */
+                               /* operand of a contraction over the bins (Gammatonegram's dense filterbank,         */
+                               /* gammatone.py:184-189).  Served by the FFT path only: kernel 1024 or 2048,         */
+                               /* n_bins = kernel/2 + 1, MISPEC_EPI_POWER, no fused filterbank, out_row_offset 0,   */
+                               /* n_bins <= out_row_stride <= kernel/2 + 64; MISPEC_E_UNSUPPORTED otherwise.        */
 
   /* Symmetric fold (optional, either precision): for a basis that is even (basis_re) / odd
    * (basis_im) about tap kernel/2 -- every Fourier basis of stft.py:230-245 -- the contraction runs

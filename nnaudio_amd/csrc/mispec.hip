@@ -163,6 +163,7 @@ struct KParams {
   float *out;
   long long out_clip_stride;
   long long out_row_stride;
+  int out_fm;  // frame-major output (mispec_framed_gemm_args.out_frame_major): the FFT path's FM instances only
   int out_row_offset;
   int out_len;
   int n_tiles_m;
@@ -1481,6 +1482,8 @@ int launch_tile(const KParams &p, int tile, hipStream_t stream) {
       return launch_pick_mask<2, 2, 2, 4>(p, masked, stream);
     case MISPEC_TILE_256x256:
       return launch_pick_mask<2, 2, 4, 4>(p, masked, stream);
+    case MISPEC_TILE_64x64:
+      return launch_pick_mask<2, 2, 1, 1>(p, false, stream);
     default:
       return fail(MISPEC_E_INVALID, "unknown tile id%s");
   }
@@ -2926,8 +2929,11 @@ int fill_params(const mispec_framed_gemm_args *a, KParams &p) {
   if (a->precision != MISPEC_PREC_F32 && a->precision != MISPEC_PREC_BF16X3 &&
       a->precision != MISPEC_PREC_F16X3)
     return fail(MISPEC_E_INVALID, "bad precision%s");
-  if (a->reserved2 != 0 || a->reserved3 != 0 || a->reserved4 != 0)
+  if (a->reserved2 != 0 || a->reserved4 != 0)
     return fail(MISPEC_E_INVALID, "reserved fields must be 0%s");
+  if (a->out_frame_major != 0 && a->out_frame_major != 1)
+    return fail(MISPEC_E_INVALID, "out_frame_major must be 0 or 1%s");
+  p.out_fm = a->out_frame_major;
   if (a->row_support_host) {  // the caller's host copy of the supports: at least well-formed
     if (!a->row_support) return fail(MISPEC_E_INVALID, "row_support_host without row_support%s");
     for (int i = 0; i < a->n_bins; ++i) {
@@ -3212,7 +3218,7 @@ bool fft_ok(const mispec_framed_gemm_args *a, const KParams &p) {
   return (long long)p.n_clips * p.n_frames <= 0x3fffffffLL;
 }
 
-template <int M, int EPI, bool FB, int CEPI = -1>
+template <int M, int EPI, bool FB, int CEPI = -1, bool FM = false>
 int launch_fft_cfg(const KParams &p, hipStream_t stream) {
   constexpr int W = (EPI == MISPEC_EPI_COMPLEX || EPI == MISPEC_EPI_PHASE_COSSIN) ? 2 : 1;
   constexpr int FT = fft_tile_frames<M, W, FB>();
@@ -3222,7 +3228,7 @@ int launch_fft_cfg(const KParams &p, hipStream_t stream) {
   const size_t lds_share = 160 * 1024 / per_cu;
   long long grid = n_tiles < per_cu * device_cus() ? n_tiles : per_cu * device_cus();
   grid = (grid + 7) / 8 * 8;
-  auto kern = stft_fft_kernel<M, EPI, FB, CEPI>;
+  auto kern = stft_fft_kernel<M, EPI, FB, CEPI, FM>;
   static std::atomic<unsigned long long> configured{0};
   constexpr size_t smem0 = (stft_fft_smem<M, W, FB>() + 15) & ~(size_t)15;
   // fused filterbank: the band weights (a mel bank has ~8 non-zeros per filter) packed into whatever LDS the
@@ -3261,6 +3267,17 @@ int launch_fft_size(const KParams &p, hipStream_t stream) {
     default:
       return launch_fft_cfg<M, MISPEC_EPI_PHASE_COSSIN, false>(p, stream);
   }
+}
+
+// frame-major output (mispec.h, out_frame_major): the power spectrum of a frame leaves the post-processing's registers as
+// one contiguous row -- what a contraction over the bins wants as its framed operand
+int launch_fft_frame_major(const KParams &p, hipStream_t stream) {
+  if (p.epilogue != MISPEC_EPI_POWER || p.fb || (p.K != 1024 && p.K != 2048) || p.n_bins != p.K / 2 + 1 || p.out_row_offset != 0 ||
+      p.out_row_stride < p.n_bins || p.out_row_stride > p.K / 2 + 64)
+    return fail(MISPEC_E_UNSUPPORTED, "out_frame_major: kernel 1024 / 2048, all kernel/2 + 1 bins, MISPEC_EPI_POWER, no fused "
+                                      "filterbank, out_row_offset 0, n_bins <= out_row_stride <= kernel/2 + 64%s");
+  return p.K == 2048 ? launch_fft_cfg<1024, MISPEC_EPI_POWER, false, -1, true>(p, stream)
+                     : launch_fft_cfg<512, MISPEC_EPI_POWER, false, -1, true>(p, stream);
 }
 
 int launch_fft(const KParams &p, hipStream_t stream) {
@@ -3492,6 +3509,10 @@ int mispec_framed_gemm_f32(const mispec_framed_gemm_args *args, void *stream) {
   int rc = fill_params(args, p);
   if (rc != MISPEC_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (p.out_fm) {
+    if (!fft_ok(args, p)) return fail(MISPEC_E_UNSUPPORTED, "out_frame_major: served by the FFT path only (basis_fold2, automatic tile, no_fft = 0)%s");
+    return launch_fft_frame_major(p, s);
+  }
   if (fft_ok(args, p)) return launch_fft(p, s);
   {
     const Fft4096Plan f4 = plan_fft4096(args, p);
@@ -3743,6 +3764,7 @@ int mispec_framed_gemm_host_f32(const mispec_framed_gemm_args *a) {
   int rc = fill_params(a, p);  // (the same argument checks as the device entry)
   if (rc != MISPEC_OK) return rc;
   if (a->fb) return fail(MISPEC_E_UNSUPPORTED, "host path: no fused filterbank (use mispec_filterbank_host_f32)%s");
+  if (p.out_fm) return fail(MISPEC_E_UNSUPPORTED, "out_frame_major: served by the FFT path only%s");
   const int E = epilogue_width_host(a->epilogue);
   const long long items = (long long)a->n_clips * a->n_bins;
   host_parallel_for(items, [&](long long it) {
@@ -3900,6 +3922,7 @@ int mispec_framed_gemm_group_f32(const mispec_framed_gemm_args *args, int32_t n,
     int rc = fill_params(&args[i], ps[i]);
     if (rc != MISPEC_OK) return rc;
     if (ps[i].fb) return fail(MISPEC_E_UNSUPPORTED, "fused filterbank: not in grouped launches%s");
+    if (ps[i].out_fm) return fail(MISPEC_E_UNSUPPORTED, "out_frame_major: served by the FFT path only%s");
     const int rows = ps[i].n_bins * (ps[i].a_im ? 2 : 1);
     const int t = args[i].tile != MISPEC_TILE_AUTO ? args[i].tile
                                                     : auto_tile(rows, false);  // (grouped launches are unmasked)
@@ -3921,6 +3944,7 @@ int mispec_framed_gemm_f32_ref(const mispec_framed_gemm_args *args, void *stream
   int rc = fill_params(args, p);
   if (rc != MISPEC_OK) return rc;
   if (p.fb) return fail(MISPEC_E_UNSUPPORTED, "fused filterbank: not in the reference kernel%s");
+  if (p.out_fm) return fail(MISPEC_E_UNSUPPORTED, "out_frame_major: served by the FFT path only%s");
   const long long total = p.n_cols * p.n_bins;
   const long long blocks = (total + 255) / 256;
   if (blocks > 0x7fffffffLL) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");

@@ -144,6 +144,8 @@ __device__ __forceinline__ void fft_wait_vm(int younger) {
     case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
     case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
     case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: case 13: case 14: case 15: case 16: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
   }
 }
@@ -258,7 +260,12 @@ constexpr int fft_tile_frames() {
 // M = n_fft / 2; EPI = the epilogue (W = floats per output element: 2 for Complex / Phase as (cos, sin)); FB = with
 // the fused filterbank (p.fb; EPI = MISPEC_EPI_POWER)
 // CEPI >= 0: the n_fft = 4096 composite's second transform (see cmb below), CEPI = the CALLER'S epilogue
-template <int M, int EPI, bool FB, int CEPI = -1>
+// FM (round 5): FRAME-MAJOR output (mispec_framed_gemm_args.out_frame_major: element (c, bin, t) at
+// out + c out_clip_stride + t out_row_stride + bin; the floats [n_bins, out_row_stride) of a frame's row are zeroed) -- the
+// spectrum leaves the registers of the post-processing directly, 256 contiguous bytes per store instruction, no tile, no
+// flush, no workgroup barrier in the tile loop.  For consumers that contract over the bins of a frame (the dense
+// filterbank of Gammatonegram: the power spectrogram is then the framed operand of the contraction kernels).
+template <int M, int EPI, bool FB, int CEPI = -1, bool FM = false>
 __global__ void __launch_bounds__((fft_waves<M, (EPI == MISPEC_EPI_COMPLEX || EPI == MISPEC_EPI_PHASE_COSSIN) ? 2 : 1>() * 64), (fft_min_waves<M, EPI, FB>()))
     stft_fft_kernel(const KParams p, const int tiles_per_clip) {
   using namespace fftcore;
@@ -273,6 +280,7 @@ __global__ void __launch_bounds__((fft_waves<M, (EPI == MISPEC_EPI_COMPLEX || EP
   constexpr int TILE_FLOATS = (M + 1) * C;     // rows 0 .. M (the Nyquist bin)
   constexpr int FFT_TILE_BYTES = (DB ? 2 : 1) * TILE_FLOATS * 4;
   static_assert(FPW >= 1 && (C & 1) == 0, "tile geometry");
+  static_assert(!FM || (W == 1 && !FB && CEPI < 0 && M >= 512), "frame-major output: Magnitude / Power of the full spectrum");
   // n_fft = 256 (or any power of two below) on the 512-point instance: the frame is zero-extended to N samples (a window of n_fft
   // taps followed by zeros), whose spectrum has the n_fft-point bins at every RS-th row of the tile
   constexpr bool ZP = M == 256;
@@ -592,7 +600,8 @@ __global__ void __launch_bounds__((fft_waves<M, (EPI == MISPEC_EPI_COMPLEX || EP
             younger += n_flush_stores;
           }
         }
-        if constexpr (!DB) __syncthreads();  // the only buffer: everyone has read the tile before it is refilled
+        if constexpr (!DB && !FM) __syncthreads();  // the only buffer: everyone has read the tile before it is refilled
+        if (FM && had_pre) younger += P + 1;  // (frame-major: the P + 1 stores of the previous frame followed its request)
       }
       FFT_STAMP(1);
       if (!live) continue;
@@ -679,6 +688,7 @@ __global__ void __launch_bounds__((fft_waves<M, (EPI == MISPEC_EPI_COMPLEX || EP
         float *const ta = tile + lane * C + W * f;
         float *const tb = tile + (M - lane) * C + W * f;
         const float ims = cmb ? 1.f : -p.im_sign;  // (composite: the tile holds O itself)
+        float *const fm_row = p.out + (long long)c * p.out_clip_stride + (long long)t * p.out_row_stride;  // (FM)
         // the mirrored values first: behind them the exchange buffer is idle until this wave's next frame, and the FIRST
         // frame of its NEXT tile is requested right here (round 5) -- it travels under the post-processing, the barrier
         // and the flush instead of being asked for at the top of the next step and waited for at once (the wave's own
@@ -721,19 +731,24 @@ __global__ void __launch_bounds__((fft_waves<M, (EPI == MISPEC_EPI_COMPLEX || EP
             fft_epilogue<EPI>(p, xk.x, ims * xk.y, a0, a1);
             fft_epilogue<EPI>(p, xm.x, ims * xm.y, b0, b1);
           }
-          if constexpr (W == 2)
+          if constexpr (FM) {  // rows k = lane + 64 i and M - k of THIS frame: two runs of 64 consecutive floats
+            fm_row[lane + 64 * i] = a0;
+            fm_row[M - lane - 64 * i] = b0;
+          } else if constexpr (W == 2) {
             *reinterpret_cast<cf *>(ta + 64 * C * i) = cf{a0, a1};
-          else
-            ta[64 * C * i] = a0;
-          if constexpr (W == 2)
             *reinterpret_cast<cf *>(tb - 64 * C * i) = cf{b0, b1};
-          else
+          } else {
+            ta[64 * C * i] = a0;
             tb[-64 * C * i] = b0;
+          }
         }
         // bin M/2 is its own mirror: X = conj(Z[M/2]), lane 0's slot P/2
         float h0, h1;
         fft_epilogue<EPI>(p, 2.f * x[P / 2].x, -ims * 2.f * x[P / 2].y, h0, h1);  // (the halved spectrum)
-        if (lane == 0) {
+        if constexpr (FM) {  // ONE store instruction: lane 0 the bin M/2, lanes 1 .. the zeros behind bin M (the row's padding)
+          const int kz = M + lane;
+          if (lane == 0 || kz < (int)p.out_row_stride) fm_row[lane == 0 ? M / 2 : kz] = lane == 0 ? h0 : 0.f;
+        } else if (lane == 0) {
           float *th = tile + (M / 2) * C + W * f;
           th[0] = h0;
           if constexpr (W == 2) th[1] = h1;
@@ -746,9 +761,9 @@ __global__ void __launch_bounds__((fft_waves<M, (EPI == MISPEC_EPI_COMPLEX || EP
     // held across it they made the instance spill; they travel under the barrier and the next step's waits)
     if (cmb) cmb_request(c, t0);
     FFT_STAMP(11);
-    __syncthreads();  // the tile is complete (two buffers: and the other one has been read out)
+    if constexpr (!FM) __syncthreads();  // the tile is complete (two buffers: and the other one has been read out)
     FFT_STAMP(12);
-    prev_oc = oc;
+    prev_oc = FM ? nullptr : oc;
     prev_t0 = t0;
     ++step;
   }

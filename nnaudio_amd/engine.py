@@ -17,7 +17,7 @@ import torch
 from . import _abi
 from ._abi import (  # noqa: F401  (re-exported for the feature modules)
     EPI_COMPLEX, EPI_MAGNITUDE, EPI_PHASE_ATAN2, EPI_PHASE_COSSIN, EPI_POWER, EPI_REAL,
-    PAD_NONE, PAD_REFLECT, PAD_ZERO, PREC_BF16X3, PREC_F16X3, PREC_F32, TILE_AUTO,
+    PAD_NONE, PAD_REFLECT, PAD_ZERO, PREC_BF16X3, PREC_F16X3, PREC_F32, TILE_64x64, TILE_AUTO,
 )
 from .basis import decimated_length
 
@@ -313,9 +313,11 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
                  eps=0.0, power=2.0, row_scale=None, row_support=None, out=None,
                  out_rows_total=None, out_row_offset=0, tile=TILE_AUTO, _debug=0,
                  need_workspace=True, precision=None, basis_split=None, basis_fold=None, fb=None,
-                 fb_support=None, basis_fold2=None, row_support_host=None, fft=None):
+                 fb_support=None, basis_fold2=None, row_support_host=None, fft=None, out_frame_major=0):
     """Validate one framed-contraction problem and fill its C argument block.
-    Returns (args, out, device, keepalive tensors)."""
+    Returns (args, out, device, keepalive tensors).  ``out_frame_major = Fp`` (> 0): the output is
+    ``(B, T, Fp)``, a frame's bins contiguous and the columns ``[n_bins, Fp)`` zero (mispec.h,
+    out_frame_major: the FFT path only)."""
     dev = _require_device(x, basis_re, basis_im, row_scale, row_support, out, fb, fb_support,
                           host_ok=fb is None and not _debug)
     host = dev.type == "cpu"
@@ -349,6 +351,10 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
         fb_support = fb_support.contiguous()
         out = alloc_out((B, fb.shape[0], T), dev)  # (cleared by the library: no ATen launch in a forward)
         rows_total = fb.shape[0]
+    elif out_frame_major:
+        if out is not None or out_rows_total is not None or out_row_offset or two or host:
+            raise RuntimeError("frame-major output: its own (B, T, Fp) tensor, one float per bin, device only")
+        out = alloc_out((B, T, int(out_frame_major)), dev)
     elif out is None:
         shape = (B, rows_total, T, 2) if two else (B, rows_total, T)
         out = alloc_out(shape, dev)
@@ -392,6 +398,8 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
     a.out_clip_stride = rows_total * T * E
     a.out_row_stride = T * E
     a.out_row_offset = int(out_row_offset)
+    if out_frame_major:
+        a.out_clip_stride, a.out_row_stride, a.out_frame_major = T * int(out_frame_major), int(out_frame_major), 1
     a.reserved = int(_debug)  # ablation bits: honoured by libmispec_ablate.so only (framed_gemm)
     keep = [x, wr, wi, row_scale, row_support, fb, fb_support]
     if row_support is not None and support_host is not None:
@@ -703,6 +711,36 @@ def fused_filterbank_plan(mod, fb, x, stft, power):
     if not fused_filterbank_ok(power, coverage, fb.shape[0]):
         return None
     return sup
+
+
+def frame_major_filterbank_plan(mod, fb, x, stft):
+    """For Gammatonegram (a DENSE filterbank, which the fused reduction of fused_filterbank_plan does not serve): the
+    filterbank zero-padded to ``(n_filters, Fp)``, Fp = n_bins rounded up to 32, when this forward can run as
+    FFT-route power spectrogram written FRAME-MAJOR ``(B, T, Fp)`` + one framed contraction over the bins of a frame
+    (``filterbank_frame_major``) -- no graph needed, device tensors, the FFT route open for this STFT
+    (n_fft 1024 / 2048, all bins, frozen Fourier kernels); else None."""
+    if needs_grad(mod, x) or stft.freq_bins is not None or compiling() or not x.is_cuda or not fft_enabled():
+        return None
+    if stft.trainable or stft.n_fft not in (1024, 2048) or fb.shape[1] != stft.n_fft // 2 + 1 or not fb.is_cuda:
+        return None
+    if not hasattr(mod, "_fb_padded"):
+        mod._fb_padded = DerivedCache()
+
+    def build():
+        F = fb.shape[1]
+        out = torch.zeros((fb.shape[0], (F + 31) // 32 * 32), dtype=torch.float32, device=fb.device)
+        out[:, :F] = fb.detach()
+        return out
+
+    return mod._fb_padded.get((fb,), build)
+
+
+def filterbank_frame_major(fb_padded, spec_fm):
+    """``out[b, m, t] = sum_k fb_padded[m, k] spec_fm[b, t, k]``: the frames of ``spec_fm`` (B, T, Fp) are the rows of the
+    framed operand (hop = kernel = Fp), fp32 MFMA tile kernel (LDS-direct loads of both operands)."""
+    B, T, Fp = spec_fm.shape
+    return framed_gemm(spec_fm.view(B, T * Fp), fb_padded, None, hop=Fp, pad=0, pad_mode=PAD_NONE, epilogue=EPI_REAL,
+                       precision="fp32", tile=TILE_64x64 if fb_padded.shape[0] <= 64 else TILE_AUTO)
 
 
 def framed_gemm_group(problems):

@@ -56,5 +56,10 @@ class FilterbankSpectrogram(nn.Module):
         fused = engine.fused_filterbank_plan(self, basis, x, self.stft, self.power)
         if fused is not None:  # reduction fused into the contraction's epilogue
             return self.stft._spectrum(x, engine.EPI_POWER, power=self.power, fb=basis, fb_support=fused)
+        padded = engine.frame_major_filterbank_plan(self, basis, x, self.stft)
+        if padded is not None:  # dense filterbank (gammatone): frame-major power spectrogram + a contraction over its bins
+            spec = self.stft._spectrum(x, engine.EPI_POWER, power=self.power, out_frame_major=padded.shape[1])
+            if spec is not None:
+                return engine.filterbank_frame_major(padded, spec)
         spec = self.stft._spectrum(x, engine.EPI_POWER, power=self.power)
         return engine.filterbank_autograd(basis, spec)

@@ -159,10 +159,11 @@ class STFT(nn.Module):
         # the reference leaves `padding` unbound for any other mode (stft.py:279-289)
         raise UnboundLocalError("local variable 'padding' referenced before assignment")
 
-    def _spectrum(self, x, epilogue, power=2.0, fb=None, fb_support=None):
+    def _spectrum(self, x, epilogue, power=2.0, fb=None, fb_support=None, out_frame_major=0):
         """The framed contraction of this layer; with ``fb`` the filterbank reduction of
         MelSpectrogram / Gammatonegram is fused into it (no autograd graph, see
-        ``engine.fused_filterbank_ok``)."""
+        ``engine.fused_filterbank_ok``); with ``out_frame_major = Fp`` the spectrogram comes back
+        ``(B, T, Fp)`` (FFT route only, no graph; None when this layer's basis does not open it)."""
         pad, mode = self._framing(x.shape[-1])
         wsin, wcos = self.wsin, self.wcos
         if self.freq_bins is not None:
@@ -176,6 +177,12 @@ class STFT(nn.Module):
             prep = self._split.get((self.wcos, self.wsin),
                                    lambda: engine.prepare_basis(wcos, wsin, precision, hop=self.stride, fold=frozen),
                                    extra=(self.freq_bins, self.stride, precision, frozen))
+        if out_frame_major:
+            if "basis_fold2" not in prep:
+                return None
+            return engine.framed_gemm(
+                x, wcos, wsin, hop=self.stride, pad=pad, pad_mode=mode, epilogue=epilogue,
+                im_sign=-1.0, eps=0.0, power=power, precision=precision, out_frame_major=out_frame_major, **prep)
         if fb is not None:
             return engine.framed_gemm(
                 x, wcos, wsin, hop=self.stride, pad=pad, pad_mode=mode, epilogue=epilogue,

@@ -146,11 +146,13 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert lib.mispec_framed_gemm_f32(ctypes.byref(a), None) == -2 and b"256 filters" in lib.mispec_last_error()
     a.n_fb, a.tile = 8, 1
     assert lib.mispec_framed_gemm_f32(ctypes.byref(a), None) == -2 and b"automatic tile" in lib.mispec_last_error()
-    a.tile, a.reserved3 = 0, 1
+    a.tile, a.reserved4 = 0, 1
     assert lib.mispec_framed_gemm_f32(ctypes.byref(a), None) == -1 and b"reserved" in lib.mispec_last_error()
     # the ablation bits of `reserved` exist only in the benchmarking build: the product library
     # refuses them instead of computing wrong spectrograms
-    a.reserved3, a.reserved = 0, 16
+    a.reserved4, a.out_frame_major = 0, 2
+    assert lib.mispec_framed_gemm_f32(ctypes.byref(a), None) == -1 and b"out_frame_major" in lib.mispec_last_error()
+    a.out_frame_major, a.reserved = 0, 16
     assert lib.mispec_framed_gemm_f32(ctypes.byref(a), None) == -1 and b"reserved must be 0" in lib.mispec_last_error()
     assert lib.mispec_framed_gemm_workspace_bytes(ctypes.byref(a)) == -1
 

@@ -519,3 +519,60 @@ def test_fused_inverse_refuses_what_it_does_not_serve():
     inner = slice(1024, 9000 - 1024)
     err = float((y[:, inner] - x[:, inner]).abs().max())
     assert err < 1e-4 * float(x.abs().max()), err
+
+
+@pytest.mark.parametrize("shape", [  # (B, L, K, hop, pad, mode, window, power)
+    (3, 40000, 2048, 512, 1024, 2, "hann", 2.0),      # Gammatonegram's default STFT
+    (2, 30011, 2048, 333, 1024, 1, "random", 1.0),    # odd hop and clip length, zero padding, asymmetric window, power 1
+    (5, 9000, 1024, 256, 512, 2, "hann", 2.0),        # the 512-point instance (two frames per wave and tile)
+    (1, 3000, 1024, 1024, 0, 0, "hamming", 3.5),      # center=False, two frames
+])
+def test_frame_major_output_is_the_spectrogram_transposed(shape):
+    """mispec.h out_frame_major: the same power spectrogram, bit for bit, as (B, T, Fp) rows with zeros behind the bins."""
+    from nnaudio_amd import engine
+
+    B, L, K, hop, pad, mode, window, power = shape
+    F = K // 2 + 1
+    rng = np.random.default_rng(K + hop)
+    x = torch.as_tensor(rng.standard_normal((B, L)).astype(np.float32)).to(DEV)
+    wr, wi = (torch.as_tensor(a).to(DEV) for a in _dft_basis(F, K, window, rng))
+    prep = engine.prepare_basis(wr, wi, "fp32", hop=hop)
+    kw = dict(hop=hop, pad=pad, pad_mode=mode, precision="fp32", epilogue=engine.EPI_POWER, power=power, eps=1e-8 if power != 2.0 else 0.0)
+    ref = engine.framed_gemm(x, wr, wi, **kw, **prep)
+    for Fp in ((F + 31) // 32 * 32, F, F + 63):
+        torch.full((B * ref.shape[2] * Fp,), float("nan"), device=DEV)  # (dirty the allocator's blocks: the zeros must be written)
+        y = engine.framed_gemm(x, wr, wi, out_frame_major=Fp, **kw, **prep)
+        assert y.shape == (B, ref.shape[2], Fp)
+        assert torch.equal(y[:, :, :F].transpose(1, 2), ref), "Fp = %d" % Fp
+        assert not y[:, :, F:].any()
+    # what the mode does not serve is refused, loudly
+    for bad in (dict(epilogue=engine.EPI_MAGNITUDE), dict(fft=False)):
+        with pytest.raises(RuntimeError, match="out_frame_major"):
+            engine.framed_gemm(x, wr, wi, out_frame_major=F, **dict(kw, **bad), **prep)
+    with pytest.raises(RuntimeError, match="out_frame_major"):
+        engine.framed_gemm(x, wr, wi, out_frame_major=F + 64, **kw, **prep)
+
+
+def test_gammatonegram_runs_frame_major_and_matches_the_two_kernels():
+    """Gammatonegram's dense filterbank (gammatone.py:184-189): FFT-route power spectrogram written frame-major + one framed
+    contraction over the bins, against the (bins x frames) spectrogram + planar filterbank kernel it replaces."""
+    from nnaudio_amd import engine, features
+
+    x = torch.randn(3, 50000, device=DEV)
+    for kw in (dict(sr=44100, n_fft=2048, n_bins=64, hop_length=512), dict(sr=22050, n_fft=1024, n_bins=96, hop_length=300, power=1.0)):
+        m = features.Gammatonegram(verbose=False, **kw).to(DEV)
+        with torch.no_grad():
+            assert engine.frame_major_filterbank_plan(m, m.gammatone_basis, x, m.stft) is not None
+            y = m(x)
+            spec = m.stft._spectrum(x, engine.EPI_POWER, power=m.power)
+            two = engine.filterbank_autograd(m.gammatone_basis, spec)
+        assert y.shape == two.shape
+        err = float((y - two).abs().max() / two.abs().max())
+        assert err <= 2e-6, err
+        ref = torch.matmul(m.gammatone_basis.double(), spec.double())
+        assert float((y - ref).abs().max() / ref.abs().max()) <= 2e-6
+    # a graph is needed, or the filterbank is trainable: the differentiable route
+    m = features.Gammatonegram(sr=44100, n_fft=2048, n_bins=64, hop_length=512, trainable_bins=True, verbose=False).to(DEV)
+    assert engine.frame_major_filterbank_plan(m, m.gammatone_basis, x, m.stft) is None
+    m(x).sum().backward()
+    assert m.gammatone_basis.grad is not None

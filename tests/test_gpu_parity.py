@@ -91,7 +91,8 @@ GT_CASES = [
 #   fp32   CQT1992v2 (round 5): the support-aware tile kernel accumulates ONE float32 FMA chain over the taps in
 #          ascending order -- the reference's conv1d arithmetic, bit-identical to MIOpen's on this GPU -- and misses
 #          NOTHING, like the reference (tests/test_reference_order.py runs the six assertions verbatim); the bar is the
-#          reference's own, 1e-4 allowed.  CQT2010v2 (octave path: 0.5 %; an exact float64 evaluation misses 0.13 %)
+#          reference's own, 1e-4 allowed.  CQT2010v2 (octave path, eps = 1e-2): no miss in fp32 and f16x3 either -- the
+#          reference's four assertions pass verbatim on the default module (tests/test_reference_order.py)
 #   f16x3  fp32-class operands (2e-6 of the peak at most, see test_cfg4_*), but CQT1992v2 runs on the
 #          strip kernel, whose hop-periodic tap order leaves partial sums of ~0.3 x peak in silent
 #          bins (aliases of the sweep): 2.7 % / 0.1 % miss on the MI355X (log / linear sweep; exact
@@ -99,7 +100,7 @@ GT_CASES = [
 #          is why CQT1992v2's default precision stays fp32.  CQT2010v2 (octave path) meets the bar.
 #   bf16x3 5e-6 of the peak is the size of those bins: 57 % / 74 %
 # The measured fractions are pinned (with margin) so that they cannot grow unnoticed.
-GT_MAX_MISS = {"fp32": {"1992": 1e-4, "2010": 5e-3}, "f16x3": {"1992": 0.04, "2010": 5e-3},
+GT_MAX_MISS = {"fp32": {"1992": 1e-4, "2010": 1e-4}, "f16x3": {"1992": 0.04, "2010": 1e-4},
                "bf16x3": {"1992": 0.80, "2010": 0.80}}
 GT_PHASE_FLOOR = {"fp32": 1e-3, "f16x3": 1e-3, "bf16x3": 1e-2}
 

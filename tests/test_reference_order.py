@@ -153,3 +153,22 @@ def test_default_module_is_one_float32_fma_chain_over_the_taps(sweep, method):
         assert err <= 2e-6, (name, err)
     print("%s sweep: default module bit-identical to torch conv1d on %.4f (this GPU) / %.4f (CPU) of the elements" % (sweep, same["gpu"], same["cpu"]))
     assert same["gpu"] >= 0.9 and same["cpu"] >= 0.5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sweep,method", SWEEPS)
+def test_cqt2010v2_default_module_passes_the_references_assertions_verbatim(sweep, method):
+    """reference tests/test_cqt.py:188-262 (log(X + 1e-2) and Complex, rtol = atol = 1e-3), exactly as written there, on
+    CQT2010v2 as it ships (f16x3, the streaming octave kernel)."""
+    g = Golden()
+    dev = torch.device("cuda:0")
+    x = _chirp(method).to(dev)
+    for fmt, tag in (("Magnitude", "mag"), ("Complex", "complex")):
+        mod = build_module(dict(cls="CQT2010v2", ctor=dict(CASE["ctor"], output_format=fmt), fwd={}), dev)
+        with torch.no_grad():
+            X = mod(x)
+        if fmt == "Magnitude":
+            X = torch.log(X + 1e-2)
+        gt = g.ground_truth("%s-sweep-cqt-2010-%s-ground-truth.npy" % (sweep, tag))
+        X = X.cpu().numpy()
+        assert np.allclose(X, gt.reshape(X.shape), rtol=1e-3, atol=1e-3), "%s sweep, %s" % (sweep, fmt)

@@ -280,6 +280,20 @@ def module_precision(name, precision):
     return "fp32" if name == "cqt" else "f16x3"
 
 
+def same_bits_as_conv1d(mod, x):
+    """CQT1992v2 module (Magnitude) on `x` against torch's conv1d with the module's own buffers (reference cqt.py:740-772):
+    fraction of the (re, im) elements with identical bits."""
+    import torch.nn.functional as F
+
+    with torch.no_grad():
+        y = mod(x, output_format="Complex")
+        xp = F.pad(x[:, None, :], (mod.kernel_width // 2,) * 2, mode="reflect")
+        s = torch.sqrt(mod.lenghts.view(-1, 1))
+        re = F.conv1d(xp, mod.cqt_kernels_real, stride=mod.hop_length) * s
+        im = -F.conv1d(xp, mod.cqt_kernels_imag, stride=mod.hop_length) * s
+        return round(float(((y[..., 0] == re) & (y[..., 1] == im)).float().mean()), 6)
+
+
 def executed_flops(meta, precision):
     """MFMA flops the kernels execute per step, from the tiling (None: no model for this workload)."""
     ex = meta.get("executed")
@@ -909,6 +923,14 @@ def main():
                     key84 = "roofline_cqt84" if default else "roofline_cqt84_f16x3"
                     out[key84] = dict(blk, workload=me2["tag"], precision=pr, default_module=default,
                                       frames_per_s=r2["frames_per_s"], ms_per_step=r2["ms_per_step"], steps=n2)
+                    if default:
+                        # measured here, on this run's module: the fraction of its complex output (one clip) that has the
+                        # SAME BITS as the reference's own operator sequence on this GPU -- reflect pad + F.conv1d with the
+                        # module's kernels (cqt.py:740-772; MIOpen's fp32 FMA chain over the taps)
+                        try:
+                            out[key84]["same_bits_as_torch_conv1d"] = same_bits_as_conv1d(m2, x2[:1, :88200])
+                        except Exception as e:
+                            out[key84]["same_bits_as_torch_conv1d"] = repr(e)[:80]
                     traffic_jobs.append(("cqt", pr2, out, key84))
                 elif pr2 is None and name != "istft":  # (its input is made by a forward STFT inside the profiled process)
                     traffic_jobs.append((name, forced, extra[key], "roofline"))

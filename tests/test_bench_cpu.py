@@ -110,3 +110,17 @@ def test_line_is_small(n_gpus, tmp_path, capsys):
     assert d["detail"].endswith(name) and len(d["detail_sha16"]) == 16
     if n_gpus > 1:
         assert d["gather"]["cqt2010_cfg5_shard"]["with_gather_ms_per_step"] == pytest.approx(1.234)
+
+
+def test_same_bits_probe_runs_on_the_host_path():
+    """bench.py's live comparison of the CQT1992v2 module with torch's conv1d (`same_bits_as_torch_conv1d` on the line) runs
+    and returns a fraction (on the CPU oneDNN blocks short kernels differently from the host loops' FMA chain: any value;
+    on the MI355X the line shows 1.0, which tests/test_reference_order.py asserts against the library's reference kernel)."""
+    import torch
+
+    import bench
+    from nnaudio_amd import features
+
+    m = features.CQT1992v2(sr=8000, hop_length=256, fmin=220, n_bins=24, bins_per_octave=12, verbose=False)
+    frac = bench.same_bits_as_conv1d(m, torch.randn(1, 8000))
+    assert 0.0 <= frac <= 1.0, frac

@@ -172,3 +172,38 @@ def test_cqt2010v2_default_module_passes_the_references_assertions_verbatim(swee
         gt = g.ground_truth("%s-sweep-cqt-2010-%s-ground-truth.npy" % (sweep, tag))
         X = X.cpu().numpy()
         assert np.allclose(X, gt.reshape(X.shape), rtol=1e-3, atol=1e-3), "%s sweep, %s" % (sweep, fmt)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F,K,hop,B,L", [(40, 1000, 100, 3, 5000),     # K % 32 != 0: the peeled tail stage; ragged supports
+                                         (84, 4096, 256, 2, 20000),    # two row blocks, centred supports (prefix runs)
+                                         (7, 333, 64, 5, 3000),        # fewer rows than one 16-row tile
+                                         (130, 2048, 512, 1, 30000)])  # three row blocks, one clip
+def test_support_aware_fp32_kernel_is_the_sequential_chain_on_random_banks(F, K, hop, B, L):
+    """The fp32 tile kernel of a bank WITH supports (every output = one float32 FMA chain over the taps in ascending order)
+    against the library's reference kernel (one thread per output, fmaf over the taps): the same bits, for shapes that take
+    the masked stages, the compiled prefix runs and the K-tail stage."""
+    from nnaudio_amd import engine
+
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(F * K)
+    wr = rng.standard_normal((F, K)).astype(np.float32)
+    wi = rng.standard_normal((F, K)).astype(np.float32)
+    sup = np.zeros((F, 2), np.int32)
+    for f in range(F):
+        if K == 4096 or K == 2048:  # centred, shrinking with the row index (a CQT bank's shape)
+            ln = max(8, int(K * 2.0 ** (-f / 12.0)))
+            lo = (K - ln) // 2
+            hi = lo + ln
+        else:
+            lo = int(rng.integers(0, K - 1))
+            hi = int(rng.integers(lo + 1, K + 1))
+        sup[f] = (lo, hi)
+        wr[f, :lo] = wr[f, hi:] = 0.0
+        wi[f, :lo] = wi[f, hi:] = 0.0
+    x = torch.as_tensor(rng.standard_normal((B, L)).astype(np.float32)).to(dev)
+    wr, wi, sup = torch.as_tensor(wr).to(dev), torch.as_tensor(wi).to(dev), torch.as_tensor(sup).to(dev)
+    kw = dict(hop=hop, pad=K // 2, pad_mode=engine.PAD_REFLECT, epilogue=engine.EPI_COMPLEX, im_sign=-1.0, precision="fp32")
+    y = engine.framed_gemm(x, wr, wi, row_support=sup, **kw)
+    ref = engine.framed_gemm(x, wr, wi, reference_kernel=True, **kw)
+    assert torch.equal(y, ref), float((y - ref).abs().max())

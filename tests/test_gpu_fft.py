@@ -387,7 +387,7 @@ def test_inverse_fft_is_not_taken_for_other_kernels():
     assert not engine.istft_basis_is_dft(bb, 2049)
 
 
-@pytest.mark.parametrize("name", ["stft", "mel", "mfcc"])
+@pytest.mark.parametrize("name", ["stft", "mel", "mfcc", "gammatone"])
 def test_fft_route_is_hip_graph_capturable(name):
     """the contraction suite's capture test with the FFT path on: one kernel per forward, no workspace, no memset"""
     _contraction_suite.test_forward_is_hip_graph_capturable(None, name)

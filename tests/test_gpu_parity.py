@@ -1610,6 +1610,9 @@ def test_forward_is_hip_graph_capturable(bf16x3, name):
     elif name == "mfcc":
         m = features.MFCC(sr=22050, n_mfcc=20, n_fft=1024, hop_length=256, n_mels=64, verbose=False)
         L = 40000
+    elif name == "gammatone":  # (FFT route: frame-major power spectrogram + the framed contraction over its bins)
+        m = features.Gammatonegram(sr=22050, n_fft=1024, hop_length=256, n_bins=48, verbose=False)
+        L = 40000
     elif name == "cqt1992v2":
         m = features.CQT1992v2(sr=22050, hop_length=256, n_bins=72, bins_per_octave=12, fmin=65.4, verbose=False)
         L = 60000  # 235 frames per clip: the strip kernel

@@ -601,7 +601,7 @@ def compact_line(out):
     for k84 in ("roofline_cqt84", "roofline_cqt84_f16x3"):  # the module as it ships (default_module: true) / the opt-in arithmetic
         if k84 in out:
             line[k84] = _pick(out[k84], ("precision", "default_module", "ms_per_step", "frames_per_s", "bound", "achieved", "peak",
-                                         "unit", "frac", "algorithmic_frac", "traffic"))
+                                         "unit", "frac", "algorithmic_frac", "traffic", "same_bits_as_torch_conv1d"))
     if "extra" in out:
         line["extra"] = {}
         for k, v in out["extra"].items():

@@ -66,7 +66,7 @@ def _canned(n_gpus=1):
                       "global_batch": 64 * n_gpus, "precision": prose, "precision_short": "fp32 FFT per frame",
                       "parallelism": "batch-sharded x%d, no data-path collective" % n_gpus},
            "roofline": blk, "paths": {k: dict(path) for k in ("fft", "f16x3", "bf16x3", "fp32")},
-           "roofline_cqt84": dict(blk, precision="fp32", default_module=True, ms_per_step=1.37, frames_per_s=4.0e7, workload=prose),
+           "roofline_cqt84": dict(blk, precision="fp32", default_module=True, ms_per_step=1.37, frames_per_s=4.0e7, workload=prose, same_bits_as_torch_conv1d=1.0),
            "roofline_cqt84_f16x3": dict(blk, precision="f16x3", default_module=False, ms_per_step=0.4, frames_per_s=1.3e8, workload=prose),
            "extra": {k: dict(path, roofline=dict(blk), workload=prose, precision="f16x3") for k in names},
            "cpu_baseline": {"value": 46194.8, "unit": "frames/s", "cores": 128, "kind": "port", "sample": prose,
@@ -103,6 +103,7 @@ def test_line_is_small(n_gpus, tmp_path, capsys):
     assert "cqt2010" in d["extra"] and "ms_per_step" in d["extra"]["cqt2010"]
     # CQT84, the other half of the metric: the module as it ships, and the opt-in arithmetic named as such
     assert d["roofline_cqt84"]["default_module"] is True and d["roofline_cqt84_f16x3"]["default_module"] is False
+    assert d["roofline_cqt84"]["same_bits_as_torch_conv1d"] == 1.0 and "same_bits_as_torch_conv1d" not in d["roofline_cqt84_f16x3"]
     # the side file holds the full record and the line names it
     name = "bench_detail.json" if n_gpus == 1 else "bench_detail_n8.json"
     full = json.load(open(tmp_path / name))

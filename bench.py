@@ -38,7 +38,10 @@ Rank 0 prints ONE JSON line: metric = spectrogram frames/s (whole job), plus
                      it exceeds 1 once symmetric folds skip work, which is why it is not "frac".  The same
                      matrix-pipe figures of the contraction kernels are under "paths" in every run;
   "roofline_cqt84":  the same block for the other half of BASELINE.json's metric (CQT1992v2,
-                     84 bins, B = 64), support-aware useful flops;
+                     84 bins, B = 64), support-aware useful flops; as the module ships (fp32, default_module: true), with
+                     same_bits_as_torch_conv1d = fraction of its complex output on this batch with the same bits as the
+                     reference's own operator sequence on this GPU (reflect pad + F.conv1d, cqt.py:740-772) and
+                     torch_conv1d_ms = what that sequence takes there; roofline_cqt84_f16x3 = the opt-in arithmetic;
   "extra":           Mel cfg3, Gammatonegram (as shipped: the FFT route, priced on bytes; "mel_f16x3" /
                      "gammatone_f16x3": the contraction route), and one rank's shard of cfg5 (CQT2010v2 and VQT,
                      64 x 30 s), each in its module's default arithmetic unless --precision is
@@ -280,18 +283,30 @@ def module_precision(name, precision):
     return "fp32" if name == "cqt" else "f16x3"
 
 
-def same_bits_as_conv1d(mod, x):
+def same_bits_as_conv1d(mod, x, timed=False):
     """CQT1992v2 module (Magnitude) on `x` against torch's conv1d with the module's own buffers (reference cqt.py:740-772):
-    fraction of the (re, im) elements with identical bits."""
+    fraction of the (re, im) elements with identical bits; timed: also the milliseconds of that operator sequence on x's device."""
     import torch.nn.functional as F
 
     with torch.no_grad():
         y = mod(x, output_format="Complex")
-        xp = F.pad(x[:, None, :], (mod.kernel_width // 2,) * 2, mode="reflect")
         s = torch.sqrt(mod.lenghts.view(-1, 1))
-        re = F.conv1d(xp, mod.cqt_kernels_real, stride=mod.hop_length) * s
-        im = -F.conv1d(xp, mod.cqt_kernels_imag, stride=mod.hop_length) * s
-        return round(float(((y[..., 0] == re) & (y[..., 1] == im)).float().mean()), 6)
+
+        def reference():
+            xp = F.pad(x[:, None, :], (mod.kernel_width // 2,) * 2, mode="reflect")
+            return (F.conv1d(xp, mod.cqt_kernels_real, stride=mod.hop_length) * s,
+                    -F.conv1d(xp, mod.cqt_kernels_imag, stride=mod.hop_length) * s)
+
+        re, im = reference()
+        same = round(float(((y[..., 0] == re) & (y[..., 1] == im)).float().mean()), 6)
+        if not timed:
+            return same
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            reference()
+        torch.cuda.synchronize()
+        return same, round((time.perf_counter() - t0) / 3 * 1e3, 3)
 
 
 def executed_flops(meta, precision):
@@ -601,7 +616,7 @@ def compact_line(out):
     for k84 in ("roofline_cqt84", "roofline_cqt84_f16x3"):  # the module as it ships (default_module: true) / the opt-in arithmetic
         if k84 in out:
             line[k84] = _pick(out[k84], ("precision", "default_module", "ms_per_step", "frames_per_s", "bound", "achieved", "peak",
-                                         "unit", "frac", "algorithmic_frac", "traffic", "same_bits_as_torch_conv1d"))
+                                         "unit", "frac", "algorithmic_frac", "traffic", "same_bits_as_torch_conv1d", "torch_conv1d_ms"))
     if "extra" in out:
         line["extra"] = {}
         for k, v in out["extra"].items():
@@ -928,7 +943,9 @@ def main():
                         # SAME BITS as the reference's own operator sequence on this GPU -- reflect pad + F.conv1d with the
                         # module's kernels (cqt.py:740-772; MIOpen's fp32 FMA chain over the taps)
                         try:
-                            out[key84]["same_bits_as_torch_conv1d"] = same_bits_as_conv1d(m2, x2[:1, :88200])
+                            # (the WHOLE bench batch: also what the reference's own GPU path costs on this device)
+                            same, ref_ms = same_bits_as_conv1d(m2, x2, timed=True)
+                            out[key84]["same_bits_as_torch_conv1d"], out[key84]["torch_conv1d_ms"] = same, ref_ms
                         except Exception as e:
                             out[key84]["same_bits_as_torch_conv1d"] = repr(e)[:80]
                     traffic_jobs.append(("cqt", pr2, out, key84))

@@ -48,6 +48,9 @@ Rank 0 prints ONE JSON line: metric = spectrogram frames/s (whole job), plus
                      given, timed with the same pre-warm and step count as the headline and priced
                      against both rooflines (with live traffic); at N > 1 also cfg4's real shard
                      (CQT1992v2, 16 clips per rank);
+  "reference_ops_on_this_gpu": the reference forward's operator sequence for the headline workload (reflect pad + 2 x F.conv1d +
+                     sqrt, stft.py:278-316) on THIS device through PyTorch-ROCm / MIOpen, inputs resident, configs[1]'s batch,
+                     with the maximum difference from the product's spectrogram (of the peak) -- N = 1 only;
   "cpu_baseline":    the reference forward's operator sequence (pad + 2 x F.conv1d + sqrt, stft.py:278-316) on torch's CPU
                      kernels with the module's own buffers -- what nnAudio itself executes on a CPU; a restatement (kind
                      "port": the reference package is not on the GPU box) -- timed on this host on a bounded sample of the
@@ -281,6 +284,37 @@ def module_precision(name, precision):
 
         return "fft" if engine.fft_enabled() else "f16x3"
     return "fp32" if name == "cqt" else "f16x3"
+
+
+def reference_ops_on_gpu(x):
+    """What the REFERENCE'S OWN operator sequence for the headline workload costs on this GPU: nnAudio's STFT.forward is
+    ReflectionPad1d + two F.conv1d with the windowed Fourier kernels + sqrt (stft.py:278-316); with PyTorch-ROCm that is
+    MIOpen on the MI355X.  Restated here on a product module's buffers (the same values the reference registers), timed with
+    inputs resident, next to the product's Magnitude of the same clips (maximum difference, of the peak)."""
+    import torch.nn.functional as F
+
+    from nnaudio_amd import features
+
+    m = features.STFT(n_fft=2048, hop_length=512, window="hann", output_format="Magnitude", verbose=False).to(x.device)
+    kc, ks = (k if k.dim() == 3 else k[:, None, :] for k in (m.wcos, m.wsin))  # (registered (freq_bins, 1, n_fft), as the reference's)
+    with torch.no_grad():
+        def reference():
+            xp = F.pad(x[:, None, :], (m.pad_amount, m.pad_amount), mode="reflect")
+            re, im = F.conv1d(xp, kc, stride=m.stride), F.conv1d(xp, ks, stride=m.stride)
+            return torch.sqrt(re.pow(2) + im.pow(2))
+
+        ref = reference()
+        y = m(x)
+        err = float((y - ref).abs().max() / ref.abs().max())
+        sync = torch.cuda.synchronize if x.is_cuda else (lambda: None)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            reference()
+        sync()
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+    return {"what": "reflect pad + 2 x F.conv1d + sqrt (stft.py:278-316) on this GPU, configs[1]'s batch", "ms_per_step": round(ms, 3),
+            "value": round(x.shape[0] * ref.shape[2] / ms * 1e3, -3), "unit": "frames/s", "max_diff_of_peak": float("%.2e" % err)}
 
 
 def same_bits_as_conv1d(mod, x, timed=False):
@@ -638,6 +672,8 @@ def compact_line(out):
         line["gather"] = ({"error": str(g["error"])[:60]} if "error" in g else
                           {k: _pick(v, ("with_gather_ms_per_step", "without_gather_ms_per_step", "bytes_per_rank"))
                            if isinstance(v, dict) else _r(v) for k, v in g.items() if k != "what"})
+    if isinstance(out.get("reference_ops_on_this_gpu"), dict):
+        line["reference_ops_on_this_gpu"] = _pick(out["reference_ops_on_this_gpu"], ("ms_per_step", "value", "unit", "max_diff_of_peak", "error"))
     cb = out.get("cpu_baseline")
     if cb:
         c = _pick(cb, ("value", "unit", "cores", "kind"))
@@ -1101,6 +1137,12 @@ def main():
                 blk["traffic"] = None
                 blk["traffic_detail"] = {"error": repr(e)[:300]}
 
+    if rank == 0 and world == 1 and args.workload == "stft":
+        try:  # the reference's operator sequence on THIS device (torch / MIOpen), beside the CPU one below
+            out["reference_ops_on_this_gpu"] = reference_ops_on_gpu(make_input(300))
+            torch.cuda.empty_cache()
+        except Exception as e:
+            out["reference_ops_on_this_gpu"] = {"error": repr(e)[:80]}
     if rank == 0 and world == 1 and args.cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline()

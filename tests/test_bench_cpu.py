@@ -125,3 +125,14 @@ def test_same_bits_probe_runs_on_the_host_path():
     m = features.CQT1992v2(sr=8000, hop_length=256, fmin=220, n_bins=24, bins_per_octave=12, verbose=False)
     frac = bench.same_bits_as_conv1d(m, torch.randn(1, 8000))
     assert 0.0 <= frac <= 1.0, frac
+
+
+def test_reference_operator_sequence_probe_runs_on_the_host_path():
+    """bench.py's `reference_ops_on_this_gpu` block (the reference's pad + conv1d + sqrt on the bench device) -- here on the CPU,
+    against the module's host path: the two agree to float32 rounding."""
+    import torch
+
+    import bench
+
+    r = bench.reference_ops_on_gpu(torch.randn(2, 6000))
+    assert r["unit"] == "frames/s" and r["value"] > 0 and r["max_diff_of_peak"] <= 1e-5, r

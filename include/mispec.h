@@ -72,9 +72,7 @@ enum {
   MISPEC_TILE_256x128 = 6,
   MISPEC_TILE_256x128_SQ = 7, /* 2x2 waves, 128x64 per wave: one wave per SIMD           */
   MISPEC_TILE_128x256_SQ = 8, /* 2x2 waves, 64x128 per wave                              */
-  MISPEC_TILE_256x256 = 9,    /* 2x2 waves, 128x128 per wave (256 accumulator registers)  */
-  MISPEC_TILE_64x64 = 10      /* 2x2 waves, one 32x32 tile per wave: few rows x short kernels x many frames (a dense   */
-                              /* filterbank over frame-major spectra) -- 4x the workgroups of 64x256                   */
+  MISPEC_TILE_256x256 = 9     /* 2x2 waves, 128x128 per wave (256 accumulator registers)  */
 };
 
 /* arithmetic of the framed contraction (the north star allows "MFMA bf16/fp32" at 1e-4 rel) */

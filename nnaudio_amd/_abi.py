@@ -18,7 +18,7 @@ E_INVALID, E_UNSUPPORTED, E_HIP = -1, -2, -3
 PAD_NONE, PAD_ZERO, PAD_REFLECT = 0, 1, 2
 EPI_COMPLEX, EPI_MAGNITUDE, EPI_POWER, EPI_PHASE_ATAN2, EPI_PHASE_COSSIN, EPI_REAL = range(6)
 (TILE_AUTO, TILE_128x128, TILE_32x256, TILE_64x256, TILE_128x128_TALL, TILE_192x128, TILE_256x128,
- TILE_256x128_SQ, TILE_128x256_SQ, TILE_256x256, TILE_64x64) = range(11)
+ TILE_256x128_SQ, TILE_128x256_SQ, TILE_256x256) = range(10)
 PREC_F32, PREC_BF16X3, PREC_F16X3 = 0, 1, 2
 
 EXPORTS = (

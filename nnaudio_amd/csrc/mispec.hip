@@ -1482,8 +1482,6 @@ int launch_tile(const KParams &p, int tile, hipStream_t stream) {
       return launch_pick_mask<2, 2, 2, 4>(p, masked, stream);
     case MISPEC_TILE_256x256:
       return launch_pick_mask<2, 2, 4, 4>(p, masked, stream);
-    case MISPEC_TILE_64x64:
-      return launch_pick_mask<2, 2, 1, 1>(p, false, stream);
     default:
       return fail(MISPEC_E_INVALID, "unknown tile id%s");
   }

@@ -17,7 +17,7 @@ import torch
 from . import _abi
 from ._abi import (  # noqa: F401  (re-exported for the feature modules)
     EPI_COMPLEX, EPI_MAGNITUDE, EPI_PHASE_ATAN2, EPI_PHASE_COSSIN, EPI_POWER, EPI_REAL,
-    PAD_NONE, PAD_REFLECT, PAD_ZERO, PREC_BF16X3, PREC_F16X3, PREC_F32, TILE_64x64, TILE_AUTO,
+    PAD_NONE, PAD_REFLECT, PAD_ZERO, PREC_BF16X3, PREC_F16X3, PREC_F32, TILE_AUTO,
 )
 from .basis import decimated_length
 
@@ -740,7 +740,7 @@ def filterbank_frame_major(fb_padded, spec_fm):
     framed operand (hop = kernel = Fp), fp32 MFMA tile kernel (LDS-direct loads of both operands)."""
     B, T, Fp = spec_fm.shape
     return framed_gemm(spec_fm.view(B, T * Fp), fb_padded, None, hop=Fp, pad=0, pad_mode=PAD_NONE, epilogue=EPI_REAL,
-                       precision="fp32", tile=TILE_64x64 if fb_padded.shape[0] <= 64 else TILE_AUTO)
+                       precision="fp32")
 
 
 def framed_gemm_group(problems):

@@ -108,3 +108,21 @@ def test_host_power_to_db_takes_the_magnitude_of_ref():
     want = 10.0 * torch.log10(torch.clamp(spec, min=1e-10)) - 10.0 * np.log10(2.5)
     want = torch.maximum(want, want.amax(dim=(1, 2), keepdim=True) - 80.0)
     assert float((a - want).abs().max()) < 1e-4
+
+
+def test_frame_major_output_is_refused_off_the_fft_path():
+    """mispec.h out_frame_major is served by the FFT path of the device entry only: the host loops (and through them every
+    CPU tensor) refuse it instead of writing a (bins x frames) spectrogram into a frame-major buffer."""
+    import numpy as np
+    import pytest
+    import torch
+
+    from nnaudio_amd import engine
+
+    x = torch.randn(2, 4096)
+    n = np.arange(1024)
+    wr = torch.tensor(np.cos(2 * np.pi * np.outer(np.arange(513), n) / 1024), dtype=torch.float32)
+    wi = torch.tensor(np.sin(2 * np.pi * np.outer(np.arange(513), n) / 1024), dtype=torch.float32)
+    with pytest.raises(RuntimeError, match="frame-major|out_frame_major"):
+        engine.framed_gemm(x, wr, wi, hop=256, pad=512, pad_mode=engine.PAD_REFLECT, epilogue=engine.EPI_POWER, power=2.0,
+                           out_frame_major=544)

@@ -73,7 +73,10 @@ class CQT1992v2(nn.Module):
         imag = torch.tensor(bank.imag).unsqueeze(1)
         _register_kernels(self, real, imag, trainable)
         self._support = SupportCache()
-        self.precision = None  # None: nnaudio_amd.get_precision(); "fp32" / "bf16x3"
+        # None: the module's default, "fp32" -- one float32 FMA chain over the taps per output, the reference's conv1d
+        # arithmetic (bit-identical to torch's conv1d on the MI355X); or "f16x3" / "bf16x3" (3.4 x / 3.8 x faster, 4.7e-7 /
+        # 4e-6 of the peak from float64, NOT the fixture's silent-bin noise), unless nnaudio_amd.set_precision(...) overrides
+        self.precision = None
         self._split = engine.DerivedCache()
         if verbose:
             print("CQT kernels created, time used = {:.4f} seconds".format(time() - start))

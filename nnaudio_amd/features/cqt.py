@@ -230,8 +230,10 @@ class CQT2010v2(nn.Module):
         imag = torch.tensor(basis.imag).unsqueeze(1)
         _register_kernels(self, real, imag, trainable)
         self._support = SupportCache()
-        # not a constructor argument: "bf16x3" (attribute or nnaudio_amd.set_precision) selects the
-        # fused octave kernel (decimated signals resident in LDS, split-bf16 matrix pipe)
+        # not a constructor argument: None = the module's default, "f16x3" on the streaming octave kernel
+        # (octave_stream.hip: the whole recursion as a stream, rings of every octave's signal in LDS, scaled fp16 pairs on
+        # the matrix pipe; the reference's four CQT2010v2 fixture assertions pass verbatim); "bf16x3" the same kernel on
+        # split bf16, "fp32" one launch per octave stage on the fp32 tile kernels (attribute or nnaudio_amd.set_precision)
         self.precision = None
         self._octaves = OctaveCache()
         if verbose:

@@ -103,7 +103,7 @@ class VQT(nn.Module):
 
         octave_sr = self.sr
         self._supports = []
-        self.precision = None  # "bf16x3": the fused octave kernel (see CQT2010v2)
+        self.precision = None  # None: "f16x3" on the streaming octave kernel (see CQT2010v2); "bf16x3" / "fp32"
         self._octaves = OctaveCache()
         for i in range(self.n_octaves):
             if i > 0:

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MISPEC_ABI_VERSION 11
+#define MISPEC_ABI_VERSION 12
 
 enum {
   MISPEC_OK = 0,
@@ -207,6 +207,15 @@ typedef struct mispec_framed_gemm_args {
   int64_t basis_fold2_bytes;
   float fold2_wmax;
   int32_t no_fft;              /* non-zero: never take the FFT path (below)                */
+
+  /* MISPEC_PREC_F32, complex bank with supports (CQT1992v2, cqt.py:749-750), optional (ABI 12): the bank as
+   * mispec_chain_basis_f32() lays it out -- 16-row x 16-tap fragments in the order the chain kernel consumes them.
+   * With it, row_support, row_support_host, 64 <= hop <= 512, hop % 64 == 0 and the automatic tile the contraction runs
+   * on the chain kernel: each wave keeps its 16 frames' samples in an LDS delay line (every sample enters LDS once per
+   * 16 frames instead of once per frame and K stage), no workspace.  The arithmetic is unchanged: every output is ONE
+   * float32 FMA chain over the taps in ascending order, the same bits as without it. */
+  const void *basis_chain;     /* or NULL                                                  */
+  int64_t basis_chain_bytes;
 } mispec_framed_gemm_args;
 
 /*
@@ -256,6 +265,19 @@ int64_t mispec_basis_frag_bytes(int32_t n_bins, int32_t kernel);
 int mispec_frag_basis_f32(const float *basis_re, const float *basis_im, int64_t basis_row_stride,
                           int32_t n_bins, int32_t kernel, void *dst, int64_t dst_bytes,
                           void *stream);
+
+/*
+ * The chain kernel's copy of a complex bank with supports (`basis_chain` above), built once per bank.
+ * row_support_host: the (n_bins, 2) [start, stop) supports in HOST memory (the layout follows from them).
+ *   mispec_basis_chain_bytes  size of `dst`; MISPEC_E_UNSUPPORTED when the supports of the bank's 16-row
+ *                             tiles (8 bins) do not nest when ordered by length (CQT kernels are centred: they
+ *                             do) or the bank has more than 576 bins -- such banks stay on the tile kernels
+ *   mispec_chain_basis_f32    fills dst (one small host-synchronous copy of the plan, then a kernel on `stream`)
+ */
+int64_t mispec_basis_chain_bytes(const int32_t *row_support_host, int32_t n_bins, int32_t kernel);
+int mispec_chain_basis_f32(const float *basis_re, const float *basis_im, int64_t basis_row_stride,
+                           int32_t n_bins, int32_t kernel, const int32_t *row_support_host, void *dst,
+                           int64_t dst_bytes, void *stream);
 
 /*
  * MISPEC_PREC_F16X3 counterpart for bases with supports (CQT banks): (hi, lo) fp16 pairs of every row

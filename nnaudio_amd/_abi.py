@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmispec.so")
 ABLATE_LIB_PATH = os.path.join(_HERE, "csrc", "libmispec_ablate.so")  # benchmarking build
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 E_INVALID, E_UNSUPPORTED, E_HIP = -1, -2, -3
 
 # enums (mirror include/mispec.h)
@@ -35,6 +35,8 @@ EXPORTS = (
     "mispec_split_basis_bf16",
     "mispec_basis_frag_bytes",
     "mispec_frag_basis_f32",
+    "mispec_basis_chain_bytes",
+    "mispec_chain_basis_f32",
     "mispec_basis_frag16_bytes",
     "mispec_basis_split16_bytes",
     "mispec_split_basis_f16",
@@ -123,6 +125,8 @@ class FramedGemmArgs(ctypes.Structure):
         ("basis_fold2_bytes", ctypes.c_int64),
         ("fold2_wmax", ctypes.c_float),
         ("no_fft", ctypes.c_int32),
+        ("basis_chain", ctypes.c_void_p),
+        ("basis_chain_bytes", ctypes.c_int64),
     ]
 
 
@@ -303,6 +307,11 @@ def _load(path, how):
     lib.mispec_frag_basis_f32.restype = ctypes.c_int
     lib.mispec_frag_basis_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                                           ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+    lib.mispec_basis_chain_bytes.restype = ctypes.c_int64
+    lib.mispec_basis_chain_bytes.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32]
+    lib.mispec_chain_basis_f32.restype = ctypes.c_int
+    lib.mispec_chain_basis_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
     lib.mispec_basis_split16_bytes.restype = ctypes.c_int64
     lib.mispec_basis_split16_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32]
     lib.mispec_split_basis_f16.restype = ctypes.c_int

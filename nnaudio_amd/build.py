@@ -22,7 +22,7 @@ def hipcc():
 
 
 # translation units of the library: (source, takes -DMISPEC_ABLATE in the benchmarking build)
-UNITS = [(SRC, True), (os.path.join(HERE, "csrc", "octave_stream.hip"), True)]
+UNITS = [(SRC, True), (os.path.join(HERE, "csrc", "octave_stream.hip"), True), (os.path.join(HERE, "csrc", "cqt_chain.hip"), False)]
 
 
 def scratch_instructions(obj):

@@ -3442,6 +3442,7 @@ int64_t mispec_framed_gemm_workspace_bytes(const mispec_framed_gemm_args *args) 
   }
   mispec_framed_gemm_args local;
   if (f16_downgrade(args, p, local)) args = &local;
+  if (mispec_chain_ok(args)) return 0;  // (the chain kernel resolves the virtual padding in its loads)
   const Fold2Plan f2 = plan_fold2(args, p);
   if (f2.ok) return f2.ws_bytes;
   const FoldPlan f = plan_fold(args, p);
@@ -3520,6 +3521,8 @@ int mispec_framed_gemm_f32(const mispec_framed_gemm_args *args, void *stream) {
   if (f16_downgrade(args, p, local)) args = &local;
   if (p.fb && (args->tile != MISPEC_TILE_AUTO || MISPEC_DBG(p, 0x2000)))
     return fail(MISPEC_E_UNSUPPORTED, "fused filterbank needs the automatic tile choice%s");
+  // CQT1992v2 in fp32 with the bank's chain copy: LDS delay lines instead of per-stage frame gathers (cqt_chain.hip)
+  if (mispec_chain_ok(args)) return mispec_chain_launch(args, (p.debug >> 24) & 15, s);
   const Fold2Plan fold2 = plan_fold2(args, p);
   if (fold2.ok) return launch_fold2(p, args, fold2, s);
   // the fused filterbank adds into its output: cleared here (in-kernel clearing by the fold's pre-pass --
@@ -3604,6 +3607,26 @@ int mispec_frag_basis_f32(const float *basis_re, const float *basis_im, int64_t 
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MISPEC_E_HIP, "basis fragment launch: %s", hipGetErrorString(e));
   return MISPEC_OK;
+}
+
+int64_t mispec_basis_chain_bytes(const int32_t *row_support_host, int32_t n_bins, int32_t kernel) {
+  if (!row_support_host || n_bins <= 0 || kernel <= 0) return fail(MISPEC_E_INVALID, "chain basis: supports and positive sizes%s");
+  for (int i = 0; i < n_bins; ++i) {
+    const int lo = row_support_host[2 * i], hi = row_support_host[2 * i + 1];
+    if (lo < 0 || hi < lo || hi > kernel) return fail(MISPEC_E_INVALID, "row_support_host: need 0 <= start <= stop <= kernel%s");
+  }
+  const int64_t b = mispec_chain_bytes_impl(row_support_host, n_bins, kernel);
+  if (b < 0) return fail(MISPEC_E_UNSUPPORTED, "chain basis: the supports of the 16-row tiles do not nest, or more than 576 bins%s");
+  return b;
+}
+
+int mispec_chain_basis_f32(const float *basis_re, const float *basis_im, int64_t basis_row_stride, int32_t n_bins,
+                           int32_t kernel, const int32_t *row_support_host, void *dst, int64_t dst_bytes, void *stream) {
+  if (!basis_re || !basis_im || !dst) return fail(MISPEC_E_INVALID, "NULL pointer%s");
+  const int64_t need = mispec_basis_chain_bytes(row_support_host, n_bins, kernel);
+  if (need < 0) return (int)need;
+  if (basis_row_stride < kernel) return fail(MISPEC_E_INVALID, "basis_row_stride < kernel%s");
+  return mispec_chain_pack_impl(basis_re, basis_im, basis_row_stride, n_bins, kernel, row_support_host, dst, dst_bytes, stream);
 }
 
 int64_t mispec_basis_split16_bytes(int32_t n_bins, int32_t kernel) {

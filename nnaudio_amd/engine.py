@@ -313,7 +313,8 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
                  eps=0.0, power=2.0, row_scale=None, row_support=None, out=None,
                  out_rows_total=None, out_row_offset=0, tile=TILE_AUTO, _debug=0,
                  need_workspace=True, precision=None, basis_split=None, basis_fold=None, fb=None,
-                 fb_support=None, basis_fold2=None, row_support_host=None, fft=None, out_frame_major=0):
+                 fb_support=None, basis_fold2=None, row_support_host=None, fft=None, out_frame_major=0,
+                 basis_chain=None):
     """Validate one framed-contraction problem and fill its C argument block.
     Returns (args, out, device, keepalive tensors).  ``out_frame_major = Fp`` (> 0): the output is
     ``(B, T, Fp)``, a frame's bins contiguous and the columns ``[n_bins, Fp)`` zero (mispec.h,
@@ -423,6 +424,12 @@ def _framed_args(x, basis_re, basis_im, *, hop, pad, pad_mode, epilogue, im_sign
         a.basis_split = basis_split.data_ptr()
         a.basis_split_bytes = basis_split.numel() * basis_split.element_size()
         keep.append(basis_split)
+    if (basis_chain is not None and need_workspace and row_support is not None and support_host is not None
+            and resolve_precision(precision) == "fp32"):
+        # fp32 with the chain kernel's copy of a bank with supports (chain_basis_f32): LDS delay lines, same bits
+        a.basis_chain = basis_chain.data_ptr()
+        a.basis_chain_bytes = basis_chain.numel() * basis_chain.element_size()
+        keep.append(basis_chain)
     if basis_fold2 is not None and need_workspace:
         # (planes, max |window|) from fold2_basis() in THIS precision: a quarter of the MFMAs
         planes, wmax = basis_fold2
@@ -499,6 +506,32 @@ def frag_basis_f32(basis_re, basis_im):
         stream = torch.cuda.current_stream(dev).cuda_stream
         _abi.check(lib.mispec_frag_basis_f32(wr.data_ptr(), wi.data_ptr(), wr.stride(0), F, K,
                                              dst.data_ptr(), need, ctypes.c_void_p(stream)))
+    return dst
+
+
+def chain_basis_f32(basis_re, basis_im, support_host):
+    """The fp32 taps of a complex bank with supports as the chain kernel consumes them
+    (mispec_chain_basis_f32: 16-row x 16-tap MFMA fragments in stream order, zero taps left out), or
+    None when the bank's supports do not nest (not a centred CQT bank).  With it, the supports and
+    their host copy, ``precision="fp32"`` contractions at hops of 64 .. 512 (multiples of 64) keep
+    the frames' samples in LDS delay lines -- the same one-FMA-chain-per-output arithmetic."""
+    dev = _require_device(basis_re, basis_im)
+    wr, wi = _rows(basis_re, "basis_re"), _rows(basis_im, "basis_im")
+    if wi.shape != wr.shape or wi.stride(0) != wr.stride(0):
+        raise RuntimeError("real / imaginary bases must have identical shape and layout")
+    lib = _abi.load()
+    F, K = wr.shape
+    sup = np.ascontiguousarray(support_host, dtype=np.int32)
+    if sup.shape != (F, 2):
+        raise RuntimeError("support_host must be (n_bins, 2)")
+    need = lib.mispec_basis_chain_bytes(sup.ctypes.data, F, K)
+    if need < 0:
+        return None
+    dst = torch.empty(need // 4, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _abi.check(lib.mispec_chain_basis_f32(wr.data_ptr(), wi.data_ptr(), wr.stride(0), F, K, sup.ctypes.data,
+                                              dst.data_ptr(), need, ctypes.c_void_p(stream)))
     return dst
 
 

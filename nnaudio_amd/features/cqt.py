@@ -130,16 +130,20 @@ class CQT1992v2(nn.Module):
                 split = self._split.get((kr, ki), lambda: engine.frag_basis_f16(kr, ki), extra=precision + "-strip")
             else:
                 split = self._split.get((kr, ki), lambda: engine.split_basis_f16(kr, ki), extra=precision)
-        # (fp32 stays on the tile kernels, which accumulate ONE float32 FMA chain over the taps in ascending
-        # order -- the reference's conv1d arithmetic: bit-identical to torch's conv1d on the MI355X, the
-        # reference's six fixture assertions pass verbatim (tests/test_reference_order.py).  The strip
-        # kernel also exists in fp32 -- engine.frag_basis_f32, 20-50 % faster -- but its hop-periodic
-        # order leaves different rounding noise in the near-silent bins, and 4.7 % of them then miss
-        # the reference's verbatim log-magnitude tolerance on its own ground truth)
+        # fp32 accumulates ONE float32 FMA chain over the taps in ascending order -- the reference's conv1d
+        # arithmetic: bit-identical to torch's conv1d on the MI355X, the reference's six fixture assertions
+        # pass verbatim (tests/test_reference_order.py).  With the bank's chain copy (hops of 64 .. 512) the
+        # chain kernel computes those bits from LDS delay lines; without it the tile kernels do.  (The
+        # hop-periodic strip kernel also exists in fp32 -- engine.frag_basis_f32 -- but its order leaves
+        # different rounding noise in the near-silent bins: 4.7 % of them miss the reference's tolerance.)
+        chain = None
+        if x.is_cuda and precision == "fp32" and sup is not None and getattr(self, "chain", True):
+            host = self._support.host(kr, ki)
+            chain = self._split.get((kr, ki), lambda: engine.chain_basis_f32(kr, ki, host), extra="fp32-chain")
         return engine.framed_gemm_autograd(
             x, self.cqt_kernels_real, self.cqt_kernels_imag, hop=self.hop_length, pad=pad,
             pad_mode=mode, epilogue=epi, im_sign=-1.0, eps=1e-8 if self.trainable else 0.0,
-            row_scale=scale, row_support=sup, precision=precision, basis_split=split,
+            row_scale=scale, row_support=sup, precision=precision, basis_split=split, basis_chain=chain,
         )
 
 

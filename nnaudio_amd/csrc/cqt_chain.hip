@@ -11,28 +11,33 @@
 //     sub-stages later.  The wave keeps that delay line in LDS: a ring of NR rows of `hop` samples (row r = samples
 //     [U0 + r hop, + hop), slot r mod NR, rows 8 dwords apart in bank space so that the 16 frames of a ds_read_b128 fall on
 //     different banks), refilled 64 samples at a time by global_load_lds_dword behind frame 0 -- each sample enters LDS once
-//     per column tile (HBM/L2 traffic: (15 hop + K) / (16 hop) of the clip bytes per bank pass) instead of once per frame and
-//     K stage.  Inside every aligned group of 16 samples the DMA stores sample 4 n + q at position 4 q + n, so a lane's four
-//     taps of four successive MFMAs are ONE ds_read_b128.  Virtual padding (reflect / zero) is resolved in the DMA's
-//     per-lane source address: no padded copy, no edge workspace.
+//     per column tile instead of once per frame and K stage.  Inside every aligned group of 16 samples the DMA stores
+//     sample 4 n + q at position 4 q + n, so a lane's four taps of four successive MFMAs are ONE ds_read_b128.  Virtual
+//     padding (reflect / zero) is resolved in the DMA's per-lane source address: no padded copy, no edge workspace.
 //   * A operand (basis).  Prepared once per bank (mispec_chain_basis_f32) as a stream of 1 KB "bricks" -- 16 rows x 16 taps
 //     in MFMA fragment order [lane][4 taps of 4 MFMAs] -- in exactly the order a workgroup consumes them; taps outside a
 //     16-row tile's support are not stored at all.  The four waves of a workgroup (4 column tiles) share the bricks through
-//     three LDS buffers of 9 bricks filled by global_load_lds_dwordx4 two batches ahead; a brick is one ds_read_b128 per
+//     four LDS buffers of 7 bricks filled by global_load_lds_dwordx4 three batches ahead; a brick is one ds_read_b128 per
 //     lane and feeds 4 MFMAs.
 //   * Work units.  The bank's 16-row tiles (8 bins; supports nested: CQT kernels are centred) are split into row sets; a
 //     workgroup = 4 column tiles x one row set, all waves doing identical work per sub-stage.  Units are issued largest
 //     first so that the dispatcher's tail is made of the short ones.
+//   * Instruction stream.  One wave per SIMD: everything besides the MFMAs has to fit into their shadow (~5 issue slots per
+//     16 x 16 x 4 MFMA).  A batch = Q sub-stages x N tiles (N Q <= 7, inside one ring row) is compiled per (N, Q) without
+//     control flow: its LDS reads use immediate offsets, its four DMA instructions (two bricks, two ring blocks: always
+//     four, a piece that is not due is fetched again) sit between the MFMA groups of its first sub-stage, the first
+//     fragments of the next batch are read before the barrier, and "everything older has landed" is `s_waitcnt vmcnt(4)`.
 //
 // Bounds: MFMA (fp32 matrix pipe, 157 TFLOP/s); LDS reads 1 KB per 4 MFMAs per wave; L2 -> LDS 1 KB per brick per workgroup.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <atomic>
+#include <type_traits>
 #include <vector>
 
 #include "mispec.h"
@@ -42,19 +47,21 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int CH_NMAX = 9;      // 16-row tiles per row set = bricks per batch buffer
-constexpr int CH_NBUF = 3;      // brick buffers (batch b multiplies one, b + 1 has landed, b + 2 is in flight)
-constexpr int CH_QMAX = 8;      // sub-stages per batch (bounds the ring's look-ahead: 3 batches <= 24 sub-stages)
+constexpr int CH_NMAX = 7;      // 16-row tiles per row set = bricks per batch buffer
+constexpr int CH_NBUF = 4;      // brick buffers: batch b multiplies one, b + 1 is published (its first fragments are read before the
+                                // barrier), b + 2 is landing, b + 3 is being requested
 constexpr int CH_MAXSETS = 8;
 constexpr int CH_SKEW = 8;      // dwords between ring rows in bank space
 constexpr int CH_BRICK = 1024;  // bytes
 constexpr int CH_ZERO_BYTES = 256;
+constexpr int CH_HOPS = 8;      // segment tables for hop = 64, 128 .. 512
+constexpr int CH_BUF_BYTES = CH_NMAX * CH_BRICK;
 
 struct ChainSetDev {
   int n_tiles;
-  int s_lo;       // first 16-tap sub-stage of the set (of its longest tile)
-  int batch0;     // index of the set's first batch in the table
-  int n_batches;
+  int s_lo;        // first 16-tap sub-stage of the set (of its longest tile)
+  int seg0;        // the set's segments in the table of this hop
+  int n_segs;
   long long brick0;  // first brick of the set's stream
   int tile[CH_NMAX];
   int pad_;
@@ -69,8 +76,9 @@ struct ChainArgs {
   int nr;           // ring rows
   int ring_bytes;   // per wave
   const float *zeros;
-  const int *batches;  // (q << 8) | n per batch
+  const int *segs;  // N | Q << 4 | count << 8: `count` batches of Q sub-stages x N tiles
   const float *bricks;
+  long long n_bricks;
   const float *row_scale;
   int n_bins, epilogue;
   float im_sign, eps, power;
@@ -90,9 +98,8 @@ __device__ __forceinline__ void ch_dma16(const void *sbase, unsigned voff, unsig
 __device__ __forceinline__ void ch_dma4(const void *src, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(src), "s"(lds_addr) : "memory", "m0");
 }
-__device__ __forceinline__ void ch_dma_barrier() {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+__device__ __forceinline__ void ch_dma4s(const void *sbase, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
 }
 
 // the pointwise epilogue of mispec.hip (epilogue_store): same operations in the same order
@@ -128,51 +135,166 @@ __device__ __forceinline__ void ch_epilogue_store(const ChainArgs &p, float *__r
   }
 }
 
-// read cursor of a wave's ring: sub-stage s' of frame f is row (f + s' 16 / hop), offset (s' 16) mod hop
-struct RingCursor {
-  int slot;  // row of frame 0, mod NR
-  int off;   // samples into the row
+typedef const int __attribute__((address_space(4))) *ch_seg_ptr;  // constant address space: scalar loads
+
+// A wave's state besides its accumulators.  Scalars are wave-uniform unless marked (lane).
+struct ChainState {
+  // constants
+  const float *xc;      // the wave's clip
+  const float *zeros;
+  const float *bricks;
+  int L, hop, nr, row_bytes, ring_samples;
+  int U0;               // signal position of ring sample v = 0
+  int lperm;            // (lane) sample of a 64-block this lane fetches
+  int lane;
+  int k0, k1;           // the two bricks of a batch this wave requests (wave, min(wave + 4, 6))
+  unsigned ring_base, a_base;
+  // brick requests: the batch being requested (three ahead of the one being multiplied)
+  ch_seg_ptr seg;        // the set's segment words
+  int n_segs;
+  int isg, irem, iword, iword_next;  // its segment, batches left in it, that segment's word, the next segment's word
+  long long brick_next;  // first brick of the batch being requested
+  int a_cnt;             // bricks in it (0: none)
+  // multiply side
+  int b;       // batch index
+  int sdone;   // sub-stages multiplied
+  int off;     // samples into the ring row (same for all frames)
+  int slot0;   // frame 0's row slot
+  int slot;    // (lane) this lane's row slot
+  unsigned row_addr;  // (lane) LDS address of this lane's row + 16 lq
 };
 
-// One batch of q sub-stages with N active tiles: bricks [j N + m] of the batch buffer at a_addr (this lane's 16 bytes of
-// brick 0), the wave's ring at ring_addr (this lane's frame row 0 + 16 lq bytes).  Fragments of sub-stage j + 1 are read
-// under the MFMAs of sub-stage j.
-template <int N>
-__device__ __forceinline__ void chain_batch(f32x4 (&acc)[CH_NMAX], const unsigned char *smem, const unsigned a_addr, const unsigned ring_addr,
-                                            const int q, RingCursor &rc, const int f, const int nr, const int hop, const int row_bytes, const int debug) {
-  f32x4 a0[N], a1[N], b0, b1;
-  int jl = 0;  // next sub-stage to load
-  auto load = [&](f32x4(&a)[N], f32x4 &b) __attribute__((always_inline)) {
-    int slot = rc.slot + f;
-    slot = slot >= nr ? slot - nr : slot;
-    b = *reinterpret_cast<const f32x4 *>(smem + ring_addr + slot * row_bytes + rc.off * 4);
-#pragma unroll
-    for (int m = 0; m < N; ++m) a[m] = *reinterpret_cast<const f32x4 *>(smem + a_addr + (jl * N + m) * CH_BRICK);
-    ++jl;
-    rc.off += 16;
-    if (rc.off == hop) {
-      rc.off = 0;
-      rc.slot = rc.slot + 1 == nr ? 0 : rc.slot + 1;
-    }
-  };
-  auto mul = [&](const f32x4(&a)[N], const f32x4 &b) __attribute__((always_inline)) {
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-      for (int m = 0; m < N; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][jj], b[jj], acc[m], 0, 0, 0);
-  };
-  load(a0, b0);
-  int j = 0;
-  while (true) {
-    if (j + 1 < q) load(a1, b1);
-    if (!(debug & 1)) mul(a0, b0);
-    if (++j >= q) break;
-    if (j + 1 < q) load(a0, b0);
-    if (!(debug & 1)) mul(a1, b1);
-    if (++j >= q) break;
+// 64 samples (lanes < n_lanes of them) from ring sample v0 on, to LDS address dst: inside each group of 16 the lane at
+// position 4 q + n fetches sample 4 n + q
+template <bool REFLECT>
+__device__ __forceinline__ void ch_fill(const ChainState &c, int v0, unsigned dst) {
+  int pos = c.U0 + v0 + c.lperm;
+  if (REFLECT) {
+    // beyond the virtually padded clip only zero taps / unstored frames read: any finite sample will do
+    const int neg = -pos;
+    pos = pos < neg ? neg : pos;
+    const int up = 2 * c.L - 2 - pos;
+    pos = pos >= c.L ? up : pos;
+    pos = pos < 0 ? 0 : pos;
+    pos = pos > c.L - 1 ? c.L - 1 : pos;
+    ch_dma4s(c.xc, (unsigned)pos * 4u, dst);
+  } else {
+    // zero / no padding: everything outside the clip is zero
+    const bool in = pos >= 0 && pos < c.L;
+    const float *src = in ? c.xc + pos : c.zeros + c.lane;
+    ch_dma4(src, dst);
   }
 }
 
+// the request side moves on to the next batch of the segment table
+__device__ __forceinline__ void ch_next_request(ChainState &c) {
+  c.brick_next += c.a_cnt;  // (the previous batch was requested completely)
+  c.a_cnt = (c.iword & 15) * ((c.iword >> 4) & 15);
+  --c.irem;
+  const bool adv = c.irem == 0;
+  c.isg += adv ? 1 : 0;
+  c.iword = adv ? c.iword_next : c.iword;
+  c.irem = adv ? (c.iword_next >> 8) : c.irem;
+  int nx = c.isg + 1;
+  nx = nx < c.n_segs ? nx : c.n_segs;  // (one zero word follows every table)
+  c.iword_next = c.seg[nx];            // (re-read every batch: no branch; consumed when the segment ends)
+}
+
+// this wave's two bricks of the requested batch -> buffer `bb` % 4 (slots past the batch's bricks receive the stream's
+// following bricks: never read; the stream ends with 8 bricks of padding)
+__device__ __forceinline__ void ch_brick(const ChainState &c, int bb, int k) {
+  const unsigned dst = c.a_base + (unsigned)((bb & (CH_NBUF - 1)) * CH_BUF_BYTES) + (unsigned)k * CH_BRICK;
+  ch_dma16(c.bricks + (c.brick_next + k) * (CH_BRICK / 4), (unsigned)c.lane * 16u, dst);
+}
+
+// `count` batches of Q sub-stages x N tiles.  In: bfirst = the signal fragment of the first sub-stage (always read ahead).
+template <int N, int Q, bool REFLECT>
+__device__ __forceinline__ void chain_segment(f32x4 (&acc)[CH_NMAX], f32x4 &bfirst, const unsigned char *smem, ChainState &c, const int count) {
+  constexpr int NF = Q > 4 ? 2 : 1;  // ring DMAs per batch (64 samples each)
+  f32x4 af[N], bf = bfirst;
+  {
+    const unsigned a_cur = c.a_base + (unsigned)((c.b & (CH_NBUF - 1)) * CH_BUF_BYTES) + (unsigned)c.lane * 16u;
+#pragma unroll
+    for (int m = 0; m < N; ++m) af[m] = *reinterpret_cast<const f32x4 *>(smem + a_cur + m * CH_BRICK);
+  }
+  for (int i = 0; i < count; ++i) {
+    const unsigned a_cur = c.a_base + (unsigned)((c.b & (CH_NBUF - 1)) * CH_BUF_BYTES) + (unsigned)c.lane * 16u;
+    const unsigned a_nxt = c.a_base + (unsigned)(((c.b + 1) & (CH_NBUF - 1)) * CH_BUF_BYTES) + (unsigned)c.lane * 16u;
+    const unsigned b_cur = c.row_addr + (unsigned)c.off * 4u;
+    // where the next batch starts: further along this row, or at the start of the lane's next row
+    const int off2 = c.off + 16 * Q;
+    const bool row_end = off2 == c.hop;
+    const bool wrap = c.slot + 1 == c.nr;
+    const unsigned row2 = wrap ? c.row_addr - (unsigned)(c.slot * c.row_bytes) : c.row_addr + (unsigned)c.row_bytes;
+    const int slot2 = wrap ? 0 : c.slot + 1;
+    const unsigned b_nxt = row_end ? row2 : b_cur + 64u * Q;
+    // what this batch reads of frame 0's row is dead afterwards: refilled (same place) with the samples one ring further
+    const unsigned fill_dst = c.ring_base + (unsigned)(c.slot0 * c.row_bytes + c.off * 4);
+    const int fill_v0 = 16 * c.sdone + c.ring_samples;
+
+    f32x4 a[2][N], bb[2];
+#pragma unroll
+    for (int m = 0; m < N; ++m) a[0][m] = af[m];
+    bb[0] = bf;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+      const int cu = j & 1, nx = cu ^ 1;
+      if (j + 1 < Q) {
+        bb[nx] = *reinterpret_cast<const f32x4 *>(smem + b_cur + 64 * (j + 1));
+#pragma unroll
+        for (int m = 0; m < N; ++m) a[nx][m] = *reinterpret_cast<const f32x4 *>(smem + a_cur + ((j + 1) * N + m) * CH_BRICK);
+      } else {
+        bb[nx] = *reinterpret_cast<const f32x4 *>(smem + b_nxt);
+#pragma unroll
+        for (int m = 0; m < N; ++m) a[nx][m] = *reinterpret_cast<const f32x4 *>(smem + a_nxt + m * CH_BRICK);
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+        for (int m = 0; m < N; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cu][m][jj], bb[cu][jj], acc[m], 0, 0, 0);
+        // the batch's DMAs, in the MFMAs' shadow: bricks of batch b + 3 early, the ring refill once the last sub-stage's
+        // fragments are in registers (this batch's reads of the ring are complete when its MFMAs issue)
+        if (j == 0 && jj == 0) {
+          ch_next_request(c);
+          ch_brick(c, c.b + 3, c.k0);
+        }
+        if (j == 0 && jj == 1) ch_brick(c, c.b + 3, c.k1);
+        if (j == Q - 1 && jj == 2) {
+          if (Q >= 4) {
+            ch_fill<REFLECT>(c, fill_v0, fill_dst);
+          } else if (c.lane < 16 * Q) {
+            ch_fill<REFLECT>(c, fill_v0, fill_dst);
+          }
+        }
+        if (NF == 2 && j == Q - 1 && jj == 3) {
+          if (Q == 8) {
+            ch_fill<REFLECT>(c, fill_v0 + 64, fill_dst + 256u);
+          } else if (c.lane < 16 * Q - 64) {
+            ch_fill<REFLECT>(c, fill_v0 + 64, fill_dst + 256u);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < N; ++m) af[m] = a[Q & 1][m];
+    bf = bb[Q & 1];
+    c.off = row_end ? 0 : off2;
+    c.row_addr = row_end ? row2 : c.row_addr;
+    c.slot = row_end ? slot2 : c.slot;
+    c.slot0 = row_end ? (c.slot0 + 1 == c.nr ? 0 : c.slot0 + 1) : c.slot0;
+    c.sdone += Q;
+    ++c.b;
+    // everything issued BEFORE this batch's DMAs has landed: the bricks of batch b + 2, ring samples
+    if (NF == 2)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    __syncthreads();
+  }
+  bfirst = bf;
+}
+
+template <bool REFLECT>
 __global__ void __launch_bounds__(256) cqt_chain_kernel(const ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -189,97 +311,85 @@ __global__ void __launch_bounds__(256) cqt_chain_kernel(const ChainArgs a) {
   const int ct = live ? ct_raw : a.n_ct - 1;  // idle waves of the last group shadow the last column tile (nothing stored)
   const int clip = ct / a.ct_per_clip;
   const int t0 = (ct - clip * a.ct_per_clip) * 16;
-  const float *xc = a.x + (long long)clip * a.x_clip_stride;
-  const int hop = a.hop, L = a.n_samples, nr = a.nr;
-  const int row_bytes = (hop + CH_SKEW) * 4;
-  const int U0 = t0 * hop + 16 * S.s_lo - a.pad;  // signal position of ring sample v = 0
-  const unsigned ring_base = (unsigned)(wave * a.ring_bytes);
-  const unsigned a_base = (unsigned)(4 * a.ring_bytes);
-  const int nb = S.n_batches;
-  const int *const bt = a.batches + S.batch0;
 
-  // ---- ring fill: block `blk` = samples v in [64 blk, +64) of the wave's delay line; inside each group of 16 the lane at
-  // position 4 q + n fetches sample 4 n + q
-  const int lperm = 16 * (lane >> 4) + 4 * (lane & 3) + ((lane >> 2) & 3);
-  int fill_blk = 0, fill_slot = 0, fill_off = 0;
-  auto fill_block = [&]() __attribute__((always_inline)) {
-    int pos = U0 + 64 * fill_blk + lperm;
-    if (a.pad_mode == MISPEC_PAD_REFLECT) {
-      pos = pos < 0 ? -pos : pos;
-      pos = pos >= L ? 2 * L - 2 - pos : pos;
-    }
-    const bool in = pos >= 0 && pos < L;
-    pos = pos < 0 ? 0 : (pos >= L ? L - 1 : pos);
-    // reflect: beyond the virtually padded clip only zero taps / unstored frames read (any finite sample will do);
-    // zero / no padding: everything outside the clip is zero
-    const float *src = (in || a.pad_mode == MISPEC_PAD_REFLECT) ? xc + pos : a.zeros + lane;
-    ch_dma4(src, ring_base + (unsigned)(fill_slot * row_bytes + fill_off * 4));
-    ++fill_blk;
-    fill_off += 64;
-    if (fill_off == hop) {
-      fill_off = 0;
-      fill_slot = fill_slot + 1 == nr ? 0 : fill_slot + 1;
-    }
-  };
-  // ---- brick stream: batch bb -> buffer bb % 3, the batch's bricks dealt out to the four waves
-  long long issue_brick = S.brick0;
-  auto issue_a = [&](int bb) __attribute__((always_inline)) {
-    const int e = bt[bb];
-    const int cnt = (e & 0xff) * (e >> 8);
-    const unsigned dst = a_base + (unsigned)((bb % CH_NBUF) * CH_NMAX * CH_BRICK);
-    for (int k = wave; k < cnt; k += 4)
-      ch_dma16(a.bricks + (issue_brick + k) * (CH_BRICK / 4), (unsigned)lane * 16u, dst + (unsigned)k * CH_BRICK);
-    issue_brick += cnt;
-  };
+  ChainState c;
+  c.xc = a.x + (long long)clip * a.x_clip_stride;
+  c.zeros = a.zeros;
+  c.bricks = a.bricks;
+  c.L = a.n_samples;
+  c.hop = a.hop;
+  c.nr = a.nr;
+  c.row_bytes = (a.hop + CH_SKEW) * 4;
+  c.ring_samples = a.nr * a.hop;
+  c.U0 = t0 * a.hop + 16 * S.s_lo - a.pad;
+  c.lperm = 16 * (lane >> 4) + 4 * (lane & 3) + ((lane >> 2) & 3);
+  c.lane = lane;
+  c.k0 = wave;
+  c.k1 = wave + 4 < CH_NMAX ? wave + 4 : CH_NMAX - 1;
+  c.ring_base = (unsigned)(wave * a.ring_bytes);
+  c.a_base = (unsigned)(4 * a.ring_bytes);
+  c.seg = (ch_seg_ptr)(a.segs + S.seg0);
+  c.n_segs = S.n_segs;
+  c.isg = 0;
+  c.iword = c.seg[0];
+  c.irem = c.iword >> 8;
+  c.iword_next = c.seg[S.n_segs > 1 ? 1 : S.n_segs];
+  c.brick_next = S.brick0;
+  c.a_cnt = 0;
+  c.b = 0;
+  c.sdone = 0;
+  c.off = 0;
+  c.slot0 = 0;
+  c.slot = f;
+  c.row_addr = c.ring_base + (unsigned)(f * c.row_bytes) + (unsigned)lq * 16u;
 
-  const int ring_samples = nr * hop;
-  if (!(a.debug & 2))
-    for (int i = 0; i < ring_samples / 64; ++i) fill_block();
-  if (nb > 0) issue_a(0);
-  if (nb > 1) issue_a(1);
-  ch_dma_barrier();
+  // prologue: the whole ring, the bricks of the first three batches
+  {
+    int slot = 0, off = 0;
+    for (int v0 = 0; v0 < c.ring_samples; v0 += 64) {
+      ch_fill<REFLECT>(c, v0, c.ring_base + (unsigned)(slot * c.row_bytes + off * 4));
+      off += 64;
+      if (off == c.hop) {
+        off = 0;
+        ++slot;
+      }
+    }
+  }
+  for (int bb = 0; bb < 3; ++bb) {
+    ch_next_request(c);
+    ch_brick(c, bb, c.k0);
+    ch_brick(c, bb, c.k1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 
   f32x4 acc[CH_NMAX];
 #pragma unroll
   for (int m = 0; m < CH_NMAX; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bfirst = *reinterpret_cast<const f32x4 *>(smem + c.row_addr);  // sub-stage 0's signal fragment
 
-  RingCursor rc{0, 0};
-  const unsigned ring_addr = ring_base + (unsigned)lq * 16u;
-  int sdone = 0;
-  for (int b = 0; b < nb; ++b) {
-    const int e = bt[b];
-    const int n = e & 0xff, q = e >> 8;
-    if (b + 2 < nb && !(a.debug & 4)) issue_a(b + 2);
-    // refill behind frame 0: sub-stages < sdone are dead
-    if (!(a.debug & 2))
-      while (64 * (fill_blk + 1) <= 16 * sdone + ring_samples) fill_block();
-    const unsigned a_addr = a_base + (unsigned)((b % CH_NBUF) * CH_NMAX * CH_BRICK) + (unsigned)lane * 16u;
-    switch (n) {
-#define CH_CASE(N)                                                                        \
-  case N:                                                                                 \
-    chain_batch<N>(acc, smem, a_addr, ring_addr, q, rc, f, nr, hop, row_bytes, a.debug); \
+  for (int sg = 0; sg < S.n_segs; ++sg) {
+    const int w = c.seg[sg];
+    const int count = w >> 8;
+    switch (w & 255) {
+#define CH_CASE(N, Q)                                               \
+  case (N) | ((Q) << 4):                                            \
+    chain_segment<N, Q, REFLECT>(acc, bfirst, smem, c, count); \
     break;
-      CH_CASE(1)
-      CH_CASE(2)
-      CH_CASE(3)
-      CH_CASE(4)
-      CH_CASE(5)
-      CH_CASE(6)
-      CH_CASE(7)
-      CH_CASE(8)
-      CH_CASE(9)
+      CH_CASE(1, 1) CH_CASE(1, 2) CH_CASE(1, 3) CH_CASE(1, 4) CH_CASE(1, 5) CH_CASE(1, 6) CH_CASE(1, 7)
+      CH_CASE(2, 1) CH_CASE(2, 2) CH_CASE(2, 3)
+      CH_CASE(3, 1) CH_CASE(3, 2)
+      CH_CASE(4, 1) CH_CASE(5, 1) CH_CASE(6, 1) CH_CASE(7, 1)
 #undef CH_CASE
       default:
         break;
     }
-    sdone += q;
-    ch_dma_barrier();
   }
 
   // ---- epilogue: element e of lane (f, lq) of tile m is D[row 16 tile + 4 lq + e][frame t0 + f]: (re, im) of bins
   // 8 tile + 2 lq and + 1 sit in one lane
   const int t = t0 + f;
-  if (!live || t >= a.n_frames || (a.debug & 8)) return;
+  if (!live || t >= a.n_frames) return;
   const int E = (a.epilogue == MISPEC_EPI_COMPLEX || a.epilogue == MISPEC_EPI_PHASE_COSSIN) ? 2 : 1;
   float *const obase = a.out + (long long)clip * a.out_clip_stride + (long long)t * E;
 #pragma unroll
@@ -324,14 +434,14 @@ __global__ void __launch_bounds__(256) chain_pack_kernel(const float *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// host: the plan (tiles, row sets, batches, brick order) from the supports
+// host: the plan (tiles, row sets, segments per hop, brick order) from the supports
 // ------------------------------------------------------------------------------------------------------------
 struct ChainSetHost {
   int n_tiles = 0;
   int tile[CH_NMAX];
   int lo[CH_NMAX], hi[CH_NMAX];  // sub-stages
   long long brick0 = 0, n_bricks = 0;
-  int batch0 = 0, n_batches = 0;
+  int seg0[CH_HOPS], n_segs[CH_HOPS];  // per hop: first segment (index into the hop's table), segments
   long long cost = 0;  // bricks + a quarter of the single-tile sub-stages (dependent MFMAs issue at 40 / 32 cycles)
 };
 
@@ -339,10 +449,10 @@ struct ChainPlan {
   bool ok = false;
   int n_sets = 0;
   ChainSetHost set[CH_MAXSETS];
-  std::vector<int> batches;
+  std::vector<int> segs[CH_HOPS];  // hop = 64 (h + 1)
   std::vector<int2> brick_map;
   long long n_bricks = 0;
-  long long batch_off = 0, map_off = 0, brick_off = 0, bytes = 0;
+  long long seg_off[CH_HOPS], map_off = 0, brick_off = 0, bytes = 0;
 };
 
 int env_int(const char *name, int dflt) {
@@ -377,11 +487,11 @@ ChainPlan chain_plan(const int32_t *sup, int n_bins, int K, bool want_map) {
     if (y.hi > y.lo && (y.lo < x.lo || y.hi > x.hi)) return pl;
   }
   // row sets: consecutive runs of the sorted tiles.  One set when they fit; otherwise the first `split` tiles apart from the
-  // rest (the long tiles' single-tile sub-stages are the cost of separating neighbours: keep the two longest together)
+  // rest (separating neighbours costs the longer one's single-tile sub-stages: keep the longest tiles together)
   int n_sets = (n_tiles + CH_NMAX - 1) / CH_NMAX;
   if (n_sets > CH_MAXSETS) return pl;
   std::vector<int> first(1, 0);
-  const int split = env_int("MISPEC_CHAIN_SPLIT", 3);
+  const int split = env_int("MISPEC_CHAIN_SPLIT", 4);
   if (n_tiles > 4 && split > 0 && split < n_tiles && n_tiles - split <= CH_NMAX && split <= CH_NMAX) {
     first.push_back(split);
   } else {
@@ -401,7 +511,7 @@ ChainPlan chain_plan(const int32_t *sup, int n_bins, int K, bool want_map) {
       S.hi[m] = t.hi;
     }
     S.brick0 = bricks;
-    S.batch0 = (int)pl.batches.size();
+    for (int h = 0; h < CH_HOPS; ++h) S.seg0[h] = (int)pl.segs[h].size();
     long long solo = 0;
     int s0 = S.lo[0];
     while (s0 < S.hi[0]) {
@@ -414,28 +524,54 @@ ChainPlan chain_plan(const int32_t *sup, int n_bins, int K, bool want_map) {
         if (S.hi[m] > s0) s1 = std::min(s1, S.hi[m]);
       }
       if (n == 1) solo += s1 - s0;
-      const int qmax = std::min(CH_QMAX, CH_NMAX / n);
-      for (int sb = s0; sb < s1; sb += qmax) {
-        const int q = std::min(qmax, s1 - sb);
-        pl.batches.push_back((q << 8) | n);
-        if (want_map)
-          for (int j = 0; j < q; ++j)
-            for (int m = 0; m < n; ++m) pl.brick_map.push_back(make_int2(S.tile[m], sb + j));
-        bricks += (long long)q * n;
+      // the bricks of the run, sub-stage major (whatever the batches: their order does not depend on the hop)
+      if (want_map)
+        for (int sb = s0; sb < s1; ++sb)
+          for (int m = 0; m < n; ++m) pl.brick_map.push_back(make_int2(S.tile[m], sb));
+      bricks += (long long)(s1 - s0) * n;
+      // batches of the run, per hop: Q <= 7 / n sub-stages, never across a ring row (hop / 16 sub-stages from the set's start)
+      const int qmax = CH_NMAX / n;
+      for (int h = 0; h < CH_HOPS; ++h) {
+        const int per_row = 4 * (h + 1);
+        std::vector<int> &sg = pl.segs[h];
+        int sb = s0;
+        while (sb < s1) {
+          const int row_end = S.lo[0] + ((sb - S.lo[0]) / per_row + 1) * per_row;
+          const int e = std::min(s1, row_end);
+          const int full = (e - sb) / qmax, rest = (e - sb) % qmax;
+          auto push = [&](int q, int cnt) {
+            if (cnt <= 0) return;
+            const int key = n | (q << 4);
+            if ((int)sg.size() > S.seg0[h] && (sg.back() & 255) == key && (sg.back() >> 8) + cnt < (1 << 22))
+              sg.back() += cnt << 8;
+            else
+              sg.push_back(key | (cnt << 8));
+          };
+          push(qmax, full);
+          push(rest, rest ? 1 : 0);
+          sb = e;
+        }
       }
       s0 = s1;
     }
+    for (int h = 0; h < CH_HOPS; ++h) {
+      S.n_segs[h] = (int)pl.segs[h].size() - S.seg0[h];
+      pl.segs[h].push_back(0);  // (what the request side reads past the set's last segment)
+    }
     S.n_bricks = bricks - S.brick0;
-    S.n_batches = (int)pl.batches.size() - S.batch0;
     S.cost = S.n_bricks + solo / 4;
   }
   // largest units first: the dispatcher's tail is then made of the short ones
   std::stable_sort(pl.set, pl.set + pl.n_sets, [](const ChainSetHost &x, const ChainSetHost &y) { return x.cost > y.cost; });
   pl.n_bricks = bricks;
-  pl.batch_off = CH_ZERO_BYTES;
-  pl.map_off = pl.batch_off + (((long long)pl.batches.size() * 4 + 255) & ~255LL);
+  long long off = CH_ZERO_BYTES;
+  for (int h = 0; h < CH_HOPS; ++h) {
+    pl.seg_off[h] = off;
+    off += ((long long)pl.segs[h].size() * 4 + 255) & ~255LL;
+  }
+  pl.map_off = off;
   pl.brick_off = (pl.map_off + bricks * 8 + 1023) & ~1023LL;
-  pl.bytes = pl.brick_off + bricks * CH_BRICK;
+  pl.bytes = pl.brick_off + (bricks + 8) * CH_BRICK;  // (the request side runs up to 7 bricks past the end)
   pl.ok = true;
   return pl;
 }
@@ -445,13 +581,13 @@ int ring_rows(int hop) { return 15 + (511 + hop) / hop; }  // NR hop >= 15 hop +
 bool chain_shape_ok(const mispec_framed_gemm_args *a) {
   if (a->precision != MISPEC_PREC_F32 || !a->basis_chain || !a->row_support || !a->row_support_host || !a->basis_im) return false;
   if (a->tile != MISPEC_TILE_AUTO || a->fb || a->out_frame_major) return false;
-  if (a->hop % 64 || a->hop < 64 || a->hop > 512) return false;
+  if (a->hop % 64 || a->hop < 64 || a->hop > 64 * CH_HOPS) return false;
   if ((long long)a->n_frames * a->hop + a->kernel + 65536 > 0x7fffffffLL) return false;
-  if ((long long)a->n_samples * 2 > 0x7fffffffLL) return false;
+  if ((long long)a->n_samples * 4 > 0x7fffffffLL) return false;
   return true;
 }
 
-std::atomic<unsigned long long> g_configured{0};
+std::atomic<unsigned long long> g_configured[2];
 
 }  // namespace
 
@@ -467,12 +603,13 @@ int mispec_chain_pack_impl(const float *basis_re, const float *basis_im, int64_t
   if (dst_bytes != pl.bytes) return mispec_fail_msg(MISPEC_E_INVALID, "chain basis: dst_bytes != mispec_basis_chain_bytes()");
   hipStream_t s = static_cast<hipStream_t>(stream);
   unsigned char *d = static_cast<unsigned char *>(dst);
-  // header: zeros | batch table | brick map (host-synchronous copies, once per bank)
+  // header: zeros | segment tables | brick map (host-synchronous copies, once per bank)
   if (hipMemsetAsync(d, 0, (size_t)pl.brick_off, s) != hipSuccess) return mispec_fail_msg(MISPEC_E_HIP, "hipMemsetAsync failed");
   if (hipStreamSynchronize(s) != hipSuccess) return mispec_fail_msg(MISPEC_E_HIP, "hipStreamSynchronize failed");
-  if (!pl.batches.empty() &&
-      hipMemcpy(d + pl.batch_off, pl.batches.data(), pl.batches.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
-    return mispec_fail_msg(MISPEC_E_HIP, "hipMemcpy failed");
+  for (int h = 0; h < CH_HOPS; ++h)
+    if (!pl.segs[h].empty() &&
+        hipMemcpy(d + pl.seg_off[h], pl.segs[h].data(), pl.segs[h].size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+      return mispec_fail_msg(MISPEC_E_HIP, "hipMemcpy failed");
   if (pl.n_bricks > 0) {
     if (hipMemcpy(d + pl.map_off, pl.brick_map.data(), pl.brick_map.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
       return mispec_fail_msg(MISPEC_E_HIP, "hipMemcpy failed");
@@ -496,6 +633,7 @@ int mispec_chain_launch(const mispec_framed_gemm_args *a, int debug, void *strea
   if (!pl.ok || pl.bytes != a->basis_chain_bytes) return mispec_fail_msg(MISPEC_E_INVALID, "chain basis does not match this bank");
   ChainArgs k;
   memset(&k, 0, sizeof(k));
+  const int h = a->hop / 64 - 1;
   k.x = a->x;
   k.x_clip_stride = a->x_clip_stride;
   k.n_clips = a->n_clips;
@@ -513,8 +651,9 @@ int mispec_chain_launch(const mispec_framed_gemm_args *a, int debug, void *strea
   k.ring_bytes = k.nr * (a->hop + CH_SKEW) * 4;
   const unsigned char *blob = static_cast<const unsigned char *>(a->basis_chain);
   k.zeros = reinterpret_cast<const float *>(blob);
-  k.batches = reinterpret_cast<const int *>(blob + pl.batch_off);
+  k.segs = reinterpret_cast<const int *>(blob + pl.seg_off[h]);
   k.bricks = reinterpret_cast<const float *>(blob + pl.brick_off);
+  k.n_bricks = pl.n_bricks;
   k.row_scale = a->row_scale;
   k.n_bins = a->n_bins;
   k.epilogue = a->epilogue;
@@ -526,29 +665,31 @@ int mispec_chain_launch(const mispec_framed_gemm_args *a, int debug, void *strea
   k.out_row_stride = a->out_row_stride;
   k.out_row_offset = a->out_row_offset;
   k.n_sets = pl.n_sets;
-  k.debug = debug;
+  k.debug = debug | env_int("MISPEC_CHAIN_DEBUG", 0);
   for (int s = 0; s < pl.n_sets; ++s) {
     const ChainSetHost &S = pl.set[s];
     k.first_wg[s] = (int)(s * n_groups);
     k.set[s].n_tiles = S.n_tiles;
     k.set[s].s_lo = S.lo[0];
-    k.set[s].batch0 = S.batch0;
-    k.set[s].n_batches = S.n_batches;
+    k.set[s].seg0 = S.seg0[h];
+    k.set[s].n_segs = S.n_segs[h];
     k.set[s].brick0 = S.brick0;
     for (int m = 0; m < S.n_tiles; ++m) k.set[s].tile[m] = S.tile[m];
   }
   for (int s = pl.n_sets; s <= CH_MAXSETS; ++s) k.first_wg[s] = (int)(pl.n_sets * n_groups);
-  const size_t smem = 4 * (size_t)k.ring_bytes + (size_t)CH_NBUF * CH_NMAX * CH_BRICK;
+  const size_t smem = 4 * (size_t)k.ring_bytes + (size_t)CH_NBUF * CH_BUF_BYTES;
   if (smem > 160 * 1024) return mispec_fail_msg(MISPEC_E_UNSUPPORTED, "chain kernel: LDS budget");
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return mispec_fail_msg(MISPEC_E_HIP, "hipGetDevice failed");
+  const bool reflect = a->pad_mode == MISPEC_PAD_REFLECT;
+  auto kern = reflect ? cqt_chain_kernel<true> : cqt_chain_kernel<false>;
   const unsigned long long bit = 1ull << (dev & 63);
-  if (!(g_configured.load(std::memory_order_acquire) & bit)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(cqt_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+  if (!(g_configured[reflect].load(std::memory_order_acquire) & bit)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return mispec_fail_msg(MISPEC_E_HIP, "hipFuncSetAttribute failed (chain kernel)");
-    g_configured.fetch_or(bit, std::memory_order_release);
+    g_configured[reflect].fetch_or(bit, std::memory_order_release);
   }
-  hipLaunchKernelGGL(cqt_chain_kernel, dim3((unsigned)(n_groups * pl.n_sets)), dim3(256), smem, static_cast<hipStream_t>(stream), k);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(n_groups * pl.n_sets)), dim3(256), smem, static_cast<hipStream_t>(stream), k);
   if (hipGetLastError() != hipSuccess) return mispec_fail_msg(MISPEC_E_HIP, "chain kernel launch failed");
   return MISPEC_OK;
 }

@@ -90,8 +90,29 @@ def check_module(dev, B=64, seconds=10.0, sr=44100):
     return same
 
 
+def ablate(dev, B=64, seconds=10.0, sr=44100):
+    import os
+
+    mod = CQT1992v2(sr=sr, hop_length=512, fmin=32.7, n_bins=84, bins_per_octave=12, output_format="Magnitude", verbose=False).to(dev)
+    x = torch.randn(B, int(seconds * sr), generator=torch.Generator().manual_seed(0)).to(dev)
+    with torch.no_grad():
+        for bits in (0, 1, 2, 4, 6, 7, 3, 5):
+            os.environ["MISPEC_CHAIN_DEBUG"] = str(bits)
+            print("debug %d (1 no MFMA, 2 no ring DMA, 4 no brick DMA): %.4f ms" % (bits, timed(lambda: mod(x))), flush=True)
+    os.environ["MISPEC_CHAIN_DEBUG"] = "0"
+
+
 if __name__ == "__main__":
     dev = torch.device("cuda:0")
+    if "--one" in sys.argv:  # (for rocprofv3: a few forwards of the bench shape)
+        mod = CQT1992v2(sr=44100, hop_length=512, fmin=32.7, n_bins=84, bins_per_octave=12, output_format="Magnitude", verbose=False).to(dev)
+        x = torch.randn(64, 441000, generator=torch.Generator().manual_seed(0)).to(dev)
+        with torch.no_grad():
+            print("%.4f ms" % timed(lambda: mod(x), n=5))
+        sys.exit(0)
+    if "--ablate" in sys.argv:
+        ablate(dev)
+        sys.exit(0)
     t = time.time()
     ok = check_random(dev)
     if "--quick" not in sys.argv:

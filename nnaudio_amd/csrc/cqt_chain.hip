@@ -47,9 +47,10 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int CH_NMAX = 7;      // 16-row tiles per row set = bricks per batch buffer
-constexpr int CH_NBUF = 4;      // brick buffers: batch b multiplies one, b + 1 is published (its first fragments are read before the
-                                // barrier), b + 2 is landing, b + 3 is being requested
+constexpr int CH_NMAX = 10;     // 16-row tiles per row set = bricks per batch buffer
+constexpr int CH_NBUF = 3;      // brick buffers: batch b multiplies one, b + 1 is landing (published by the barrier inside batch b's
+                                // last sub-stage), b + 2 is being requested
+constexpr int CH_QMAX = 8;      // sub-stages per batch (the ring's look-ahead: 3 batches + 1 sub-stage <= 27)
 constexpr int CH_MAXSETS = 8;
 constexpr int CH_SKEW = 8;      // dwords between ring rows in bank space
 constexpr int CH_BRICK = 1024;  // bytes
@@ -62,6 +63,8 @@ struct ChainSetDev {
   int s_lo;        // first 16-tap sub-stage of the set (of its longest tile)
   int seg0;        // the set's segments in the table of this hop
   int n_segs;
+  int boff0;       // ... and its batches' first bricks (relative to brick0; 4 entries of padding)
+  int pad2_;
   long long brick0;  // first brick of the set's stream
   int tile[CH_NMAX];
   int pad_;
@@ -76,7 +79,7 @@ struct ChainArgs {
   int nr;           // ring rows
   int ring_bytes;   // per wave
   const float *zeros;
-  const int *segs;  // N | Q << 4 | count << 8: `count` batches of Q sub-stages x N tiles
+  const int *segs;  // this hop's table.  Segment words: N | Q << 4 | count << 8 = `count` batches of Q sub-stages x N tiles
   const float *bricks;
   long long n_bricks;
   const float *row_scale;
@@ -142,19 +145,15 @@ struct ChainState {
   // constants
   const float *xc;      // the wave's clip
   const float *zeros;
-  const float *bricks;
+  const float *bricks;  // the set's first brick
   int L, hop, nr, row_bytes, ring_samples;
   int U0;               // signal position of ring sample v = 0
   int lperm;            // (lane) sample of a 64-block this lane fetches
   int lane;
-  int k0, k1;           // the two bricks of a batch this wave requests (wave, min(wave + 4, 6))
+  int k0, k1, k2;       // the three slots of a batch buffer this wave requests (wave, wave + 4, min(wave + 8, 9))
   unsigned ring_base, a_base;
-  // brick requests: the batch being requested (three ahead of the one being multiplied)
-  ch_seg_ptr seg;        // the set's segment words
-  int n_segs;
-  int isg, irem, iword, iword_next;  // its segment, batches left in it, that segment's word, the next segment's word
-  long long brick_next;  // first brick of the batch being requested
-  int a_cnt;             // bricks in it (0: none)
+  ch_seg_ptr boff;      // first brick of every batch of the set
+  int req;              // first brick of the batch to request next (batch b + 2), read one batch ahead
   // multiply side
   int b;       // batch index
   int sdone;   // sub-stages multiplied
@@ -164,8 +163,8 @@ struct ChainState {
   unsigned row_addr;  // (lane) LDS address of this lane's row + 16 lq
 };
 
-// 64 samples (lanes < n_lanes of them) from ring sample v0 on, to LDS address dst: inside each group of 16 the lane at
-// position 4 q + n fetches sample 4 n + q
+// 64 samples from ring sample v0 on, to LDS address dst: inside each group of 16 the lane at position 4 q + n fetches
+// sample 4 n + q
 template <bool REFLECT>
 __device__ __forceinline__ void ch_fill(const ChainState &c, int v0, unsigned dst) {
   int pos = c.U0 + v0 + c.lperm;
@@ -186,40 +185,38 @@ __device__ __forceinline__ void ch_fill(const ChainState &c, int v0, unsigned ds
   }
 }
 
-// the request side moves on to the next batch of the segment table
-__device__ __forceinline__ void ch_next_request(ChainState &c) {
-  c.brick_next += c.a_cnt;  // (the previous batch was requested completely)
-  c.a_cnt = (c.iword & 15) * ((c.iword >> 4) & 15);
-  --c.irem;
-  const bool adv = c.irem == 0;
-  c.isg += adv ? 1 : 0;
-  c.iword = adv ? c.iword_next : c.iword;
-  c.irem = adv ? (c.iword_next >> 8) : c.irem;
-  int nx = c.isg + 1;
-  nx = nx < c.n_segs ? nx : c.n_segs;  // (one zero word follows every table)
-  c.iword_next = c.seg[nx];            // (re-read every batch: no branch; consumed when the segment ends)
-}
-
-// this wave's two bricks of the requested batch -> buffer `bb` % 4 (slots past the batch's bricks receive the stream's
-// following bricks: never read; the stream ends with 8 bricks of padding)
+// slot k of buffer `bb` % 3 <- brick req + k of the set's stream (slots past the batch's bricks receive the stream's
+// following bricks: never read; the stream ends with 12 bricks of padding)
 __device__ __forceinline__ void ch_brick(const ChainState &c, int bb, int k) {
-  const unsigned dst = c.a_base + (unsigned)((bb & (CH_NBUF - 1)) * CH_BUF_BYTES) + (unsigned)k * CH_BRICK;
-  ch_dma16(c.bricks + (c.brick_next + k) * (CH_BRICK / 4), (unsigned)c.lane * 16u, dst);
+  int buf = bb % CH_NBUF;
+  const unsigned dst = c.a_base + (unsigned)(buf * CH_BUF_BYTES + k * CH_BRICK);
+  ch_dma16(c.bricks + (long long)(c.req + k) * (CH_BRICK / 4), (unsigned)c.lane * 16u, dst);
 }
 
 // `count` batches of Q sub-stages x N tiles.  In: bfirst = the signal fragment of the first sub-stage (always read ahead).
+//
+// One batch, in issue order (no control flow; everything but the MFMAs sits in their shadow):
+//   sub-stage 0:      MFMAs | three brick DMAs of batch b + 2 -> buffer (b + 2) % 3 (free since the barrier of batch b - 1)
+//   sub-stage j:      fragments of sub-stage j + 1 (ds_read_b128, immediate offsets) | 4 N MFMAs
+//   sub-stage Q - 1:  first half of its MFMAs | ring refill: what this batch read of frame 0's row, one ring further on
+//                     | s_waitcnt vmcnt(this batch's DMAs): everything older has landed -- the bricks of batch b + 1, ring
+//                     samples | s_barrier: they are published, and every wave has its last fragments of batch b in registers
+//                     | first fragments of batch b + 1 | second half of the MFMAs
 template <int N, int Q, bool REFLECT>
 __device__ __forceinline__ void chain_segment(f32x4 (&acc)[CH_NMAX], f32x4 &bfirst, const unsigned char *smem, ChainState &c, const int count) {
   constexpr int NF = Q > 4 ? 2 : 1;  // ring DMAs per batch (64 samples each)
   f32x4 af[N], bf = bfirst;
   {
-    const unsigned a_cur = c.a_base + (unsigned)((c.b & (CH_NBUF - 1)) * CH_BUF_BYTES) + (unsigned)c.lane * 16u;
+    const unsigned a_cur = c.a_base + (unsigned)((c.b % CH_NBUF) * CH_BUF_BYTES) + (unsigned)c.lane * 16u;
 #pragma unroll
     for (int m = 0; m < N; ++m) af[m] = *reinterpret_cast<const f32x4 *>(smem + a_cur + m * CH_BRICK);
   }
+  int buf = c.b % CH_NBUF;
   for (int i = 0; i < count; ++i) {
-    const unsigned a_cur = c.a_base + (unsigned)((c.b & (CH_NBUF - 1)) * CH_BUF_BYTES) + (unsigned)c.lane * 16u;
-    const unsigned a_nxt = c.a_base + (unsigned)(((c.b + 1) & (CH_NBUF - 1)) * CH_BUF_BYTES) + (unsigned)c.lane * 16u;
+    const int buf1 = buf + 1 == CH_NBUF ? 0 : buf + 1;
+    const int buf2 = buf1 + 1 == CH_NBUF ? 0 : buf1 + 1;
+    const unsigned a_cur = c.a_base + (unsigned)(buf * CH_BUF_BYTES) + (unsigned)c.lane * 16u;
+    const unsigned a_nxt = c.a_base + (unsigned)(buf1 * CH_BUF_BYTES) + (unsigned)c.lane * 16u;
     const unsigned b_cur = c.row_addr + (unsigned)c.off * 4u;
     // where the next batch starts: further along this row, or at the start of the lane's next row
     const int off2 = c.off + 16 * Q;
@@ -231,6 +228,7 @@ __device__ __forceinline__ void chain_segment(f32x4 (&acc)[CH_NMAX], f32x4 &bfir
     // what this batch reads of frame 0's row is dead afterwards: refilled (same place) with the samples one ring further
     const unsigned fill_dst = c.ring_base + (unsigned)(c.slot0 * c.row_bytes + c.off * 4);
     const int fill_v0 = 16 * c.sdone + c.ring_samples;
+    const int req_next = c.boff[c.b + 3];
 
     f32x4 a[2][N], bb[2];
 #pragma unroll
@@ -243,34 +241,40 @@ __device__ __forceinline__ void chain_segment(f32x4 (&acc)[CH_NMAX], f32x4 &bfir
         bb[nx] = *reinterpret_cast<const f32x4 *>(smem + b_cur + 64 * (j + 1));
 #pragma unroll
         for (int m = 0; m < N; ++m) a[nx][m] = *reinterpret_cast<const f32x4 *>(smem + a_cur + ((j + 1) * N + m) * CH_BRICK);
-      } else {
-        bb[nx] = *reinterpret_cast<const f32x4 *>(smem + b_nxt);
-#pragma unroll
-        for (int m = 0; m < N; ++m) a[nx][m] = *reinterpret_cast<const f32x4 *>(smem + a_nxt + m * CH_BRICK);
       }
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
+        if (j == Q - 1 && jj == 2) {
+          // everything issued BEFORE this batch's DMAs has landed; publish; the next batch's first fragments
+          if (NF == 2)
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+          else
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          __syncthreads();
+          bb[nx] = *reinterpret_cast<const f32x4 *>(smem + b_nxt);
+#pragma unroll
+          for (int m = 0; m < N; ++m) a[nx][m] = *reinterpret_cast<const f32x4 *>(smem + a_nxt + m * CH_BRICK);
+        }
 #pragma unroll
         for (int m = 0; m < N; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cu][m][jj], bb[cu][jj], acc[m], 0, 0, 0);
-        // the batch's DMAs, in the MFMAs' shadow: bricks of batch b + 3 early, the ring refill once the last sub-stage's
-        // fragments are in registers (this batch's reads of the ring are complete when its MFMAs issue)
         if (j == 0 && jj == 0) {
-          ch_next_request(c);
-          ch_brick(c, c.b + 3, c.k0);
+          ch_brick(c, buf2, c.k0);
+          ch_brick(c, buf2, c.k1);
+          ch_brick(c, buf2, c.k2);
         }
-        if (j == 0 && jj == 1) ch_brick(c, c.b + 3, c.k1);
-        if (j == Q - 1 && jj == 2) {
+        if (j == Q - 1 && jj == (Q == 1 ? 1 : 0)) {
+          // (this batch's reads of the ring are complete: its last sub-stage's MFMAs have their operands)
           if (Q >= 4) {
             ch_fill<REFLECT>(c, fill_v0, fill_dst);
           } else if (c.lane < 16 * Q) {
             ch_fill<REFLECT>(c, fill_v0, fill_dst);
           }
-        }
-        if (NF == 2 && j == Q - 1 && jj == 3) {
-          if (Q == 8) {
-            ch_fill<REFLECT>(c, fill_v0 + 64, fill_dst + 256u);
-          } else if (c.lane < 16 * Q - 64) {
-            ch_fill<REFLECT>(c, fill_v0 + 64, fill_dst + 256u);
+          if (NF == 2) {
+            if (Q == 8) {
+              ch_fill<REFLECT>(c, fill_v0 + 64, fill_dst + 256u);
+            } else if (c.lane < 16 * Q - 64) {
+              ch_fill<REFLECT>(c, fill_v0 + 64, fill_dst + 256u);
+            }
           }
         }
       }
@@ -283,13 +287,9 @@ __device__ __forceinline__ void chain_segment(f32x4 (&acc)[CH_NMAX], f32x4 &bfir
     c.slot = row_end ? slot2 : c.slot;
     c.slot0 = row_end ? (c.slot0 + 1 == c.nr ? 0 : c.slot0 + 1) : c.slot0;
     c.sdone += Q;
+    c.req = req_next;
     ++c.b;
-    // everything issued BEFORE this batch's DMAs has landed: the bricks of batch b + 2, ring samples
-    if (NF == 2)
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    __syncthreads();
+    buf = buf1;
   }
   bfirst = bf;
 }
@@ -315,7 +315,6 @@ __global__ void __launch_bounds__(256) cqt_chain_kernel(const ChainArgs a) {
   ChainState c;
   c.xc = a.x + (long long)clip * a.x_clip_stride;
   c.zeros = a.zeros;
-  c.bricks = a.bricks;
   c.L = a.n_samples;
   c.hop = a.hop;
   c.nr = a.nr;
@@ -325,17 +324,13 @@ __global__ void __launch_bounds__(256) cqt_chain_kernel(const ChainArgs a) {
   c.lperm = 16 * (lane >> 4) + 4 * (lane & 3) + ((lane >> 2) & 3);
   c.lane = lane;
   c.k0 = wave;
-  c.k1 = wave + 4 < CH_NMAX ? wave + 4 : CH_NMAX - 1;
+  c.k1 = wave + 4;
+  c.k2 = wave + 8 < CH_NMAX ? wave + 8 : CH_NMAX - 1;
   c.ring_base = (unsigned)(wave * a.ring_bytes);
   c.a_base = (unsigned)(4 * a.ring_bytes);
-  c.seg = (ch_seg_ptr)(a.segs + S.seg0);
-  c.n_segs = S.n_segs;
-  c.isg = 0;
-  c.iword = c.seg[0];
-  c.irem = c.iword >> 8;
-  c.iword_next = c.seg[S.n_segs > 1 ? 1 : S.n_segs];
-  c.brick_next = S.brick0;
-  c.a_cnt = 0;
+  const ch_seg_ptr seg = (ch_seg_ptr)(a.segs + S.seg0);
+  c.boff = (ch_seg_ptr)(a.segs + S.boff0);
+  c.bricks = a.bricks + S.brick0 * (CH_BRICK / 4);
   c.b = 0;
   c.sdone = 0;
   c.off = 0;
@@ -343,7 +338,7 @@ __global__ void __launch_bounds__(256) cqt_chain_kernel(const ChainArgs a) {
   c.slot = f;
   c.row_addr = c.ring_base + (unsigned)(f * c.row_bytes) + (unsigned)lq * 16u;
 
-  // prologue: the whole ring, the bricks of the first three batches
+  // prologue: the whole ring, the bricks of the first two batches
   {
     int slot = 0, off = 0;
     for (int v0 = 0; v0 < c.ring_samples; v0 += 64) {
@@ -355,11 +350,13 @@ __global__ void __launch_bounds__(256) cqt_chain_kernel(const ChainArgs a) {
       }
     }
   }
-  for (int bb = 0; bb < 3; ++bb) {
-    ch_next_request(c);
+  for (int bb = 0; bb < 2; ++bb) {
+    c.req = c.boff[bb];
     ch_brick(c, bb, c.k0);
     ch_brick(c, bb, c.k1);
+    ch_brick(c, bb, c.k2);
   }
+  c.req = c.boff[2];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -369,17 +366,18 @@ __global__ void __launch_bounds__(256) cqt_chain_kernel(const ChainArgs a) {
   f32x4 bfirst = *reinterpret_cast<const f32x4 *>(smem + c.row_addr);  // sub-stage 0's signal fragment
 
   for (int sg = 0; sg < S.n_segs; ++sg) {
-    const int w = c.seg[sg];
+    const int w = seg[sg];
     const int count = w >> 8;
     switch (w & 255) {
 #define CH_CASE(N, Q)                                               \
   case (N) | ((Q) << 4):                                            \
     chain_segment<N, Q, REFLECT>(acc, bfirst, smem, c, count); \
     break;
-      CH_CASE(1, 1) CH_CASE(1, 2) CH_CASE(1, 3) CH_CASE(1, 4) CH_CASE(1, 5) CH_CASE(1, 6) CH_CASE(1, 7)
-      CH_CASE(2, 1) CH_CASE(2, 2) CH_CASE(2, 3)
-      CH_CASE(3, 1) CH_CASE(3, 2)
-      CH_CASE(4, 1) CH_CASE(5, 1) CH_CASE(6, 1) CH_CASE(7, 1)
+      CH_CASE(1, 1) CH_CASE(1, 2) CH_CASE(1, 3) CH_CASE(1, 4) CH_CASE(1, 5) CH_CASE(1, 6) CH_CASE(1, 7) CH_CASE(1, 8)
+      CH_CASE(2, 1) CH_CASE(2, 2) CH_CASE(2, 3) CH_CASE(2, 4) CH_CASE(2, 5)
+      CH_CASE(3, 1) CH_CASE(3, 2) CH_CASE(3, 3)
+      CH_CASE(4, 1) CH_CASE(4, 2) CH_CASE(5, 1) CH_CASE(5, 2)
+      CH_CASE(6, 1) CH_CASE(7, 1) CH_CASE(8, 1) CH_CASE(9, 1) CH_CASE(10, 1)
 #undef CH_CASE
       default:
         break;
@@ -441,7 +439,7 @@ struct ChainSetHost {
   int tile[CH_NMAX];
   int lo[CH_NMAX], hi[CH_NMAX];  // sub-stages
   long long brick0 = 0, n_bricks = 0;
-  int seg0[CH_HOPS], n_segs[CH_HOPS];  // per hop: first segment (index into the hop's table), segments
+  int seg0[CH_HOPS], n_segs[CH_HOPS], boff0[CH_HOPS];  // per hop: first segment (index into the hop's table), segments, first batch offset
   long long cost = 0;  // bricks + a quarter of the single-tile sub-stages (dependent MFMAs issue at 40 / 32 cycles)
 };
 
@@ -511,6 +509,7 @@ ChainPlan chain_plan(const int32_t *sup, int n_bins, int K, bool want_map) {
       S.hi[m] = t.hi;
     }
     S.brick0 = bricks;
+    std::vector<int> boffs[CH_HOPS];
     for (int h = 0; h < CH_HOPS; ++h) S.seg0[h] = (int)pl.segs[h].size();
     long long solo = 0;
     int s0 = S.lo[0];
@@ -528,9 +527,8 @@ ChainPlan chain_plan(const int32_t *sup, int n_bins, int K, bool want_map) {
       if (want_map)
         for (int sb = s0; sb < s1; ++sb)
           for (int m = 0; m < n; ++m) pl.brick_map.push_back(make_int2(S.tile[m], sb));
-      bricks += (long long)(s1 - s0) * n;
       // batches of the run, per hop: Q <= 7 / n sub-stages, never across a ring row (hop / 16 sub-stages from the set's start)
-      const int qmax = CH_NMAX / n;
+      const int qmax = std::min(CH_QMAX, CH_NMAX / n);
       for (int h = 0; h < CH_HOPS; ++h) {
         const int per_row = 4 * (h + 1);
         std::vector<int> &sg = pl.segs[h];
@@ -541,6 +539,8 @@ ChainPlan chain_plan(const int32_t *sup, int n_bins, int K, bool want_map) {
           const int full = (e - sb) / qmax, rest = (e - sb) % qmax;
           auto push = [&](int q, int cnt) {
             if (cnt <= 0) return;
+            for (int t = 0; t < cnt; ++t) boffs[h].push_back((int)(bricks - S.brick0) + ((sb - s0) + t * q) * n);
+            sb += cnt * q;
             const int key = n | (q << 4);
             if ((int)sg.size() > S.seg0[h] && (sg.back() & 255) == key && (sg.back() >> 8) + cnt < (1 << 22))
               sg.back() += cnt << 8;
@@ -549,14 +549,16 @@ ChainPlan chain_plan(const int32_t *sup, int n_bins, int K, bool want_map) {
           };
           push(qmax, full);
           push(rest, rest ? 1 : 0);
-          sb = e;
         }
       }
+      bricks += (long long)(s1 - s0) * n;
       s0 = s1;
     }
     for (int h = 0; h < CH_HOPS; ++h) {
       S.n_segs[h] = (int)pl.segs[h].size() - S.seg0[h];
-      pl.segs[h].push_back(0);  // (what the request side reads past the set's last segment)
+      S.boff0[h] = (int)pl.segs[h].size();
+      pl.segs[h].insert(pl.segs[h].end(), boffs[h].begin(), boffs[h].end());
+      for (int t = 0; t < 4; ++t) pl.segs[h].push_back((int)(bricks - S.brick0));  // (requests past the last batch: the stream's padding)
     }
     S.n_bricks = bricks - S.brick0;
     S.cost = S.n_bricks + solo / 4;
@@ -571,7 +573,7 @@ ChainPlan chain_plan(const int32_t *sup, int n_bins, int K, bool want_map) {
   }
   pl.map_off = off;
   pl.brick_off = (pl.map_off + bricks * 8 + 1023) & ~1023LL;
-  pl.bytes = pl.brick_off + (bricks + 8) * CH_BRICK;  // (the request side runs up to 7 bricks past the end)
+  pl.bytes = pl.brick_off + (bricks + 12) * CH_BRICK;  // (the request side runs up to 12 bricks past the end)
   pl.ok = true;
   return pl;
 }
@@ -673,6 +675,7 @@ int mispec_chain_launch(const mispec_framed_gemm_args *a, int debug, void *strea
     k.set[s].s_lo = S.lo[0];
     k.set[s].seg0 = S.seg0[h];
     k.set[s].n_segs = S.n_segs[h];
+    k.set[s].boff0 = S.boff0[h];
     k.set[s].brick0 = S.brick0;
     for (int m = 0; m < S.n_tiles; ++m) k.set[s].tile[m] = S.tile[m];
   }

@@ -56,7 +56,7 @@ def scratch_instructions(obj):
     return counts
 
 
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-inline-asm"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-inline-asm", "-Wno-int-to-pointer-cast"]
 
 
 def _sidecar(obj):

@@ -43,6 +43,12 @@
 #include "mispec.h"
 #include "mispec_internal.h"
 
+// development ablations (results are WRONG with any of them): -DCH_ABL=bits
+//   1 no barrier, 2 no vmcnt wait, 4 no ring refill, 8 no brick requests, 16 no MFMAs
+#ifndef CH_ABL
+#define CH_ABL 0
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -104,6 +110,39 @@ __device__ __forceinline__ void ch_dma4(const void *src, unsigned lds_addr) {
 __device__ __forceinline__ void ch_dma4s(const void *sbase, unsigned voff, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
 }
+// ... the first LANES lanes only (EXEC is all ones in this kernel's main loop: set and restored here, no branch)
+template <int LANES>
+__device__ __forceinline__ void ch_dma4s_lanes(const void *sbase, unsigned voff, unsigned lds_addr) {
+  static_assert(LANES > 0 && LANES < 64, "a partial wave");
+  constexpr unsigned lo = LANES >= 32 ? 0xffffffffu : ((1u << LANES) - 1u);
+  constexpr unsigned hi = LANES > 32 ? ((1u << (LANES - 32)) - 1u) : 0u;
+  asm volatile(
+      "s_mov_b32 exec_lo, %3\n\ts_mov_b32 exec_hi, %4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1\n\ts_mov_b64 exec, -1"
+      :
+      : "v"(voff), "s"(sbase), "s"(lds_addr), "i"(lo), "i"(hi)
+      : "memory", "m0");
+}
+template <int LANES>
+__device__ __forceinline__ void ch_dma4_lanes(const void *src, unsigned lds_addr) {
+  static_assert(LANES > 0 && LANES < 64, "a partial wave");
+  constexpr unsigned lo = LANES >= 32 ? 0xffffffffu : ((1u << LANES) - 1u);
+  constexpr unsigned hi = LANES > 32 ? ((1u << (LANES - 32)) - 1u) : 0u;
+  asm volatile(
+      "s_mov_b32 exec_lo, %2\n\ts_mov_b32 exec_hi, %3\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off\n\ts_mov_b64 exec, -1"
+      :
+      : "v"(src), "s"(lds_addr), "i"(lo), "i"(hi)
+      : "memory", "m0");
+}
+// three 16-byte pieces per lane from one scalar base: lane offsets v0..v2, LDS addresses d0..d2
+__device__ __forceinline__ void ch_dma16x3(const void *sbase, unsigned v0, unsigned v1, unsigned v2, unsigned d0, unsigned d1, unsigned d2) {
+  asm volatile(
+      "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3\n\t"
+      "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+      "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"
+      :
+      : "v"(v0), "v"(v1), "v"(v2), "s"(sbase), "s"(d0), "s"(d1), "s"(d2)
+      : "memory", "m0");
+}
 
 // the pointwise epilogue of mispec.hip (epilogue_store): same operations in the same order
 __device__ __forceinline__ void ch_epilogue_store(const ChainArgs &p, float *__restrict__ dst, float re, float im) {
@@ -139,6 +178,7 @@ __device__ __forceinline__ void ch_epilogue_store(const ChainArgs &p, float *__r
 }
 
 typedef const int __attribute__((address_space(4))) *ch_seg_ptr;  // constant address space: scalar loads
+typedef const volatile f32x4 __attribute__((address_space(3))) *ch_lds_pinned;  // an LDS read the compiler leaves where it is written
 
 // A wave's state besides its accumulators.  Scalars are wave-uniform unless marked (lane).
 struct ChainState {
@@ -150,7 +190,8 @@ struct ChainState {
   int U0;               // signal position of ring sample v = 0
   int lperm;            // (lane) sample of a 64-block this lane fetches
   int lane;
-  int k0, k1, k2;       // the three slots of a batch buffer this wave requests (wave, wave + 4, min(wave + 8, 9))
+  unsigned kd0, kd1, kd2;  // the three slots of a batch buffer this wave requests (wave, wave + 4, min(wave + 8, 9)): byte offsets
+  unsigned kv0, kv1, kv2;  // (lane) ... + 16 lane
   unsigned ring_base, a_base;
   ch_seg_ptr boff;      // first brick of every batch of the set
   int req;              // first brick of the batch to request next (batch b + 2), read one batch ahead
@@ -163,9 +204,9 @@ struct ChainState {
   unsigned row_addr;  // (lane) LDS address of this lane's row + 16 lq
 };
 
-// 64 samples from ring sample v0 on, to LDS address dst: inside each group of 16 the lane at position 4 q + n fetches
+// LANES samples from ring sample v0 on, to LDS address dst: inside each group of 16 the lane at position 4 q + n fetches
 // sample 4 n + q
-template <bool REFLECT>
+template <bool REFLECT, int LANES>
 __device__ __forceinline__ void ch_fill(const ChainState &c, int v0, unsigned dst) {
   int pos = c.U0 + v0 + c.lperm;
   if (REFLECT) {
@@ -176,21 +217,26 @@ __device__ __forceinline__ void ch_fill(const ChainState &c, int v0, unsigned ds
     pos = pos >= c.L ? up : pos;
     pos = pos < 0 ? 0 : pos;
     pos = pos > c.L - 1 ? c.L - 1 : pos;
-    ch_dma4s(c.xc, (unsigned)pos * 4u, dst);
+    if (LANES == 64)
+      ch_dma4s(c.xc, (unsigned)pos * 4u, dst);
+    else
+      ch_dma4s_lanes<(LANES < 64 ? LANES : 1)>(c.xc, (unsigned)pos * 4u, dst);
   } else {
     // zero / no padding: everything outside the clip is zero
     const bool in = pos >= 0 && pos < c.L;
     const float *src = in ? c.xc + pos : c.zeros + c.lane;
-    ch_dma4(src, dst);
+    if (LANES == 64)
+      ch_dma4(src, dst);
+    else
+      ch_dma4_lanes<(LANES < 64 ? LANES : 1)>(src, dst);
   }
 }
 
-// slot k of buffer `bb` % 3 <- brick req + k of the set's stream (slots past the batch's bricks receive the stream's
-// following bricks: never read; the stream ends with 12 bricks of padding)
-__device__ __forceinline__ void ch_brick(const ChainState &c, int bb, int k) {
-  int buf = bb % CH_NBUF;
-  const unsigned dst = c.a_base + (unsigned)(buf * CH_BUF_BYTES + k * CH_BRICK);
-  ch_dma16(c.bricks + (long long)(c.req + k) * (CH_BRICK / 4), (unsigned)c.lane * 16u, dst);
+// this wave's three slots of buffer `buf` <- bricks req + k of the set's stream (slots past the batch's bricks receive the
+// stream's following bricks: never read; the stream ends with 12 bricks of padding)
+__device__ __forceinline__ void ch_bricks(const ChainState &c, int buf) {
+  const unsigned d = c.a_base + (unsigned)(buf * CH_BUF_BYTES);
+  ch_dma16x3(c.bricks + (long long)c.req * (CH_BRICK / 4), c.kv0, c.kv1, c.kv2, d + c.kd0, d + c.kd1, d + c.kd2);
 }
 
 // `count` batches of Q sub-stages x N tiles.  In: bfirst = the signal fragment of the first sub-stage (always read ahead).
@@ -222,7 +268,7 @@ __device__ __forceinline__ void chain_segment(f32x4 (&acc)[CH_NMAX], f32x4 &bfir
     const int off2 = c.off + 16 * Q;
     const bool row_end = off2 == c.hop;
     const bool wrap = c.slot + 1 == c.nr;
-    const unsigned row2 = wrap ? c.row_addr - (unsigned)(c.slot * c.row_bytes) : c.row_addr + (unsigned)c.row_bytes;
+    const unsigned row2 = c.row_addr + (wrap ? (unsigned)(-(c.nr - 1) * c.row_bytes) : (unsigned)c.row_bytes);
     const int slot2 = wrap ? 0 : c.slot + 1;
     const unsigned b_nxt = row_end ? row2 : b_cur + 64u * Q;
     // what this batch reads of frame 0's row is dead afterwards: refilled (same place) with the samples one ring further
@@ -246,36 +292,34 @@ __device__ __forceinline__ void chain_segment(f32x4 (&acc)[CH_NMAX], f32x4 &bfir
       for (int jj = 0; jj < 4; ++jj) {
         if (j == Q - 1 && jj == 2) {
           // everything issued BEFORE this batch's DMAs has landed; publish; the next batch's first fragments
-          if (NF == 2)
-            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+          if (!(CH_ABL & 2)) {
+            constexpr int ND = ((CH_ABL & 8) ? 0 : 3) + ((CH_ABL & 4) ? 0 : NF);
+            if (ND == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            if (ND == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (ND == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            if (ND == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if (ND == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            if (ND == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          if (!(CH_ABL & 1)) __syncthreads();
+          // (volatile: these reads stay HERE, under the second half of the MFMAs -- the compiler otherwise sinks them to
+          // the top of the next batch, in front of its first MFMA)
+          bb[nx] = *(ch_lds_pinned)(b_nxt);
+#pragma unroll
+          for (int m = 0; m < N; ++m) a[nx][m] = *(ch_lds_pinned)(a_nxt + m * CH_BRICK);
+        }
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+          if (CH_ABL & 16)
+            acc[m][0] += a[cu][m][jj] * bb[cu][jj];
           else
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-          __syncthreads();
-          bb[nx] = *reinterpret_cast<const f32x4 *>(smem + b_nxt);
-#pragma unroll
-          for (int m = 0; m < N; ++m) a[nx][m] = *reinterpret_cast<const f32x4 *>(smem + a_nxt + m * CH_BRICK);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cu][m][jj], bb[cu][jj], acc[m], 0, 0, 0);
         }
-#pragma unroll
-        for (int m = 0; m < N; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cu][m][jj], bb[cu][jj], acc[m], 0, 0, 0);
-        if (j == 0 && jj == 0) {
-          ch_brick(c, buf2, c.k0);
-          ch_brick(c, buf2, c.k1);
-          ch_brick(c, buf2, c.k2);
-        }
+        if (j == 0 && jj == 0 && !(CH_ABL & 8)) ch_bricks(c, buf2);
         if (j == Q - 1 && jj == (Q == 1 ? 1 : 0)) {
           // (this batch's reads of the ring are complete: its last sub-stage's MFMAs have their operands)
-          if (Q >= 4) {
-            ch_fill<REFLECT>(c, fill_v0, fill_dst);
-          } else if (c.lane < 16 * Q) {
-            ch_fill<REFLECT>(c, fill_v0, fill_dst);
-          }
-          if (NF == 2) {
-            if (Q == 8) {
-              ch_fill<REFLECT>(c, fill_v0 + 64, fill_dst + 256u);
-            } else if (c.lane < 16 * Q - 64) {
-              ch_fill<REFLECT>(c, fill_v0 + 64, fill_dst + 256u);
-            }
-          }
+          if (!(CH_ABL & 4)) ch_fill<REFLECT, (Q >= 4 ? 64 : 16 * Q)>(c, fill_v0, fill_dst);
+          if (NF == 2 && !(CH_ABL & 4)) ch_fill<REFLECT, (Q == 8 ? 64 : (Q > 4 ? 16 * Q - 64 : 1))>(c, fill_v0 + 64, fill_dst + 256u);
         }
       }
     }
@@ -323,9 +367,12 @@ __global__ void __launch_bounds__(256) cqt_chain_kernel(const ChainArgs a) {
   c.U0 = t0 * a.hop + 16 * S.s_lo - a.pad;
   c.lperm = 16 * (lane >> 4) + 4 * (lane & 3) + ((lane >> 2) & 3);
   c.lane = lane;
-  c.k0 = wave;
-  c.k1 = wave + 4;
-  c.k2 = wave + 8 < CH_NMAX ? wave + 8 : CH_NMAX - 1;
+  c.kd0 = (unsigned)wave * CH_BRICK;
+  c.kd1 = (unsigned)(wave + 4) * CH_BRICK;
+  c.kd2 = (unsigned)(wave + 8 < CH_NMAX ? wave + 8 : CH_NMAX - 1) * CH_BRICK;
+  c.kv0 = c.kd0 + (unsigned)lane * 16u;
+  c.kv1 = c.kd1 + (unsigned)lane * 16u;
+  c.kv2 = c.kd2 + (unsigned)lane * 16u;
   c.ring_base = (unsigned)(wave * a.ring_bytes);
   c.a_base = (unsigned)(4 * a.ring_bytes);
   const ch_seg_ptr seg = (ch_seg_ptr)(a.segs + S.seg0);
@@ -342,7 +389,7 @@ __global__ void __launch_bounds__(256) cqt_chain_kernel(const ChainArgs a) {
   {
     int slot = 0, off = 0;
     for (int v0 = 0; v0 < c.ring_samples; v0 += 64) {
-      ch_fill<REFLECT>(c, v0, c.ring_base + (unsigned)(slot * c.row_bytes + off * 4));
+      ch_fill<REFLECT, 64>(c, v0, c.ring_base + (unsigned)(slot * c.row_bytes + off * 4));
       off += 64;
       if (off == c.hop) {
         off = 0;
@@ -352,9 +399,7 @@ __global__ void __launch_bounds__(256) cqt_chain_kernel(const ChainArgs a) {
   }
   for (int bb = 0; bb < 2; ++bb) {
     c.req = c.boff[bb];
-    ch_brick(c, bb, c.k0);
-    ch_brick(c, bb, c.k1);
-    ch_brick(c, bb, c.k2);
+    ch_bricks(c, bb);
   }
   c.req = c.boff[2];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

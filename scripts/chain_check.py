@@ -110,6 +110,12 @@ if __name__ == "__main__":
         with torch.no_grad():
             print("%.4f ms" % timed(lambda: mod(x), n=5))
         sys.exit(0)
+    if "--small" in sys.argv:  # one work unit per CU at most: the time of the longest unit
+        mod = CQT1992v2(sr=44100, hop_length=512, fmin=32.7, n_bins=84, bins_per_octave=12, output_format="Magnitude", verbose=False).to(dev)
+        x = torch.randn(2, 3 * 44100, generator=torch.Generator().manual_seed(0)).to(dev)
+        with torch.no_grad():
+            print("%.4f ms" % timed(lambda: mod(x), n=5))
+        sys.exit(0)
     if "--ablate" in sys.argv:
         ablate(dev)
         sys.exit(0)

@@ -48,6 +48,9 @@
 #ifndef CH_ABL
 #define CH_ABL 0
 #endif
+#ifndef CH_PRIO
+#define CH_PRIO 2
+#endif
 
 namespace {
 
@@ -96,6 +99,7 @@ struct ChainArgs {
   int out_row_offset;
   int n_sets;
   int debug;
+  long long *stamps;  // (CH_ABL & 64) phase clock of workgroup 0
   int first_wg[CH_MAXSETS + 1];
   ChainSetDev set[CH_MAXSETS];
 };
@@ -179,244 +183,294 @@ __device__ __forceinline__ void ch_epilogue_store(const ChainArgs &p, float *__r
 
 typedef const int __attribute__((address_space(4))) *ch_seg_ptr;  // constant address space: scalar loads
 typedef const volatile f32x4 __attribute__((address_space(3))) *ch_lds_pinned;  // an LDS read the compiler leaves where it is written
+typedef const f32x4 __attribute__((address_space(3))) *ch_lds;
 
-// A wave's state besides its accumulators.  Scalars are wave-uniform unless marked (lane).
-struct ChainState {
-  // constants
-  const float *xc;      // the wave's clip
-  const float *zeros;
-  const float *bricks;  // the set's first brick
-  int L, hop, nr, row_bytes, ring_samples;
-  int U0;               // signal position of ring sample v = 0
-  int lperm;            // (lane) sample of a 64-block this lane fetches
-  int lane;
-  unsigned kd0, kd1, kd2;  // the three slots of a batch buffer this wave requests (wave, wave + 4, min(wave + 8, 9)): byte offsets
-  unsigned kv0, kv1, kv2;  // (lane) ... + 16 lane
-  unsigned ring_base, a_base;
-  ch_seg_ptr boff;      // first brick of every batch of the set
-  int req;              // first brick of the batch to request next (batch b + 2), read one batch ahead
-  // multiply side
-  int b;       // batch index
-  int sdone;   // sub-stages multiplied
-  int off;     // samples into the ring row (same for all frames)
-  int slot0;   // frame 0's row slot
-  int slot;    // (lane) this lane's row slot
-  unsigned row_addr;  // (lane) LDS address of this lane's row + 16 lq
+// ------------------------------------------------------------------------------------------------------------
+// Workgroup = 4 multiplying waves (wave w: column tile w, all the set's tiles) + 4 loading waves (wave 4 + w: the ring of
+// column tile w, a quarter of the bricks).  Waves w and 4 + w share a SIMD (dispatch order; only speed depends on it): the
+// loader's address arithmetic and DMA issue fill the issue slots the MFMA stream leaves, and the MFMA stream itself is
+// LDS reads + MFMAs + one barrier per batch, nothing else.
+//
+// Batch b (Q sub-stages x N tiles; bricks in buffer b % 3), between barrier(b - 1) and barrier(b):
+//   multiplying wave: sub-stage j's 4 N MFMAs under the LDS reads of sub-stage j + 1; in the last sub-stage, after half
+//     of its MFMAs, barrier(b) (all of the wave's reads of batch b are in registers) and the reads of batch b + 1's first
+//     fragments (published by that barrier) under the other half.
+//   loading wave: requests its bricks of batch b + 2 into buffer (b + 2) % 3 (last read in batch b - 1: free since
+//     barrier(b - 1)); refills what batch b - 1 read of frame 0's ring row (same place, the samples one ring further on:
+//     first needed >= 30 sub-stages later); waits until everything it requested in earlier batches has landed
+//     (s_waitcnt vmcnt(this batch's requests)): the bricks of batch b + 1; barrier(b) publishes them.
+// ------------------------------------------------------------------------------------------------------------
+
+// `count` batches of Q sub-stages x N tiles on a multiplying wave.  In / out: bfirst = the signal fragment of the next
+// sub-stage (always read ahead).
+//
+// The instruction stream is written out slot by slot: every MFMA is followed by AT MOST one LDS read or one small piece of
+// address arithmetic, and a scheduling fence keeps it there.  Measured (experiments/chain/mfma_rate.hip): fragment reads
+// issued as a burst in front of a sub-stage's MFMAs cost 2 .. 4.5 cycles per MFMA, address arithmetic in front of a read
+// another 5 .. 10; one ds_read_b128 with an immediate offset behind each MFMA costs 0.3 .. 1 (32.3 .. 33 cycles per MFMA).
+struct MulState {
+  unsigned a_lane;    // (lane) LDS address of brick slot 0 of buffer 0 + 16 lane
+  int buf;            // buffer of the current batch
+  int off, hop, nr, row_bytes;
+  int slot;           // (lane) the lane's ring row slot
+  unsigned a_cur;     // (lane) this batch's bricks
+  unsigned b_cur;     // (lane) this batch's first signal fragment
+  unsigned row_next;  // (lane) the lane's next ring row (+ 16 lq)
 };
 
-// LANES samples from ring sample v0 on, to LDS address dst: inside each group of 16 the lane at position 4 q + n fetches
-// sample 4 n + q
-template <bool REFLECT, int LANES>
-__device__ __forceinline__ void ch_fill(const ChainState &c, int v0, unsigned dst) {
-  int pos = c.U0 + v0 + c.lperm;
-  if (REFLECT) {
-    // beyond the virtually padded clip only zero taps / unstored frames read: any finite sample will do
-    const int neg = -pos;
-    pos = pos < neg ? neg : pos;
-    const int up = 2 * c.L - 2 - pos;
-    pos = pos >= c.L ? up : pos;
-    pos = pos < 0 ? 0 : pos;
-    pos = pos > c.L - 1 ? c.L - 1 : pos;
-    if (LANES == 64)
-      ch_dma4s(c.xc, (unsigned)pos * 4u, dst);
-    else
-      ch_dma4s_lanes<(LANES < 64 ? LANES : 1)>(c.xc, (unsigned)pos * 4u, dst);
-  } else {
-    // zero / no padding: everything outside the clip is zero
-    const bool in = pos >= 0 && pos < c.L;
-    const float *src = in ? c.xc + pos : c.zeros + c.lane;
-    if (LANES == 64)
-      ch_dma4(src, dst);
-    else
-      ch_dma4_lanes<(LANES < 64 ? LANES : 1)>(src, dst);
-  }
-}
-
-// this wave's three slots of buffer `buf` <- bricks req + k of the set's stream (slots past the batch's bricks receive the
-// stream's following bricks: never read; the stream ends with 12 bricks of padding)
-__device__ __forceinline__ void ch_bricks(const ChainState &c, int buf) {
-  const unsigned d = c.a_base + (unsigned)(buf * CH_BUF_BYTES);
-  ch_dma16x3(c.bricks + (long long)c.req * (CH_BRICK / 4), c.kv0, c.kv1, c.kv2, d + c.kd0, d + c.kd1, d + c.kd2);
-}
-
-// `count` batches of Q sub-stages x N tiles.  In: bfirst = the signal fragment of the first sub-stage (always read ahead).
-//
-// One batch, in issue order (no control flow; everything but the MFMAs sits in their shadow):
-//   sub-stage 0:      MFMAs | three brick DMAs of batch b + 2 -> buffer (b + 2) % 3 (free since the barrier of batch b - 1)
-//   sub-stage j:      fragments of sub-stage j + 1 (ds_read_b128, immediate offsets) | 4 N MFMAs
-//   sub-stage Q - 1:  first half of its MFMAs | ring refill: what this batch read of frame 0's row, one ring further on
-//                     | s_waitcnt vmcnt(this batch's DMAs): everything older has landed -- the bricks of batch b + 1, ring
-//                     samples | s_barrier: they are published, and every wave has its last fragments of batch b in registers
-//                     | first fragments of batch b + 1 | second half of the MFMAs
-template <int N, int Q, bool REFLECT>
-__device__ __forceinline__ void chain_segment(f32x4 (&acc)[CH_NMAX], f32x4 &bfirst, const unsigned char *smem, ChainState &c, const int count) {
-  constexpr int NF = Q > 4 ? 2 : 1;  // ring DMAs per batch (64 samples each)
+template <int N, int Q>
+__device__ __forceinline__ void mul_segment(f32x4 (&acc)[CH_NMAX], f32x4 &bfirst, MulState &c, const int count) {
   f32x4 af[N], bf = bfirst;
-  {
-    const unsigned a_cur = c.a_base + (unsigned)((c.b % CH_NBUF) * CH_BUF_BYTES) + (unsigned)c.lane * 16u;
 #pragma unroll
-    for (int m = 0; m < N; ++m) af[m] = *reinterpret_cast<const f32x4 *>(smem + a_cur + m * CH_BRICK);
-  }
-  int buf = c.b % CH_NBUF;
+  for (int m = 0; m < N; ++m) af[m] = *(ch_lds_pinned)(c.a_cur + m * CH_BRICK);
   for (int i = 0; i < count; ++i) {
-    const int buf1 = buf + 1 == CH_NBUF ? 0 : buf + 1;
-    const int buf2 = buf1 + 1 == CH_NBUF ? 0 : buf1 + 1;
-    const unsigned a_cur = c.a_base + (unsigned)(buf * CH_BUF_BYTES) + (unsigned)c.lane * 16u;
-    const unsigned a_nxt = c.a_base + (unsigned)(buf1 * CH_BUF_BYTES) + (unsigned)c.lane * 16u;
-    const unsigned b_cur = c.row_addr + (unsigned)c.off * 4u;
-    // where the next batch starts: further along this row, or at the start of the lane's next row
-    const int off2 = c.off + 16 * Q;
-    const bool row_end = off2 == c.hop;
-    const bool wrap = c.slot + 1 == c.nr;
-    const unsigned row2 = c.row_addr + (wrap ? (unsigned)(-(c.nr - 1) * c.row_bytes) : (unsigned)c.row_bytes);
-    const int slot2 = wrap ? 0 : c.slot + 1;
-    const unsigned b_nxt = row_end ? row2 : b_cur + 64u * Q;
-    // what this batch reads of frame 0's row is dead afterwards: refilled (same place) with the samples one ring further
-    const unsigned fill_dst = c.ring_base + (unsigned)(c.slot0 * c.row_bytes + c.off * 4);
-    const int fill_v0 = 16 * c.sdone + c.ring_samples;
-    const int req_next = c.boff[c.b + 3];
-
     f32x4 a[2][N], bb[2];
 #pragma unroll
     for (int m = 0; m < N; ++m) a[0][m] = af[m];
     bb[0] = bf;
+    unsigned a_nxt = 0, b_nxt = 0;
+    bool row_end = false;
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < Q; ++j) {
       const int cu = j & 1, nx = cu ^ 1;
-      if (j + 1 < Q) {
-        bb[nx] = *reinterpret_cast<const f32x4 *>(smem + b_cur + 64 * (j + 1));
 #pragma unroll
-        for (int m = 0; m < N; ++m) a[nx][m] = *reinterpret_cast<const f32x4 *>(smem + a_cur + ((j + 1) * N + m) * CH_BRICK);
-      }
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        if (j == Q - 1 && jj == 2) {
-          // everything issued BEFORE this batch's DMAs has landed; publish; the next batch's first fragments
-          if (!(CH_ABL & 2)) {
-            constexpr int ND = ((CH_ABL & 8) ? 0 : 3) + ((CH_ABL & 4) ? 0 : NF);
-            if (ND == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            if (ND == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            if (ND == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            if (ND == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            if (ND == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            if (ND == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          }
+      for (int t = 0; t < 4 * N; ++t) {
+        const int jj = t / N, m = t % N;
+        if (j == Q - 1 && t == 2 * N) {
+          // every read of this batch is in registers (the fragments of its last sub-stage feed the MFMAs above): the
+          // loading waves may overwrite its bricks and what it read of the ring; the next batch's bricks are published
           if (!(CH_ABL & 1)) __syncthreads();
-          // (volatile: these reads stay HERE, under the second half of the MFMAs -- the compiler otherwise sinks them to
-          // the top of the next batch, in front of its first MFMA)
-          bb[nx] = *(ch_lds_pinned)(b_nxt);
-#pragma unroll
-          for (int m = 0; m < N; ++m) a[nx][m] = *(ch_lds_pinned)(a_nxt + m * CH_BRICK);
+          __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int m = 0; m < N; ++m) {
-          if (CH_ABL & 16)
-            acc[m][0] += a[cu][m][jj] * bb[cu][jj];
-          else
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cu][m][jj], bb[cu][jj], acc[m], 0, 0, 0);
+        if (CH_ABL & 16)
+          acc[m][0] += a[cu][m][jj] * bb[cu][jj];
+        else
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cu][m][jj], bb[cu][jj], acc[m], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- the slot behind this MFMA
+        if (j + 1 < Q) {
+          if (t == 0) bb[nx] = *(ch_lds_pinned)(c.b_cur + 64 * (j + 1));
+          if (t >= 1 && t <= N) a[nx][t - 1] = *(ch_lds_pinned)(c.a_cur + ((j + 1) * N + t - 1) * CH_BRICK);
+        } else {
+          if (t == 2 * N) bb[nx] = *(ch_lds_pinned)(b_nxt);
+          if (t > 2 * N && t <= 3 * N) a[nx][t - 2 * N - 1] = *(ch_lds_pinned)(a_nxt + (t - 2 * N - 1) * CH_BRICK);
         }
-        if (j == 0 && jj == 0 && !(CH_ABL & 8)) ch_bricks(c, buf2);
-        if (j == Q - 1 && jj == (Q == 1 ? 1 : 0)) {
-          // (this batch's reads of the ring are complete: its last sub-stage's MFMAs have their operands)
-          if (!(CH_ABL & 4)) ch_fill<REFLECT, (Q >= 4 ? 64 : 16 * Q)>(c, fill_v0, fill_dst);
-          if (NF == 2 && !(CH_ABL & 4)) ch_fill<REFLECT, (Q == 8 ? 64 : (Q > 4 ? 16 * Q - 64 : 1))>(c, fill_v0 + 64, fill_dst + 256u);
+        if (j == 0 && t == (Q == 1 ? 0 : N + 1)) {
+          // where the next batch's fragments are: the next buffer; further along the ring row or at the start of the next one
+          const int buf1 = c.buf + 1 == CH_NBUF ? 0 : c.buf + 1;
+          a_nxt = c.a_lane + (unsigned)(buf1 * CH_BUF_BYTES);
+          c.buf = buf1;
+          const int off2 = c.off + 16 * Q;
+          row_end = off2 == c.hop;  // (batches never straddle ring rows)
+          c.off = row_end ? 0 : off2;
+          b_nxt = row_end ? c.row_next : c.b_cur + 64u * Q;
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
 #pragma unroll
     for (int m = 0; m < N; ++m) af[m] = a[Q & 1][m];
     bf = bb[Q & 1];
-    c.off = row_end ? 0 : off2;
-    c.row_addr = row_end ? row2 : c.row_addr;
-    c.slot = row_end ? slot2 : c.slot;
-    c.slot0 = row_end ? (c.slot0 + 1 == c.nr ? 0 : c.slot0 + 1) : c.slot0;
-    c.sdone += Q;
-    c.req = req_next;
-    ++c.b;
-    buf = buf1;
+    c.a_cur = a_nxt;
+    c.b_cur = b_nxt;
+    if (row_end) {  // (rare: every hop / 16 sub-stages) the lane moves on to its next ring row
+      const bool wrap = c.slot + 1 == c.nr;
+      c.slot = wrap ? 0 : c.slot + 1;
+      const bool wrap2 = c.slot + 1 == c.nr;
+      c.row_next = c.row_next + (wrap2 ? (unsigned)(-(c.nr - 1) * c.row_bytes) : (unsigned)c.row_bytes);
+    }
   }
   bfirst = bf;
 }
 
+// 64 (or `lanes` < 64) samples from ring sample v0 on, to LDS address dst: inside each group of 16 the lane at position
+// 4 q + n fetches sample 4 n + q
 template <bool REFLECT>
-__global__ void __launch_bounds__(256) cqt_chain_kernel(const ChainArgs a) {
+__device__ __forceinline__ void ch_fill(const float *xc, const float *zeros, int L, int U0, int lane, int lperm, int v0, unsigned dst, int lanes) {
+  int pos = U0 + v0 + lperm;
+  if (lane < lanes) {
+    if (REFLECT) {
+      // beyond the virtually padded clip only zero taps / unstored frames read: any finite sample will do
+      pos = pos < 0 ? -pos : pos;
+      pos = pos >= L ? 2 * L - 2 - pos : pos;
+      pos = pos < 0 ? 0 : (pos > L - 1 ? L - 1 : pos);
+      ch_dma4s(xc, (unsigned)pos * 4u, dst);
+    } else {
+      // zero / no padding: everything outside the clip is zero
+      const bool in = pos >= 0 && pos < L;
+      const float *src = in ? xc + pos : zeros + lane;
+      ch_dma4(src, dst);
+    }
+  }
+}
+
+__device__ __forceinline__ void ch_wait_vmcnt(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;  // (never more than 3 + 2 requests per batch)
+  }
+}
+
+template <bool REFLECT>
+__global__ void __launch_bounds__(512) cqt_chain_kernel(const ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cw = wave & 3;  // column tile of the workgroup
   const int f = lane & 15, lq = lane >> 4;
 
   int s = 0;
   while (s + 1 < a.n_sets && (int)blockIdx.x >= a.first_wg[s + 1]) ++s;
   const ChainSetDev &S = a.set[s];
   const int g = (int)blockIdx.x - a.first_wg[s];
-  const int ct_raw = 4 * g + wave;
+  const int ct_raw = 4 * g + cw;
   const bool live = ct_raw < a.n_ct;
   const int ct = live ? ct_raw : a.n_ct - 1;  // idle waves of the last group shadow the last column tile (nothing stored)
   const int clip = ct / a.ct_per_clip;
   const int t0 = (ct - clip * a.ct_per_clip) * 16;
-
-  ChainState c;
-  c.xc = a.x + (long long)clip * a.x_clip_stride;
-  c.zeros = a.zeros;
-  c.L = a.n_samples;
-  c.hop = a.hop;
-  c.nr = a.nr;
-  c.row_bytes = (a.hop + CH_SKEW) * 4;
-  c.ring_samples = a.nr * a.hop;
-  c.U0 = t0 * a.hop + 16 * S.s_lo - a.pad;
-  c.lperm = 16 * (lane >> 4) + 4 * (lane & 3) + ((lane >> 2) & 3);
-  c.lane = lane;
-  c.kd0 = (unsigned)wave * CH_BRICK;
-  c.kd1 = (unsigned)(wave + 4) * CH_BRICK;
-  c.kd2 = (unsigned)(wave + 8 < CH_NMAX ? wave + 8 : CH_NMAX - 1) * CH_BRICK;
-  c.kv0 = c.kd0 + (unsigned)lane * 16u;
-  c.kv1 = c.kd1 + (unsigned)lane * 16u;
-  c.kv2 = c.kd2 + (unsigned)lane * 16u;
-  c.ring_base = (unsigned)(wave * a.ring_bytes);
-  c.a_base = (unsigned)(4 * a.ring_bytes);
+  const int hop = a.hop, nr = a.nr;
+  const int row_bytes = (hop + CH_SKEW) * 4;
+  const unsigned ring_base = (unsigned)(cw * a.ring_bytes);
+  const unsigned a_base = (unsigned)(4 * a.ring_bytes);
   const ch_seg_ptr seg = (ch_seg_ptr)(a.segs + S.seg0);
-  c.boff = (ch_seg_ptr)(a.segs + S.boff0);
-  c.bricks = a.bricks + S.brick0 * (CH_BRICK / 4);
-  c.b = 0;
-  c.sdone = 0;
-  c.off = 0;
-  c.slot0 = 0;
-  c.slot = f;
-  c.row_addr = c.ring_base + (unsigned)(f * c.row_bytes) + (unsigned)lq * 16u;
+  const int n_segs = S.n_segs;
 
-  // prologue: the whole ring, the bricks of the first two batches
-  {
-    int slot = 0, off = 0;
-    for (int v0 = 0; v0 < c.ring_samples; v0 += 64) {
-      ch_fill<REFLECT, 64>(c, v0, c.ring_base + (unsigned)(slot * c.row_bytes + off * 4));
-      off += 64;
-      if (off == c.hop) {
-        off = 0;
-        ++slot;
+  if ((CH_ABL & 64) && blockIdx.x == 0 && wave == 0 && lane == 0) a.stamps[0] = clock64();
+  if (wave >= 4) {
+    // ------------------------------------------------------------------ loading wave
+#if CH_PRIO == 2
+    __builtin_amdgcn_s_setprio(3);  // (its batch of address arithmetic and requests must be over before its SIMD partner's batch of MFMAs)
+#endif
+    const float *xc = a.x + (long long)clip * a.x_clip_stride;
+    const int L = a.n_samples;
+    const int U0 = t0 * hop + 16 * S.s_lo - a.pad;  // signal position of ring sample v = 0
+    const int lperm = 16 * (lane >> 4) + 4 * (lane & 3) + ((lane >> 2) & 3);
+    const int ring_samples = nr * hop;
+    const float *bricks = a.bricks + S.brick0 * (CH_BRICK / 4);
+    // the whole ring
+    {
+      int slot = 0, off = 0;
+      for (int v0 = 0; v0 < ring_samples; v0 += 64) {
+        ch_fill<REFLECT>(xc, a.zeros, L, U0, lane, lperm, v0, ring_base + (unsigned)(slot * row_bytes + off * 4), 64);
+        off += 64;
+        if (off == hop) {
+          off = 0;
+          ++slot;
+        }
       }
     }
+    // request cursor over the batches: segment, batches left in it, first brick
+    int rsg = 0, rword = n_segs > 0 ? seg[0] : 0, rrem = rword >> 8;
+    long long rbrick = 0;
+    int rbuf = 0;
+    auto request = [&]() -> int {  // this wave's bricks of the next batch to request; returns the DMAs issued
+      if (rsg >= n_segs) return 0;
+      const int cnt = (rword & 15) * ((rword >> 4) & 15);
+      int issued = 0;
+      if (!(CH_ABL & 8))
+        for (int k = cw; k < cnt; k += 4) {
+          ch_dma16(bricks + (rbrick + k) * (CH_BRICK / 4), (unsigned)lane * 16u, a_base + (unsigned)(rbuf * CH_BUF_BYTES + k * CH_BRICK));
+          ++issued;
+        }
+      rbrick += cnt;
+      rbuf = rbuf + 1 == CH_NBUF ? 0 : rbuf + 1;
+      if (--rrem == 0) {
+        ++rsg;
+        rword = rsg < n_segs ? seg[rsg] : 0;
+        rrem = rword >> 8;
+      }
+      return issued;
+    };
+    if ((CH_ABL & 64) && blockIdx.x == 0 && wave == 4 && lane == 0) a.stamps[1] = clock64();
+    request();
+    request();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((CH_ABL & 64) && blockIdx.x == 0 && wave == 4 && lane == 0) a.stamps[2] = clock64();
+    __syncthreads();
+    // ring cursor of the batches being multiplied: frame 0's row slot and offset, sub-stages done
+    int slot0 = 0, off0 = 0, sdone = 0;
+    int pq = 0, pslot = 0, poff = 0, psdone = 0;  // the previous batch's Q and where it started
+    int lb = 0;
+    for (int sg = 0; sg < n_segs; ++sg) {
+      const int w = seg[sg];
+      const int q = (w >> 4) & 15, count = w >> 8;
+      for (int i = 0; i < count; ++i) {
+        const bool st = (CH_ABL & 64) && blockIdx.x == 0 && wave == 4 && lane == 0 && lb < 700;
+        if (st) a.stamps[1024 + 4 * lb] = clock64();
+        int issued = request();  // batch b + 2
+        if (st) a.stamps[1025 + 4 * lb] = clock64();
+        if (pq > 0 && !(CH_ABL & 4)) {
+          // what the previous batch read of frame 0's row: 16 pq samples at (pslot, poff), now the samples one ring further on
+          const unsigned dst = ring_base + (unsigned)(pslot * row_bytes + poff * 4);
+          const int v0 = 16 * psdone + ring_samples;
+          ch_fill<REFLECT>(xc, a.zeros, L, U0, lane, lperm, v0, dst, 16 * pq);
+          ++issued;
+          if (pq > 4) {
+            ch_fill<REFLECT>(xc, a.zeros, L, U0, lane, lperm, v0 + 64, dst + 256u, 16 * pq - 64);
+            ++issued;
+          }
+        }
+        pq = q;
+        pslot = slot0;
+        poff = off0;
+        psdone = sdone;
+        sdone += q;
+        off0 += 16 * q;
+        if (off0 == hop) {
+          off0 = 0;
+          slot0 = slot0 + 1 == nr ? 0 : slot0 + 1;
+        }
+        if (st) a.stamps[1026 + 4 * lb] = clock64();
+        if (!(CH_ABL & 2)) ch_wait_vmcnt(issued);  // everything requested in earlier batches has landed
+        if (st) a.stamps[1027 + 4 * lb] = clock64();
+        ++lb;
+        if (!(CH_ABL & 1)) __syncthreads();
+      }
+    }
+    return;
   }
-  for (int bb = 0; bb < 2; ++bb) {
-    c.req = c.boff[bb];
-    ch_bricks(c, bb);
-  }
-  c.req = c.boff[2];
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+
+  // -------------------------------------------------------------------- multiplying wave
+  MulState c;
+  c.a_lane = a_base + (unsigned)lane * 16u;
+  c.buf = 0;
+  c.off = 0;
+  c.hop = hop;
+  c.nr = nr;
+  c.row_bytes = row_bytes;
+  c.slot = f;
+  c.a_cur = c.a_lane;
+  c.b_cur = ring_base + (unsigned)(f * row_bytes) + (unsigned)lq * 16u;
+  c.row_next = c.b_cur + (f + 1 == nr ? (unsigned)(-(nr - 1) * row_bytes) : (unsigned)row_bytes);
+#if CH_PRIO == 1
+  __builtin_amdgcn_s_setprio(3);  // (the MFMA stream before its SIMD partner's address arithmetic)
+#endif
+  __syncthreads();  // the ring and the first two batches are in LDS
 
   f32x4 acc[CH_NMAX];
 #pragma unroll
   for (int m = 0; m < CH_NMAX; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 bfirst = *reinterpret_cast<const f32x4 *>(smem + c.row_addr);  // sub-stage 0's signal fragment
+  f32x4 bfirst = *(ch_lds_pinned)(c.b_cur);  // sub-stage 0's signal fragment
 
-  for (int sg = 0; sg < S.n_segs; ++sg) {
+  if ((CH_ABL & 64) && blockIdx.x == 0 && wave == 0 && lane == 0) a.stamps[3] = clock64();
+  for (int sg = 0; sg < n_segs; ++sg) {
     const int w = seg[sg];
     const int count = w >> 8;
+    if ((CH_ABL & 64) && blockIdx.x == 0 && wave == 0 && lane == 0 && sg < 200) {
+      a.stamps[8 + 2 * sg] = clock64();
+      a.stamps[9 + 2 * sg] = w;
+    }
     switch (w & 255) {
-#define CH_CASE(N, Q)                                               \
-  case (N) | ((Q) << 4):                                            \
-    chain_segment<N, Q, REFLECT>(acc, bfirst, smem, c, count); \
+#define CH_CASE(N, Q)                            \
+  case (N) | ((Q) << 4):                         \
+    mul_segment<N, Q>(acc, bfirst, c, count); \
     break;
       CH_CASE(1, 1) CH_CASE(1, 2) CH_CASE(1, 3) CH_CASE(1, 4) CH_CASE(1, 5) CH_CASE(1, 6) CH_CASE(1, 7) CH_CASE(1, 8)
       CH_CASE(2, 1) CH_CASE(2, 2) CH_CASE(2, 3) CH_CASE(2, 4) CH_CASE(2, 5)
@@ -429,6 +483,10 @@ __global__ void __launch_bounds__(256) cqt_chain_kernel(const ChainArgs a) {
     }
   }
 
+  if ((CH_ABL & 64) && blockIdx.x == 0 && wave == 0 && lane == 0) {
+    a.stamps[4] = clock64();
+    a.stamps[5] = n_segs;
+  }
   // ---- epilogue: element e of lane (f, lq) of tile m is D[row 16 tile + 4 lq + e][frame t0 + f]: (re, im) of bins
   // 8 tile + 2 lq and + 1 sit in one lane
   const int t = t0 + f;
@@ -737,7 +795,41 @@ int mispec_chain_launch(const mispec_framed_gemm_args *a, int debug, void *strea
       return mispec_fail_msg(MISPEC_E_HIP, "hipFuncSetAttribute failed (chain kernel)");
     g_configured[reflect].fetch_or(bit, std::memory_order_release);
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(n_groups * pl.n_sets)), dim3(256), smem, static_cast<hipStream_t>(stream), k);
+  static long long *stamps = nullptr;
+  if (CH_ABL & 64) {
+    if (!stamps) (void)hipMalloc(&stamps, 4096 * 8);
+    (void)hipMemsetAsync(stamps, 0, 4096 * 8, static_cast<hipStream_t>(stream));
+    k.stamps = stamps;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(n_groups * pl.n_sets)), dim3(512), smem, static_cast<hipStream_t>(stream), k);
   if (hipGetLastError() != hipSuccess) return mispec_fail_msg(MISPEC_E_HIP, "chain kernel launch failed");
+  if ((CH_ABL & 64) && getenv("MISPEC_CHAIN_STAMPS")) {
+    (void)hipStreamSynchronize(static_cast<hipStream_t>(stream));
+    std::vector<long long> h(4096);
+    (void)hipMemcpy(h.data(), stamps, 4096 * 8, hipMemcpyDeviceToHost);
+    const long long t0 = h[0];
+    fprintf(stderr, "chain stamps (cycles from start): loader ring issued %lld, ring+2 batches landed %lld, first segment %lld, epilogue %lld\n",
+            h[1] - t0, h[2] - t0, h[3] - t0, h[4] - t0);
+    long long prev = h[8];
+    for (int i = 0; i < (int)h[5] && i < 200; ++i) {
+      const long long w = h[9 + 2 * i];
+      const long long nextt = (i + 1 < (int)h[5] && i + 1 < 200) ? h[8 + 2 * (i + 1)] : h[4];
+      const long long n = w & 15, q = (w >> 4) & 15, cnt = w >> 8;
+      fprintf(stderr, "  seg %3d: N=%lld Q=%lld count=%4lld  %8lld cycles  = %.1f per MFMA\n", i, n, q, cnt, nextt - h[8 + 2 * i], (double)(nextt - h[8 + 2 * i]) / (double)(4 * n * q * cnt));
+      prev = nextt;
+    }
+    (void)prev;
+    double s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+    int nn = 0;
+    for (int i = 40; i < 680; ++i) {
+      if (!h[1024 + 4 * i] || !h[1024 + 4 * (i + 1)]) break;
+      s1 += h[1025 + 4 * i] - h[1024 + 4 * i];
+      s2 += h[1026 + 4 * i] - h[1025 + 4 * i];
+      s3 += h[1027 + 4 * i] - h[1026 + 4 * i];
+      s4 += h[1024 + 4 * (i + 1)] - h[1027 + 4 * i];
+      ++nn;
+    }
+    if (nn) fprintf(stderr, "loader wave 4, batches 40..%d: request %.0f, refill + bookkeeping %.0f, vmcnt wait %.0f, barrier %.0f cycles\n", 40 + nn, s1 / nn, s2 / nn, s3 / nn, s4 / nn);
+  }
   return MISPEC_OK;
 }

@@ -48,6 +48,9 @@
 #ifndef CH_ABL
 #define CH_ABL 0
 #endif
+#ifndef CH_STAMP_WG
+#define CH_STAMP_WG 2
+#endif
 #ifndef CH_PRIO
 #define CH_PRIO 2
 #endif
@@ -73,7 +76,7 @@ struct ChainSetDev {
   int seg0;        // the set's segments in the table of this hop
   int n_segs;
   int boff0;       // ... and its batches' first bricks (relative to brick0; 4 entries of padding)
-  int pad2_;
+  int n_sub;       // sub-stages of the set
   long long brick0;  // first brick of the set's stream
   int tile[CH_NMAX];
   int pad_;
@@ -136,6 +139,13 @@ __device__ __forceinline__ void ch_dma4_lanes(const void *src, unsigned lds_addr
       :
       : "v"(src), "s"(lds_addr), "i"(lo), "i"(hi)
       : "memory", "m0");
+}
+// ... the lanes of `mask` only (EXEC is all ones in the loading waves' loop: set and restored here, no branch)
+__device__ __forceinline__ void ch_dma4s_mask(const void *sbase, unsigned voff, unsigned lds_addr, unsigned long long mask) {
+  asm volatile("s_mov_b64 exec, %3\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1\n\ts_mov_b64 exec, -1"
+               :
+               : "v"(voff), "s"(sbase), "s"(lds_addr), "s"(mask)
+               : "memory", "m0");
 }
 // three 16-byte pieces per lane from one scalar base: lane offsets v0..v2, LDS addresses d0..d2
 __device__ __forceinline__ void ch_dma16x3(const void *sbase, unsigned v0, unsigned v1, unsigned v2, unsigned d0, unsigned d1, unsigned d2) {
@@ -239,7 +249,7 @@ __device__ __forceinline__ void mul_segment(f32x4 (&acc)[CH_NMAX], f32x4 &bfirst
         const int jj = t / N, m = t % N;
         if (j == Q - 1 && t == 2 * N) {
           // every read of this batch is in registers (the fragments of its last sub-stage feed the MFMAs above): the
-          // loading waves may overwrite its bricks and what it read of the ring; the next batch's bricks are published
+          // loading waves may overwrite its bricks; the next batch's bricks are published
           if (!(CH_ABL & 1)) __syncthreads();
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -333,7 +343,7 @@ __global__ void __launch_bounds__(512) cqt_chain_kernel(const ChainArgs a) {
   const int ct_raw = 4 * g + cw;
   const bool live = ct_raw < a.n_ct;
   const int ct = live ? ct_raw : a.n_ct - 1;  // idle waves of the last group shadow the last column tile (nothing stored)
-  const int clip = ct / a.ct_per_clip;
+  const int clip = __builtin_amdgcn_readfirstlane(ct / a.ct_per_clip);  // (the division runs on the vector unit)
   const int t0 = (ct - clip * a.ct_per_clip) * 16;
   const int hop = a.hop, nr = a.nr;
   const int row_bytes = (hop + CH_SKEW) * 4;
@@ -342,7 +352,7 @@ __global__ void __launch_bounds__(512) cqt_chain_kernel(const ChainArgs a) {
   const ch_seg_ptr seg = (ch_seg_ptr)(a.segs + S.seg0);
   const int n_segs = S.n_segs;
 
-  if ((CH_ABL & 64) && blockIdx.x == 0 && wave == 0 && lane == 0) a.stamps[0] = clock64();
+  if ((CH_ABL & 64) && blockIdx.x == CH_STAMP_WG && wave == 0 && lane == 0) a.stamps[0] = clock64();
   if (wave >= 4) {
     // ------------------------------------------------------------------ loading wave
 #if CH_PRIO == 2
@@ -388,49 +398,61 @@ __global__ void __launch_bounds__(512) cqt_chain_kernel(const ChainArgs a) {
       }
       return issued;
     };
-    if ((CH_ABL & 64) && blockIdx.x == 0 && wave == 4 && lane == 0) a.stamps[1] = clock64();
+    if ((CH_ABL & 64) && blockIdx.x == CH_STAMP_WG && wave == 4 && lane == 0) a.stamps[1] = clock64();
     request();
     request();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if ((CH_ABL & 64) && blockIdx.x == 0 && wave == 4 && lane == 0) a.stamps[2] = clock64();
+    if ((CH_ABL & 64) && blockIdx.x == CH_STAMP_WG && wave == 4 && lane == 0) a.stamps[2] = clock64();
     __syncthreads();
-    // ring cursor of the batches being multiplied: frame 0's row slot and offset, sub-stages done
+    // A wave whose span touches the virtual padding: its ring is refilled from here, by DMA (the index arithmetic of the
+    // padding stays out of the MFMA stream): what batch b - 1 read of frame 0's row, after barrier(b - 1).
+    const bool edge = U0 < 0 || U0 + ring_samples + 16 * S.n_sub + 256 >= L;
     int slot0 = 0, off0 = 0, sdone = 0;
-    int pq = 0, pslot = 0, poff = 0, psdone = 0;  // the previous batch's Q and where it started
-    int lb = 0;
+    int pq = 0;            // the previous batch's Q ...
+    unsigned pdst = 0;     // ... where its part of frame 0's row is ...
+    int pv0 = 0;           // ... and the ring sample that replaces its first sample
+    const unsigned lperm4 = 4u * (unsigned)lperm;
     for (int sg = 0; sg < n_segs; ++sg) {
       const int w = seg[sg];
       const int q = (w >> 4) & 15, count = w >> 8;
       for (int i = 0; i < count; ++i) {
-        const bool st = (CH_ABL & 64) && blockIdx.x == 0 && wave == 4 && lane == 0 && lb < 700;
-        if (st) a.stamps[1024 + 4 * lb] = clock64();
-        int issued = request();  // batch b + 2
-        if (st) a.stamps[1025 + 4 * lb] = clock64();
+        // Between barrier(b - 1) and barrier(b).  First the ring: what batch b - 1 read of frame 0's row (dead since
+        // barrier(b - 1)) <- the samples one ring further on, first read >= 31 sub-stages after batch b - 1 began, i.e. in
+        // batch b + 2 or later: they have until barrier(b + 1) = two batches, like the bricks requested next.
+        int issued = 0;
         if (pq > 0 && !(CH_ABL & 4)) {
-          // what the previous batch read of frame 0's row: 16 pq samples at (pslot, poff), now the samples one ring further on
-          const unsigned dst = ring_base + (unsigned)(pslot * row_bytes + poff * 4);
-          const int v0 = 16 * psdone + ring_samples;
-          ch_fill<REFLECT>(xc, a.zeros, L, U0, lane, lperm, v0, dst, 16 * pq);
-          ++issued;
-          if (pq > 4) {
-            ch_fill<REFLECT>(xc, a.zeros, L, U0, lane, lperm, v0 + 64, dst + 256u, 16 * pq - 64);
+          if (!edge) {
+            const unsigned voff = lperm4 + 4u * (unsigned)(U0 + pv0);
+            if (pq >= 4)
+              ch_dma4s(xc, voff, pdst);
+            else
+              ch_dma4s_mask(xc, voff, pdst, (1ull << (16 * pq)) - 1ull);
             ++issued;
+            if (pq > 4) {
+              ch_dma4s_mask(xc, voff + 256u, pdst + 256u, pq == 8 ? ~0ull : (1ull << (16 * pq - 64)) - 1ull);
+              ++issued;
+            }
+          } else {
+            ch_fill<REFLECT>(xc, a.zeros, L, U0, lane, lperm, pv0, pdst, 16 * pq);
+            ++issued;
+            if (pq > 4) {
+              ch_fill<REFLECT>(xc, a.zeros, L, U0, lane, lperm, pv0 + 64, pdst + 256u, 16 * pq - 64);
+              ++issued;
+            }
           }
         }
         pq = q;
-        pslot = slot0;
-        poff = off0;
-        psdone = sdone;
+        pdst = ring_base + (unsigned)(slot0 * row_bytes + off0 * 4);
+        pv0 = 16 * sdone + ring_samples;
         sdone += q;
         off0 += 16 * q;
         if (off0 == hop) {
           off0 = 0;
           slot0 = slot0 + 1 == nr ? 0 : slot0 + 1;
         }
-        if (st) a.stamps[1026 + 4 * lb] = clock64();
-        if (!(CH_ABL & 2)) ch_wait_vmcnt(issued);  // everything requested in earlier batches has landed
-        if (st) a.stamps[1027 + 4 * lb] = clock64();
-        ++lb;
+        issued += request();  // batch b + 2's bricks
+        // everything requested in earlier batches has landed: batch b + 1's bricks, the ring samples of batch b - 2's part
+        if (!(CH_ABL & 2)) ch_wait_vmcnt(issued);
         if (!(CH_ABL & 1)) __syncthreads();
       }
     }
@@ -459,17 +481,17 @@ __global__ void __launch_bounds__(512) cqt_chain_kernel(const ChainArgs a) {
   for (int m = 0; m < CH_NMAX; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 bfirst = *(ch_lds_pinned)(c.b_cur);  // sub-stage 0's signal fragment
 
-  if ((CH_ABL & 64) && blockIdx.x == 0 && wave == 0 && lane == 0) a.stamps[3] = clock64();
+  if ((CH_ABL & 64) && blockIdx.x == CH_STAMP_WG && wave == 0 && lane == 0) a.stamps[3] = clock64();
   for (int sg = 0; sg < n_segs; ++sg) {
     const int w = seg[sg];
     const int count = w >> 8;
-    if ((CH_ABL & 64) && blockIdx.x == 0 && wave == 0 && lane == 0 && sg < 200) {
+    if ((CH_ABL & 64) && blockIdx.x == CH_STAMP_WG && wave == 0 && lane == 0 && sg < 200) {
       a.stamps[8 + 2 * sg] = clock64();
       a.stamps[9 + 2 * sg] = w;
     }
     switch (w & 255) {
-#define CH_CASE(N, Q)                            \
-  case (N) | ((Q) << 4):                         \
+#define CH_CASE(N, Q)                                     \
+  case (N) | ((Q) << 4):                                  \
     mul_segment<N, Q>(acc, bfirst, c, count); \
     break;
       CH_CASE(1, 1) CH_CASE(1, 2) CH_CASE(1, 3) CH_CASE(1, 4) CH_CASE(1, 5) CH_CASE(1, 6) CH_CASE(1, 7) CH_CASE(1, 8)
@@ -483,7 +505,7 @@ __global__ void __launch_bounds__(512) cqt_chain_kernel(const ChainArgs a) {
     }
   }
 
-  if ((CH_ABL & 64) && blockIdx.x == 0 && wave == 0 && lane == 0) {
+  if ((CH_ABL & 64) && blockIdx.x == CH_STAMP_WG && wave == 0 && lane == 0) {
     a.stamps[4] = clock64();
     a.stamps[5] = n_segs;
   }
@@ -779,6 +801,7 @@ int mispec_chain_launch(const mispec_framed_gemm_args *a, int debug, void *strea
     k.set[s].seg0 = S.seg0[h];
     k.set[s].n_segs = S.n_segs[h];
     k.set[s].boff0 = S.boff0[h];
+    k.set[s].n_sub = S.hi[0] - S.lo[0];
     k.set[s].brick0 = S.brick0;
     for (int m = 0; m < S.n_tiles; ++m) k.set[s].tile[m] = S.tile[m];
   }

@@ -5,7 +5,7 @@ TAG=${1:-chain}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/pmc_$TAG
 mkdir -p $OUT
-CMD="python scripts/chain_check.py --one"
+CMD="timeout 120 python scripts/chain_check.py --one"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32"
 P2="FETCH_SIZE"

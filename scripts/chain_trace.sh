@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/trace_${1:-chain}
 mkdir -p $OUT
 for m in small one; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$m -o t -- python scripts/chain_check.py --$m > $OUT/$m.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$m -o t -- timeout 120 python scripts/chain_check.py --$m > $OUT/$m.log 2>&1
   python - <<PY
 import csv, glob
 for f in glob.glob("$OUT/$m/**/*kernel_stats.csv", recursive=True):

@@ -315,6 +315,56 @@ __device__ __forceinline__ void ch_fill(const float *xc, const float *zeros, int
   }
 }
 
+// What a loading (or, in the prologue, multiplying) wave knows about its clip
+struct FillCtx {
+  const float *xc;
+  const float *zeros;
+  int L, pad, U0, lane, lperm;
+  unsigned lperm4, nlperm4, lane4;
+};
+
+// `lanes` (1 .. 64, wave-uniform) samples from ring sample v0 on, to LDS address dst (inside each group of 16 the lane at
+// position 4 q + n fetches sample 4 n + q).  Returns the DMA instructions issued (0: nothing but unstored frames reads
+// this block).  A block that lies entirely inside the clip, or entirely inside one of its mirror images / its zero padding,
+// is one DMA with one vector add in front of it; only the blocks across a boundary take the per-lane arithmetic.
+template <bool REFLECT>
+__device__ __forceinline__ int ch_fill_block(const FillCtx &c, int v0, unsigned dst, int lanes) {
+  dst = __builtin_amdgcn_readfirstlane(dst);  // (wave-uniform by construction; the compiler does not always see it)
+  const int p0 = __builtin_amdgcn_readfirstlane(c.U0 + v0), p1 = p0 + lanes;  // signal positions [p0, p1)
+  if (p0 >= c.L + c.pad) return 0;            // beyond the virtually padded clip: frames that are not stored
+  const unsigned long long mask = lanes >= 64 ? ~0ull : ((1ull << lanes) - 1ull);
+  if (p0 >= 0 && p1 <= c.L) {
+    ch_dma4s_mask(c.xc, c.lperm4 + 4u * (unsigned)p0, dst, mask);
+  } else if (REFLECT && p1 <= 0) {  // left mirror image: position p <- sample -p
+    ch_dma4s_mask(c.xc, c.nlperm4 + 4u * (unsigned)(-p0), dst, mask);
+  } else if (REFLECT && p0 >= c.L && p1 <= 2 * c.L - 1) {  // right mirror image: p <- 2 L - 2 - p
+    ch_dma4s_mask(c.xc, c.nlperm4 + 4u * (unsigned)(2 * c.L - 2 - p0), dst, mask);
+  } else if (!REFLECT && (p1 <= 0 || p0 >= c.L)) {
+    ch_dma4s_mask(c.zeros, c.lane4, dst, mask);
+  } else {
+    ch_fill<REFLECT>(c.xc, c.zeros, c.L, c.U0, c.lane, c.lperm, v0, dst, lanes);
+  }
+  return 1;
+}
+
+// every second 64-sample block of a wave's ring, from block `first` (0 or 1) on
+template <bool REFLECT>
+__device__ __forceinline__ void ch_fill_ring(const FillCtx &c, unsigned ring_base, int ring_samples, int hop, int row_bytes, int first) {
+  int slot = 0, off = 64 * first;
+  if (off == hop) {
+    off = 0;
+    slot = 1;
+  }
+  for (int v0 = 64 * first; v0 < ring_samples; v0 += 128) {
+    ch_fill_block<REFLECT>(c, v0, ring_base + (unsigned)(slot * row_bytes + off * 4), 64);
+    off += 128;
+    while (off >= hop) {
+      off -= hop;
+      ++slot;
+    }
+  }
+}
+
 __device__ __forceinline__ void ch_wait_vmcnt(int n) {
   switch (n) {
     case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -358,24 +408,21 @@ __global__ void __launch_bounds__(512) cqt_chain_kernel(const ChainArgs a) {
 #if CH_PRIO == 2
     __builtin_amdgcn_s_setprio(3);  // (its batch of address arithmetic and requests must be over before its SIMD partner's batch of MFMAs)
 #endif
-    const float *xc = a.x + (long long)clip * a.x_clip_stride;
-    const int L = a.n_samples;
-    const int U0 = t0 * hop + 16 * S.s_lo - a.pad;  // signal position of ring sample v = 0
-    const int lperm = 16 * (lane >> 4) + 4 * (lane & 3) + ((lane >> 2) & 3);
+    FillCtx fc;
+    fc.xc = a.x + (long long)clip * a.x_clip_stride;
+    fc.zeros = a.zeros;
+    fc.L = a.n_samples;
+    fc.pad = a.pad;
+    fc.U0 = t0 * hop + 16 * S.s_lo - a.pad;  // signal position of ring sample v = 0
+    fc.lane = lane;
+    fc.lperm = 16 * (lane >> 4) + 4 * (lane & 3) + ((lane >> 2) & 3);
+    fc.lperm4 = 4u * (unsigned)fc.lperm;
+    fc.nlperm4 = 0u - fc.lperm4;
+    fc.lane4 = 4u * (unsigned)lane;
     const int ring_samples = nr * hop;
     const float *bricks = a.bricks + S.brick0 * (CH_BRICK / 4);
-    // the whole ring
-    {
-      int slot = 0, off = 0;
-      for (int v0 = 0; v0 < ring_samples; v0 += 64) {
-        ch_fill<REFLECT>(xc, a.zeros, L, U0, lane, lperm, v0, ring_base + (unsigned)(slot * row_bytes + off * 4), 64);
-        off += 64;
-        if (off == hop) {
-          off = 0;
-          ++slot;
-        }
-      }
-    }
+    // its half of the ring (the even 64-sample blocks; the multiplying wave, idle until the first barrier, takes the odd ones)
+    ch_fill_ring<REFLECT>(fc, ring_base, ring_samples, hop, row_bytes, 0);
     // request cursor over the batches: segment, batches left in it, first brick
     int rsg = 0, rword = n_segs > 0 ? seg[0] : 0, rrem = rword >> 8;
     long long rbrick = 0;
@@ -404,14 +451,10 @@ __global__ void __launch_bounds__(512) cqt_chain_kernel(const ChainArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if ((CH_ABL & 64) && blockIdx.x == CH_STAMP_WG && wave == 4 && lane == 0) a.stamps[2] = clock64();
     __syncthreads();
-    // A wave whose span touches the virtual padding: its ring is refilled from here, by DMA (the index arithmetic of the
-    // padding stays out of the MFMA stream): what batch b - 1 read of frame 0's row, after barrier(b - 1).
-    const bool edge = U0 < 0 || U0 + ring_samples + 16 * S.n_sub + 256 >= L;
     int slot0 = 0, off0 = 0, sdone = 0;
     int pq = 0;            // the previous batch's Q ...
     unsigned pdst = 0;     // ... where its part of frame 0's row is ...
     int pv0 = 0;           // ... and the ring sample that replaces its first sample
-    const unsigned lperm4 = 4u * (unsigned)lperm;
     for (int sg = 0; sg < n_segs; ++sg) {
       const int w = seg[sg];
       const int q = (w >> 4) & 15, count = w >> 8;
@@ -421,25 +464,8 @@ __global__ void __launch_bounds__(512) cqt_chain_kernel(const ChainArgs a) {
         // batch b + 2 or later: they have until barrier(b + 1) = two batches, like the bricks requested next.
         int issued = 0;
         if (pq > 0 && !(CH_ABL & 4)) {
-          if (!edge) {
-            const unsigned voff = lperm4 + 4u * (unsigned)(U0 + pv0);
-            if (pq >= 4)
-              ch_dma4s(xc, voff, pdst);
-            else
-              ch_dma4s_mask(xc, voff, pdst, (1ull << (16 * pq)) - 1ull);
-            ++issued;
-            if (pq > 4) {
-              ch_dma4s_mask(xc, voff + 256u, pdst + 256u, pq == 8 ? ~0ull : (1ull << (16 * pq - 64)) - 1ull);
-              ++issued;
-            }
-          } else {
-            ch_fill<REFLECT>(xc, a.zeros, L, U0, lane, lperm, pv0, pdst, 16 * pq);
-            ++issued;
-            if (pq > 4) {
-              ch_fill<REFLECT>(xc, a.zeros, L, U0, lane, lperm, pv0 + 64, pdst + 256u, 16 * pq - 64);
-              ++issued;
-            }
-          }
+          issued += ch_fill_block<REFLECT>(fc, pv0, pdst, pq >= 4 ? 64 : 16 * pq);
+          if (pq > 4) issued += ch_fill_block<REFLECT>(fc, pv0 + 64, pdst + 256u, 16 * pq - 64);
         }
         pq = q;
         pdst = ring_base + (unsigned)(slot0 * row_bytes + off0 * 4);
@@ -474,6 +500,21 @@ __global__ void __launch_bounds__(512) cqt_chain_kernel(const ChainArgs a) {
 #if CH_PRIO == 1
   __builtin_amdgcn_s_setprio(3);  // (the MFMA stream before its SIMD partner's address arithmetic)
 #endif
+  {
+    FillCtx fc;
+    fc.xc = a.x + (long long)clip * a.x_clip_stride;
+    fc.zeros = a.zeros;
+    fc.L = a.n_samples;
+    fc.pad = a.pad;
+    fc.U0 = t0 * hop + 16 * S.s_lo - a.pad;
+    fc.lane = lane;
+    fc.lperm = 16 * (lane >> 4) + 4 * (lane & 3) + ((lane >> 2) & 3);
+    fc.lperm4 = 4u * (unsigned)fc.lperm;
+    fc.nlperm4 = 0u - fc.lperm4;
+    fc.lane4 = 4u * (unsigned)lane;
+    ch_fill_ring<REFLECT>(fc, ring_base, nr * hop, hop, row_bytes, 1);  // the odd blocks of the ring
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __syncthreads();  // the ring and the first two batches are in LDS
 
   f32x4 acc[CH_NMAX];

@@ -230,6 +230,12 @@ struct MulState {
 
 template <int N, int Q>
 __device__ __forceinline__ void mul_segment(f32x4 (&acc)[CH_NMAX], f32x4 &bfirst, MulState &c, const int count) {
+  // The barrier's slot in the batch's last sub-stage: the N + 1 reads behind it want >= 4 MFMAs of cover before the next
+  // batch's first MFMA needs them (N = 1: the barrier opens the sub-stage and 3 MFMAs are all there is)
+  constexpr int TB = 4 * N - 5 < 0 ? 0 : (2 * N < 4 * N - 5 ? 2 * N : 4 * N - 5);
+  // slots of the first sub-stage that carry the address arithmetic (behind its reads)
+  // (a single sub-stage: in front of it -- its barrier slot may be the first)
+  constexpr int TK0 = Q == 1 ? -1 : N + 1, TK1 = Q == 1 ? -1 : (TK0 + 1 < 4 * N ? TK0 + 1 : TK0);
   f32x4 af[N], bf = bfirst;
 #pragma unroll
   for (int m = 0; m < N; ++m) af[m] = *(ch_lds_pinned)(c.a_cur + m * CH_BRICK);
@@ -240,6 +246,15 @@ __device__ __forceinline__ void mul_segment(f32x4 (&acc)[CH_NMAX], f32x4 &bfirst
     bb[0] = bf;
     unsigned a_nxt = 0, b_nxt = 0;
     bool row_end = false;
+    if (Q == 1) {
+      const int buf1 = c.buf + 1 == CH_NBUF ? 0 : c.buf + 1;
+      a_nxt = c.a_lane + (unsigned)(buf1 * CH_BUF_BYTES);
+      c.buf = buf1;
+      const int off2 = c.off + 16;
+      row_end = off2 == c.hop;
+      c.off = row_end ? 0 : off2;
+      b_nxt = row_end ? c.row_next : c.b_cur + 64u;
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < Q; ++j) {
@@ -247,9 +262,10 @@ __device__ __forceinline__ void mul_segment(f32x4 (&acc)[CH_NMAX], f32x4 &bfirst
 #pragma unroll
       for (int t = 0; t < 4 * N; ++t) {
         const int jj = t / N, m = t % N;
-        if (j == Q - 1 && t == 2 * N) {
-          // every read of this batch is in registers (the fragments of its last sub-stage feed the MFMAs above): the
-          // loading waves may overwrite its bricks; the next batch's bricks are published
+        if (j == Q - 1 && t == TB) {
+          // every read of this batch is in registers (the fragments of its last sub-stage are waited for here at the
+          // latest): the loading waves may overwrite its bricks and what it read of the ring; the next batch's bricks are
+          // published
           if (!(CH_ABL & 1)) __syncthreads();
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -263,14 +279,17 @@ __device__ __forceinline__ void mul_segment(f32x4 (&acc)[CH_NMAX], f32x4 &bfirst
           if (t == 0) bb[nx] = *(ch_lds_pinned)(c.b_cur + 64 * (j + 1));
           if (t >= 1 && t <= N) a[nx][t - 1] = *(ch_lds_pinned)(c.a_cur + ((j + 1) * N + t - 1) * CH_BRICK);
         } else {
-          if (t == 2 * N) bb[nx] = *(ch_lds_pinned)(b_nxt);
-          if (t > 2 * N && t <= 3 * N) a[nx][t - 2 * N - 1] = *(ch_lds_pinned)(a_nxt + (t - 2 * N - 1) * CH_BRICK);
+          if (t == TB) bb[nx] = *(ch_lds_pinned)(b_nxt);
+          if (t > TB && t <= TB + N) a[nx][t - TB - 1] = *(ch_lds_pinned)(a_nxt + (t - TB - 1) * CH_BRICK);
         }
-        if (j == 0 && t == (Q == 1 ? 0 : N + 1)) {
-          // where the next batch's fragments are: the next buffer; further along the ring row or at the start of the next one
+        if (j == 0 && t == TK0) {
+          // where the next batch's bricks are: the next buffer
           const int buf1 = c.buf + 1 == CH_NBUF ? 0 : c.buf + 1;
           a_nxt = c.a_lane + (unsigned)(buf1 * CH_BUF_BYTES);
           c.buf = buf1;
+        }
+        if (j == 0 && t == TK1) {
+          // ... and its first signal fragment: further along the ring row or at the start of the next one
           const int off2 = c.off + 16 * Q;
           row_end = off2 == c.hop;  // (batches never straddle ring rows)
           c.off = row_end ? 0 : off2;

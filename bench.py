@@ -172,7 +172,7 @@ def workload(name, device, B=None):
         tag = "CQT1992v2 84 bins / 12 bpo hop=512, B=%d x 10 s @ 44.1 kHz, Magnitude" % B
         bound = "mfma"
         # executed: 8-bin (16-row MFMA) tiles over the tap range of their longest bin, zero padding included
-        # (round 5: framed_gemm_kernel<..., T16>; 16-bin tiles before: 1.49 x the useful products, now 1.22 x)
+        # (round 5: framed_gemm_kernel<..., T16>, round 6: cqt_chain_kernel; 16-bin tiles before: 1.49 x the useful products, now 1.22 x)
         lens = m.lenghts.detach().cpu().numpy()
         executed = {"fp32": 2.0 * sum(16 * float(lens[i:i + 8].max()) for i in range(0, 84, 8)) * B * T,
                     # the split arithmetics' strip kernel: 16-bin tiles
@@ -966,7 +966,9 @@ def main():
                     # 2.7 % of the log-magnitude one: tests/test_reference_order.py); roofline_cqt84_f16x3 is the opt-in
                     # `module.precision = "f16x3"` (4.7e-7 of the peak against float64: inside north_star's 1e-4).
                     default = pr2 is None
-                    blk["kernel"] = (("one step = edge pre-pass + framed_gemm_kernel<.., T16> (fp32 16x16x4 MFMA tiles, supports per 8 bins, taps ascending = the reference's FMA chain); "
+                    blk["kernel"] = (("one step = ONE launch of cqt_chain_kernel (round 6: fp32 16x16x4 MFMA tiles, supports per 8 bins, taps ascending = the reference's "
+                                      "FMA chain; the frames' samples in LDS delay lines refilled by LDS-DMA, the bank streamed through LDS as MFMA "
+                                      "fragments; 4 multiplying + 4 loading waves per workgroup; no pre-pass, no workspace); "
                                       if pr == "fp32" else
                                       "one step = clip absmax + split pre-passes + framed_%s_strip_kernel; " % pr) +
                                      "achieved = executed MFMA flops (row tiles over the tap range of their longest bin) / "

@@ -3312,6 +3312,7 @@ Fft4096Plan plan_fft4096(const mispec_framed_gemm_args *a, const KParams &p) {
   // (the (cos, sin) phase format -- CQT's, never an STFT module's -- spills in the second transform's flush: contraction kernels)
   if (p.epilogue < MISPEC_EPI_COMPLEX || p.epilogue >= MISPEC_EPI_PHASE_COSSIN) return pl;
   if (p.n_bins > 2049 || p.n_frames <= 0 || (long long)p.n_clips * p.n_frames > 0x3fffffffLL) return pl;
+  if (p.n_clips > 65535) return pl;  // (the split pre-pass puts the clips on gridDim.y; the contraction kernels take larger batches)
   const long long Lp = (long long)p.n_samples + 2LL * p.pad;
   pl.Lh = (Lp + 1) / 2;
   if (pl.Lh + 64 > 0x7fffffffLL) return pl;
@@ -3361,6 +3362,10 @@ int launch_fft4096(const KParams &p, const mispec_framed_gemm_args *a, const Fft
   float *const xe = ws, *const xo = ws + pl.off_xo, *const w = ws + pl.off_w, *const E = ws + pl.off_E;
   hipLaunchKernelGGL(fft4096_split_kernel, dim3((unsigned)((pl.slot + 255) / 256), (unsigned)p.n_clips), dim3(256), 0, stream, p.x,
                      p.x_clip_stride, p.n_samples, p.pad, p.pad_mode, p.a_re, xe, xo, pl.slot, pl.Lh, w);
+  {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MISPEC_E_HIP, "fft4096 split launch: %s", hipGetErrorString(e));
+  }
   for (int h = 0; h < 2; ++h) {
     KParams q = p;
     q.x = h ? xo : xe;

@@ -756,6 +756,15 @@ def frame_major_filterbank_plan(mod, fb, x, stft):
         return None
     if stft.trainable or stft.n_fft not in (1024, 2048) or fb.shape[1] != stft.n_fft // 2 + 1 or not fb.is_cuda:
         return None
+    #  what the library would refuse from inside the two calls -- clips x frames of the FFT route, the int32
+    # sample count of the second contraction's (T * Fp)-sample "clips" -- is checked here: the generic two-kernel path
+    # serves such calls
+    xs = x.reshape(-1, x.shape[-1])
+    B, L = xs.shape
+    T = (L + 2 * (stft.n_fft // 2 if stft.center else 0) - stft.n_fft) // stft.stride + 1
+    Fp = (fb.shape[1] + 31) // 32 * 32
+    if T <= 0 or B * T > (1 << 30) or T * Fp + Fp + 64 > 0x7FFFFFFF:
+        return None
     if not hasattr(mod, "_fb_padded"):
         mod._fb_padded = DerivedCache()
 
@@ -1370,8 +1379,13 @@ class _FramedGemmFn(torch.autograd.Function):
             # contractions run side by side on side streams (split-K by hand: 64 workgroups each), added in chunk order.
             n_par = 1
             if use16 and B >= 8 and not torch.cuda.is_current_stream_capturing():
-                n_par = 4
-                per = min(per, (B + n_par - 1) // n_par)
+                #  the side streams keep n_par chunks alive at once -- frame matrix, G, its fp16 planes, the
+                # workspace, in per-stream allocator pools the main stream cannot reuse: only when all of them together
+                # stay inside the budget one serial chunk had (2^29 floats of frames); else the serial loop
+                want = (B + 3) // 4
+                if 4 * want * K * T <= (1 << 29):
+                    n_par = 4
+                    per = min(per, want)
 
             def d_basis_chunk(b0, b1):
                 nb = (b1 - b0) * T

@@ -30,7 +30,7 @@ for f in find("*counter_collection.csv"):
         agg[k][r.get("Counter_Name")] += float(r.get("Counter_Value", 0) or 0)
         cnt[(k, r.get("Counter_Name"))] += 1
     for k, d in agg.items():
-        if not any(t in k for t in ("framed_", "split_signal", "fold", "octave_pyramid", "octave_stream", "fir_decimate", "clip_absmax", "stft_fft")):
+        if not any(t in k for t in ("framed_", "split_signal", "fold", "octave_pyramid", "octave_stream", "fir_decimate", "clip_absmax", "stft_fft", "cqt_chain")):
             continue
         print("  kernel:", k)
         for c, v in sorted(d.items()):
@@ -43,7 +43,7 @@ try:
     dom, dur, best = None, None, -1.0
     for f in find("*kernel_stats.csv"):
         for r in csv.DictReader(open(f)):
-            if any(t in r.get("Name", "") for t in ("framed_", "octave_pyramid", "octave_stream", "stft_fft")) and float(r["TotalDurationNs"]) > best:
+            if any(t in r.get("Name", "") for t in ("framed_", "octave_pyramid", "octave_stream", "stft_fft", "cqt_chain")) and float(r["TotalDurationNs"]) > best:
                 best = float(r["TotalDurationNs"])
                 dom, dur = r["Name"], float(r["AverageNs"]) * 1e-9
     vals = {}

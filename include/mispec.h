@@ -271,7 +271,7 @@ int mispec_frag_basis_f32(const float *basis_re, const float *basis_im, int64_t 
  * row_support_host: the (n_bins, 2) [start, stop) supports in HOST memory (the layout follows from them).
  *   mispec_basis_chain_bytes  size of `dst`; MISPEC_E_UNSUPPORTED when the supports of the bank's 16-row
  *                             tiles (8 bins) do not nest when ordered by length (CQT kernels are centred: they
- *                             do) or the bank has more than 576 bins -- such banks stay on the tile kernels
+ *                             do) or the bank has more than 640 bins -- such banks stay on the tile kernels
  *   mispec_chain_basis_f32    fills dst (one small host-synchronous copy of the plan, then a kernel on `stream`)
  */
 int64_t mispec_basis_chain_bytes(const int32_t *row_support_host, int32_t n_bins, int32_t kernel);

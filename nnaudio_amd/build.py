@@ -172,7 +172,7 @@ def build(force=False, verbose=True, ablate=False):
     jobs, objs = [], []
     with ThreadPoolExecutor(len(UNITS)) as ex:
         for src, takes_ablate in UNITS:
-            tag = "_ablate" if (ablate and takes_ablate) else ""
+            tag = "_ablate" if ablate else ""  # (own objects for every unit: the two builds may run side by side)
             obj = os.path.join(objdir, os.path.basename(src).replace(".hip", tag + ".o"))
             objs.append(obj)
             # a unit depends on its own source, the headers and (mispec.hip) the .inl files it includes

@@ -16,19 +16,21 @@
 //     padding (reflect / zero) is resolved in the DMA's per-lane source address: no padded copy, no edge workspace.
 //   * A operand (basis).  Prepared once per bank (mispec_chain_basis_f32) as a stream of 1 KB "bricks" -- 16 rows x 16 taps
 //     in MFMA fragment order [lane][4 taps of 4 MFMAs] -- in exactly the order a workgroup consumes them; taps outside a
-//     16-row tile's support are not stored at all.  The four waves of a workgroup (4 column tiles) share the bricks through
-//     four LDS buffers of 7 bricks filled by global_load_lds_dwordx4 three batches ahead; a brick is one ds_read_b128 per
-//     lane and feeds 4 MFMAs.
+//     16-row tile's support are not stored at all.  The four multiplying waves of a workgroup (4 column tiles) share the
+//     bricks through three LDS buffers of 10 bricks filled by global_load_lds_dwordx4 two batches ahead; a brick is one
+//     ds_read_b128 per lane and feeds 4 MFMAs.
 //   * Work units.  The bank's 16-row tiles (8 bins; supports nested: CQT kernels are centred) are split into row sets; a
 //     workgroup = 4 column tiles x one row set, all waves doing identical work per sub-stage.  Units are issued largest
 //     first so that the dispatcher's tail is made of the short ones.
-//   * Instruction stream.  One wave per SIMD: everything besides the MFMAs has to fit into their shadow (~5 issue slots per
-//     16 x 16 x 4 MFMA).  A batch = Q sub-stages x N tiles (N Q <= 7, inside one ring row) is compiled per (N, Q) without
-//     control flow: its LDS reads use immediate offsets, its four DMA instructions (two bricks, two ring blocks: always
-//     four, a piece that is not due is fetched again) sit between the MFMA groups of its first sub-stage, the first
-//     fragments of the next batch are read before the barrier, and "everything older has landed" is `s_waitcnt vmcnt(4)`.
+//   * Wave specialization.  512 threads: waves 0-3 multiply, waves 4-7 load (one of each per SIMD).  The multiplying wave's
+//     stream is MFMAs with one LDS read behind each and one barrier per batch, nothing else: a batch = Q sub-stages x N
+//     tiles (N <= 10, Q <= 8, inside one ring row) is compiled per (N, Q) without control flow, its LDS reads use immediate
+//     offsets, the first fragments of the next batch are read behind the barrier.  The loading wave requests the bricks of
+//     batch b + 2, refills the ring blocks batch b - 1 consumed, and states "everything older has landed" as a counted
+//     `s_waitcnt vmcnt(n)` before the batch's barrier.
 //
-// Bounds: MFMA (fp32 matrix pipe, 157 TFLOP/s); LDS reads 1 KB per 4 MFMAs per wave; L2 -> LDS 1 KB per brick per workgroup.
+// Bounds: MFMA (fp32 matrix pipe, 157 TFLOP/s); LDS reads 1 KB per 4 MFMAs per wave; L2 -> LDS 1 KB per brick per workgroup;
+// and, measured, the issue rate of LDS-DMA instructions beside an MFMA stream.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -392,7 +394,8 @@ __device__ __forceinline__ void ch_wait_vmcnt(int n) {
     case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
     case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
     case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;  // (never more than 3 + 2 requests per batch)
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;  // (never more than 3 + 2 + 2; a smaller count only waits longer)
   }
 }
 
@@ -471,27 +474,48 @@ __global__ void __launch_bounds__(512) cqt_chain_kernel(const ChainArgs a) {
     if ((CH_ABL & 64) && blockIdx.x == CH_STAMP_WG && wave == 4 && lane == 0) a.stamps[2] = clock64();
     __syncthreads();
     int slot0 = 0, off0 = 0, sdone = 0;
-    int pq = 0;            // the previous batch's Q ...
-    unsigned pdst = 0;     // ... where its part of frame 0's row is ...
-    int pv0 = 0;           // ... and the ring sample that replaces its first sample
+    // Ring refill: the part of frame 0's row that the batches up to b - 1 have read and that is not requested yet = `pend`
+    // groups of 16 samples from LDS address pdst on, to be replaced by the ring samples from pv0 on.  Whole 64-sample blocks
+    // only (one DMA instruction each: it is the NUMBER of DMA instructions a loading wave issues beside the MFMA stream that
+    // is scarce, 3.14); what is left of a row when frame 0 leaves it goes as one partial block.
+    int pend = 0;
+    unsigned pdst = 0;
+    int pv0 = 0;
+    bool prow_end = false;
     for (int sg = 0; sg < n_segs; ++sg) {
       const int w = seg[sg];
       const int q = (w >> 4) & 15, count = w >> 8;
       for (int i = 0; i < count; ++i) {
-        // Between barrier(b - 1) and barrier(b).  First the ring: what batch b - 1 read of frame 0's row (dead since
-        // barrier(b - 1)) <- the samples one ring further on, first read >= 31 sub-stages after batch b - 1 began, i.e. in
-        // batch b + 2 or later: they have until barrier(b + 1) = two batches, like the bricks requested next.
+        // Between barrier(b - 1) and barrier(b).  First the ring: what the batches up to b - 1 read of frame 0's row is dead
+        // since barrier(b - 1); its replacement is first read >= 32 sub-stages after the group it replaces.  A group waits for
+        // at most 3 later ones (<= 13 sub-stages with the batch that brings them), its block is requested in the iteration
+        // after, waited for in the next, readable from the batch after that: <= 13 + 8 + 8 sub-stages.
+        // (Bricks first and the ring blocks allowed another batch in flight -- s_waitcnt vmcnt(+ the previous iteration's
+        // ring blocks) -- ran the N = 1 phases at 52 instead of 38 cycles per MFMA.)
         int issued = 0;
-        if (pq > 0 && !(CH_ABL & 4)) {
-          issued += ch_fill_block<REFLECT>(fc, pv0, pdst, pq >= 4 ? 64 : 16 * pq);
-          if (pq > 4) issued += ch_fill_block<REFLECT>(fc, pv0 + 64, pdst + 256u, 16 * pq - 64);
+        if (!(CH_ABL & 4)) {
+          while (pend >= 4) {
+            issued += ch_fill_block<REFLECT>(fc, pv0, pdst, 64);
+            pv0 += 64;
+            pdst += 256u;
+            pend -= 4;
+          }
+          if (prow_end && pend > 0) {
+            issued += ch_fill_block<REFLECT>(fc, pv0, pdst, 16 * pend);
+            pend = 0;
+          }
+        } else {
+          pend = 0;
         }
-        pq = q;
-        pdst = ring_base + (unsigned)(slot0 * row_bytes + off0 * 4);
-        pv0 = 16 * sdone + ring_samples;
+        if (pend == 0) {
+          pdst = ring_base + (unsigned)(slot0 * row_bytes + off0 * 4);
+          pv0 = 16 * sdone + ring_samples;
+        }
+        pend += q;  // (batch b's part: dead at barrier(b), i.e. from the next iteration on)
         sdone += q;
         off0 += 16 * q;
-        if (off0 == hop) {
+        prow_end = off0 == hop;
+        if (prow_end) {
           off0 = 0;
           slot0 = slot0 + 1 == nr ? 0 : slot0 + 1;
         }
@@ -542,8 +566,10 @@ __global__ void __launch_bounds__(512) cqt_chain_kernel(const ChainArgs a) {
   f32x4 bfirst = *(ch_lds_pinned)(c.b_cur);  // sub-stage 0's signal fragment
 
   if ((CH_ABL & 64) && blockIdx.x == CH_STAMP_WG && wave == 0 && lane == 0) a.stamps[3] = clock64();
+  int w_next = n_segs > 0 ? seg[0] : 0;
   for (int sg = 0; sg < n_segs; ++sg) {
-    const int w = seg[sg];
+    const int w = w_next;
+    w_next = seg[sg + 1 < n_segs ? sg + 1 : sg];  // (requested a segment ahead: the scalar load's latency is off the path)
     const int count = w >> 8;
     if ((CH_ABL & 64) && blockIdx.x == CH_STAMP_WG && wave == 0 && lane == 0 && sg < 200) {
       a.stamps[8 + 2 * sg] = clock64();
@@ -713,7 +739,10 @@ ChainPlan chain_plan(const int32_t *sup, int n_bins, int K, bool want_map) {
         for (int sb = s0; sb < s1; ++sb)
           for (int m = 0; m < n; ++m) pl.brick_map.push_back(make_int2(S.tile[m], sb));
       // batches of the run, per hop: Q <= 7 / n sub-stages, never across a ring row (hop / 16 sub-stages from the set's start)
-      const int qmax = std::min(CH_QMAX, CH_NMAX / n);
+      // Q: what the loading waves can keep up with.  A loading wave issues ceil(Q / 4) ring blocks + ceil(n Q / 4) bricks per
+      // batch at ~300 cycles each beside the MFMA stream (3.14's DMA-issue wall) against 128 n Q cycles of MFMAs:
+      // n = 2, Q = 5 is (2 + 3) 300 / 1280 = 1.17 (measured 42 cycles per MFMA), Q = 4 is (1 + 2) 300 / 1024 = 0.88
+      const int qmax = n == 2 ? env_int("MISPEC_CHAIN_Q2", 4) : std::min(CH_QMAX, CH_NMAX / n);
       for (int h = 0; h < CH_HOPS; ++h) {
         const int per_row = 4 * (h + 1);
         std::vector<int> &sg = pl.segs[h];
@@ -721,7 +750,10 @@ ChainPlan chain_plan(const int32_t *sup, int n_bins, int K, bool want_map) {
         while (sb < s1) {
           const int row_end = S.lo[0] + ((sb - S.lo[0]) / per_row + 1) * per_row;
           const int e = std::min(s1, row_end);
-          const int full = (e - sb) / qmax, rest = (e - sb) % qmax;
+          // as few batches as qmax allows, of equal length +- 1: a short remainder batch would still cost the loading
+          // waves a full round of requests (measured: 1.5 .. 2 k cycles for 8 .. 16 MFMAs)
+          const int len = e - sb, nb = (len + qmax - 1) / qmax;
+          const int q_lo = len / nb, n_big = len % nb;
           auto push = [&](int q, int cnt) {
             if (cnt <= 0) return;
             for (int t = 0; t < cnt; ++t) boffs[h].push_back((int)(bricks - S.brick0) + ((sb - s0) + t * q) * n);
@@ -732,8 +764,8 @@ ChainPlan chain_plan(const int32_t *sup, int n_bins, int K, bool want_map) {
             else
               sg.push_back(key | (cnt << 8));
           };
-          push(qmax, full);
-          push(rest, rest ? 1 : 0);
+          push(q_lo + 1, n_big);
+          push(q_lo, nb - n_big);
         }
       }
       bricks += (long long)(s1 - s0) * n;

@@ -8,12 +8,15 @@
 //
 //   * B operand (signal).  A wave owns 16 consecutive frames of one clip (one MFMA column tile).  Frame f at 16-tap
 //     sub-stage s needs padded samples  (t0 + f) hop + 16 s .. + 16:  what frame f reads now, frame f - 1 reads hop / 16
-//     sub-stages later.  The wave keeps that delay line in LDS: a ring of NR rows of `hop` samples (row r = samples
-//     [U0 + r hop, + hop), slot r mod NR, rows 8 dwords apart in bank space so that the 16 frames of a ds_read_b128 fall on
-//     different banks), refilled 64 samples at a time by global_load_lds_dword behind frame 0 -- each sample enters LDS once
-//     per column tile instead of once per frame and K stage.  Inside every aligned group of 16 samples the DMA stores
-//     sample 4 n + q at position 4 q + n, so a lane's four taps of four successive MFMAs are ONE ds_read_b128.  Virtual
-//     padding (reflect / zero) is resolved in the DMA's per-lane source address: no padded copy, no edge workspace.
+//     sub-stages later.  That delay line lives in LDS: a ring of rows of `hop` samples (row r = samples [U0 + r hop, + hop),
+//     rows 8 dwords apart in bank space so that the 16 frames of a ds_read_b128 fall on different banks), refilled 64
+//     samples at a time by global_load_lds_dword behind its first frame.  The waves of a workgroup whose column tiles
+//     follow each other inside one clip (normally all four: 64 frames) share ONE ring of 63 + ceil((511 + hop) / hop) rows --
+//     each sample enters LDS once per workgroup instead of once per frame and K stage; a workgroup across a clip boundary
+//     splits into one ring per run of tiles (the LDS is the same: 16 rows per wave + the look-ahead).  Inside every aligned
+//     group of 16 samples the DMA stores sample 4 n + q at position 4 q + n, so a lane's four taps of four successive MFMAs
+//     are ONE ds_read_b128.  Virtual padding (reflect / zero) is resolved in the DMA's per-lane source address: no padded
+//     copy, no edge workspace.
 //   * A operand (basis).  Prepared once per bank (mispec_chain_basis_f32) as a stream of 1 KB "bricks" -- 16 rows x 16 taps
 //     in MFMA fragment order [lane][4 taps of 4 MFMAs] -- in exactly the order a workgroup consumes them; taps outside a
 //     16-row tile's support are not stored at all.  The four multiplying waves of a workgroup (4 column tiles) share the
@@ -368,21 +371,53 @@ __device__ __forceinline__ int ch_fill_block(const FillCtx &c, int v0, unsigned 
   return 1;
 }
 
-// every second 64-sample block of a wave's ring, from block `first` (0 or 1) on
+// every `step`-th 64-sample block of a ring, from block `first` on
 template <bool REFLECT>
-__device__ __forceinline__ void ch_fill_ring(const FillCtx &c, unsigned ring_base, int ring_samples, int hop, int row_bytes, int first) {
-  int slot = 0, off = 64 * first;
-  if (off == hop) {
-    off = 0;
-    slot = 1;
-  }
-  for (int v0 = 64 * first; v0 < ring_samples; v0 += 128) {
+__device__ __forceinline__ void ch_fill_ring(const FillCtx &c, unsigned ring_base, int ring_samples, int hop, int row_bytes, int first, int step) {
+  for (int v0 = 64 * first; v0 < ring_samples; v0 += 64 * step) {
+    const int slot = v0 / hop, off = v0 - slot * hop;
     ch_fill_block<REFLECT>(c, v0, ring_base + (unsigned)(slot * row_bytes + off * 4), 64);
-    off += 128;
-    while (off >= hop) {
-      off -= hop;
-      ++slot;
+  }
+}
+
+// The same through registers, for the prologue of a ring whose rows are multiples of 256 samples: a block of 256 samples
+// inside the clip is ONE global_load_dwordx4 per lane (lane i: samples 4 i .. 4 i + 3 = group i >> 2, n = i & 3, q = 0 .. 3)
+// and four ds_write_b32 to positions 16 g + 4 q + n -- a quarter of the address work of four LDS-DMA dwords per lane, which
+// is what bounds the DMA fill (4 lanes per clock and CU: experiments/chain/dma_rate.hip).  Blocks across the clip's ends
+// (or in the padding) take the DMA path.  Every `step`-th 256-block from block `first` on (16 of them cover the ring when
+// `step` waves share the work); all loads are in flight at once.
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float __attribute__((address_space(3))) *ch_lds_f32;
+template <bool REFLECT>
+__device__ __forceinline__ void ch_fill_ring_wide(const FillCtx &c, unsigned ring_base, int ring_samples, int hop, int row_bytes, int first, int step) {
+  constexpr int NB = 16;  // blocks per wave: the ring has at most 17 x 256 (hop 256) or 16 x 512 (hop 512) samples
+  const int nblk = ring_samples >> 8;
+  const int sh = hop >> 9;  // 256-blocks per row: 1 << sh
+  f32x4 v[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int p0 = c.U0 + 256 * (first + step * j);
+    const int pc = p0 < 0 ? 0 : (p0 > c.L - 256 ? c.L - 256 : p0);  // (a block that is not inside the clip loads something valid)
+    v[j] = *(const f32x4_u *)(c.xc + pc + 4 * c.lane);
+  }
+  const unsigned lane_off = 64u * (unsigned)(c.lane >> 2) + 4u * (unsigned)(c.lane & 3);
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int k = first + step * j;
+    const int p0 = c.U0 + 256 * k;
+    if (k < nblk && p0 >= 0 && p0 + 256 <= c.L) {
+      const unsigned dst = ring_base + (unsigned)((k >> sh) * row_bytes + ((k & ((1 << sh) - 1)) << 10)) + lane_off;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *(ch_lds_f32)(dst + 16u * q) = v[j][q];
     }
+  }
+#pragma unroll 1
+  for (int k = first; k < nblk; k += step) {
+    const int p0 = c.U0 + 256 * k;
+    if (p0 >= 0 && p0 + 256 <= c.L) continue;
+    const unsigned dst = ring_base + (unsigned)((k >> sh) * row_bytes + ((k & ((1 << sh) - 1)) << 10));
+#pragma unroll 1
+    for (int b = 0; b < 4; ++b) ch_fill_block<REFLECT>(c, 256 * k + 64 * b, dst + 256u * b, 64);
   }
 }
 
@@ -416,10 +451,21 @@ __global__ void __launch_bounds__(512) cqt_chain_kernel(const ChainArgs a) {
   const bool live = ct_raw < a.n_ct;
   const int ct = live ? ct_raw : a.n_ct - 1;  // idle waves of the last group shadow the last column tile (nothing stored)
   const int clip = __builtin_amdgcn_readfirstlane(ct / a.ct_per_clip);  // (the division runs on the vector unit)
-  const int t0 = (ct - clip * a.ct_per_clip) * 16;
-  const int hop = a.hop, nr = a.nr;
+  const int tic = ct - clip * a.ct_per_clip;  // the wave's column tile inside its clip
+  const int t0 = tic * 16;
+  // Waves whose column tiles follow each other inside one clip share ONE delay line: frame 16 (w + 1) reads now what frame
+  // 16 w + 15 reads a row later, so the rings of a run of `nw` waves are one ring of 16 (nw - 1) more rows, filled once
+  // behind the run's first frame.  (A group across a clip boundary, or the idle waves of the last group, are runs of their
+  // own: nw = 1 is a ring per wave.)
+  const int lead = live ? cw - (cw < tic ? cw : tic) : cw;  // first wave of the run
+  int last = live ? cw + (a.ct_per_clip - 1 - tic) : cw;
+  last = last > 3 ? 3 : last;
+  if (live && 4 * g + last > a.n_ct - 1) last = a.n_ct - 1 - 4 * g;
+  const int nw = last - lead + 1, widx = cw - lead;
+  const int hop = a.hop, nr = a.nr + 16 * (nw - 1);
   const int row_bytes = (hop + CH_SKEW) * 4;
-  const unsigned ring_base = (unsigned)(cw * a.ring_bytes);
+  const unsigned ring_base = (unsigned)(lead * a.ring_bytes);  // (a run owns the LDS of its waves' rings: nw a.nr >= nr rows)
+  const int U0 = (t0 - 16 * widx) * hop + 16 * S.s_lo - a.pad;   // signal position of ring sample v = 0: the run's first frame
   const unsigned a_base = (unsigned)(4 * a.ring_bytes);
   const ch_seg_ptr seg = (ch_seg_ptr)(a.segs + S.seg0);
   const int n_segs = S.n_segs;
@@ -435,7 +481,7 @@ __global__ void __launch_bounds__(512) cqt_chain_kernel(const ChainArgs a) {
     fc.zeros = a.zeros;
     fc.L = a.n_samples;
     fc.pad = a.pad;
-    fc.U0 = t0 * hop + 16 * S.s_lo - a.pad;  // signal position of ring sample v = 0
+    fc.U0 = U0;
     fc.lane = lane;
     fc.lperm = 16 * (lane >> 4) + 4 * (lane & 3) + ((lane >> 2) & 3);
     fc.lperm4 = 4u * (unsigned)fc.lperm;
@@ -444,7 +490,11 @@ __global__ void __launch_bounds__(512) cqt_chain_kernel(const ChainArgs a) {
     const int ring_samples = nr * hop;
     const float *bricks = a.bricks + S.brick0 * (CH_BRICK / 4);
     // its half of the ring (the even 64-sample blocks; the multiplying wave, idle until the first barrier, takes the odd ones)
-    ch_fill_ring<REFLECT>(fc, ring_base, ring_samples, hop, row_bytes, 0);
+    // (the 2 nw waves of the run take every 2 nw-th block of its ring)
+    if ((hop & 255) == 0 && fc.L >= 256)
+      ch_fill_ring_wide<REFLECT>(fc, ring_base, ring_samples, hop, row_bytes, 2 * widx, 2 * nw);
+    else
+      ch_fill_ring<REFLECT>(fc, ring_base, ring_samples, hop, row_bytes, 2 * widx, 2 * nw);
     // request cursor over the batches: segment, batches left in it, first brick
     int rsg = 0, rword = n_segs > 0 ? seg[0] : 0, rrem = rword >> 8;
     long long rbrick = 0;
@@ -482,6 +532,7 @@ __global__ void __launch_bounds__(512) cqt_chain_kernel(const ChainArgs a) {
     unsigned pdst = 0;
     int pv0 = 0;
     bool prow_end = false;
+    int turn = 0;  // the run's loading waves take its blocks in turn
     for (int sg = 0; sg < n_segs; ++sg) {
       const int w = seg[sg];
       const int q = (w >> 4) & 15, count = w >> 8;
@@ -495,13 +546,15 @@ __global__ void __launch_bounds__(512) cqt_chain_kernel(const ChainArgs a) {
         int issued = 0;
         if (!(CH_ABL & 4)) {
           while (pend >= 4) {
-            issued += ch_fill_block<REFLECT>(fc, pv0, pdst, 64);
+            if (turn == widx) issued += ch_fill_block<REFLECT>(fc, pv0, pdst, 64);
+            turn = turn + 1 == nw ? 0 : turn + 1;
             pv0 += 64;
             pdst += 256u;
             pend -= 4;
           }
           if (prow_end && pend > 0) {
-            issued += ch_fill_block<REFLECT>(fc, pv0, pdst, 16 * pend);
+            if (turn == widx) issued += ch_fill_block<REFLECT>(fc, pv0, pdst, 16 * pend);
+            turn = turn + 1 == nw ? 0 : turn + 1;
             pend = 0;
           }
         } else {
@@ -536,10 +589,10 @@ __global__ void __launch_bounds__(512) cqt_chain_kernel(const ChainArgs a) {
   c.hop = hop;
   c.nr = nr;
   c.row_bytes = row_bytes;
-  c.slot = f;
+  c.slot = 16 * widx + f;  // the lane's frame in the run
   c.a_cur = c.a_lane;
-  c.b_cur = ring_base + (unsigned)(f * row_bytes) + (unsigned)lq * 16u;
-  c.row_next = c.b_cur + (f + 1 == nr ? (unsigned)(-(nr - 1) * row_bytes) : (unsigned)row_bytes);
+  c.b_cur = ring_base + (unsigned)(c.slot * row_bytes) + (unsigned)lq * 16u;
+  c.row_next = c.b_cur + (c.slot + 1 == nr ? (unsigned)(-(nr - 1) * row_bytes) : (unsigned)row_bytes);
 #if CH_PRIO == 1
   __builtin_amdgcn_s_setprio(3);  // (the MFMA stream before its SIMD partner's address arithmetic)
 #endif
@@ -549,13 +602,16 @@ __global__ void __launch_bounds__(512) cqt_chain_kernel(const ChainArgs a) {
     fc.zeros = a.zeros;
     fc.L = a.n_samples;
     fc.pad = a.pad;
-    fc.U0 = t0 * hop + 16 * S.s_lo - a.pad;
+    fc.U0 = U0;
     fc.lane = lane;
     fc.lperm = 16 * (lane >> 4) + 4 * (lane & 3) + ((lane >> 2) & 3);
     fc.lperm4 = 4u * (unsigned)fc.lperm;
     fc.nlperm4 = 0u - fc.lperm4;
     fc.lane4 = 4u * (unsigned)lane;
-    ch_fill_ring<REFLECT>(fc, ring_base, nr * hop, hop, row_bytes, 1);  // the odd blocks of the ring
+    if ((hop & 255) == 0 && fc.L >= 256)
+      ch_fill_ring_wide<REFLECT>(fc, ring_base, nr * hop, hop, row_bytes, 2 * widx + 1, 2 * nw);
+    else
+      ch_fill_ring<REFLECT>(fc, ring_base, nr * hop, hop, row_bytes, 2 * widx + 1, 2 * nw);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();  // the ring and the first two batches are in LDS

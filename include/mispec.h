@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MISPEC_ABI_VERSION 12
+#define MISPEC_ABI_VERSION 13
 
 enum {
   MISPEC_OK = 0,
@@ -423,6 +423,12 @@ int mispec_unpad_adjoint_f32(const float *dxp, int32_t n_clips, int32_t n_sample
                              int32_t pad_mode, float *dx, int64_t dx_clip_stride, void *stream);
 int mispec_frame_offsets_i64(int64_t *k_offsets, int32_t n_clips, int32_t n_frames,
                              int64_t clip_stride, int32_t hop, void *stream);
+/* The pointwise epilogue alone: z (B, F, T, 2) = the Complex output of a framed contraction (row scale and im_sign
+ * applied) -> out (B, F, T[, 2]) in `epilogue`, by the very code the contraction kernels end with: the same bits as
+ * the fused launch.  A training step runs the contraction once with the Complex epilogue, keeps z for the backward
+ * (stft.py:238-242: trainable kernels) and derives the module's output here. */
+int mispec_framed_epilogue_fwd_f32(const float *z, int32_t n_clips, int32_t n_bins, int32_t n_frames,
+                                   int32_t epilogue, float eps, float power, float *out, void *stream);
 int mispec_framed_epilogue_bwd_f32(const float *grad_out, const float *z, int32_t n_clips,
                                    int32_t n_bins, int32_t n_frames, int32_t epilogue, float eps,
                                    float power, float im_sign, const float *row_scale, float *g,

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmispec.so")
 ABLATE_LIB_PATH = os.path.join(_HERE, "csrc", "libmispec_ablate.so")  # benchmarking build
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 E_INVALID, E_UNSUPPORTED, E_HIP = -1, -2, -3
 
 # enums (mirror include/mispec.h)
@@ -58,6 +58,7 @@ EXPORTS = (
     "mispec_unpad_adjoint_f32",
     "mispec_frame_offsets_i64",
     "mispec_framed_epilogue_bwd_f32",
+    "mispec_framed_epilogue_fwd_f32",
     "mispec_frames_transpose_f32",
     "mispec_istft_frames_f32",
     "mispec_istft_frames_fft_f32",
@@ -389,6 +390,11 @@ def _load(path, how):
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
         ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+    ]
+    lib.mispec_framed_epilogue_fwd_f32.restype = ctypes.c_int
+    lib.mispec_framed_epilogue_fwd_f32.argtypes = [
+        ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
+        ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
     ]
     lib.mispec_frames_transpose_f32.restype = ctypes.c_int
     lib.mispec_frames_transpose_f32.argtypes = [

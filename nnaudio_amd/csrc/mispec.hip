@@ -319,8 +319,8 @@ __device__ __forceinline__ const float *frame_ptr(const KParams &p, int c, int t
 // ---------------------------------------------------------------------------------
 // pointwise epilogue on one (bin, frame) pair, shared by the MFMA and the reference kernel
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ void epilogue_store(const KParams &p, float *__restrict__ dst, float re,
-                                               float im) {
+template <typename P>
+__device__ __forceinline__ void epilogue_store(const P &p, float *__restrict__ dst, float re, float im) {
   switch (p.epilogue) {
     case MISPEC_EPI_COMPLEX: {
       float2 v = make_float2(re, im);
@@ -1709,6 +1709,19 @@ __global__ void __launch_bounds__(256) frame_offsets_kernel(long long *__restric
   const int c = (int)(k / n_frames);
   const int t = (int)(k - (long long)c * n_frames);
   koff[k] = (long long)c * clip_stride + (long long)t * hop;
+}
+
+// the epilogue of the contraction kernels as a pass of its own: out <- epilogue(z), z = their Complex output
+struct EpiParams {
+  int epilogue;
+  float eps, power;
+};
+__global__ void __launch_bounds__(256) framed_epilogue_fwd_kernel(const float *__restrict__ z, long long total, EpiParams ep,
+                                                                  float *__restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const float2 v = *reinterpret_cast<const float2 *>(z + 2 * i);
+  epilogue_store(ep, out + i * epilogue_width(ep.epilogue), v.x, v.y);
 }
 
 __global__ void __launch_bounds__(256) framed_epilogue_bwd_kernel(
@@ -4086,6 +4099,25 @@ int mispec_frames_transpose_f32(const float *xpad, int64_t clip_stride, int32_t 
   hipLaunchKernelGGL(frames_transpose_kernel, dim3((unsigned)((cols + 31) / 32), (unsigned)((kernel + 31) / 32)),
                      dim3(256), 0, static_cast<hipStream_t>(stream), xpad, (long long)clip_stride, n_frames,
                      hop, kernel, cols, xt);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return MISPEC_OK;
+}
+
+int mispec_framed_epilogue_fwd_f32(const float *z, int32_t n_clips, int32_t n_bins, int32_t n_frames,
+                                   int32_t epilogue, float eps, float power, float *out, void *stream) {
+  if (!z || !out) return fail(MISPEC_E_INVALID, "NULL device pointer%s");
+  if (n_clips <= 0 || n_bins <= 0 || n_frames <= 0) return fail(MISPEC_E_INVALID, "non-positive size%s");
+  if (epilogue < MISPEC_EPI_COMPLEX || epilogue > MISPEC_EPI_PHASE_COSSIN)
+    return fail(MISPEC_E_INVALID, "bad epilogue%s");
+  const long long total = (long long)n_clips * n_bins * n_frames;
+  if ((total + 255) / 256 > 0x7fffffffLL) return fail(MISPEC_E_UNSUPPORTED, "grid too large%s");
+  EpiParams ep;
+  ep.epilogue = epilogue;
+  ep.eps = eps;
+  ep.power = power;
+  hipLaunchKernelGGL(framed_epilogue_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), z, total, ep, out);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MISPEC_E_HIP, "kernel launch: %s", hipGetErrorString(e));
   return MISPEC_OK;

@@ -1300,6 +1300,22 @@ def contract_planar(a, x, *, k, n_clips, n_cols, x_clip_stride, x_k_stride=0, x_
     return out
 
 
+def epilogue_fwd(z, epilogue, *, eps=0.0, power=2.0):
+    """The contraction kernels' pointwise epilogue as a pass of its own (mispec_framed_epilogue_fwd_f32):
+    ``z`` (B, F, T, 2) = a Complex output -> (B, F, T[, 2]) in ``epilogue``."""
+    dev = _require_device(z)
+    if z.dim() != 4 or z.shape[-1] != 2 or not z.is_contiguous() or z.dtype != torch.float32:
+        raise RuntimeError("z must be a contiguous float32 (B, F, T, 2) tensor")
+    B, F, T, _ = z.shape
+    two = int(epilogue) in (EPI_COMPLEX, EPI_PHASE_COSSIN)
+    out = torch.empty((B, F, T, 2) if two else (B, F, T), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _abi.check(_abi.load().mispec_framed_epilogue_fwd_f32(z.data_ptr(), B, F, T, int(epilogue), float(eps),
+                                                              float(power), out.data_ptr(), stream))
+    return out
+
+
 class _FramedGemmFn(torch.autograd.Function):
     """Autograd wrapper of ``framed_gemm`` for trainable bases / differentiable inputs."""
 
@@ -1308,12 +1324,32 @@ class _FramedGemmFn(torch.autograd.Function):
         if not x.is_cuda:
             raise _gpu_only(x)  # (the host path is forward-only)
         ctx.kw = dict(kw)
-        ctx.save_for_backward(x, basis_re, basis_im)
-        return framed_gemm(x, basis_re, basis_im, **kw)
+        # The backward needs the Complex values z of this very contraction.  With HBM to spare they are kept instead of
+        # recomputed (round 6: the recomputation was 1.3 of the 6.1 ms of a cfg2-sized training step): the contraction runs
+        # ONCE with the Complex epilogue and the module's output is the pointwise epilogue of z
+        # (mispec_framed_epilogue_fwd_f32: the code the contraction kernels end with -- the same bits as the fused launch).
+        # Not for bf16x3 (its backward recomputes z in fp32), in-place row blocks, or z beyond MISPEC_SAVE_Z_MAX_BYTES.
+        z = None
+        epi = int(kw["epilogue"])
+        plain = kw.get("out") is None and kw.get("out_rows_total") is None and not kw.get("out_row_offset")
+        if plain and resolve_precision(kw.get("precision")) != "bf16x3":
+            xs = _signal(x.detach())
+            F = basis_re.shape[0]
+            T = n_frames(xs.shape[1], basis_re.shape[-1], int(kw["hop"]), int(kw["pad"]))
+            if 8 * xs.shape[0] * F * T <= int(os.environ.get("MISPEC_SAVE_Z_MAX_BYTES", str(8 << 30))):
+                z = framed_gemm(x, basis_re, basis_im, **dict(kw, epilogue=EPI_COMPLEX))
+        if z is None:
+            ctx.save_for_backward(x, basis_re, basis_im)
+            return framed_gemm(x, basis_re, basis_im, **kw)
+        ctx.save_for_backward(x, basis_re, basis_im, z)
+        if epi == EPI_COMPLEX:
+            return z.clone()  # (the caller may write into its output; z is the backward's)
+        return epilogue_fwd(z, epi, eps=float(kw.get("eps", 0.0)), power=float(kw.get("power", 2.0)))
 
     @staticmethod
     def backward(ctx, grad_out):
-        x, basis_re, basis_im = ctx.saved_tensors
+        x, basis_re, basis_im = ctx.saved_tensors[:3]
+        z_saved = ctx.saved_tensors[3] if len(ctx.saved_tensors) > 3 else None
         kw = ctx.kw
         lib = _abi.load()
         dev = x.device
@@ -1336,7 +1372,7 @@ class _FramedGemmFn(torch.autograd.Function):
             zkw.update(precision="fp32", row_support=None)
             for k in ("basis_split", "basis_fold", "basis_fold2"):  # (planes in the forward's precision, not in fp32)
                 zkw.pop(k, None)
-        z = framed_gemm(xs, wr, wi, **zkw)
+        z = z_saved if z_saved is not None else framed_gemm(xs, wr, wi, **zkw)
         T = z.shape[2]
         go = _f32(grad_out, "grad_output").contiguous()
         need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
@@ -1382,7 +1418,10 @@ class _FramedGemmFn(torch.autograd.Function):
                 #  the side streams keep n_par chunks alive at once -- frame matrix, G, its fp16 planes, the
                 # workspace, in per-stream allocator pools the main stream cannot reuse: only when all of them together
                 # stay inside the budget one serial chunk had (2^29 floats of frames); else the serial loop
-                want = (B + 3) // 4
+                # (eight chunks on the four queues: 4.57 ms per cfg2-sized step against 4.83 with four -- a chunk's 272
+                # long-lived workgroups fill half of the device's 512 slots, shorter ones pack better)
+                n_chunks = max(1, min(B, int(os.environ.get("MISPEC_DBASIS_CHUNKS", "8"))))
+                want = (B + n_chunks - 1) // n_chunks
                 if 4 * want * K * T <= (1 << 29):
                     n_par = 4
                     per = min(per, want)
@@ -1394,7 +1433,9 @@ class _FramedGemmFn(torch.autograd.Function):
                     st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
                     _abi.check(lib.mispec_frames_transpose_f32(xp[b0:b1].data_ptr(), Lp, b1 - b0, T, hop, K,
                                                                xt.data_ptr(), st))
-                gc = g[:, :, b0:b1].reshape(2 * F, nb) if b1 - b0 >= B else g[:, :, b0:b1].reshape(2 * F, nb).contiguous()
+                gc = g[:, :, b0:b1].reshape(2 * F, nb)  # (a view: rows B*T apart, the chunk's (b, t) contiguous)
+                if not (use16 and nb % 2 == 0):
+                    gc = gc.contiguous()
                 if use16 and nb % 2 == 0:
                     # the forward's arithmetic for its adjoint too (round 5): (g_re, g_im) as the complex "basis" of the
                     # staged dense f16x3 kernel (scaled fp16 pairs per row, split here: G changes every step), Complex
@@ -1414,17 +1455,26 @@ class _FramedGemmFn(torch.autograd.Function):
                 start = torch.cuda.Event()
                 start.record(cur)
                 done = []
+                # n_par - 1 side streams + the current one: the device runs four hardware queues, and a fifth stream
+                # shares one of them (round 6's trace: three chunks side by side, the fourth after them)
+                done = [None] * len(chunks)
                 for i, (b0, b1) in enumerate(chunks):
-                    side = _side_stream(dev, i % n_par)
+                    if i % n_par == 0:
+                        continue
+                    side = _side_stream(dev, i % n_par - 1)
                     side.wait_event(start)
                     with torch.cuda.stream(side):
                         part = d_basis_chunk(b0, b1)
                         ev = torch.cuda.Event()
                         ev.record(side)
-                    done.append((part, ev))
+                    done[i] = (part, ev)
+                for i, (b0, b1) in enumerate(chunks):
+                    if i % n_par == 0:
+                        done[i] = (d_basis_chunk(b0, b1), None)
                 for part, ev in done:
-                    cur.wait_event(ev)
-                    part.record_stream(cur)
+                    if ev is not None:
+                        cur.wait_event(ev)
+                        part.record_stream(cur)
                     dw = part if dw is None else dw.add_(part)
             else:
                 for b0, b1 in chunks:

@@ -81,6 +81,12 @@ CASES = [  # F, K, hop, B, L, pad mode, epilogue
     (33, 512, 320, 4, 7001, "none", "complex"),          # center=False
     (84, 4096, 384, 1, 2100, "reflect", "phase"),        # a clip barely longer than the padding: every block is mirrored
     (12, 640, 448, 9, 5000, "zero", "magnitude"),        # 9 clips x 2 column tiles: idle waves in the last group
+    # shared delay lines (round 6): runs of column tiles of one clip inside a workgroup, workgroups across clip boundaries
+    (48, 2048, 256, 5, 20000, "reflect", "complex"),     # hop 256: 5 tiles per clip -> runs of 4, 1 + 3, 2 + 2, 3 + 1; register-path prologue
+    (84, 4096, 512, 5, 20000, "reflect", "magnitude"),   # hop 512: 3 tiles per clip -> runs of 3 + 1, 2 + 2, 1 + 3
+    (20, 1024, 512, 3, 70001, "zero", "complex"),        # 9 tiles per clip: runs of 4, 4, 1 + 3 ...; zero padding through the register path
+    (7, 256, 256, 3, 200, "reflect", "complex"),         # clips shorter than a 256-block: the DMA prologue
+    (16, 512, 256, 2, 512, "none", "complex"),           # one frame per clip, center=False, L = two blocks exactly
 ]
 
 

@@ -57,7 +57,7 @@
 #define CH_STAMP_WG 2
 #endif
 #ifndef CH_PRIO
-#define CH_PRIO 2
+#define CH_PRIO 1  // 1: the multiplying waves at s_setprio 3 (0.905 ms); 2: the loading waves (0.932); 0: neither (0.910)
 #endif
 
 namespace {
@@ -533,6 +533,7 @@ __global__ void __launch_bounds__(512) cqt_chain_kernel(const ChainArgs a) {
     int pv0 = 0;
     bool prow_end = false;
     int turn = 0;  // the run's loading waves take its blocks in turn
+    long long st_issue = 0, st_wait = 0, st_barrier = 0, st_n = 0, st_prev = (CH_ABL & 64) ? clock64() : 0;
     for (int sg = 0; sg < n_segs; ++sg) {
       const int w = seg[sg];
       const int q = (w >> 4) & 15, count = w >> 8;
@@ -574,9 +575,26 @@ __global__ void __launch_bounds__(512) cqt_chain_kernel(const ChainArgs a) {
         }
         issued += request();  // batch b + 2's bricks
         // everything requested in earlier batches has landed: batch b + 1's bricks, the ring samples of batch b - 2's part
+        long long tw0 = 0, tw1 = 0;
+        if (CH_ABL & 64) tw0 = clock64();
         if (!(CH_ABL & 2)) ch_wait_vmcnt(issued);
+        if (CH_ABL & 64) tw1 = clock64();
         if (!(CH_ABL & 1)) __syncthreads();
+        if (CH_ABL & 64) {  // where a loading wave's iteration goes: issue, wait for the landing, barrier (sums; a.stamps[1000 ..])
+          const long long tw2 = clock64();
+          st_issue += tw0 - st_prev;
+          st_wait += tw1 - tw0;
+          st_barrier += tw2 - tw1;
+          st_prev = tw2;
+          ++st_n;
+        }
       }
+    }
+    if ((CH_ABL & 64) && blockIdx.x == CH_STAMP_WG && lane == 0) {
+      a.stamps[1000 + 4 * cw] = st_issue;
+      a.stamps[1001 + 4 * cw] = st_wait;
+      a.stamps[1002 + 4 * cw] = st_barrier;
+      a.stamps[1003 + 4 * cw] = st_n;
     }
     return;
   }
@@ -990,17 +1008,12 @@ int mispec_chain_launch(const mispec_framed_gemm_args *a, int debug, void *strea
       prev = nextt;
     }
     (void)prev;
-    double s1 = 0, s2 = 0, s3 = 0, s4 = 0;
-    int nn = 0;
-    for (int i = 40; i < 680; ++i) {
-      if (!h[1024 + 4 * i] || !h[1024 + 4 * (i + 1)]) break;
-      s1 += h[1025 + 4 * i] - h[1024 + 4 * i];
-      s2 += h[1026 + 4 * i] - h[1025 + 4 * i];
-      s3 += h[1027 + 4 * i] - h[1026 + 4 * i];
-      s4 += h[1024 + 4 * (i + 1)] - h[1027 + 4 * i];
-      ++nn;
+    for (int w = 0; w < 4; ++w) {
+      const double n = (double)h[1003 + 4 * w];
+      if (n > 0)
+        fprintf(stderr, "loading wave %d: %.0f iterations; per iteration: issue + bookkeeping %.0f, vmcnt wait %.0f, barrier %.0f cycles\n", 4 + w, n,
+                h[1000 + 4 * w] / n, h[1001 + 4 * w] / n, h[1002 + 4 * w] / n);
     }
-    if (nn) fprintf(stderr, "loader wave 4, batches 40..%d: request %.0f, refill + bookkeeping %.0f, vmcnt wait %.0f, barrier %.0f cycles\n", 40 + nn, s1 / nn, s2 / nn, s3 / nn, s4 / nn);
   }
   return MISPEC_OK;
 }

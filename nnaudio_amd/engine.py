@@ -1328,10 +1328,13 @@ class _FramedGemmFn(torch.autograd.Function):
         # recomputed (round 6: the recomputation was 1.3 of the 6.1 ms of a cfg2-sized training step): the contraction runs
         # ONCE with the Complex epilogue and the module's output is the pointwise epilogue of z
         # (mispec_framed_epilogue_fwd_f32: the code the contraction kernels end with -- the same bits as the fused launch).
-        # Not for bf16x3 (its backward recomputes z in fp32), in-place row blocks, or z beyond MISPEC_SAVE_Z_MAX_BYTES.
+        # Not for bf16x3 (its backward recomputes z in fp32), in-place row blocks, z beyond MISPEC_SAVE_Z_MAX_BYTES, or frozen
+        # Fourier bases with the quarter fold (differentiable input only: their forward may run on the FFT kernel, whose fused
+        # Magnitude is not the pointwise pass's last bit -- and recomputing z there costs a tenth of a contraction).
         z = None
         epi = int(kw["epilogue"])
-        plain = kw.get("out") is None and kw.get("out_rows_total") is None and not kw.get("out_row_offset")
+        plain = (kw.get("out") is None and kw.get("out_rows_total") is None and not kw.get("out_row_offset")
+                 and kw.get("basis_fold2") is None)
         if plain and resolve_precision(kw.get("precision")) != "bf16x3":
             xs = _signal(x.detach())
             F = basis_re.shape[0]

@@ -61,7 +61,13 @@ def _prepare(basis_re, basis_im, precision, hop, support):
         frag = engine.frag_basis_f16(basis_re, basis_im)
         if frag is not None:
             return {"basis_split": frag}
-    return engine.prepare_basis(basis_re, basis_im, precision, hop=hop)
+    prep = engine.prepare_basis(basis_re, basis_im, precision, hop=hop)
+    if support and precision == "fp32" and basis_re.is_cuda:
+        # banks with supports in fp32: the chain kernel's copy (LDS delay lines, the tile kernels' bits; None = not served)
+        chain = engine.chain_basis_f32(basis_re, basis_im, _supports(basis_re, basis_im).host_copy)
+        if chain is not None:
+            prep = dict(prep, basis_chain=chain)
+    return prep
 
 
 def _prepared(basis_re, basis_im, precision, hop, support=False):

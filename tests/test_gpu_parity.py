@@ -1533,6 +1533,9 @@ def test_torch_compile_runs_the_custom_ops(cls, ctor, precision):
             # contraction's epilogue; the octave recursion on the pyramid kernel in bf16x3): bit for
             # bit -- the unfused launch structure differs in the last bits
             assert torch.equal(got, want), "compiled %s did not take the fused path" % cls
+        if cls == "CQT1992v2" and precision == "fp32":
+            # one float32 FMA chain per output whichever kernel serves it (the op prepares the chain kernel's copy as well)
+            assert torch.equal(got, want)
     finally:
         nnaudio_amd.set_precision(old)
         torch._dynamo.reset()

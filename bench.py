@@ -1040,6 +1040,13 @@ def main():
                 prewarm(m2, x2, args.prewarm_ms)
                 w2, d2, r2 = run_path(m2, x2, me2, pr, n2, max(5, args.warmup // 2), fft=pr == "fft")
                 blk = roofline_block(me2, d2 / n2, pr)
+                if name == "gammatone" and pr == "fft":
+                    # ("hbm" describes the first of the step's two launches only)
+                    blk["bound_note"] = ("two launches: the FFT kernel writes the power spectrogram frame-major (priced on bytes: "
+                                         "this block), then the dense 64 x 1025 filterbank is an fp32 MFMA contraction over a frame's "
+                                         "bins -- 2*64*1025 flop per frame, MFMA-bound (~0.082 ms = 0.56 of the fp32 matrix peak; "
+                                         "profiles/r06/rocprofv3_gammatone_frame_major_kernel_stats.csv)")
+                    blk["second_launch_mfma_flops"] = 2.0 * 64 * 1025 * me2["frames"]
                 r2.update(workload=me2["tag"], precision=pr, steps=n2, roofline=blk)
                 extra[key] = r2
                 if name == "cqt" and not b2 and (pr2 is None or pr2 == "f16x3"):
